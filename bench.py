@@ -1,0 +1,225 @@
+"""Headline benchmark: MSENet14 biomass-regression TRAINING throughput (plots/s) on synthetic 16k-point plots.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
+
+One step = one pass of the hot path over one batch: set_input (coordinate hash + kernel maps on device),
+forward, backward, gradient all-reduce (N>1), clip, AdaBelief, LR schedule — BASELINE.json config
+"MSENet14 sparse-voxel, 1xMI355X, 0.5m voxel, batch=32" per GPU (weak scaling).  Inputs are pre-voxelised and
+resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="plots per GPU")
+    ap.add_argument("--points", type=int, default=16000)
+    ap.add_argument("--model", default="SENet14")
+    ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated batches cycled per rank")
+    ap.add_argument("--features", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-plots", type=int, default=2)
+    return ap.parse_args()
+
+
+def conv_cost(rec, pairs):
+    """SURVEY.md §8(d) algorithmic bytes / FLOPs of one sparse-conv launch (fp32, e = 4)."""
+    cin, cout, K3 = rec["cin"], rec["cout"], rec["K3"]
+    flops = 2.0 * pairs * cin * cout
+    if rec["kind"] == "wgrad":
+        byts = pairs * (cin + cout) * 4 + pairs * 8 + K3 * cin * cout * 4
+    else:
+        byts = pairs * (cin + cout) * 4 + pairs * 8 + K3 * cin * cout * 4
+    return byts, flops
+
+
+def roofline_from_profile(prof):
+    """Group launches by kernel flavour; the dominant one (largest total time) is reported."""
+    groups = {}
+    pair_cache = {}
+    for rec in prof:
+        ms = rec["start"].elapsed_time(rec["end"])
+        p = rec["pairs"]
+        if p is None:
+            continue
+        key = id(p)
+        if key not in pair_cache:
+            pair_cache[key] = int(p.item())
+        pairs = pair_cache[key]
+        byts, flops = conv_cost(rec, pairs)
+        small = rec["cin"] in (4, 8)
+        name = ("k_spconv_dw" if rec["kind"] == "wgrad" else "k_spconv_fwd") + ("<small-Cin>" if small else "<generic>")
+        g = groups.setdefault(name, dict(ms=0.0, n=0, bytes=0.0, flops=0.0))
+        g["ms"] += ms
+        g["n"] += 1
+        g["bytes"] += byts
+        g["flops"] += flops
+    if not groups:
+        return None, {}
+    dom = max(groups, key=lambda k: groups[k]["ms"])
+    g = groups[dom]
+    secs = g["ms"] / 1e3
+    intensity = g["flops"] / g["bytes"]
+    ridge = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if intensity >= ridge:
+        ach = g["flops"] / secs / 1e12
+        roof = dict(bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                    frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=None)
+    else:
+        ach = g["bytes"] / secs / 1e9
+        roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None)
+    roof.update(kernel=dom, launches=g["n"], avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2),
+                alg_bytes_per_launch=round(g["bytes"] / g["n"]), alg_flops_per_launch=round(g["flops"] / g["n"]))
+    summary = {k: dict(total_ms=round(v["ms"], 3), launches=v["n"],
+                       gbs=round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1),
+                       tflops=round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)) for k, v in groups.items()}
+    return roof, summary
+
+
+def cpu_baseline(args, model_sd, stats):
+    """The oracle (torch-CPU restatement, fp32, all host cores) on a bounded sample of the same workload:
+    full training steps (fwd + bwd + AdaBelief) on `--cpu-plots` synthetic 16k-point plots."""
+    from oracle import sparse_ref as R
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.optim import AdaBelief
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    batch = synthetic.make_sparse_batch(list(range(900_000, 900_000 + args.cpu_plots)), n_points=args.points)
+    sd = {k: (v.detach().clone().float().requires_grad_(v.is_floating_point() and "running" not in k))
+          for k, v in model_sd.items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = AdaBelief(params, lr=0.005, weight_decay=1e-2)
+    coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
+    center, scale, w = stats
+    t0 = time.time()
+    steps = 0
+    while steps < 1 or (time.time() - t0 < 10 and steps < 3):
+        out = R.resnet_forward(sd, coords, batch.x, (1, 1, 1, 1), batch_size=args.cpu_plots)
+        loss = R.reg_loss(out, batch.y_reg, center, scale, w)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(params, 100)
+        opt.step()
+        steps += 1
+    dt = time.time() - t0
+    return dict(value=round(args.cpu_plots * steps / dt, 4), unit="plots/s", cores=cores, kind="port",
+                sample=f"{steps} training step(s) of MSENet14 on {args.cpu_plots} synthetic {args.points}-pt plots "
+                       f"(oracle/sparse_ref.py, torch-CPU fp32, {cores} threads), {dt:.1f} s")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dpcr_agb_amd import sparse_ops, synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
+    from dpcr_agb_amd.dist import GradAllReduce, broadcast_parameters, shard_seeds
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=args.features, stat_seeds=range(10_000, 10_064))
+    model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS[args.model]), "minkowski", ds)
+    model_sd_cpu = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    model.to(dev).train()
+    broadcast_parameters(model)
+    model.init_train_objects(TRAINING_NFI)
+    sync = None
+    if world > 1:
+        sync = GradAllReduce(model.parameters())
+        model.grad_sync = sync
+
+    # pre-generated, pre-voxelised, device-resident batches (disjoint seeds per rank)
+    pool = []
+    gb = args.batch * world
+    for i in range(args.pool):
+        seeds = shard_seeds(gb, rank, world, i)
+        pool.append(synthetic.make_sparse_batch(seeds, n_points=args.points,
+                                                extra_feature=args.features == 4).to(dev))
+    voxels = sum(int(b.coords.shape[0]) for b in pool) / len(pool) / args.batch
+    steps_per_epoch = 133  # 4271 train plots / 32
+
+    def step(i):
+        model.set_input(pool[i % len(pool)], dev)
+        model.optimize_parameters(epoch=i // steps_per_epoch, batch_size=args.batch, num_batches=steps_per_epoch)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if rank == 0:
+        sparse_ops.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, sparse_ops.PROFILE = sparse_ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(model.loss)
+
+    if rank == 0:
+        roof, summary = roofline_from_profile(prof or [])
+        line = {
+            "metric": "training plots/sec (16k-pt NFI plots) MSENet14",
+            "value": round(world * args.batch * args.steps / elapsed, 2),
+            "unit": "plots/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} sparse-voxel training step, {args.points}-pt synthetic plots, "
+                                   f"voxel 0.0125 (0.375x0.375x0.5 m), batch {args.batch}/GPU, F={args.features}, "
+                                   f"~{voxels:.0f} voxels/plot, fwd+bwd+AdaBelief incl. coordinate hash/kernel maps",
+                       "global_batch": gb, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
+            "roofline": roof,
+            "kernels": summary,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            stats = (model.reg_center_targets.cpu(), model.reg_scale_targets.cpu(), model.reg_weights.cpu())
+            line["cpu_baseline"] = cpu_baseline(args, model_sd_cpu, stats)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""ctypes binding of libagbhip.so — the C-ABI drop-in library (include/agb_hip.h).
+
+There is deliberately NO fallback: if the library is missing, or a tensor that is not resident on a
+HIP device is handed to a kernel wrapper, the call raises.  The oracle under ``oracle/`` is test
+infrastructure only and is never imported from here.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libagbhip.so")
+
+c_int = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+
+# name -> argtypes (all functions return int except where noted in _RESTYPES)
+_SIGNATURES = {
+    "agb_hash_capacity": [c_int],
+    "agb_scan_scratch_elems": [c_int],
+    "agb_hash_clear": [c_void_p, c_void_p, c_int, c_void_p],
+    "agb_coords_insert": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "agb_coords_stride": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "agb_kernel_map": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                       c_ll, c_void_p, c_void_p],
+    "agb_batch_ptr": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p],
+    "agb_spconv_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                       c_int, c_int, c_void_p],
+    "agb_spconv_bwd_weight": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int,
+                              c_void_p],
+    "agb_maxpool_fwd": [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "agb_maxpool_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "agb_segment_reduce": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                           c_void_p],
+    "agb_segment_broadcast": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                              c_void_p],
+    "agb_segment_max_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+}
+
+_lib = None
+
+
+class AgbError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libagbhip.so (once). Raises if it has not been built: run ``python __graft_entry__.py``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AgbError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (needs hipcc). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.agb_last_error.restype = ctypes.c_char_p
+    lib.agb_last_error.argtypes = []
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue  # optional symbols are checked by tests/test_abi.py against include/agb_hip.h
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def declare(name, argtypes):
+    """Register one more entry point (used by the modules that bind the later-added kernels)."""
+    _SIGNATURES[name] = argtypes
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). Refuses host tensors: the product path is HIP-only."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AgbError("libagbhip kernels need tensors resident on a HIP device (got a CPU tensor); "
+                       "there is no CPU fallback in the product path")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise AgbError(f"{name} failed ({rc}): {lib.agb_last_error().decode()}")
+    return rc
+
+
+def hash_capacity(n):
+    return load().agb_hash_capacity(int(n))
+
+
+def scan_scratch_elems(n):
+    return load().agb_scan_scratch_elems(int(n))

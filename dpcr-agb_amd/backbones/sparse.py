@@ -1,0 +1,270 @@
+"""Sparse-voxel ResNet / SENet backbones (MSENet14 / MSENet50 of the reference) on the HIP sparse ops.
+
+Same constructor arguments, module attribute names and state_dict keys as the reference
+(torch_points3d/modules/MinkowskiEngine/SENet.py:14-118 ResNetBase, :151 SENet14, :185 SENet50;
+resnet_block.py:31-133 BasicBlock/Bottleneck; senet_block.py:33-147 SELayer/SEBasicBlock/SEBottleneck;
+common.py:215-226 ConvNormActivation, :344-366 MinkowskiDropPath), so checkpoints trained with the reference
+load unchanged:  blocks.0.0.{conv,norm.bn}, blocks.<s>.<i>.{conv1,norm1.bn,conv2,norm2.bn,se.fc.{0,2}.linear,
+downsample.{0,1.bn}}, final.linear.
+"""
+import random
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import me_compat as ME
+
+ACTIVATIONS = {
+    "relu": ME.MinkowskiReLU,
+    "celu": partial(ME.MinkowskiCELU, alpha=0.54),
+    "silu": ME.MinkowskiSiLU,
+    "swish": ME.MinkowskiSiLU,
+    "elu": partial(ME.MinkowskiELU, alpha=0.54),
+    "sigmoid": ME.MinkowskiSigmoid,
+    "tanh": ME.MinkowskiTanh,
+    "gelu": ME.MinkowskiGELU,
+}
+
+GLOBAL_POOL = {
+    "max": ME.MinkowskiGlobalMaxPooling,
+    "mean": ME.MinkowskiGlobalAvgPooling,
+    "sum": ME.MinkowskiGlobalSumPooling,
+}
+
+
+class MinkowskiDropPath(nn.Module):
+    """Stochastic depth per batch element; draws one ``random.uniform(0, 1)`` per element in batch order,
+    like the reference (common.py:355-361), so a seeded run drops the same samples."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        cm = x.coordinate_manager
+        keep_prob = 1 - self.drop_prob
+        keep = [1.0 if random.uniform(0, 1) > self.drop_prob else 0.0 for _ in range(cm.batch_size)]
+        if all(k == 1.0 for k in keep) and not (keep_prob > 0.0 and self.scale_by_keep):
+            return x
+        scale = torch.tensor(keep, dtype=torch.float32)
+        if keep_prob > 0.0 and self.scale_by_keep:
+            scale = scale / keep_prob
+        scale = scale.to(x.device, non_blocking=True).view(-1, 1).expand(-1, x.F.shape[1]).contiguous()
+        glob = ME.SparseTensor(scale, coordinate_map_key=ME.CoordinateMapKey(0), coordinate_manager=cm)
+        return ME.MinkowskiBroadcastMultiplication()(x, glob)
+
+
+class ConvNormActivation(nn.Module):
+    def __init__(self, input_channels, out_channels, kernel_size, stride, norm_layer, activation_layer, bias, D):
+        super().__init__()
+        self.conv = ME.MinkowskiConvolution(input_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                            dimension=D, bias=bias)
+        self.norm = norm_layer(out_channels)
+        self.act = nn.Identity() if activation_layer is None else activation_layer
+
+    def forward(self, x):
+        return self.act(self.norm(self.conv(x)))
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, act_fn, norm_layer, stride=1, dilation=1, downsample=None, drop_path=0.0,
+                 bias=True, dimension=-1):
+        super().__init__()
+        assert dimension > 0
+        self.conv1 = ME.MinkowskiConvolution(inplanes, planes, kernel_size=3, stride=stride, dilation=dilation,
+                                             dimension=dimension, bias=bias)
+        self.norm1 = norm_layer(planes)
+        self.conv2 = ME.MinkowskiConvolution(planes, planes, kernel_size=3, stride=1, dilation=dilation,
+                                             dimension=dimension, bias=bias)
+        self.norm2 = norm_layer(planes)
+        self.relu = act_fn
+        self.downsample = downsample if downsample is not None else nn.Identity()
+        self.drop_path = MinkowskiDropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def _main(self, x):
+        out = self.relu(self.norm1(self.conv1(x)))
+        return self.norm2(self.conv2(out))
+
+    def forward(self, x):
+        out = self._main(x)
+        residual = self.downsample(x)
+        return self.relu(self.drop_path(out) + residual)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, act_fn, norm_layer, stride=1, dilation=1, downsample=None, drop_path=0.0,
+                 bias=True, dimension=-1):
+        super().__init__()
+        assert dimension > 0
+        self.conv1 = ME.MinkowskiConvolution(inplanes, planes, kernel_size=1, dimension=dimension, bias=bias)
+        self.norm1 = norm_layer(planes)
+        self.conv2 = ME.MinkowskiConvolution(planes, planes, kernel_size=3, stride=stride, dilation=dilation,
+                                             dimension=dimension, bias=bias)
+        self.norm2 = norm_layer(planes)
+        self.conv3 = ME.MinkowskiConvolution(planes, planes * self.expansion, kernel_size=1, dimension=dimension,
+                                             bias=bias)
+        self.norm3 = norm_layer(planes * self.expansion)
+        self.relu = act_fn
+        self.downsample = downsample if downsample is not None else nn.Identity()
+        self.drop_path = MinkowskiDropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def _main(self, x):
+        out = self.relu(self.norm1(self.conv1(x)))
+        out = self.relu(self.norm2(self.conv2(out)))
+        return self.norm3(self.conv3(out))
+
+    def forward(self, x):
+        out = self._main(x)
+        residual = self.downsample(x)
+        return self.relu(self.drop_path(out) + residual)
+
+
+class SELayer(nn.Module):
+    """Squeeze-excite: global AVERAGE pool -> Linear(C, C/r) -> act -> Linear(C/r, C) -> sigmoid -> broadcast mul."""
+
+    def __init__(self, channel, act_fn, reduction=16, dimension=-1):
+        super().__init__()
+        self.fc = nn.Sequential(
+            ME.MinkowskiLinear(channel, channel // reduction),
+            act_fn,
+            ME.MinkowskiLinear(channel // reduction, channel),
+            ME.MinkowskiSigmoid(),
+        )
+        self.pooling = ME.MinkowskiGlobalPooling()
+        self.broadcast_mul = ME.MinkowskiBroadcastMultiplication()
+
+    def forward(self, x):
+        return self.broadcast_mul(x, self.fc(self.pooling(x)))
+
+
+class SEBasicBlock(BasicBlock):
+    def __init__(self, inplanes, planes, act_fn, norm_layer, stride=1, dilation=1, downsample=None, reduction=16,
+                 drop_path=0.0, bias=True, dimension=-1):
+        super().__init__(inplanes, planes, act_fn, norm_layer, stride=stride, dilation=dilation,
+                         downsample=downsample, drop_path=drop_path, bias=bias, dimension=dimension)
+        self.se = SELayer(planes, act_fn, reduction=reduction, dimension=dimension)
+
+    def _main(self, x):
+        return self.se(super()._main(x))
+
+
+class SEBottleneck(Bottleneck):
+    def __init__(self, inplanes, planes, act_fn, norm_layer, stride=1, dilation=1, downsample=None, dimension=-1,
+                 drop_path=0.0, bias=True, reduction=16):
+        super().__init__(inplanes, planes, act_fn, norm_layer, stride=stride, dilation=dilation,
+                         downsample=downsample, drop_path=drop_path, bias=bias, dimension=dimension)
+        self.se = SELayer(planes * self.expansion, act_fn, reduction=reduction, dimension=dimension)
+
+    def _main(self, x):
+        return self.se(super()._main(x))
+
+
+class ResNetBase(nn.Module):
+    BLOCK = None
+    LAYERS = ()
+    STRIDES = None
+    INIT_DIM = 64
+    PLANES = (64, 128, 256, 512)
+
+    def __init__(self, in_channels, out_channels, activation="relu", D=3, first_stride=2, dropout=0.0, drop_path=0.0,
+                 bn_momentum=0.1, norm_type="bn", global_pool="mean", use_gn=False, bias=True, **kwargs):
+        super().__init__()
+        assert self.BLOCK is not None and self.STRIDES is not None
+        self.D, self.bias, self.bn_momentum, self.drop_path = D, bias, bn_momentum, drop_path
+        self.act_fn = ACTIVATIONS[activation]()
+        self.norm_type = norm_type
+        if norm_type == "bn":
+            self.norm_layer = partial(ME.MinkowskiBatchNorm, momentum=bn_momentum)
+        elif norm_type == "bn_no_affine":
+            self.norm_layer = partial(ME.MinkowskiBatchNorm, momentum=bn_momentum, affine=False)
+        elif norm_type == "in":
+            self.norm_layer = ME.MinkowskiInstanceNorm
+        else:
+            raise NotImplementedError(f"norm_type '{norm_type}': choose 'bn', 'bn_no_affine' or 'in'")
+
+        self.inplanes = self.INIT_DIM
+        stem = nn.Sequential(
+            ConvNormActivation(in_channels, self.inplanes, kernel_size=7, stride=first_stride, D=D, bias=bias,
+                               activation_layer=self.act_fn, norm_layer=self.norm_layer),
+            ME.MinkowskiMaxPooling(kernel_size=3, stride=2, dimension=D),
+        )
+        stages = [stem]
+        for planes, layers, stride in zip(self.PLANES, self.LAYERS, self.STRIDES):
+            stages.append(self._make_layer(self.BLOCK, planes, layers, stride=stride))
+        self.blocks = nn.ModuleList(stages)
+
+        self.glob_avg = GLOBAL_POOL[global_pool]()
+        if dropout > 0:
+            self.glob_avg = nn.Sequential(self.glob_avg, ME.MinkowskiDropout(dropout))
+        self.final = ME.MinkowskiLinear(self.inplanes, out_channels, bias=True)
+        self.apply(self.init_weights)
+
+    @staticmethod
+    def init_weights(m):
+        if isinstance(m, ME.MinkowskiBatchNorm) and m.bn.affine:
+            nn.init.constant_(m.bn.weight, 1)
+            nn.init.constant_(m.bn.bias, 0)
+        if isinstance(m, ME.MinkowskiConvolution):
+            nn.init.trunc_normal_(m.kernel, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        if isinstance(m, ME.MinkowskiLinear):
+            nn.init.trunc_normal_(m.linear.weight, std=0.02)
+            if m.linear.bias is not None:
+                nn.init.constant_(m.linear.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                ME.MinkowskiConvolution(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride,
+                                        dimension=self.D, dilation=1, bias=self.bias),
+                self.norm_layer(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, self.act_fn, stride=stride, dilation=dilation, downsample=downsample,
+                        dimension=self.D, drop_path=self.drop_path, bias=self.bias, norm_layer=self.norm_layer)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, self.act_fn, stride=1, dilation=dilation, dimension=self.D,
+                                drop_path=self.drop_path, bias=self.bias, norm_layer=self.norm_layer))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        for block in self.blocks:
+            x = block(x)
+        x = self.glob_avg(x)
+        return self.final(x)
+
+
+def _variant(name, block, layers, strides=(1, 2, 2, 2), init_dim=64, planes=(64, 128, 256, 512)):
+    return type(name, (ResNetBase,), dict(BLOCK=block, LAYERS=layers, STRIDES=strides, INIT_DIM=init_dim,
+                                          PLANES=planes))
+
+
+ResNet14_ = _variant("ResNet14_", BasicBlock, (1, 1, 1, 1))
+ResNet18_ = _variant("ResNet18_", BasicBlock, (2, 2, 2, 2))
+ResNet34_ = _variant("ResNet34_", BasicBlock, (3, 4, 6, 3))
+ResNet50_ = _variant("ResNet50_", Bottleneck, (3, 4, 6, 3))
+ResNet101_ = _variant("ResNet101_", Bottleneck, (3, 4, 23, 3))
+SENet14 = _variant("SENet14", SEBasicBlock, (1, 1, 1, 1))
+SENet18 = _variant("SENet18", SEBasicBlock, (2, 2, 2, 2))
+SENet34 = _variant("SENet34", SEBasicBlock, (3, 4, 6, 3))
+SENet50 = _variant("SENet50", SEBottleneck, (3, 4, 6, 3))
+SENet101 = _variant("SENet101", SEBottleneck, (3, 4, 23, 3))
+SENet17_6deep = _variant("SENet17_6deep", SEBasicBlock, (1, 1, 1, 1, 2, 1), (1, 2, 2, 2, 2, 2), 32,
+                         (32, 64, 128, 256, 512, 1024))
+SENet17_5deep = _variant("SENet17_5deep", SEBasicBlock, (1, 1, 1, 2, 2), (1, 2, 2, 2, 2), 64,
+                         (64, 128, 256, 512, 1024))
+
+__all__ = ["ResNetBase", "ResNet14_", "ResNet18_", "ResNet34_", "ResNet50_", "ResNet101_", "SENet14", "SENet18",
+           "SENet34", "SENet50", "SENet101", "SENet17_6deep", "SENet17_5deep", "BasicBlock", "Bottleneck",
+           "SEBasicBlock", "SEBottleneck", "SELayer", "ConvNormActivation", "MinkowskiDropPath", "ACTIVATIONS",
+           "GLOBAL_POOL"]

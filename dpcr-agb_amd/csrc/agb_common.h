@@ -1,0 +1,69 @@
+// agb_common.h — shared device/host helpers for libagbhip (gfx950 / MI355X only).
+//
+// Conventions of the C ABI (see include/agb_hip.h):
+//   * every entry point returns 0 on success or a negative AGB_E* code and
+//     records a message retrievable with agb_last_error();
+//   * the caller owns every buffer (device pointers unless stated otherwise);
+//   * nothing here allocates, frees or synchronises — kernels are enqueued on
+//     the hipStream_t passed in (passed as void* across the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define AGB_OK 0
+#define AGB_EINVAL (-1)
+#define AGB_ELAUNCH (-2)
+#define AGB_ERANGE (-3)
+#define AGB_EUNSUPPORTED (-4)
+
+extern "C" const char* agb_last_error(void);
+void agb_set_error(const char* fmt, ...);
+
+#define AGB_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            agb_set_error(__VA_ARGS__);          \
+            return AGB_EINVAL;                   \
+        }                                        \
+    } while (0)
+
+#define AGB_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            agb_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return AGB_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+static inline int agb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- coordinate key packing -------------------------------------------------
+// [b | z | y | x], 16 bits each, spatial components biased by 32768 so that
+// negative voxel coordinates (ME allows them) order correctly.
+#define AGB_COORD_BIAS 32768
+#define AGB_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__host__ __device__ static inline uint64_t agb_pack_key(int b, int x, int y, int z) {
+    return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)(z + AGB_COORD_BIAS) << 32) |
+           ((uint64_t)(uint16_t)(y + AGB_COORD_BIAS) << 16) | (uint64_t)(uint16_t)(x + AGB_COORD_BIAS);
+}
+
+__host__ __device__ static inline uint32_t agb_hash_key(uint64_t k) {
+    // 64-bit finaliser (murmur3 fmix64); table capacity is a power of two.
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+// floor division for possibly negative numerators, positive divisor
+__host__ __device__ static inline int agb_floordiv(int a, int d) {
+    int q = a / d;
+    int r = a % d;
+    return (r != 0 && ((r < 0) != (d < 0))) ? q - 1 : q;
+}

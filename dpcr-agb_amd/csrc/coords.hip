@@ -1,0 +1,385 @@
+// coords.hip — sparse-voxel coordinate management on device:
+//   * open-addressing hash of packed [b,x,y,z] keys            (ME SparseTensor insert;
+//     reference call site torch_points3d/models/instance/minkowski.py:67-80)
+//   * strided output coordinates floor(c/ts)*ts + deterministic unique
+//     (ME coordinate-map stride; call sites modules/MinkowskiEngine/SENet.py:47-53,
+//     resnet_block.py:48-55)
+//   * kernel maps as dense neighbour tables nbr[K^3][n_out]     (ME kernel map)
+//   * per-batch row ranges (rows stay batch-contiguous at every level)
+//
+// HBM-bound integer work: every kernel is one thread per row (or per row x offset),
+// rows fastest so that table writes and coordinate reads coalesce.
+#include "agb_common.h"
+#include <limits.h>
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+extern "C" const char* agb_last_error(void) { return g_err; }
+void agb_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define TPB 256
+
+__device__ __forceinline__ int eff_n(int n_bound, const int32_t* n_dev) {
+    if (n_dev) {
+        int v = *n_dev;
+        return v < n_bound ? v : n_bound;
+    }
+    return n_bound;
+}
+
+// ---------------------------------------------------------------- hash table
+__global__ void k_hash_clear(uint64_t* keys, int32_t* vals, int cap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        keys[i] = AGB_KEY_EMPTY;
+        vals[i] = INT_MAX;
+    }
+}
+
+__device__ __forceinline__ int hash_insert_min(uint64_t* keys, int32_t* vals, uint32_t mask, uint64_t key,
+                                               int row) {
+    uint32_t h = agb_hash_key(key) & mask;
+    while (true) {
+        unsigned long long prev =
+            atomicCAS((unsigned long long*)&keys[h], (unsigned long long)AGB_KEY_EMPTY, (unsigned long long)key);
+        if (prev == AGB_KEY_EMPTY || prev == key) {
+            atomicMin(&vals[h], row);
+            return (int)h;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int hash_find_slot(const uint64_t* keys, uint32_t mask, uint64_t key) {
+    uint32_t h = agb_hash_key(key) & mask;
+    while (true) {
+        uint64_t kk = keys[h];
+        if (kk == key) return (int)h;
+        if (kk == AGB_KEY_EMPTY) return -1;
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ bool coord_in_range(int b, int x, int y, int z) {
+    return b >= 0 && b < 65536 && x >= -AGB_COORD_BIAS && x < AGB_COORD_BIAS && y >= -AGB_COORD_BIAS &&
+           y < AGB_COORD_BIAS && z >= -AGB_COORD_BIAS && z < AGB_COORD_BIAS;
+}
+
+// status[0] = rows whose coordinate duplicates an earlier row
+// status[1] = rows with a component outside the 16-bit packed range
+// status[2] = rows whose batch index is smaller than the previous row's
+__global__ void k_coords_insert(const int4* __restrict__ coords, int n, const int32_t* n_dev, uint64_t* keys,
+                                int32_t* vals, uint32_t mask, int32_t* slot_of_row, int32_t* status) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];  // (b, x, y, z)
+    if (!coord_in_range(c.x, c.y, c.z, c.w)) {
+        atomicAdd(&status[1], 1);
+        slot_of_row[i] = -1;
+        return;
+    }
+    if (i > 0 && coords[i - 1].x > c.x) atomicAdd(&status[2], 1);
+    uint64_t key = agb_pack_key(c.x, c.y, c.z, c.w);
+    slot_of_row[i] = hash_insert_min(keys, vals, mask, key, i);
+}
+
+__global__ void k_count_dups(int n, const int32_t* n_dev, const int32_t* vals, const int32_t* slot_of_row,
+                             int32_t* status) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s = slot_of_row[i];
+    if (s >= 0 && vals[s] != i) atomicAdd(&status[0], 1);
+}
+
+// ------------------------------------------------------------ strided coords
+// pass 1: insert floor(c / ts_out) * ts_out with the smallest input row as value
+__global__ void k_stride_insert(const int4* __restrict__ coords, int n, const int32_t* n_dev, int ts_out,
+                                uint64_t* keys, int32_t* vals, uint32_t mask, int32_t* slot_of_row) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    int x = agb_floordiv(c.y, ts_out) * ts_out;
+    int y = agb_floordiv(c.z, ts_out) * ts_out;
+    int z = agb_floordiv(c.w, ts_out) * ts_out;
+    uint64_t key = agb_pack_key(c.x, x, y, z);
+    slot_of_row[i] = hash_insert_min(keys, vals, mask, key, i);
+}
+
+// pass 2: flag[i] = 1 when row i is the first occurrence of its strided key
+__global__ void k_stride_flag(int n, const int32_t* n_dev, const int32_t* vals, const int32_t* slot_of_row,
+                              int32_t* flags) {
+    int nn = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i < nn && vals[slot_of_row[i]] == i) ? 1 : 0;
+}
+
+// ---- exclusive scan over int32 flags (three small kernels, deterministic) ----
+#define SCAN_ITEMS 4
+#define SCAN_BLOCK (TPB * SCAN_ITEMS)
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+    // 256 threads = 4 waves; wave scan by shuffles, then scan of 4 wave sums
+    __shared__ int wsum[TPB / 64];
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < TPB / 64; ++j) {
+        int s = wsum[j];
+        if (j < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ void k_scan_block_sums(const int32_t* __restrict__ in, int n, int32_t* block_sums) {
+    int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < n) s += in[base + j];
+    int tot;
+    block_exclusive_scan(s, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ void k_scan_sums(int32_t* block_sums, int nb, int32_t* total_out) {
+    // single workgroup; sequential over chunks of 256 block sums
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += TPB) {
+        int i = b0 + threadIdx.x;
+        int v = i < nb ? block_sums[i] : 0;
+        int tot;
+        int ex = block_exclusive_scan(v, &tot);
+        int c = carry;
+        if (i < nb) block_sums[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void k_scan_apply(const int32_t* __restrict__ in, int n, const int32_t* __restrict__ block_sums,
+                             int32_t* out) {
+    int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        v[j] = (base + j < n) ? in[base + j] : 0;
+        s += v[j];
+    }
+    int tot;
+    int ex = block_exclusive_scan(s, &tot) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < n) out[base + j] = ex;
+        ex += v[j];
+    }
+}
+
+// pass 3: representatives write the output coordinate and publish their row id in the table
+__global__ void k_stride_emit(const int4* __restrict__ coords, int n, const int32_t* n_dev, int ts_out,
+                              const int32_t* __restrict__ flags, const int32_t* __restrict__ excl,
+                              const int32_t* __restrict__ slot_of_row, int32_t* vals, int4* out_coords) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    int4 c = coords[i];
+    int r = excl[i];
+    out_coords[r] = make_int4(c.x, agb_floordiv(c.y, ts_out) * ts_out, agb_floordiv(c.z, ts_out) * ts_out,
+                              agb_floordiv(c.w, ts_out) * ts_out);
+    vals[slot_of_row[i]] = r;
+}
+
+// optional: out row of every input row (valid after k_stride_emit)
+__global__ void k_stride_rowmap(int n, const int32_t* n_dev, const int32_t* vals, const int32_t* slot_of_row,
+                                int32_t* out_row_of_in) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out_row_of_in[i] = vals[slot_of_row[i]];
+}
+
+// ----------------------------------------------------------------- kernel map
+// nbr[k][r] = row (in the probed table) of coordinate q_coords[r] + sign*offset_k*step, or -1.
+// offset_k for k = ix + K*(iy + K*iz): odd K -> (ix - K/2, ...), even K -> (ix, ...)   (ME region HYPER_CUBE)
+__global__ void k_kernel_map(const int4* __restrict__ q_coords, int n, const int32_t* n_dev, int K, int step, int sign,
+                             int require_multiple_of, const uint64_t* __restrict__ keys,
+                             const int32_t* __restrict__ vals, uint32_t mask, int32_t* nbr, long long nbr_stride,
+                             unsigned long long* pair_count) {
+    int nn = eff_n(n, n_dev);
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    if (r >= nn) return;
+    int ix = k % K, iy = (k / K) % K, iz = k / (K * K);
+    int half = (K & 1) ? K / 2 : 0;
+    int4 c = q_coords[r];
+    int x = c.y + sign * (ix - half) * step;
+    int y = c.z + sign * (iy - half) * step;
+    int z = c.w + sign * (iz - half) * step;
+    int res = -1;
+    bool ok = coord_in_range(c.x, x, y, z);
+    if (ok && require_multiple_of > 1) {
+        // transposed map: the probed coordinate must lie on the (coarser) output lattice
+        ok = (x % require_multiple_of == 0) && (y % require_multiple_of == 0) && (z % require_multiple_of == 0);
+    }
+    if (ok) {
+        int s = hash_find_slot(keys, mask, agb_pack_key(c.x, x, y, z));
+        if (s >= 0) res = vals[s];
+    }
+    nbr[(long long)k * nbr_stride + r] = res;
+    if (pair_count) {
+        // one atomic per wave: number of (input,output) pairs of this map (ME's kernel-map size)
+        // (__ballot only sees the lanes still active here, i.e. the in-range rows of this wave)
+        unsigned long long m = __ballot(res >= 0);
+        unsigned long long active = __ballot(1);
+        int leader = __ffsll((long long)active) - 1;
+        if ((int)(threadIdx.x & 63) == leader && m) atomicAdd(pair_count, (unsigned long long)__popcll(m));
+    }
+}
+
+// ----------------------------------------------------------------- batch rows
+__global__ void k_batch_count(const int4* __restrict__ coords, int n, const int32_t* n_dev, int B, int32_t* ptr) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b = coords[i].x;
+    // rows are batch-contiguous: only segment heads touch memory
+    if (i == 0 || coords[i - 1].x != b) {
+        if (b >= 0 && b < B) ptr[b] = i;
+    }
+    if (i == n - 1) ptr[B] = n;
+}
+
+__global__ void k_batch_fix(int B, int32_t* ptr) {
+    // empty batches (ptr == -1) take the start of the next non-empty one
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (ptr[B] < 0) ptr[B] = 0;
+        for (int b = B - 1; b >= 0; --b)
+            if (ptr[b] < 0) ptr[b] = ptr[b + 1];
+    }
+}
+
+__global__ void k_fill_i32(int32_t* p, int n, int v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// =============================================================== C ABI
+extern "C" {
+
+int agb_hash_capacity(int n) {
+    long long c = 1024;
+    while (c < 2LL * n) c <<= 1;
+    return (int)c;
+}
+
+// scratch ints needed by agb_coords_stride for n rows
+int agb_scan_scratch_elems(int n) { return agb_cdiv(n, SCAN_BLOCK) + 8; }
+
+int agb_hash_clear(uint64_t* keys, int32_t* vals, int cap, void* stream) {
+    AGB_CHECK_ARG(cap > 0 && (cap & (cap - 1)) == 0, "agb_hash_clear: capacity %d is not a power of two", cap);
+    hipLaunchKernelGGL(k_hash_clear, dim3(agb_cdiv(cap, TPB)), dim3(TPB), 0, (hipStream_t)stream, keys, vals, cap);
+    AGB_CHECK_LAUNCH("agb_hash_clear");
+    return AGB_OK;
+}
+
+int agb_coords_insert(const int32_t* coords, int n, const int32_t* n_dev, uint64_t* keys, int32_t* vals, int cap,
+                      int32_t* slot_of_row, int32_t* status, void* stream) {
+    AGB_CHECK_ARG(n >= 0, "agb_coords_insert: n < 0");
+    AGB_CHECK_ARG(cap >= 2 * n && (cap & (cap - 1)) == 0, "agb_coords_insert: capacity %d too small for %d rows", cap,
+                  n);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_hash_clear, dim3(agb_cdiv(cap, TPB)), dim3(TPB), 0, s, keys, vals, cap);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s, status, 4, 0);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_coords_insert, dim3(agb_cdiv(n, TPB)), dim3(TPB), 0, s, (const int4*)coords, n, n_dev,
+                           keys, vals, (uint32_t)(cap - 1), slot_of_row, status);
+        hipLaunchKernelGGL(k_count_dups, dim3(agb_cdiv(n, TPB)), dim3(TPB), 0, s, n, n_dev, vals, slot_of_row,
+                           status);
+    }
+    AGB_CHECK_LAUNCH("agb_coords_insert");
+    return AGB_OK;
+}
+
+int agb_coords_stride(const int32_t* in_coords, int n, const int32_t* n_dev, int ts_out, uint64_t* keys,
+                      int32_t* vals, int cap, int32_t* slot_of_row, int32_t* flags, int32_t* excl, int32_t* scratch,
+                      int32_t* out_coords, int32_t* n_out_dev, int32_t* out_row_of_in, void* stream) {
+    AGB_CHECK_ARG(n >= 0 && ts_out > 0, "agb_coords_stride: bad n/ts");
+    AGB_CHECK_ARG(cap >= 2 * n && (cap & (cap - 1)) == 0, "agb_coords_stride: capacity %d too small for %d rows", cap,
+                  n);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_hash_clear, dim3(agb_cdiv(cap, TPB)), dim3(TPB), 0, s, keys, vals, cap);
+    if (n == 0) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s, n_out_dev, 1, 0);
+        AGB_CHECK_LAUNCH("agb_coords_stride");
+        return AGB_OK;
+    }
+    dim3 g(agb_cdiv(n, TPB)), b(TPB);
+    uint32_t mask = (uint32_t)(cap - 1);
+    hipLaunchKernelGGL(k_stride_insert, g, b, 0, s, (const int4*)in_coords, n, n_dev, ts_out, keys, vals, mask,
+                       slot_of_row);
+    hipLaunchKernelGGL(k_stride_flag, g, b, 0, s, n, n_dev, vals, slot_of_row, flags);
+    int nb = agb_cdiv(n, SCAN_BLOCK);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), b, 0, s, flags, n, scratch);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, scratch, nb, n_out_dev);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), b, 0, s, flags, n, scratch, excl);
+    hipLaunchKernelGGL(k_stride_emit, g, b, 0, s, (const int4*)in_coords, n, n_dev, ts_out, flags, excl, slot_of_row,
+                       vals, (int4*)out_coords);
+    if (out_row_of_in)
+        hipLaunchKernelGGL(k_stride_rowmap, g, b, 0, s, n, n_dev, vals, slot_of_row, out_row_of_in);
+    AGB_CHECK_LAUNCH("agb_coords_stride");
+    return AGB_OK;
+}
+
+// Forward map of a conv/pool with kernel size K from level `in` to level `out`:
+//   q_coords = out coords, table = in level, step = ts_in*dilation, sign=+1, require_multiple_of=0
+// Transposed map (for data gradients of strided ops):
+//   q_coords = in coords, table = out level, step = ts_in*dilation, sign=-1, require_multiple_of=ts_out
+int agb_kernel_map(const int32_t* q_coords, int n, const int32_t* n_dev, int K, int step, int sign,
+                   int require_multiple_of, const uint64_t* keys, const int32_t* vals, int cap, int32_t* nbr,
+                   long long nbr_stride, unsigned long long* pair_count, void* stream) {
+    AGB_CHECK_ARG(K >= 1 && K <= 9, "agb_kernel_map: kernel size %d unsupported", K);
+    AGB_CHECK_ARG(nbr_stride >= n, "agb_kernel_map: nbr_stride < n");
+    if (n == 0) return AGB_OK;
+    hipLaunchKernelGGL(k_kernel_map, dim3(agb_cdiv(n, TPB), K * K * K), dim3(TPB), 0, (hipStream_t)stream,
+                       (const int4*)q_coords, n, n_dev, K, step, sign, require_multiple_of, keys, vals,
+                       (uint32_t)(cap - 1), nbr, nbr_stride, pair_count);
+    AGB_CHECK_LAUNCH("agb_kernel_map");
+    return AGB_OK;
+}
+
+int agb_batch_ptr(const int32_t* coords, int n, const int32_t* n_dev, int B, int32_t* ptr, void* stream) {
+    AGB_CHECK_ARG(B >= 1, "agb_batch_ptr: B < 1");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_fill_i32, dim3(agb_cdiv(B + 1, TPB)), dim3(TPB), 0, s, ptr, B + 1, -1);
+    if (n > 0)
+        hipLaunchKernelGGL(k_batch_count, dim3(agb_cdiv(n, TPB)), dim3(TPB), 0, s, (const int4*)coords, n, n_dev, B,
+                           ptr);
+    hipLaunchKernelGGL(k_batch_fix, dim3(1), dim3(64), 0, s, B, ptr);
+    AGB_CHECK_LAUNCH("agb_batch_ptr");
+    return AGB_OK;
+}
+
+}  // extern "C"

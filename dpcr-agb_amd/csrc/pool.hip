@@ -1,0 +1,200 @@
+// pool.hip — HBM-bound pooling / broadcast kernels of the sparse-voxel path.
+//   * max pooling over a kernel map (ME.MinkowskiMaxPooling; reference call site
+//     torch_points3d/modules/MinkowskiEngine/SENet.py:53)
+//   * per-batch segment reductions = global sum / avg / max pooling (ME.MinkowskiGlobal*Pooling;
+//     SENet.py:63, senet_block.py:43, PointNet.py:29) and their gradients
+//   * broadcast multiply x.F * y.F[batch] (ME.MinkowskiBroadcastMultiplication; senet_block.py:44-50)
+// Rows of a batch element are contiguous (coords.hip keeps that invariant), so reductions are
+// deterministic segment sums — no float atomics.
+#include "agb_common.h"
+#include <float.h>
+
+// ------------------------------------------------------------------ max pool
+// one thread per (out row, 4 channels); lanes of a row read one contiguous feature row
+__global__ void k_maxpool_fwd(const float* __restrict__ X, int ldx, const int32_t* __restrict__ nbr,
+                              long long nbr_stride, float* __restrict__ Y, int ldy, int32_t* __restrict__ arg,
+                              int n_out, int K3, int C4) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4);
+    int c = (int)(t % C4) * 4;
+    if (r >= n_out) return;
+    float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    int4 bi = make_int4(-1, -1, -1, -1);
+    for (int k = 0; k < K3; ++k) {
+        int idx = nbr[(long long)k * nbr_stride + r];
+        if (idx < 0) continue;
+        float4 v = *reinterpret_cast<const float4*>(X + (long long)idx * ldx + c);
+        if (v.x > best.x) { best.x = v.x; bi.x = idx; }
+        if (v.y > best.y) { best.y = v.y; bi.y = idx; }
+        if (v.z > best.z) { best.z = v.z; bi.z = idx; }
+        if (v.w > best.w) { best.w = v.w; bi.w = idx; }
+    }
+    if (bi.x < 0) best.x = 0.f;
+    if (bi.y < 0) best.y = 0.f;
+    if (bi.z < 0) best.z = 0.f;
+    if (bi.w < 0) best.w = 0.f;
+    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = best;
+    *reinterpret_cast<int4*>(arg + (long long)r * (C4 * 4) + c) = bi;
+}
+
+// input-stationary gradient: each input row collects from the (at most K3) outputs that could have chosen it
+__global__ void k_maxpool_bwd(const float* __restrict__ dY, int ldy, const int32_t* __restrict__ arg,
+                              const int32_t* __restrict__ nbrT, long long nbrT_stride, float* __restrict__ dX,
+                              int ldx, int n_in, int K3, int C4) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int q = (int)(t / C4);
+    int c = (int)(t % C4) * 4;
+    if (q >= n_in) return;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K3; ++k) {
+        int o = nbrT[(long long)k * nbrT_stride + q];
+        if (o < 0) continue;
+        int4 a = *reinterpret_cast<const int4*>(arg + (long long)o * (C4 * 4) + c);
+        float4 d = *reinterpret_cast<const float4*>(dY + (long long)o * ldy + c);
+        if (a.x == q) g.x += d.x;
+        if (a.y == q) g.y += d.y;
+        if (a.z == q) g.z += d.z;
+        if (a.w == q) g.w += d.w;
+    }
+    *reinterpret_cast<float4*>(dX + (long long)q * ldx + c) = g;
+}
+
+// ------------------------------------------------------------ segment reduce
+// grid (B, ceil(C/64)), block 256 = 4 row lanes x 64 channels.
+// mode 0 sum, 1 average, 2 max (arg receives the winning row); optional second operand: reduce A*Bm.
+__global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict__ A, int lda,
+                                                        const float* __restrict__ Bm, int ldb,
+                                                        const int32_t* __restrict__ ptr, int C, int mode,
+                                                        float* __restrict__ Y, int32_t* __restrict__ arg) {
+    __shared__ float s_val[4][64];
+    __shared__ int s_arg[4][64];
+    const int b = blockIdx.x;
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int beg = ptr[b], end = ptr[b + 1];
+    float acc = (mode == 2) ? -FLT_MAX : 0.f;
+    int ai = -1;
+    if (c < C) {
+        for (int r = beg + rl; r < end; r += 4) {
+            float v = A[(long long)r * lda + c];
+            if (Bm) v *= Bm[(long long)r * ldb + c];
+            if (mode == 2) {
+                if (v > acc) { acc = v; ai = r; }
+            } else {
+                acc += v;
+            }
+        }
+    }
+    s_val[rl][threadIdx.x & 63] = acc;
+    s_arg[rl][threadIdx.x & 63] = ai;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        int l = threadIdx.x & 63;
+        if (mode == 2) {
+            // rows visited by lane j are j, j+4, ...; keep the smallest row on ties
+            for (int j = 1; j < 4; ++j) {
+                float v = s_val[j][l];
+                int a = s_arg[j][l];
+                if (a >= 0 && (v > acc || (v == acc && a < ai))) { acc = v; ai = a; }
+            }
+            if (ai < 0) acc = 0.f;
+            arg[(long long)b * C + c] = ai;
+        } else {
+            acc = ((s_val[0][l] + s_val[1][l]) + (s_val[2][l] + s_val[3][l]));
+            if (mode == 1) {
+                int n = end - beg;
+                acc = n > 0 ? acc / (float)n : 0.f;
+            }
+        }
+        Y[(long long)b * C + c] = acc;
+    }
+}
+
+// gradient of sum/avg pooling, and the forward of a broadcast: out[r,c] = S[batch(r),c] * scale(b) [* M[r,c]]
+__global__ void k_segment_broadcast(const float* __restrict__ S, const int32_t* __restrict__ coords,
+                                    const int32_t* __restrict__ ptr, const float* __restrict__ M, int ldm,
+                                    float* __restrict__ out, int ldo, int n, int C4, int average) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4);
+    int c = (int)(t % C4) * 4;
+    if (r >= n) return;
+    int b = coords[4 * (long long)r];
+    float4 s = *reinterpret_cast<const float4*>(S + (long long)b * (C4 * 4) + c);
+    if (average) {
+        float inv = 1.f / (float)(ptr[b + 1] - ptr[b]);
+        s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+    }
+    if (M) {
+        float4 m = *reinterpret_cast<const float4*>(M + (long long)r * ldm + c);
+        s.x *= m.x; s.y *= m.y; s.z *= m.z; s.w *= m.w;
+    }
+    *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = s;
+}
+
+// gradient of global max pooling: dX = 0 except dX[arg[b,c], c] = dY[b,c]
+__global__ void k_segment_max_bwd(const float* __restrict__ dY, const int32_t* __restrict__ arg, float* dX, int ldx,
+                                  int B, int C) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    int a = arg[t];
+    if (a >= 0) dX[(long long)a * ldx + (t % C)] = dY[t];
+}
+
+// =============================================================== C ABI
+extern "C" {
+
+int agb_maxpool_fwd(const float* X, int ldx, const int32_t* nbr, long long nbr_stride, float* Y, int ldy,
+                    int32_t* argmax, int n_out, int K3, int C, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_maxpool_fwd: C/ld must be multiples of 4");
+    if (n_out == 0) return AGB_OK;
+    long long total = (long long)n_out * (C / 4);
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, nbr,
+                       nbr_stride, Y, ldy, argmax, n_out, K3, C / 4);
+    AGB_CHECK_LAUNCH("agb_maxpool_fwd");
+    return AGB_OK;
+}
+
+int agb_maxpool_bwd(const float* dY, int ldy, const int32_t* argmax, const int32_t* nbrT, long long nbrT_stride,
+                    float* dX, int ldx, int n_in, int K3, int C, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_maxpool_bwd: C/ld must be multiples of 4");
+    if (n_in == 0) return AGB_OK;
+    long long total = (long long)n_in * (C / 4);
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dY, ldy, argmax,
+                       nbrT, nbrT_stride, dX, ldx, n_in, K3, C / 4);
+    AGB_CHECK_LAUNCH("agb_maxpool_bwd");
+    return AGB_OK;
+}
+
+int agb_segment_reduce(const float* A, int lda, const float* Bm, int ldb, const int32_t* ptr, int B, int C, int mode,
+                       float* Y, int32_t* argmax, void* stream) {
+    AGB_CHECK_ARG(mode >= 0 && mode <= 2, "agb_segment_reduce: mode %d", mode);
+    AGB_CHECK_ARG(mode != 2 || argmax != nullptr, "agb_segment_reduce: max mode needs an argmax buffer");
+    if (B == 0 || C == 0) return AGB_OK;
+    hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, A, lda, Bm, ldb,
+                       ptr, C, mode, Y, argmax);
+    AGB_CHECK_LAUNCH("agb_segment_reduce");
+    return AGB_OK;
+}
+
+int agb_segment_broadcast(const float* S, const int32_t* coords, const int32_t* ptr, const float* M, int ldm,
+                          float* out, int ldo, int n, int C, int average, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldo % 4 == 0 && (M == nullptr || ldm % 4 == 0),
+                  "agb_segment_broadcast: C/ld must be multiples of 4");
+    if (n == 0) return AGB_OK;
+    long long total = (long long)n * (C / 4);
+    hipLaunchKernelGGL(k_segment_broadcast, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, S, coords,
+                       ptr, M, ldm, out, ldo, n, C / 4, average);
+    AGB_CHECK_LAUNCH("agb_segment_broadcast");
+    return AGB_OK;
+}
+
+// dX must be zero-filled by the caller.
+int agb_segment_max_bwd(const float* dY, const int32_t* argmax, float* dX, int ldx, int B, int C, void* stream) {
+    if (B * C == 0) return AGB_OK;
+    hipLaunchKernelGGL(k_segment_max_bwd, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dY, argmax, dX, ldx, B, C);
+    AGB_CHECK_LAUNCH("agb_segment_max_bwd");
+    return AGB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+"""Model <-> trainer contract of the reference, restated for the hot path:
+``set_input(data, device)``, ``forward(epoch=)``, ``optimize_parameters(epoch, batch_size, num_batches)``,
+``get_reg_output()``, ``get_reg_input()``, ``get_current_losses()``, ``loss_names``.
+
+Follows torch_points3d/models/base_model.py:230-256 (train step: forward, backward, clip_grad_value_,
+optimizer step, LR scheduler stepped per batch with a fractional epoch :219-226) and
+torch_points3d/models/instance/base.py:54-208 (target standardisation buffers :86-114, output slice :139-146,
+smooth-L1 on standardised targets weighted by mean(task weights) :154-179, de-standardised report :181-185).
+Mixed precision: the reference's published sparse models run fp32; GradScaler is a no-op here.
+"""
+from collections import OrderedDict
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..optim import AdaBelief
+
+REG_LOSSES = {"smoothl1": F.smooth_l1_loss, "l2": F.mse_loss, "l1": F.l1_loss}
+OUT_ACT = {"linear": lambda x: x, "elu": F.elu, "relu": F.relu}
+
+
+class InstanceBase(torch.nn.Module):
+    def __init__(self, option, model_type, dataset, modules=None):
+        super().__init__()
+        self.opt = option
+        self.loss_names: List[str] = []
+        self.visual_names = ["data_visual"]
+        self.output = None
+        self.model = None
+        self._conv_type = option.get("conv_type", None)
+        self._optimizer = None
+        self._lr_scheduler = None
+        self._num_epochs = 0
+        self._num_batches = 0
+        self._num_samples = -1
+        self._grad_clip = -1
+        self._update_lr_scheduler_on = "on_epoch"
+        self.grad_sync = None  # data-parallel hook: called between backward and clip/step
+
+        self.loss_fns = {}
+        self.has_reg_targets = dataset.has_reg_targets
+        self.reg_targets_idx = dataset.reg_targets_idx
+        if self.has_reg_targets:
+            self.loss_names.append("loss_reg")
+            self._register_target_stats(dataset)
+            self.reg_out_act = OUT_ACT[option.get("reg_out_activation", "linear").lower()]
+            self.reg_report_out_act = OUT_ACT[option.get("reg_out_report_activation", "linear").lower()]
+            names = option.get("reg_loss_fn", "smoothl1")
+            self.loss_fns["reg"] = [REG_LOSSES[n] for n in names.split(",")] if names else []
+        self.num_reg_classes = dataset.num_reg_classes
+        self.double_batch = option.get("double_batch", dataset.double_batch)
+
+    # ----------------------------------------------------------- target statistics (base.py:86-134)
+    def _register_target_stats(self, dataset):
+        n = int(sum(self.reg_targets_idx))
+        center, scale, weights = np.zeros(n), np.ones(n), []
+        i = 0
+        for name in dataset.targets:
+            t = dataset.targets[name]
+            if t["task"] != "regression":
+                continue
+            weights.append(t.get("weight", 1))
+            norm = t.get("normalization", "standard")
+            if norm == "standard":
+                center[i] = self._avg_stat(dataset, "mean", i)
+                scale[i] = self._avg_stat(dataset, "std", i)
+            elif norm == "min-max":
+                center[i] = self._avg_stat(dataset, "min", i)
+                scale[i] = self._avg_stat(dataset, "max", i) - center[i]
+            center[i] = t.get("center_override", center[i])
+            scale[i] = t.get("scale_override", scale[i])
+            scale[i] *= t.get("scale_mult", 1.0)
+            i += 1
+        self.register_buffer("reg_scale_targets", torch.tensor(scale.reshape(1, -1), dtype=torch.float))
+        self.register_buffer("reg_center_targets", torch.tensor(center.reshape(1, -1), dtype=torch.float))
+        self.register_buffer("reg_weights", torch.tensor(weights, dtype=torch.float))
+
+    @staticmethod
+    def _avg_stat(dataset, stat, i):
+        vals = np.array([np.asarray(area["train"])[i] for area in getattr(dataset, f"get_{stat}_targets")().values()
+                         if "train" in area], dtype=np.float64)
+        return float(np.nanmean(vals))
+
+    # ----------------------------------------------------------- contract
+    @property
+    def conv_type(self):
+        return self._conv_type
+
+    def set_input(self, data, device):
+        raise NotImplementedError
+
+    def convert_outputs(self, outputs):
+        if outputs is None or not self.has_reg_targets:
+            return None
+        return self.reg_out_act(outputs[:, :self.num_reg_classes])
+
+    def compute_reg_loss(self):
+        if not (self.has_reg_targets and self.loss_fns.get("reg")):
+            return
+        output = self.reg_out
+        labels = (self.reg_y - self.reg_center_targets) / self.reg_scale_targets
+        if self._reg_mask_all is False:
+            if not bool(self.reg_y_mask.any()):
+                return
+            output, labels = output[self.reg_y_mask], labels[self.reg_y_mask]
+        self.loss_reg = 0
+        for fn in self.loss_fns["reg"]:
+            self.loss_reg = self.loss_reg + fn(output, labels)
+        self.loss = self.loss + self.reg_weights.mean() * self.loss_reg
+
+    def compute_loss(self):
+        self.loss = 0
+        self.compute_reg_loss()
+
+    def get_reg_output(self):
+        return self.reg_report_out_act(self.reg_out * self.reg_scale_targets + self.reg_center_targets)
+
+    def get_reg_input(self):
+        return self.reg_y
+
+    def get_current_losses(self):
+        out = OrderedDict()
+        for name in self.loss_names:
+            if hasattr(self, name):
+                try:
+                    out[name] = float(getattr(self, name))
+                except Exception:
+                    out[name] = None
+        return out
+
+    def get_parameter_list(self) -> List[dict]:
+        return [{"params": list(self.parameters())}]
+
+    # ----------------------------------------------------------- training objects (base_model.py:279-341)
+    def init_train_objects(self, training):
+        """training: Opt like config.TRAINING_NFI (optimizer class/params, lr_scheduler, grad_clip)."""
+        opt = training.optim.optimizer
+        name = opt.get("name", opt.get("class", "AdaBelief"))
+        params = dict(opt.get("params", {}))
+        cls = AdaBelief if name == "AdaBelief" else getattr(torch.optim, name)
+        self._optimizer = cls(self.get_parameter_list(), **params)
+        sch = training.get("lr_scheduler", None)
+        if sch:
+            self._update_lr_scheduler_on = sch.get("update_scheduler_on", "on_epoch")
+            self._lr_scheduler = getattr(torch.optim.lr_scheduler, sch.name)(self._optimizer, **dict(sch.params))
+        self._grad_clip = training.get("grad_clip", -1)
+
+    @property
+    def optimizer(self):
+        return self._optimizer
+
+    def _step_scheduler(self, epoch, batch_size, num_batches):
+        if self._lr_scheduler is None:
+            return
+        mode = self._update_lr_scheduler_on
+        if mode == "on_epoch":
+            for _ in range(epoch - self._num_epochs):
+                self._lr_scheduler.step(epoch)
+        elif mode == "on_num_batch":
+            self._lr_scheduler.step(self._num_batches / num_batches)
+        elif mode == "on_num_sample":
+            for _ in range(batch_size):
+                self._lr_scheduler.step(epoch)
+
+    def optimize_parameters(self, epoch, batch_size, num_batches):
+        self(epoch=epoch)
+        self._optimizer.zero_grad(set_to_none=False)
+        self.loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        if self._grad_clip > 0:
+            torch.nn.utils.clip_grad_value_(self.parameters(), self._grad_clip)
+        self._optimizer.step()
+        self._step_scheduler(epoch, batch_size, num_batches)
+        self._num_epochs = epoch
+        self._num_batches += 1
+        self._num_samples += batch_size

@@ -1,0 +1,69 @@
+"""``MinkowskiBaselineModel`` — the reference's wrapper for MSENet14/50 and MPointNet
+(torch_points3d/models/instance/minkowski.py:15-89): builds the backbone through
+``initialize_minkowski_unet`` (:32-38), replaces ``model.final`` by one ``Linear(C, 1)`` per regression target
+(:39-46), ``set_input`` builds ``SparseTensor(features, [batch,x,y,z] int32)`` (:67-80), head/backbone
+parameter groups (:54-65).
+"""
+from typing import List
+
+import torch
+
+from .. import me_compat as ME
+from ..backbones import initialize_minkowski_unet
+from .base import InstanceBase
+
+
+class SeparateLinear(torch.nn.Module):
+    def __init__(self, in_channel, num_reg_classes):
+        super().__init__()
+        self.linears = torch.nn.ModuleList([torch.nn.Linear(in_channel, 1, bias=True)
+                                            for _ in range(max(num_reg_classes, 0))])
+
+    def forward(self, x):
+        return torch.cat([lin(x.F) for lin in self.linears], 1)
+
+
+class MinkowskiBaselineModel(InstanceBase):
+    def __init__(self, option, model_type, dataset, modules=None):
+        super().__init__(option, model_type, dataset, modules)
+        self.model = initialize_minkowski_unet(
+            option.model_name, dataset.feature_dimension, dataset.num_classes, activation=option.activation,
+            first_stride=option.first_stride, global_pool=option.global_pool, bias=option.get("bias", True),
+            bn_momentum=option.get("bn_momentum", 0.1), norm_type=option.get("norm_type", "bn"),
+            dropout=option.get("dropout", 0.0), drop_path=option.get("drop_path", 0.0),
+            **option.get("extra_options", {}))
+        in_channel = self.model.final.linear.weight.shape[1]
+        self.model.final = SeparateLinear(in_channel, self.num_reg_classes)
+        for m in self.model.final.linears:
+            torch.nn.init.trunc_normal_(m.weight, std=0.02)
+            torch.nn.init.constant_(m.bias, 0)
+        self.head_namespace = option.get("head_namespace", "final.linears")
+        self.head_optim_settings = option.get("head_optim_settings", {})
+        self.backbone_optim_settings = option.get("backbone_optim_settings", {})
+        self.add_pos = option.get("add_pos", False)
+
+    def get_parameter_list(self) -> List[dict]:
+        head, backbone = [], []
+        for name, p in self.model.named_parameters():
+            (head if self.head_namespace in name else backbone).append(p)
+        return [{"params": head, **self.head_optim_settings}, {"params": backbone, **self.backbone_optim_settings}]
+
+    def set_input(self, data, device):
+        self.batch_idx = data.batch.squeeze()
+        coords = torch.cat([data.batch.unsqueeze(-1).int(), data.coords.int()], -1)
+        self.data_visual = data
+        features = data.x
+        if self.add_pos:
+            features = torch.cat([data.pos, features], 1)
+        self.input = ME.SparseTensor(features=features, coordinates=coords, device=device, batch_size=len(data))
+        if len(self.loss_fns) > 0:
+            bs = len(data)
+            if self.has_reg_targets and data.y_reg is not None:
+                self._reg_mask_all = bool(data.y_reg_mask.all())  # host-side: no device sync in the loss
+                self.reg_y_mask = data.y_reg_mask.to(device, non_blocking=True).view(bs, -1)
+                self.reg_y = data.y_reg.to(device, non_blocking=True).view(bs, -1)
+
+    def forward(self, *args, **kwargs):
+        self.output = self.model(self.input)
+        self.reg_out = self.convert_outputs(self.output)
+        self.compute_loss()

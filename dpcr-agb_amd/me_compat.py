@@ -1,0 +1,343 @@
+"""The subset of the MinkowskiEngine Python API that the reference's sparse-voxel backbones use
+(torch_points3d/modules/MinkowskiEngine/{SENet,PointNet,resnet_block,senet_block,common}.py and
+torch_points3d/models/instance/minkowski.py:67-80), implemented on libagbhip's HIP kernels.
+
+Usage mirrors the reference:  ``import dpcr_agb_amd.me_compat as ME``  then ``ME.SparseTensor(features=...,
+coordinates=int32[N,1+3], device=...)``, ``ME.MinkowskiConvolution(...)`` etc.  Semantics follow ME 0.5.x's
+documented behaviour (the engine itself is not vendored by the reference: parity is pinned by this repo's own
+known-answer tests, see DESIGN.md "parity unpinned"):
+  * output coordinates of a stride-s op: unique(floor(c / (s*ts)) * s*ts)
+  * kernel offsets: odd k -> {-(k//2) .. k//2} * ts * dilation, even k -> {0 .. k-1}; x fastest
+  * kernel [K^3, Cin, Cout] ([Cin, Cout] when K^3 == 1 and stride == 1), bias [1, Cout]
+  * max pooling over present inputs only; global pooling per batch index; MinkowskiGlobalPooling = average
+"""
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .coords import CoordinateManager, CoordinateMapKey, _as_int
+from .sparse_ops import (BroadcastMulFunction, GlobalPoolFunction, MaxPoolFunction, SparseConvFunction)
+
+
+class SparseTensor:
+    def __init__(self, features: torch.Tensor, coordinates: Optional[torch.Tensor] = None,
+                 coordinate_map_key: Optional[CoordinateMapKey] = None,
+                 coordinate_manager: Optional[CoordinateManager] = None, tensor_stride: int = 1, device=None,
+                 batch_size: Optional[int] = None, **kwargs):
+        if coordinates is not None:
+            if device is None:
+                device = features.device
+            ts = _as_int(tensor_stride)
+            coordinate_manager = CoordinateManager(coordinates, device=device, tensor_stride=ts,
+                                                   batch_size=batch_size)
+            coordinate_map_key = CoordinateMapKey(ts)
+            features = features.to(device=coordinate_manager.device, dtype=torch.float32, non_blocking=True)
+        if coordinate_manager is None or coordinate_map_key is None:
+            raise ValueError("SparseTensor needs either coordinates or (coordinate_map_key, coordinate_manager)")
+        n = coordinate_manager.num_rows(coordinate_map_key)
+        if features.shape[0] != n:
+            raise ValueError(f"features have {features.shape[0]} rows but the coordinate map has {n}")
+        self._F = features
+        self.coordinate_map_key = coordinate_map_key
+        self.coordinate_manager = coordinate_manager
+
+    # --- ME attribute surface used by the reference
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def features(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self.coordinate_manager.coords_of(self.coordinate_map_key)
+
+    @property
+    def coordinates(self):
+        return self.C
+
+    @property
+    def tensor_stride(self):
+        return [self.coordinate_map_key.tensor_stride] * 3
+
+    @property
+    def device(self):
+        return self._F.device
+
+    @property
+    def dtype(self):
+        return self._F.dtype
+
+    @property
+    def shape(self):
+        return self._F.shape
+
+    @property
+    def D(self):
+        return 3
+
+    def size(self):
+        return self._F.size()
+
+    def __len__(self):
+        return self._F.shape[0]
+
+    @property
+    def _ts(self):
+        return self.coordinate_map_key.tensor_stride
+
+    def _ptr_list(self) -> List[int]:
+        cm = self.coordinate_manager
+        if self._ts == 0:
+            return list(range(cm.batch_size + 1))
+        return cm.batch_ptr(self._ts).tolist()
+
+    @property
+    def decomposed_coordinates(self):
+        p, c = self._ptr_list(), self.C
+        return [c[p[b]:p[b + 1], 1:] for b in range(len(p) - 1)]
+
+    @property
+    def decomposed_features(self):
+        p = self._ptr_list()
+        return [self._F[p[b]:p[b + 1]] for b in range(len(p) - 1)]
+
+    def _like(self, feats):
+        return SparseTensor(feats, coordinate_map_key=self.coordinate_map_key,
+                            coordinate_manager=self.coordinate_manager)
+
+    def _check_same_map(self, other):
+        if not isinstance(other, SparseTensor):
+            return
+        if other.coordinate_manager is not self.coordinate_manager or \
+                other.coordinate_map_key != self.coordinate_map_key:
+            raise ValueError("binary operations need both SparseTensors on the same coordinate map")
+
+    def __add__(self, other):
+        self._check_same_map(other)
+        return self._like(self._F + (other._F if isinstance(other, SparseTensor) else other))
+
+    def __sub__(self, other):
+        self._check_same_map(other)
+        return self._like(self._F - (other._F if isinstance(other, SparseTensor) else other))
+
+    def __mul__(self, other):
+        self._check_same_map(other)
+        return self._like(self._F * (other._F if isinstance(other, SparseTensor) else other))
+
+    def __repr__(self):
+        return f"SparseTensor(F={tuple(self._F.shape)}, tensor_stride={self._ts}, device={self.device})"
+
+
+# --------------------------------------------------------------------------- convolution / pooling
+class MinkowskiConvolution(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, expand_coordinates=False, dimension=None, **kwargs):
+        super().__init__()
+        if dimension is not None and dimension != 3:
+            raise NotImplementedError("only D=3 sparse convolutions are implemented")
+        if expand_coordinates:
+            raise NotImplementedError("expand_coordinates is not supported")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.dilation = _as_int(kernel_size), _as_int(stride), _as_int(dilation)
+        if self.kernel_size < 1:
+            raise ValueError("kernel_size must be >= 1")
+        self.kernel_volume = self.kernel_size ** 3
+        self.use_mm = self.kernel_volume == 1 and self.stride == 1
+        shape = (in_channels, out_channels) if self.use_mm else (self.kernel_volume, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(*shape, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.empty(1, out_channels, dtype=torch.float32)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.in_channels * self.kernel_volume)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def forward(self, input: SparseTensor, coordinates=None) -> SparseTensor:
+        if coordinates is not None:
+            raise NotImplementedError("explicit output coordinates are not supported")
+        cm, ts = input.coordinate_manager, input._ts
+        if self.use_mm:
+            out = input.F @ self.kernel
+            if self.bias is not None:
+                out = out + self.bias
+            return input._like(out)
+        nbr = cm.kernel_map(ts, self.kernel_size, self.stride, self.dilation)
+        ts_out = ts * self.stride
+        nbrT = None
+        needs_dx = input.F.requires_grad and torch.is_grad_enabled()
+        if needs_dx and not (self.stride == 1 and self.kernel_size % 2 == 1):
+            nbrT = cm.transposed_map(ts, self.kernel_size, self.stride, self.dilation)
+        n_in, n_out = cm.level(ts).n, cm.level(ts_out).n
+        out = SparseConvFunction.apply(input.F, self.kernel, self.bias, nbr, nbrT, n_in, n_out)
+        return SparseTensor(out, coordinate_map_key=CoordinateMapKey(ts_out), coordinate_manager=cm)
+
+    def extra_repr(self):
+        return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
+                f"stride={self.stride}, dilation={self.dilation}")
+
+
+class MinkowskiMaxPooling(nn.Module):
+    def __init__(self, kernel_size, stride=1, dilation=1, kernel_generator=None, dimension=None, **kwargs):
+        super().__init__()
+        self.kernel_size, self.stride, self.dilation = _as_int(kernel_size), _as_int(stride), _as_int(dilation)
+
+    def forward(self, input: SparseTensor, coordinates=None) -> SparseTensor:
+        cm, ts = input.coordinate_manager, input._ts
+        nbr = cm.kernel_map(ts, self.kernel_size, self.stride, self.dilation)
+        ts_out = ts * self.stride
+        if input.F.requires_grad and torch.is_grad_enabled():
+            nbrT = cm.transposed_map(ts, self.kernel_size, self.stride, self.dilation)
+        else:
+            nbrT = nbr  # placeholder, never used without a backward pass
+        n_in, n_out = cm.level(ts).n, cm.level(ts_out).n
+        out = MaxPoolFunction.apply(input.F, nbr, nbrT, n_in, n_out)
+        return SparseTensor(out, coordinate_map_key=CoordinateMapKey(ts_out), coordinate_manager=cm)
+
+
+class _GlobalPoolBase(nn.Module):
+    MODE = "sum"
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        cm, ts = input.coordinate_manager, input._ts
+        if ts == 0:
+            return input
+        lvl = cm.level(ts)
+        out = GlobalPoolFunction.apply(input.F, lvl.coords, cm.batch_ptr(ts), cm.batch_size, self.MODE)
+        return SparseTensor(out, coordinate_map_key=CoordinateMapKey(0), coordinate_manager=cm)
+
+
+class MinkowskiGlobalSumPooling(_GlobalPoolBase):
+    MODE = "sum"
+
+
+class MinkowskiGlobalAvgPooling(_GlobalPoolBase):
+    MODE = "avg"
+
+
+class MinkowskiGlobalMaxPooling(_GlobalPoolBase):
+    MODE = "max"
+
+
+class MinkowskiGlobalPooling(MinkowskiGlobalAvgPooling):
+    """ME 0.5.x keeps this name as the average pooling."""
+
+
+class MinkowskiBroadcastMultiplication(nn.Module):
+    def forward(self, input: SparseTensor, input_glob: SparseTensor) -> SparseTensor:
+        cm, ts = input.coordinate_manager, input._ts
+        if input_glob._ts != 0:
+            raise ValueError("the second operand must be a globally pooled tensor (one row per batch)")
+        lvl = cm.level(ts)
+        out = BroadcastMulFunction.apply(input.F, input_glob.F, lvl.coords, cm.batch_ptr(ts))
+        return input._like(out)
+
+
+class MinkowskiBroadcastAddition(nn.Module):
+    def forward(self, input: SparseTensor, input_glob: SparseTensor) -> SparseTensor:
+        cm, ts = input.coordinate_manager, input._ts
+        lvl = cm.level(ts)
+        ones = torch.ones_like(input.F)
+        return input._like(input.F + BroadcastMulFunction.apply(ones, input_glob.F, lvl.coords, cm.batch_ptr(ts)))
+
+
+# --------------------------------------------------------------------------- per-row (dense) layers
+class MinkowskiLinear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        return input._like(self.linear(input.F))
+
+
+class MinkowskiBatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        return input._like(self.bn(input.F))
+
+
+class MinkowskiInstanceNorm(nn.Module):
+    """Per-batch-element, per-channel normalisation (ME.MinkowskiInstanceNorm), eps = 1e-6."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = 1e-6
+        self.weight = nn.Parameter(torch.ones(1, num_features))
+        self.bias = nn.Parameter(torch.zeros(1, num_features))
+        self._avg = MinkowskiGlobalAvgPooling()
+        self._bmul = MinkowskiBroadcastMultiplication()
+
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        ones = input._like(torch.ones_like(input.F))
+        mean = self._bmul(ones, self._avg(input))
+        centred = input - mean
+        var = self._avg(centred * centred)
+        inv = SparseTensor(torch.rsqrt(var.F + self.eps), coordinate_map_key=var.coordinate_map_key,
+                           coordinate_manager=var.coordinate_manager)
+        out = self._bmul(centred, inv)
+        return input._like(out.F * self.weight + self.bias)
+
+
+class MinkowskiDropout(nn.Module):
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        self.dropout = nn.Dropout(p, inplace=False)
+
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        return input._like(self.dropout(input.F))
+
+
+def _pointwise(name, torch_cls):
+    class _Act(nn.Module):
+        def __init__(self, *args, **kwargs):
+            super().__init__()
+            kwargs.pop("inplace", None)  # features may alias saved activations of the HIP ops
+            self.module = torch_cls(*args, **kwargs)
+
+        def forward(self, input: SparseTensor) -> SparseTensor:
+            return input._like(self.module(input.F))
+
+    _Act.__name__ = _Act.__qualname__ = name
+    return _Act
+
+
+MinkowskiReLU = _pointwise("MinkowskiReLU", nn.ReLU)
+MinkowskiGELU = _pointwise("MinkowskiGELU", nn.GELU)
+MinkowskiCELU = _pointwise("MinkowskiCELU", nn.CELU)
+MinkowskiSiLU = _pointwise("MinkowskiSiLU", nn.SiLU)
+MinkowskiELU = _pointwise("MinkowskiELU", nn.ELU)
+MinkowskiSigmoid = _pointwise("MinkowskiSigmoid", nn.Sigmoid)
+MinkowskiTanh = _pointwise("MinkowskiTanh", nn.Tanh)
+MinkowskiLeakyReLU = _pointwise("MinkowskiLeakyReLU", nn.LeakyReLU)
+
+
+class _Namespace:
+    pass
+
+
+# ``from MinkowskiEngine import MinkowskiNormalization as N`` / ``MinkowskiNonlinearity as NL`` look-alikes
+MinkowskiNormalization = _Namespace()
+MinkowskiNormalization.MinkowskiBatchNorm = MinkowskiBatchNorm
+MinkowskiNormalization.MinkowskiInstanceNorm = MinkowskiInstanceNorm
+MinkowskiNonlinearity = _Namespace()
+for _n in ("ReLU", "GELU", "CELU", "SiLU", "ELU", "Sigmoid", "Tanh", "LeakyReLU"):
+    setattr(MinkowskiNonlinearity, "Minkowski" + _n, globals()["Minkowski" + _n])
+
+__all__ = [n for n in dir() if n.startswith("Minkowski")] + ["SparseTensor", "CoordinateManager", "CoordinateMapKey"]

@@ -1,0 +1,210 @@
+"""autograd bindings of the sparse-voxel HIP kernels (csrc/spconv.hip, csrc/pool.hip).
+
+Each Function only marshals pointers/sizes into the C ABI on torch's current stream; all arithmetic of the
+sparse path happens in libagbhip.so.  Host tensors are refused (see _lib.ptr).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+_P = _lib.ptr
+
+# When set to a list, every sparse-conv launch appends
+#   dict(kind, K3, cin, cout, rows, pairs (device int64 tensor or None), start, end (torch.cuda.Event))
+# bench.py uses this to time the dominant kernel with HIP events on the launch stream.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _prof_end(ev0, kind, K3, cin, cout, rows, pairs):
+    if ev0 is None:
+        return
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record()
+    PROFILE.append(dict(kind=kind, K3=K3, cin=cin, cout=cout, rows=rows, pairs=pairs, start=ev0, end=ev1))
+
+
+def _pad_cols(x, mult):
+    c = x.shape[-1]
+    pad = (-c) % mult
+    if pad == 0:
+        return x.contiguous()
+    return F.pad(x, (0, pad)).contiguous()
+
+
+def _small_cin_pad(cin):
+    """Channel count the kernels want: 4 or 8 for the stem-like small-Cin path, else a multiple of 4."""
+    if cin <= 4:
+        return 4
+    if cin <= 8:
+        return 8
+    return (cin + 3) // 4 * 4
+
+
+def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None):
+    """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout]."""
+    y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+    ev = _prof_begin()
+    _lib.call("agb_spconv_fwd", _P(x), x.stride(0), _P(w2d), _P(nbr), nbr.stride(0), int(kflip), _P(bias), _P(y),
+              y.stride(0), n_out, K3, cin, cout, _lib.stream())
+    _prof_end(ev, kind, K3, cin, cout, n_out, pairs)
+    return y
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """Generalized sparse convolution. kernel: [K3, Cin, Cout]; nbr: forward map [K3, N_out];
+    nbrT: transposed map [K3, N_in] or None when the k-flipped forward map serves (stride 1, odd kernel)."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, bias, nbr, nbrT, n_in, n_out):
+        K3, cin, cout = kernel.shape
+        cin_p = _small_cin_pad(cin)
+        cout_p = (cout + 3) // 4 * 4
+        x = (feats if cin_p == cin else F.pad(feats, (0, cin_p - cin))).contiguous()
+        w = kernel
+        if cin_p != cin or cout_p != cout:
+            w = F.pad(kernel, (0, cout_p - cout, 0, cin_p - cin))
+        w2d = w.contiguous().view(K3 * cin_p, cout_p)
+        b = None
+        if bias is not None:
+            b = bias.reshape(-1)
+            if cout_p != cout:
+                b = F.pad(b, (0, cout_p - cout))
+            b = b.contiguous()
+        pairs = getattr(nbr, "agb_pairs", None)
+        y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs)
+        ctx.pairs = pairs
+        ctx.save_for_backward(x, w, nbr, nbrT if nbrT is not None else torch.empty(0))
+        ctx.dims = (K3, cin, cout, cin_p, cout_p, n_in, n_out, nbrT is not None, bias is not None,
+                    None if bias is None else bias.shape)
+        return y if cout_p == cout else y[:, :cout].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, nbr, nbrT = ctx.saved_tensors
+        K3, cin, cout, cin_p, cout_p, n_in, n_out, has_T, has_bias, bias_shape = ctx.dims
+        dy = dy.contiguous()
+        if cout_p != cout:
+            dy = F.pad(dy, (0, cout_p - cout)).contiguous()
+        dx = dk = db = None
+        if ctx.needs_input_grad[0]:
+            # dX[q] = sum_k dY[nbrT[k][q]] @ W[k]^T : same implicit GEMM with the transposed weights
+            wt2d = w.transpose(1, 2).contiguous().view(K3 * cout_p, cin_p)
+            if has_T:
+                dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs)
+            else:
+                dxp = spconv_forward_raw(dy, wt2d, nbr, 1, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs)
+            dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
+            ev = _prof_begin()
+            _lib.call("agb_spconv_bwd_weight", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
+                      _P(dwp), n_out, K3, cin_p, cout_p, _lib.stream())
+            _prof_end(ev, "wgrad", K3, cin_p, cout_p, n_out, ctx.pairs)
+            dk = dwp if (cin_p == cin and cout_p == cout) else dwp[:, :cin, :cout].contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy[:, :cout].sum(0).reshape(bias_shape)
+        return dx, dk, db, None, None, None, None
+
+
+class MaxPoolFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, nbr, nbrT, n_in, n_out):
+        c = feats.shape[1]
+        x = _pad_cols(feats, 4)
+        cp = x.shape[1]
+        K3 = nbr.shape[0]
+        y = torch.empty(n_out, cp, dtype=torch.float32, device=x.device)
+        arg = torch.empty(n_out, cp, dtype=torch.int32, device=x.device)
+        _lib.call("agb_maxpool_fwd", _P(x), x.stride(0), _P(nbr), nbr.stride(0), _P(y), y.stride(0), _P(arg), n_out,
+                  K3, cp, _lib.stream())
+        ctx.save_for_backward(arg, nbrT)
+        ctx.dims = (c, cp, n_in, K3)
+        return y if cp == c else y[:, :c].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        arg, nbrT = ctx.saved_tensors
+        c, cp, n_in, K3 = ctx.dims
+        dy = _pad_cols(dy, 4)
+        dx = torch.empty(n_in, cp, dtype=torch.float32, device=dy.device)
+        _lib.call("agb_maxpool_bwd", _P(dy), dy.stride(0), _P(arg), _P(nbrT), nbrT.stride(0), _P(dx), dx.stride(0),
+                  n_in, K3, cp, _lib.stream())
+        return (dx if cp == c else dx[:, :c].contiguous()), None, None, None, None
+
+
+_MODES = {"sum": 0, "avg": 1, "max": 2}
+
+
+class GlobalPoolFunction(torch.autograd.Function):
+    """Per-batch segment reduction of [N, C] rows -> [B, C]."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, ptr, B, mode):
+        x = feats.contiguous()
+        n, c = x.shape
+        m = _MODES[mode]
+        y = torch.empty(B, c, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, c, dtype=torch.int32, device=x.device) if m == 2 else None
+        _lib.call("agb_segment_reduce", _P(x), x.stride(0), None, 0, _P(ptr), B, c, m, _P(y), _P(arg), _lib.stream())
+        ctx.save_for_backward(coords, ptr, arg if arg is not None else torch.empty(0))
+        ctx.dims = (n, c, B, m)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        coords, ptr, arg = ctx.saved_tensors
+        n, c, B, m = ctx.dims
+        dy = dy.contiguous()
+        if m == 2:
+            dx = torch.zeros(n, c, dtype=torch.float32, device=dy.device)
+            _lib.call("agb_segment_max_bwd", _P(dy), _P(arg), _P(dx), dx.stride(0), B, c, _lib.stream())
+            return dx, None, None, None, None
+        if c % 4 != 0:
+            raise _lib.AgbError("global sum/avg pooling gradient needs a channel count that is a multiple of 4")
+        dx = torch.empty(n, c, dtype=torch.float32, device=dy.device)
+        _lib.call("agb_segment_broadcast", _P(dy), _P(coords), _P(ptr), None, 0, _P(dx), dx.stride(0), n, c,
+                  1 if m == 1 else 0, _lib.stream())
+        return dx, None, None, None, None
+
+
+class BroadcastMulFunction(torch.autograd.Function):
+    """out[r, :] = x[r, :] * s[batch(r), :]   (ME.MinkowskiBroadcastMultiplication)."""
+
+    @staticmethod
+    def forward(ctx, x, s, coords, ptr):
+        x = x.contiguous()
+        s = s.contiguous()
+        n, c = x.shape
+        if c % 4 != 0:
+            raise _lib.AgbError("broadcast multiplication needs a channel count that is a multiple of 4")
+        out = torch.empty_like(x)
+        _lib.call("agb_segment_broadcast", _P(s), _P(coords), _P(ptr), _P(x), x.stride(0), _P(out), out.stride(0), n,
+                  c, 0, _lib.stream())
+        ctx.save_for_backward(x, s, coords, ptr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, s, coords, ptr = ctx.saved_tensors
+        dout = dout.contiguous()
+        n, c = x.shape
+        B = s.shape[0]
+        dx = ds = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call("agb_segment_broadcast", _P(s), _P(coords), _P(ptr), _P(dout), dout.stride(0), _P(dx),
+                      dx.stride(0), n, c, 0, _lib.stream())
+        if ctx.needs_input_grad[1]:
+            ds = torch.empty(B, c, dtype=torch.float32, device=x.device)
+            _lib.call("agb_segment_reduce", _P(dout), dout.stride(0), _P(x), x.stride(0), _P(ptr), B, c, 0, _P(ds),
+                      None, _lib.stream())
+        return dx, ds, None, None

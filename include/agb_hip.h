@@ -1,0 +1,105 @@
+/* agb_hip.h — C ABI of libagbhip.so: the MI355X (gfx950) drop-in kernels for the point-cloud encoder hot path
+ * of StefOe/DPCR-AGB.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative code (AGB_E*); agb_last_error() gives the message
+ *     (thread-local);
+ *   - all pointers are DEVICE pointers unless a parameter is documented as host;
+ *   - the caller owns every buffer; nothing is allocated, freed or synchronised inside — kernels are enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - variable-size results are two-phase: the count lands in a device int that the caller reads back;
+ *   - feature matrices are row-major float32 with an explicit leading dimension (ld*, in floats).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/torch-points3d/torch_points3d/).  MinkowskiEngine itself is an un-vendored dependency of
+ * the reference: for those entry points the citation is the reference's CALL SITE of the ME operator.
+ */
+#ifndef AGB_HIP_H
+#define AGB_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGB_OK 0
+#define AGB_EINVAL (-1)
+#define AGB_ELAUNCH (-2)
+#define AGB_ERANGE (-3)
+#define AGB_EUNSUPPORTED (-4)
+
+const char* agb_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sparse-voxel coordinates (replaces ME's coordinate manager behind
+ *   models/instance/minkowski.py:74   ME.SparseTensor(features=, coordinates=int32[N,1+3], device=)
+ *   modules/MinkowskiEngine/SENet.py:47-53, resnet_block.py:48-55   strided convolution / pooling maps)
+ * coords: int32 [n,4] = (batch, x, y, z), rows ordered by batch.  Hash table: keys uint64[cap],
+ * vals int32[cap], cap = agb_hash_capacity(n) (power of two >= 2n).
+ * n_dev (optional, may be NULL): device int with the live row count when n is only an upper bound.
+ * --------------------------------------------------------------------------------------------------------- */
+int agb_hash_capacity(int n);          /* host helper */
+int agb_scan_scratch_elems(int n);     /* host helper: int32 scratch elements agb_coords_stride needs */
+int agb_hash_clear(uint64_t* keys, int32_t* vals, int cap, void* stream);
+
+/* Insert level-0 coordinates. slot_of_row int32[n] (scratch/out). status int32[4] (out):
+ * [0] duplicate rows, [1] rows outside the packed 16-bit range, [2] rows breaking batch order. */
+int agb_coords_insert(const int32_t* coords, int n, const int32_t* n_dev, uint64_t* keys, int32_t* vals, int cap,
+                      int32_t* slot_of_row, int32_t* status, void* stream);
+
+/* Strided level: out_coords = unique(floor(c / ts_out) * ts_out) in first-occurrence order (deterministic),
+ * hash of the new level in keys/vals, *n_out_dev = number of rows.  slot_of_row, flags, excl: int32[n] scratch;
+ * scratch: int32[agb_scan_scratch_elems(n)]; out_coords: int32[n,4] (upper bound); out_row_of_in: int32[n] or NULL. */
+int agb_coords_stride(const int32_t* in_coords, int n, const int32_t* n_dev, int ts_out, uint64_t* keys,
+                      int32_t* vals, int cap, int32_t* slot_of_row, int32_t* flags, int32_t* excl, int32_t* scratch,
+                      int32_t* out_coords, int32_t* n_out_dev, int32_t* out_row_of_in, void* stream);
+
+/* Kernel map as a dense neighbour table: nbr[k*nbr_stride + r] = row (in the hashed level) of
+ * q_coords[r] + sign*offset_k*step, or -1.  offset_k, k = ix + K*(iy + K*iz): odd K -> (ix-K/2,..), even K -> (ix,..).
+ * Forward map of a conv/pool in->out:  q = out coords, table = in level, sign=+1, require_multiple_of=0.
+ * Transposed map (data gradients):     q = in coords, table = out level, sign=-1, require_multiple_of=ts_out.
+ * pair_count (optional): device uint64 accumulating the number of non-empty entries (ME's kernel-map size). */
+int agb_kernel_map(const int32_t* q_coords, int n, const int32_t* n_dev, int K, int step, int sign,
+                   int require_multiple_of, const uint64_t* keys, const int32_t* vals, int cap, int32_t* nbr,
+                   long long nbr_stride, unsigned long long* pair_count, void* stream);
+
+/* Row range of every batch element: ptr int32[B+1]. */
+int agb_batch_ptr(const int32_t* coords, int n, const int32_t* n_dev, int B, int32_t* ptr, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sparse convolution (replaces ME.MinkowskiConvolution forward/backward at
+ *   modules/MinkowskiEngine/common.py:215-226, resnet_block.py:48-55,95-107, SENet.py:47-52,93-99)
+ * W: [K3*Cin, Cout] = ME's kernel [K3, Cin, Cout] flattened.  Cin, Cout, ldx multiples of 4
+ * (Cin == 4 or 8 selects the small-Cin/stem kernel; pad 3 -> 4 channels).
+ *   Y[r,:]  = bias + sum_k X[nbr[k][r],:] @ W[k]
+ * Data gradient = the same call with X=dY, W = W^T per offset ([K3*Cout, Cin]) and either the transposed map or,
+ * for stride 1 / odd K, the forward map with kflip=1 (reads nbr[K3-1-k]).
+ * --------------------------------------------------------------------------------------------------------- */
+int agb_spconv_fwd(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                   const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, void* stream);
+
+/* dW[k] += sum_r X[nbr[k][r],:]^T @ dY[r,:]; dW ([K3*Cin, Cout]) must be zero-filled by the caller. */
+int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
+                          long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Pooling / broadcast (replaces ME.MinkowskiMaxPooling SENet.py:53; ME.MinkowskiGlobal{Sum,Avg,Max}Pooling
+ * SENet.py:63, senet_block.py:43, PointNet.py:29; ME.MinkowskiBroadcastMultiplication senet_block.py:44-50)
+ * --------------------------------------------------------------------------------------------------------- */
+int agb_maxpool_fwd(const float* X, int ldx, const int32_t* nbr, long long nbr_stride, float* Y, int ldy,
+                    int32_t* argmax /* [n_out, C] */, int n_out, int K3, int C, void* stream);
+int agb_maxpool_bwd(const float* dY, int ldy, const int32_t* argmax, const int32_t* nbrT, long long nbrT_stride,
+                    float* dX, int ldx, int n_in, int K3, int C, void* stream);
+/* Y[b,:] = reduce over rows ptr[b]..ptr[b+1] of A (optionally A*Bm); mode 0 sum, 1 average, 2 max (+argmax rows) */
+int agb_segment_reduce(const float* A, int lda, const float* Bm, int ldb, const int32_t* ptr, int B, int C, int mode,
+                       float* Y, int32_t* argmax, void* stream);
+/* out[r,:] = S[batch(r),:] (/ rows of the batch if average) (* M[r,:] if M) */
+int agb_segment_broadcast(const float* S, const int32_t* coords, const int32_t* ptr, const float* M, int ldm,
+                          float* out, int ldo, int n, int C, int average, void* stream);
+/* dX[argmax[b,c], c] = dY[b,c]; dX zero-filled by the caller */
+int agb_segment_max_bwd(const float* dY, const int32_t* argmax, float* dX, int ldx, int B, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGB_HIP_H */

@@ -1,0 +1,59 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/agb_hip.h declares;
+the Python binding declares the same set (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "agb_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(agb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    syms = declared_symbols()
+    assert "agb_spconv_fwd" in syms and "agb_last_error" in syms and len(syms) >= 15
+
+
+def test_library_exports_every_declared_symbol():
+    from dpcr_agb_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail(f"{_lib.LIB_PATH} is not built: run __graft_entry__.build()")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in agb_hip.h but not exported: {missing}"
+
+
+def test_binding_covers_header():
+    from dpcr_agb_amd import _lib
+    _lib.load()
+    bound = set(_lib._SIGNATURES) | {"agb_last_error"}
+    assert set(declared_symbols()) <= bound, sorted(set(declared_symbols()) - bound)
+
+
+def test_host_helpers_and_error_path():
+    from dpcr_agb_amd import _lib
+    assert _lib.hash_capacity(1000) == 2048
+    assert _lib.hash_capacity(0) == 1024
+    lib = _lib.load()
+    # argument validation happens before any launch: safe without a GPU
+    rc = lib.agb_hash_clear(None, None, 1000, None)
+    assert rc == -1 and b"power of two" in lib.agb_last_error()
+    with pytest.raises(_lib.AgbError):
+        _lib.call("agb_spconv_fwd", None, 3, None, None, 0, 0, None, None, 4, 10, 27, 3, 4, None)
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from dpcr_agb_amd import _lib
+    import dpcr_agb_amd.me_compat as ME
+    with pytest.raises(_lib.AgbError):
+        ME.SparseTensor(torch.zeros(2, 3), coordinates=torch.tensor([[0, 0, 0, 0], [0, 1, 0, 0]]), device="cpu")
+    with pytest.raises(_lib.AgbError):
+        _lib.ptr(torch.zeros(3))

@@ -1,0 +1,269 @@
+"""GPU parity of the sparse-voxel HIP path against the CPU oracle (oracle/sparse_ref.py), through the C ABI.
+
+Index work (levels, kernel maps) is compared exactly (per coordinate); fp32 conv/pool results within 1e-4
+relative of an fp64 oracle evaluation (tolerance stated by BASELINE.json's north_star)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ref as R
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def random_coords(rng, B, n_per, extent, negative=False):
+    rows = []
+    for b in range(B):
+        pts = np.unique(rng.integers(-extent if negative else 0, extent, size=(n_per, 3)), axis=0)
+        rng.shuffle(pts)
+        rows.append(np.concatenate([np.full((len(pts), 1), b), pts], 1))
+    return np.concatenate(rows).astype(np.int64)
+
+
+def _cm(coords, device):
+    from dpcr_agb_amd.coords import CoordinateManager
+    cm = CoordinateManager(torch.from_numpy(coords).int(), device=device)
+    cm.validate()
+    return cm
+
+
+@pytest.mark.parametrize("negative", [False, True])
+def test_levels_and_kernel_maps_exact(device, negative):
+    rng = np.random.default_rng(0)
+    coords = random_coords(rng, 3, 700, 12, negative)
+    cm = _cm(coords, device)
+    ref = R.Coords(coords, 3)
+    for ts_in, K, s in [(1, 3, 1), (1, 7, 1), (1, 3, 2), (2, 3, 1), (2, 3, 2), (2, 1, 2), (4, 3, 1), (1, 2, 2)]:
+        nbr = cm.kernel_map(ts_in, K, s).cpu().numpy()
+        ts_out = ts_in * s
+        ref_nbr = ref.map(ts_in, K, s).numpy()
+        lvl = cm.level(ts_out)
+        got_c = lvl.coords[:lvl.n].cpu().numpy()
+        # first-occurrence order is part of this repo's contract -> exact equality, not just set equality
+        assert np.array_equal(got_c, ref.levels[ts_out]), f"level {ts_out} coords differ"
+        assert np.array_equal(nbr[:, :lvl.n], ref_nbr), f"kernel map ts={ts_in} K={K} s={s} differs"
+        ptr = cm.batch_ptr(ts_out).cpu().numpy()
+        counts = np.bincount(ref.levels[ts_out][:, 0], minlength=3)
+        assert np.array_equal(np.diff(ptr), counts)
+
+
+def test_transposed_map_inverts_forward(device):
+    rng = np.random.default_rng(1)
+    coords = random_coords(rng, 2, 900, 14)
+    cm = _cm(coords, device)
+    for ts_in, K, s in [(1, 3, 2), (2, 1, 2), (1, 2, 2), (1, 3, 1)]:
+        nbr = cm.kernel_map(ts_in, K, s).cpu().numpy()
+        nbrT = cm.transposed_map(ts_in, K, s).cpu().numpy()
+        n_out, n_in = cm.level(ts_in * s).n, cm.level(ts_in).n
+        fwd = {(k, int(nbr[k, r]), r) for k in range(K ** 3) for r in range(n_out) if nbr[k, r] >= 0}
+        bwd = {(k, q, int(nbrT[k, q])) for k in range(K ** 3) for q in range(n_in) if nbrT[k, q] >= 0}
+        assert fwd == bwd
+
+
+def test_duplicate_and_order_checks(device):
+    from dpcr_agb_amd._lib import AgbError
+    from dpcr_agb_amd.coords import CoordinateManager
+    dup = torch.tensor([[0, 1, 1, 1], [0, 2, 2, 2], [0, 1, 1, 1]], dtype=torch.int32)
+    with pytest.raises(AgbError):
+        CoordinateManager(dup, device=device).validate()
+    unordered = torch.tensor([[1, 1, 1, 1], [0, 2, 2, 2]], dtype=torch.int32)
+    with pytest.raises(AgbError):
+        CoordinateManager(unordered, device=device).validate()
+    with pytest.raises(AgbError):
+        CoordinateManager(dup, device="cpu")
+
+
+CONV_CASES = [
+    # cin, cout, K, stride, ts_in
+    (3, 64, 7, 1, 1),
+    (4, 32, 3, 1, 1),
+    (6, 16, 3, 1, 1),
+    (64, 64, 3, 1, 2),
+    (64, 128, 3, 2, 2),
+    (64, 128, 1, 2, 2),
+    (128, 128, 3, 1, 4),
+    (96, 80, 3, 1, 1),
+    (16, 8, 3, 2, 1),
+    (32, 32, 2, 2, 1),
+]
+
+
+@pytest.mark.parametrize("cin,cout,K,stride,ts_in", CONV_CASES)
+def test_conv_forward_backward(device, cin, cout, K, stride, ts_in):
+    import dpcr_agb_amd.me_compat as ME
+    rng = np.random.default_rng(cin * 131 + cout + K)
+    torch.manual_seed(cin + cout + K + stride)
+    coords = random_coords(rng, 2, 1500, 16)
+    ref = R.Coords(coords, 2)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    # walk to the requested input level with stride-2 pools
+    ts = 1
+    while ts < ts_in:
+        cm.stride(ts, 2)
+        ref.level(ts, 2)
+        ts *= 2
+    n_in = cm.level(ts_in).n
+    assert n_in == len(ref.levels[ts_in])
+    x = torch.randn(n_in, cin)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=K, stride=stride, bias=True, dimension=3).to(device)
+    xg = x.to(device).requires_grad_(True)
+    inp = ME.SparseTensor(xg, coordinate_map_key=ME.CoordinateMapKey(ts_in), coordinate_manager=cm)
+    out = conv(inp)
+    g = torch.randn(out.F.shape[0], cout)
+    out.F.backward(g.to(device))
+
+    # oracle in fp64
+    xr = x.double().requires_grad_(True)
+    wr = conv.kernel.detach().cpu().double().requires_grad_(True)
+    br = conv.bias.detach().cpu().double().requires_grad_(True)
+    nbr = ref.map(ts_in, K, stride)
+    outr = R.conv(xr, nbr, wr, br)
+    outr.backward(g.double())
+    assert out.F.shape == outr.shape
+    assert rel_err(out.F, outr) < RTOL
+    assert rel_err(xg.grad, xr.grad) < RTOL
+    assert rel_err(conv.kernel.grad, wr.grad) < RTOL
+    assert rel_err(conv.bias.grad, br.grad) < RTOL
+
+
+def test_maxpool_and_global_pools(device):
+    import dpcr_agb_amd.me_compat as ME
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    coords = random_coords(rng, 3, 1200, 14)
+    ref = R.Coords(coords, 3)
+    x = torch.randn(len(coords), 64)
+    xg = x.to(device).requires_grad_(True)
+    inp = ME.SparseTensor(xg, coordinates=torch.from_numpy(coords).int(), device=device)
+    # features handed in with coordinates are re-wrapped: keep the leaf for gradients
+    inp = ME.SparseTensor(xg, coordinate_map_key=inp.coordinate_map_key, coordinate_manager=inp.coordinate_manager)
+    pooled = ME.MinkowskiMaxPooling(3, 2, dimension=3)(inp)
+    g = torch.randn(*pooled.F.shape)
+    pooled.F.backward(g.to(device))
+    xr = x.double().requires_grad_(True)
+    pr = R.max_pool(xr, ref.map(1, 3, 2))
+    pr.backward(g.double())
+    assert rel_err(pooled.F, pr) < 1e-6
+    assert rel_err(xg.grad, xr.grad) < 1e-6
+
+    bidx = ref.batch_index(2)
+    for name, mod in [("sum", ME.MinkowskiGlobalSumPooling()), ("avg", ME.MinkowskiGlobalPooling()),
+                      ("max", ME.MinkowskiGlobalMaxPooling())]:
+        f = pooled.F.detach().clone().requires_grad_(True)
+        t = ME.SparseTensor(f, coordinate_map_key=pooled.coordinate_map_key,
+                            coordinate_manager=pooled.coordinate_manager)
+        o = mod(t)
+        go = torch.randn(3, 64)
+        o.F.backward(go.to(device))
+        fr = pooled.F.detach().cpu().double().requires_grad_(True)
+        orf = R.global_pool(fr, bidx, 3, name)
+        orf.backward(go.double())
+        assert rel_err(o.F, orf) < 1e-5, name
+        assert rel_err(f.grad, fr.grad) < 1e-5, name
+
+    # broadcast multiplication (SE layer)
+    f = pooled.F.detach().clone().requires_grad_(True)
+    s = torch.rand(3, 64, device=device, requires_grad=True)
+    t = ME.SparseTensor(f, coordinate_map_key=pooled.coordinate_map_key, coordinate_manager=pooled.coordinate_manager)
+    sg = ME.SparseTensor(s, coordinate_map_key=ME.CoordinateMapKey(0), coordinate_manager=pooled.coordinate_manager)
+    o = ME.MinkowskiBroadcastMultiplication()(t, sg)
+    go = torch.randn(*o.F.shape)
+    o.F.backward(go.to(device))
+    fr = f.detach().cpu().double().requires_grad_(True)
+    sr = s.detach().cpu().double().requires_grad_(True)
+    orf = fr * sr[bidx]
+    orf.backward(go.double())
+    assert rel_err(o.F, orf) < 1e-6
+    assert rel_err(f.grad, fr.grad) < 1e-6
+    assert rel_err(s.grad, sr.grad) < 1e-5
+
+
+def _model_and_batch(name, device, n_points, seeds, drop_path=0.0):
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_032))
+    opt = Opt(MODEL_OPTIONS[name])
+    opt["drop_path"] = drop_path
+    model = MinkowskiBaselineModel(opt, "minkowski", ds)
+    batch = synthetic.make_sparse_batch(seeds, n_points=n_points)
+    return model, batch
+
+
+@pytest.mark.parametrize("name,layers", [("SENet14", (1, 1, 1, 1)), ("ResNet14", (1, 1, 1, 1)),
+                                         ("SENet50", (3, 4, 6, 3))])
+def test_network_forward_backward_matches_oracle(device, name, layers):
+    model, batch = _model_and_batch(name, device, 1500, [0, 1, 2])
+    sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    model.to(device).train()
+    model.set_input(batch, device)
+    model.forward()
+    model.loss.backward()
+
+    # oracle (fp64, training-mode batch norm)
+    sd = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd32.items()}
+    coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
+    out = R.resnet_forward(sd, coords, batch.x.double(), layers, batch_size=len(batch))
+    loss = R.reg_loss(out, batch.y_reg.double(), model.reg_center_targets.cpu().double(),
+                      model.reg_scale_targets.cpu().double(), model.reg_weights.cpu().double())
+    loss.backward()
+    assert rel_err(model.output, out) < RTOL
+    assert abs(float(model.loss) - float(loss)) < RTOL * max(1.0, abs(float(loss)))
+    worst = 0.0
+    for k, p in model.model.named_parameters():
+        worst = max(worst, rel_err(p.grad, sd[k].grad))
+    # gradients pass through training-mode BN of ~10 layers: allow 10x the forward tolerance
+    assert worst < 10 * RTOL, worst
+
+
+def test_drop_path_consumes_rng_like_oracle(device):
+    model, batch = _model_and_batch("SENet14", device, 800, [3, 4, 5, 6], drop_path=0.5)
+    sd = {k: v.detach().clone().double() for k, v in model.model.state_dict().items()}
+    model.to(device).train()
+    model.set_input(batch, device)
+    random.seed(123)
+    model.forward()
+    coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
+    random.seed(123)
+    out = R.resnet_forward(sd, coords, batch.x.double(), (1, 1, 1, 1), drop_path_prob=0.5, batch_size=4)
+    assert rel_err(model.output, out) < RTOL
+
+
+def test_train_steps_track_oracle(device):
+    """Three optimizer steps (AdaBelief, clip 100, cosine warm restarts) on GPU vs the fp64 oracle."""
+    from dpcr_agb_amd.config import TRAINING_NFI
+    from dpcr_agb_amd.optim import AdaBelief
+    model, batch = _model_and_batch("SENet14", device, 1000, [7, 8])
+    sd = {k: (v.detach().clone().double().requires_grad_(v.is_floating_point() and "running" not in k))
+          for k, v in model.model.state_dict().items()}
+    model.to(device).train()
+    model.init_train_objects(TRAINING_NFI)
+    params = [v for k, v in sd.items() if v.requires_grad]
+    ref_opt = AdaBelief(params, lr=0.005, weight_decay=1e-2)
+    coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
+    for step in range(3):
+        model.set_input(batch, device)
+        model.optimize_parameters(epoch=0, batch_size=2, num_batches=100)
+        upd = {}
+        out = R.resnet_forward(sd, coords, batch.x.double(), (1, 1, 1, 1), batch_size=2, update=upd)
+        loss = R.reg_loss(out, batch.y_reg.double(), model.reg_center_targets.cpu().double(),
+                          model.reg_scale_targets.cpu().double(), model.reg_weights.cpu().double())
+        ref_opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(params, 100)
+        ref_opt.step()
+        for k, v in upd.items():
+            sd[k] = v
+        assert abs(float(model.loss) - float(loss)) < 1e-3 * max(1.0, abs(float(loss))), (step, float(model.loss),
+                                                                                          float(loss))
