@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated batches cycled per rank")
     ap.add_argument("--features", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-plots", type=int, default=2)
+    ap.add_argument("--cpu-plots", type=int, default=1)
     return ap.parse_args()
 
 
@@ -95,14 +95,35 @@ def roofline_from_profile(prof):
     return roof, summary
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask, cgroup CPU quota, capped at 32 (oversubscribing a
+    quota-limited container with one OpenMP thread per visible core makes the CPU leg arbitrarily slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def cpu_baseline(args, model_sd, stats):
     """The oracle (torch-CPU restatement, fp32, all host cores) on a bounded sample of the same workload:
     full training steps (fwd + bwd + AdaBelief) on `--cpu-plots` synthetic 16k-point plots."""
     from oracle import sparse_ref as R
     from dpcr_agb_amd import synthetic
     from dpcr_agb_amd.optim import AdaBelief
-    cores = os.cpu_count()
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log(f"cpu baseline: {cores} threads (os.cpu_count()={os.cpu_count()})")
     batch = synthetic.make_sparse_batch(list(range(900_000, 900_000 + args.cpu_plots)), n_points=args.points)
     sd = {k: (v.detach().clone().float().requires_grad_(v.is_floating_point() and "running" not in k))
           for k, v in model_sd.items()}
@@ -120,6 +141,7 @@ def cpu_baseline(args, model_sd, stats):
         torch.nn.utils.clip_grad_value_(params, 100)
         opt.step()
         steps += 1
+        log(f"cpu baseline: step {steps} done after {time.time() - t0:.1f}s")
     dt = time.time() - t0
     return dict(value=round(args.cpu_plots * steps / dt, 4), unit="plots/s", cores=cores, kind="port",
                 sample=f"{steps} training step(s) of MSENet14 on {args.cpu_plots} synthetic {args.points}-pt plots "
@@ -173,8 +195,12 @@ def main():
         model.set_input(pool[i % len(pool)], dev)
         model.optimize_parameters(epoch=i // steps_per_epoch, batch_size=args.batch, num_batches=steps_per_epoch)
 
+    log(f"model + {len(pool)} batches resident ({voxels:.0f} voxels/plot); warmup")
     for i in range(args.warmup):
         step(i)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,7 +220,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(model.loss)
+    loss = float(model.loss.detach())
+    log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
 
     if rank == 0:
         roof, summary = roofline_from_profile(prof or [])

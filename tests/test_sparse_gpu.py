@@ -16,7 +16,7 @@ RTOL = 1e-4
 
 
 def rel_err(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
@@ -212,19 +212,28 @@ def test_network_forward_backward_matches_oracle(device, name, layers):
     model.loss.backward()
 
     # oracle (fp64, training-mode batch norm)
-    sd = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd32.items()}
+    sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v)
+          for k, v in sd32.items()}
     coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
     out = R.resnet_forward(sd, coords, batch.x.double(), layers, batch_size=len(batch))
     loss = R.reg_loss(out, batch.y_reg.double(), model.reg_center_targets.cpu().double(),
                       model.reg_scale_targets.cpu().double(), model.reg_weights.cpu().double())
     loss.backward()
     assert rel_err(model.output, out) < RTOL
-    assert abs(float(model.loss) - float(loss)) < RTOL * max(1.0, abs(float(loss)))
-    worst = 0.0
+    assert abs(float(model.loss.detach()) - float(loss.detach())) < RTOL * max(1.0, abs(float(loss.detach())))
+    # Conv biases that feed a training-mode BatchNorm have a mathematically ZERO gradient (BN removes the mean);
+    # fp32 leaves ~1e-8 noise there, so every tensor is measured against max(its own scale, 1e-3 of the largest
+    # gradient in the network).
+    gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.model.named_parameters())
+    worst, worst_name = 0.0, None
     for k, p in model.model.named_parameters():
-        worst = max(worst, rel_err(p.grad, sd[k].grad))
+        ref_g = sd[k].grad
+        denom = max(float(ref_g.abs().max()), 1e-3 * gmax)
+        e = float((p.grad.detach().cpu().double() - ref_g).abs().max()) / denom
+        if e > worst:
+            worst, worst_name = e, k
     # gradients pass through training-mode BN of ~10 layers: allow 10x the forward tolerance
-    assert worst < 10 * RTOL, worst
+    assert worst < 10 * RTOL, (worst, worst_name)
 
 
 def test_drop_path_consumes_rng_like_oracle(device):
@@ -265,5 +274,5 @@ def test_train_steps_track_oracle(device):
         ref_opt.step()
         for k, v in upd.items():
             sd[k] = v
-        assert abs(float(model.loss) - float(loss)) < 1e-3 * max(1.0, abs(float(loss))), (step, float(model.loss),
-                                                                                          float(loss))
+        lg, lr_ = float(model.loss.detach()), float(loss.detach())
+        assert abs(lg - lr_) < 1e-3 * max(1.0, abs(lr_)), (step, lg, lr_)
