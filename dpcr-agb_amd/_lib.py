@@ -27,6 +27,12 @@ _SIGNATURES = {
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "agb_kernel_map": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                        c_ll, c_void_p, c_void_p],
+    "agb_coords_bbox": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "agb_grid_insert": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "agb_grid_stride": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                        c_void_p, c_void_p, c_void_p, c_void_p],
+    "agb_grid_kernel_map": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_ll,
+                            c_void_p, c_void_p],
     "agb_batch_ptr": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "agb_spconv_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                        c_int, c_int, c_void_p],
@@ -34,8 +40,8 @@ _SIGNATURES = {
                               c_void_p],
     "agb_maxpool_fwd": [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "agb_maxpool_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
-    "agb_segment_reduce": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
-                           c_void_p],
+    "agb_segment_reduce": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                           c_void_p, c_void_p, c_void_p],
     "agb_segment_broadcast": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                               c_void_p],
     "agb_segment_max_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

@@ -190,6 +190,12 @@ class ResNetBase(nn.Module):
         else:
             raise NotImplementedError(f"norm_type '{norm_type}': choose 'bn', 'bn_no_affine' or 'in'")
 
+        # tensor strides the forward pass will visit (lets set_input build the whole coordinate pyramid at once)
+        ts, self.tensor_strides = first_stride * 2, [first_stride, first_stride * 2]
+        for s in self.STRIDES:
+            ts *= s
+            self.tensor_strides.append(ts)
+
         self.inplanes = self.INIT_DIM
         stem = nn.Sequential(
             ConvNormActivation(in_channels, self.inplanes, kernel_size=7, stride=first_stride, D=D, bias=bias,

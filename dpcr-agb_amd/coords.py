@@ -6,16 +6,24 @@ that ``ME.MinkowskiConvolution`` / ``ME.MinkowskiMaxPooling`` request (SENet.py:
 
 MI355X-first layout: every level keeps
   * coords   int32 [N, 4]  (b, x, y, z), rows batch-contiguous, order = first occurrence in the parent level
-  * a 64-bit-key open-addressing hash (capacity = pow2 >= 2N) in HBM
+  * a lookup structure in HBM: a dense grid int32[B][Z][Y][X] when the batch's bounding volume is small
+    (LiDAR plots: ~81^3 cells per plot -> 68 MB at B=32; one load per probe, coalesced), otherwise a
+    64-bit-key open-addressing hash (capacity = pow2 >= 2N)
   * kernel maps as dense neighbour tables nbr[K^3][N_out] (int32, -1 = absent) so that the convolution
     can run output-stationary (no scatter atomics); tables are cached per (level, kernel, stride, dilation)
     exactly like ME caches kernel maps per coordinate-map key pair.
+
+``prefetch_strides`` builds a whole pyramid of levels with device-side row counts and reads all counts back
+in ONE host synchronisation; without it every new level costs one read-back (ME-like lazy behaviour).
 """
-from typing import Dict, Tuple
+import ctypes
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 
 from . import _lib
+
+GRID_MAX_CELLS = 1 << 28  # 1 GiB of int32 per level at most; beyond that the hash mode is used
 
 
 class CoordinateMapKey:
@@ -41,13 +49,15 @@ class CoordinateMapKey:
 
 
 class _Level:
-    __slots__ = ("coords", "n", "ts", "keys", "vals", "cap", "_ptr", "slot")
+    """One coordinate level. ``n`` is the host row count (None until read back), ``bound`` an upper bound that
+    sizes buffers, ``n_dev`` the device-side count (None when n is exact from the start)."""
+    __slots__ = ("coords", "n", "bound", "n_dev", "ts", "keys", "vals", "cap", "grid", "desc_host", "_ptr",
+                 "status")
 
-    def __init__(self, coords, n, ts, keys, vals, cap):
-        self.coords, self.n, self.ts = coords, n, ts
-        self.keys, self.vals, self.cap = keys, vals, cap
-        self._ptr = None
-        self.slot = None
+    def __init__(self, coords, n, bound, n_dev, ts):
+        self.coords, self.n, self.bound, self.n_dev, self.ts = coords, n, bound, n_dev, ts
+        self.keys = self.vals = self.grid = self.desc_host = self._ptr = self.status = None
+        self.cap = 0
 
 
 def _as_int(v):
@@ -57,8 +67,15 @@ def _as_int(v):
     return int(v)
 
 
+def _floor_to(v, ts):
+    return (v // ts) * ts  # python floor division: correct for negatives
+
+
 class CoordinateManager:
-    def __init__(self, coordinates: torch.Tensor, device=None, tensor_stride: int = 1, batch_size: int = None):
+    def __init__(self, coordinates: torch.Tensor, device=None, tensor_stride: int = 1, batch_size: int = None,
+                 bounds: Optional[Sequence[int]] = None, mode: str = "auto"):
+        """bounds: optional (min_x, min_y, min_z, max_x, max_y, max_z) known by the caller (e.g. computed by the
+        voxeliser); saves the bounding-box read-back. mode: 'auto' | 'grid' | 'hash'."""
         if coordinates.dim() != 2 or coordinates.shape[1] != 4:
             raise ValueError("coordinates must be [N, 1+3] = (batch, x, y, z)")
         if device is None:
@@ -67,37 +84,75 @@ class CoordinateManager:
         if device.type != "cuda":
             raise _lib.AgbError("the sparse-voxel path runs on a HIP device only (no CPU fallback); got device "
                                 f"'{device}'")
+        n = coordinates.shape[0]
+        if mode not in ("auto", "grid", "hash"):
+            raise ValueError(f"mode '{mode}'")
+        if bounds is None and mode != "hash" and n > 0 and not coordinates.is_cuda:
+            c = coordinates[:, 1:]
+            bounds = tuple(int(v) for v in c.min(0).values.tolist()) + tuple(int(v) for v in c.max(0).values.tolist())
+        if batch_size is None:
+            batch_size = int(coordinates[:, 0].max().item()) + 1 if n > 0 else 1
         coords = coordinates.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
         self.device = device
         self.D = 3
-        n = coords.shape[0]
-        if batch_size is None:
-            batch_size = int(coordinates[:, 0].max().item()) + 1 if n > 0 else 1
         self.batch_size = int(batch_size)
         self.levels: Dict[int, _Level] = {}
         self.kernel_maps: Dict[Tuple, torch.Tensor] = {}
-        self.origin_ts = int(tensor_stride)
+        self.origin_ts = ts0 = int(tensor_stride)
+        if bounds is None and mode != "hash" and n > 0:
+            bbox = torch.empty(8, dtype=torch.int32, device=device)
+            _lib.call("agb_coords_bbox", _lib.ptr(coords), n, None, _lib.ptr(bbox), _lib.stream())
+            bounds = tuple(bbox[:6].tolist())  # one host read (callers that know the bounds pass them in)
+        self.bounds = None if bounds is None else tuple(int(v) for v in bounds)
+        self.mode = "hash"
+        if mode != "hash" and n > 0 and self._grid_cells(ts0) <= GRID_MAX_CELLS:
+            self.mode = "grid"
+        elif mode == "grid":
+            raise _lib.AgbError("dense-grid mode requested but the bounding volume is empty or too large")
 
-        cap = _lib.hash_capacity(n)
-        keys = torch.empty(cap, dtype=torch.int64, device=device)
-        vals = torch.empty(cap, dtype=torch.int32, device=device)
-        slot = torch.empty(max(n, 1), dtype=torch.int32, device=device)
-        status = torch.empty(4, dtype=torch.int32, device=device)
-        _lib.call("agb_coords_insert", _lib.ptr(coords), n, None, _lib.ptr(keys), _lib.ptr(vals), cap,
-                  _lib.ptr(slot), _lib.ptr(status), _lib.stream())
-        lvl = _Level(coords, n, self.origin_ts, keys, vals, cap)
-        self.levels[self.origin_ts] = lvl
-        self._status = status  # checked lazily (one host read) in validate()
+        lvl = _Level(coords, n, n, None, ts0)
+        lvl.status = torch.empty(4, dtype=torch.int32, device=device)
+        if self.mode == "grid":
+            self._alloc_grid(lvl)
+            cell = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+            _lib.call("agb_grid_insert", _lib.ptr(coords), n, None, lvl.desc_host, _lib.ptr(lvl.grid),
+                      _lib.ptr(cell), _lib.ptr(lvl.status), _lib.stream())
+        else:
+            lvl.cap = _lib.hash_capacity(n)
+            lvl.keys = torch.empty(lvl.cap, dtype=torch.int64, device=device)
+            lvl.vals = torch.empty(lvl.cap, dtype=torch.int32, device=device)
+            slot = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+            _lib.call("agb_coords_insert", _lib.ptr(coords), n, None, _lib.ptr(lvl.keys), _lib.ptr(lvl.vals),
+                      lvl.cap, _lib.ptr(slot), _lib.ptr(lvl.status), _lib.stream())
+        self.levels[ts0] = lvl
         self._validated = False
+
+    # ------------------------------------------------------------------ dense-grid geometry
+    def _grid_geometry(self, ts):
+        lo = [_floor_to(v, ts) for v in self.bounds[:3]]
+        hi = [_floor_to(v, ts) for v in self.bounds[3:]]
+        dims = [(h - l) // ts + 1 for l, h in zip(lo, hi)]
+        return lo, dims
+
+    def _grid_cells(self, ts):
+        _, dims = self._grid_geometry(ts)
+        return self.batch_size * dims[0] * dims[1] * dims[2]
+
+    def _alloc_grid(self, lvl: _Level):
+        lo, dims = self._grid_geometry(lvl.ts)
+        lvl.desc_host = (ctypes.c_int32 * 8)(lo[0], lo[1], lo[2], dims[0], dims[1], dims[2], lvl.ts,
+                                             self.batch_size)
+        lvl.grid = torch.empty(self.batch_size * dims[0] * dims[1] * dims[2], dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------ helpers
     def validate(self):
         """Host-side check of the insert status (duplicates / range / batch order). One device read."""
         if self._validated:
             return
-        dup, rng, order, _ = self._status.tolist()
+        dup, rng, order, _ = self.levels[self.origin_ts].status.tolist()
         if rng:
-            raise _lib.AgbError(f"{rng} coordinates fall outside the packed 16-bit range [-32768, 32767]")
+            raise _lib.AgbError(f"{rng} coordinates fall outside the supported range (packed 16-bit keys / the "
+                                "declared bounds)")
         if dup:
             raise _lib.AgbError(f"{dup} duplicate coordinates: voxelise first (GridSampling3D keeps one point per "
                                 "voxel), duplicates are not merged here")
@@ -105,85 +160,130 @@ class CoordinateManager:
             raise _lib.AgbError("rows must be ordered by batch index (as torch_geometric's Batch collation gives)")
         self._validated = True
 
+    def _resolve(self, lvl: _Level):
+        """Make the host row count of a level available (one read-back if it is still device-only)."""
+        if lvl.n is None:
+            lvl.n = int(lvl.n_dev.item())
+            lvl.n_dev = None
+            lvl.bound = lvl.n
+        return lvl
+
     def level(self, ts: int) -> _Level:
-        return self.levels[int(ts)]
+        return self._resolve(self.levels[int(ts)])
 
     def num_rows(self, key: CoordinateMapKey) -> int:
         if key.tensor_stride == 0:
             return self.batch_size
-        return self.levels[key.tensor_stride].n
+        return self.level(key.tensor_stride).n
 
     def coords_of(self, key: CoordinateMapKey) -> torch.Tensor:
         if key.tensor_stride == 0:
             c = torch.zeros(self.batch_size, 4, dtype=torch.int32, device=self.device)
             c[:, 0] = torch.arange(self.batch_size, device=self.device, dtype=torch.int32)
             return c
-        lvl = self.levels[key.tensor_stride]
+        lvl = self.level(key.tensor_stride)
         return lvl.coords[: lvl.n]
 
     def batch_ptr(self, ts: int) -> torch.Tensor:
         lvl = self.levels[int(ts)]
         if lvl._ptr is None:
             p = torch.empty(self.batch_size + 1, dtype=torch.int32, device=self.device)
-            _lib.call("agb_batch_ptr", _lib.ptr(lvl.coords), lvl.n, None, self.batch_size, _lib.ptr(p),
-                      _lib.stream())
+            _lib.call("agb_batch_ptr", _lib.ptr(lvl.coords), lvl.bound, _lib.ptr(lvl.n_dev), self.batch_size,
+                      _lib.ptr(p), _lib.stream())
             lvl._ptr = p
         return lvl._ptr
 
     # ------------------------------------------------------------------ levels
+    def _make_level(self, ts_in: int, ts_out: int) -> _Level:
+        """Enqueue the construction of level ts_out from ts_in; the row count stays on the device."""
+        src = self.levels[int(ts_in)]
+        dev = self.device
+        bound = src.bound
+        if self.mode == "grid":
+            bound = min(bound, self._grid_cells(ts_out))
+        nb = max(src.bound, 1)
+        flags = torch.empty(nb, dtype=torch.int32, device=dev)
+        excl = torch.empty(nb, dtype=torch.int32, device=dev)
+        scratch = torch.empty(_lib.scan_scratch_elems(nb), dtype=torch.int32, device=dev)
+        out_coords = torch.empty(max(bound, 1), 4, dtype=torch.int32, device=dev)
+        n_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        lvl = _Level(out_coords, None, bound, n_out_dev, ts_out)
+        if self.mode == "grid":
+            self._alloc_grid(lvl)
+            cell = torch.empty(nb, dtype=torch.int64, device=dev)
+            _lib.call("agb_grid_stride", _lib.ptr(src.coords), src.bound, _lib.ptr(src.n_dev), lvl.desc_host,
+                      _lib.ptr(lvl.grid), _lib.ptr(cell), _lib.ptr(flags), _lib.ptr(excl), _lib.ptr(scratch),
+                      _lib.ptr(out_coords), _lib.ptr(n_out_dev), _lib.ptr(self.levels[self.origin_ts].status),
+                      _lib.stream())
+        else:
+            lvl.cap = _lib.hash_capacity(src.bound)
+            lvl.keys = torch.empty(lvl.cap, dtype=torch.int64, device=dev)
+            lvl.vals = torch.empty(lvl.cap, dtype=torch.int32, device=dev)
+            slot = torch.empty(nb, dtype=torch.int32, device=dev)
+            _lib.call("agb_coords_stride", _lib.ptr(src.coords), src.bound, _lib.ptr(src.n_dev), ts_out,
+                      _lib.ptr(lvl.keys), _lib.ptr(lvl.vals), lvl.cap, _lib.ptr(slot), _lib.ptr(flags),
+                      _lib.ptr(excl), _lib.ptr(scratch), _lib.ptr(out_coords), _lib.ptr(n_out_dev), None,
+                      _lib.stream())
+        self.levels[ts_out] = lvl
+        return lvl
+
     def stride(self, ts_in: int, stride: int) -> int:
         """Create (or fetch) the level with tensor stride ts_in*stride: unique(floor(c/ts_out)*ts_out)."""
         stride = _as_int(stride)
         ts_out = int(ts_in) * stride
         if stride == 1 or ts_out in self.levels:
             return ts_out
-        src = self.levels[int(ts_in)]
-        n = src.n
-        dev = self.device
-        cap = _lib.hash_capacity(n)
-        keys = torch.empty(cap, dtype=torch.int64, device=dev)
-        vals = torch.empty(cap, dtype=torch.int32, device=dev)
-        slot = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        flags = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        excl = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        scratch = torch.empty(_lib.scan_scratch_elems(n), dtype=torch.int32, device=dev)
-        out_coords = torch.empty(max(n, 1), 4, dtype=torch.int32, device=dev)
-        n_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.call("agb_coords_stride", _lib.ptr(src.coords), n, None, ts_out, _lib.ptr(keys), _lib.ptr(vals), cap,
-                  _lib.ptr(slot), _lib.ptr(flags), _lib.ptr(excl), _lib.ptr(scratch), _lib.ptr(out_coords),
-                  _lib.ptr(n_out_dev), None, _lib.stream())
-        n_out = int(n_out_dev.item())  # the one host read per new level (sizes the level's tensors)
-        self.levels[ts_out] = _Level(out_coords, n_out, ts_out, keys, vals, cap)
+        self._make_level(ts_in, ts_out)
         return ts_out
 
+    def prefetch_strides(self, tensor_strides: Sequence[int]):
+        """Build the levels ts0 -> tensor_strides[0] -> tensor_strides[1] ... without any host synchronisation in
+        between, then read every row count back at once."""
+        ts = self.origin_ts
+        todo = []
+        for t in tensor_strides:
+            t = int(t)
+            if t not in self.levels:
+                todo.append(self._make_level(ts, t))
+            ts = t
+        pending = [lv for lv in todo if lv.n is None]
+        if pending:
+            counts = torch.cat([lv.n_dev for lv in pending]).tolist()  # the single read-back
+            for lv, c in zip(pending, counts):
+                lv.n, lv.n_dev, lv.bound = int(c), None, int(c)
+
     # -------------------------------------------------------------- kernel maps
+    def _lookup(self, q: _Level, table: _Level, K, step, sign, require_multiple_of, count_pairs):
+        self._resolve(q)
+        nbr = torch.empty(K ** 3, max(q.n, 1), dtype=torch.int32, device=self.device)
+        pairs = torch.zeros(1, dtype=torch.int64, device=self.device) if count_pairs else None
+        if self.mode == "grid":
+            _lib.call("agb_grid_kernel_map", _lib.ptr(q.coords), q.n, None, K, step, sign, table.desc_host,
+                      _lib.ptr(table.grid), _lib.ptr(nbr), nbr.stride(0), _lib.ptr(pairs), _lib.stream())
+        else:
+            _lib.call("agb_kernel_map", _lib.ptr(q.coords), q.n, None, K, step, sign, require_multiple_of,
+                      _lib.ptr(table.keys), _lib.ptr(table.vals), table.cap, _lib.ptr(nbr), nbr.stride(0),
+                      _lib.ptr(pairs), _lib.stream())
+        if count_pairs:
+            nbr.agb_pairs = pairs  # device-side kernel-map size (ME's kernel-map size); read only by profiling code
+        return nbr
+
     def kernel_map(self, ts_in: int, kernel_size: int, stride: int = 1, dilation: int = 1) -> torch.Tensor:
         """nbr[K^3, N_out]: row (at level ts_in) of out_coord + offset_k * ts_in * dilation, or -1."""
         K, s, d = _as_int(kernel_size), _as_int(stride), _as_int(dilation)
         key = ("fwd", int(ts_in), K, s, d)
-        if key in self.kernel_maps:
-            return self.kernel_maps[key]
-        ts_out = self.stride(ts_in, s)
-        src, dst = self.levels[int(ts_in)], self.levels[ts_out]
-        nbr = torch.empty(K ** 3, max(dst.n, 1), dtype=torch.int32, device=self.device)
-        pairs = torch.zeros(1, dtype=torch.int64, device=self.device)
-        _lib.call("agb_kernel_map", _lib.ptr(dst.coords), dst.n, None, K, int(ts_in) * d, 1, 0, _lib.ptr(src.keys),
-                  _lib.ptr(src.vals), src.cap, _lib.ptr(nbr), nbr.stride(0), _lib.ptr(pairs), _lib.stream())
-        nbr.agb_pairs = pairs  # device-side kernel-map size (ME's kernel-map size); read only by profiling code
-        self.kernel_maps[key] = nbr
-        return nbr
+        if key not in self.kernel_maps:
+            ts_out = self.stride(ts_in, s)
+            self.kernel_maps[key] = self._lookup(self.levels[ts_out], self.levels[int(ts_in)], K, int(ts_in) * d, 1,
+                                                 0, True)
+        return self.kernel_maps[key]
 
     def transposed_map(self, ts_in: int, kernel_size: int, stride: int = 1, dilation: int = 1) -> torch.Tensor:
         """nbrT[K^3, N_in]: row (at level ts_out) of in_coord - offset_k * ts_in * dilation, or -1."""
         K, s, d = _as_int(kernel_size), _as_int(stride), _as_int(dilation)
         key = ("bwd", int(ts_in), K, s, d)
-        if key in self.kernel_maps:
-            return self.kernel_maps[key]
-        ts_out = self.stride(ts_in, s)
-        src, dst = self.levels[int(ts_in)], self.levels[ts_out]
-        nbrT = torch.empty(K ** 3, max(src.n, 1), dtype=torch.int32, device=self.device)
-        _lib.call("agb_kernel_map", _lib.ptr(src.coords), src.n, None, K, int(ts_in) * d, -1, ts_out,
-                  _lib.ptr(dst.keys), _lib.ptr(dst.vals), dst.cap, _lib.ptr(nbrT), nbrT.stride(0), None,
-                  _lib.stream())
-        self.kernel_maps[key] = nbrT
-        return nbrT
+        if key not in self.kernel_maps:
+            ts_out = self.stride(ts_in, s)
+            self.kernel_maps[key] = self._lookup(self.levels[int(ts_in)], self.levels[ts_out], K, int(ts_in) * d, -1,
+                                                 ts_out, False)
+        return self.kernel_maps[key]

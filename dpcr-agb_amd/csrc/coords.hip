@@ -286,6 +286,163 @@ __global__ void k_fill_i32(int32_t* p, int n, int v) {
     if (i < n) p[i] = v;
 }
 
+// ================================================================ dense-grid mode
+// When the batch's bounding volume is small (LiDAR plots: ~81^3 cells x B), every level keeps a dense
+// lookup grid int32[B][Z][Y][X] (x fastest) instead of the hash: one load per probe, no collisions, and
+// neighbouring rows probe neighbouring cells (coalesced).  Empty cells hold INT_MAX.
+struct GridDesc {
+    int ox, oy, oz;  // origin (multiples of ts)
+    int X, Y, Z;     // cells per axis
+    int ts;          // tensor stride of the level
+    int B;
+};
+
+__device__ __forceinline__ long long grid_cell(const GridDesc& g, int b, int x, int y, int z) {
+    // returns -1 when (b,x,y,z) is outside the grid or off the level's lattice
+    int dx = x - g.ox, dy = y - g.oy, dz = z - g.oz;
+    if (b < 0 || b >= g.B || dx < 0 || dy < 0 || dz < 0) return -1;
+    if (g.ts > 1) {
+        if ((dx % g.ts) | (dy % g.ts) | (dz % g.ts)) return -1;
+        dx /= g.ts; dy /= g.ts; dz /= g.ts;
+    }
+    if (dx >= g.X || dy >= g.Y || dz >= g.Z) return -1;
+    return (((long long)b * g.Z + dz) * g.Y + dy) * g.X + dx;
+}
+
+// bbox[0..2] = min x,y,z   bbox[3..5] = max x,y,z   bbox[6] = max batch   (caller pre-fills +/- extremes)
+__global__ void k_coords_bbox(const int4* __restrict__ coords, int n, const int32_t* n_dev, int32_t* bbox) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int mnx = INT_MAX, mny = INT_MAX, mnz = INT_MAX, mxx = INT_MIN, mxy = INT_MIN, mxz = INT_MIN, mxb = INT_MIN;
+    for (; i < n; i += gridDim.x * blockDim.x) {
+        int4 c = coords[i];
+        mnx = min(mnx, c.y); mny = min(mny, c.z); mnz = min(mnz, c.w);
+        mxx = max(mxx, c.y); mxy = max(mxy, c.z); mxz = max(mxz, c.w);
+        mxb = max(mxb, c.x);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, d, 64)); mny = min(mny, __shfl_xor(mny, d, 64));
+        mnz = min(mnz, __shfl_xor(mnz, d, 64)); mxx = max(mxx, __shfl_xor(mxx, d, 64));
+        mxy = max(mxy, __shfl_xor(mxy, d, 64)); mxz = max(mxz, __shfl_xor(mxz, d, 64));
+        mxb = max(mxb, __shfl_xor(mxb, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && mxb != INT_MIN) {
+        atomicMin(&bbox[0], mnx); atomicMin(&bbox[1], mny); atomicMin(&bbox[2], mnz);
+        atomicMax(&bbox[3], mxx); atomicMax(&bbox[4], mxy); atomicMax(&bbox[5], mxz);
+        atomicMax(&bbox[6], mxb);
+    }
+}
+
+__global__ void k_bbox_init(int32_t* bbox) {
+    int t = threadIdx.x;
+    if (t < 3) bbox[t] = INT_MAX;
+    else if (t < 7) bbox[t] = INT_MIN;
+    else if (t == 7) bbox[t] = 0;
+}
+
+// level 0: cell <- smallest row with that coordinate. cell_of_row keeps the cell (or -1) for the follow-up passes.
+__global__ void k_grid_insert(const int4* __restrict__ coords, int n, const int32_t* n_dev, GridDesc g,
+                              int32_t* grid, long long* cell_of_row, int32_t* status) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    if (i > 0 && coords[i - 1].x > c.x) atomicAdd(&status[2], 1);
+    long long cell = grid_cell(g, c.x, c.y, c.z, c.w);
+    cell_of_row[i] = cell;
+    if (cell < 0) {
+        atomicAdd(&status[1], 1);
+        return;
+    }
+    atomicMin(&grid[cell], i);
+}
+
+__global__ void k_grid_count_dups(int n, const int32_t* n_dev, const int32_t* grid, const long long* cell_of_row,
+                                  int32_t* status) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long cell = cell_of_row[i];
+    if (cell >= 0 && grid[cell] != i) atomicAdd(&status[0], 1);
+}
+
+__global__ void k_grid_stride_insert(const int4* __restrict__ coords, int n, const int32_t* n_dev, GridDesc g,
+                                     int32_t* grid, long long* cell_of_row, int32_t* status) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    int x = agb_floordiv(c.y, g.ts) * g.ts, y = agb_floordiv(c.z, g.ts) * g.ts, z = agb_floordiv(c.w, g.ts) * g.ts;
+    long long cell = grid_cell(g, c.x, x, y, z);
+    cell_of_row[i] = cell;
+    if (cell < 0) {
+        atomicAdd(&status[1], 1);
+        return;
+    }
+    atomicMin(&grid[cell], i);
+}
+
+__global__ void k_grid_stride_flag(int n, const int32_t* n_dev, const int32_t* grid, const long long* cell_of_row,
+                                   int32_t* flags) {
+    int nn = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int f = 0;
+    if (i < nn) {
+        long long cell = cell_of_row[i];
+        f = (cell >= 0 && grid[cell] == i) ? 1 : 0;
+    }
+    flags[i] = f;
+}
+
+__global__ void k_grid_stride_emit(const int4* __restrict__ coords, int n, const int32_t* n_dev, int ts_out,
+                                   const int32_t* __restrict__ flags, const int32_t* __restrict__ excl,
+                                   const long long* __restrict__ cell_of_row, int32_t* grid, int4* out_coords) {
+    n = eff_n(n, n_dev);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    int4 c = coords[i];
+    int r = excl[i];
+    out_coords[r] = make_int4(c.x, agb_floordiv(c.y, ts_out) * ts_out, agb_floordiv(c.z, ts_out) * ts_out,
+                              agb_floordiv(c.w, ts_out) * ts_out);
+    grid[cell_of_row[i]] = r;
+}
+
+// one thread per (row, iy, iz); loops the K offsets along x so the K probes of a thread are adjacent cells
+__global__ void k_grid_kernel_map(const int4* __restrict__ q_coords, int n, const int32_t* n_dev, int K, int step,
+                                  int sign, GridDesc g, const int32_t* __restrict__ grid, int32_t* nbr,
+                                  long long nbr_stride, unsigned long long* pair_count) {
+    int nn = eff_n(n, n_dev);
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int cnt = 0;
+    if (r < nn) {
+        int iy = blockIdx.y % K, iz = blockIdx.y / K;
+        int half = (K & 1) ? K / 2 : 0;
+        int4 c = q_coords[r];
+        int y = c.z + sign * (iy - half) * step;
+        int z = c.w + sign * (iz - half) * step;
+        for (int ix = 0; ix < K; ++ix) {
+            int x = c.y + sign * (ix - half) * step;
+            long long cell = grid_cell(g, c.x, x, y, z);
+            int res = -1;
+            if (cell >= 0) {
+                int v = grid[cell];
+                if (v != INT_MAX) res = v;
+            }
+            cnt += res >= 0;
+            int k = ix + K * (iy + K * iz);
+            nbr[(long long)k * nbr_stride + r] = res;
+        }
+    }
+    if (pair_count) {
+        // every lane of the wave is active here (no early return above): plain butterfly reduction
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(pair_count, (unsigned long long)cnt);
+    }
+}
+
 // =============================================================== C ABI
 extern "C" {
 
@@ -379,6 +536,95 @@ int agb_batch_ptr(const int32_t* coords, int n, const int32_t* n_dev, int B, int
                            ptr);
     hipLaunchKernelGGL(k_batch_fix, dim3(1), dim3(64), 0, s, B, ptr);
     AGB_CHECK_LAUNCH("agb_batch_ptr");
+    return AGB_OK;
+}
+
+// ---- dense-grid mode --------------------------------------------------------------------------------
+// desc = {ox, oy, oz, X, Y, Z, ts, B} (host ints). grid: int32[B*Z*Y*X], filled with INT_MAX by these calls.
+static inline GridDesc mk_desc(const int32_t* d) {
+    GridDesc g;
+    g.ox = d[0]; g.oy = d[1]; g.oz = d[2]; g.X = d[3]; g.Y = d[4]; g.Z = d[5]; g.ts = d[6]; g.B = d[7];
+    return g;
+}
+static inline long long desc_cells(const int32_t* d) { return (long long)d[7] * d[5] * d[4] * d[3]; }
+
+int agb_coords_bbox(const int32_t* coords, int n, const int32_t* n_dev, int32_t* bbox, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
+    if (n > 0) {
+        int blocks = agb_cdiv(n, TPB);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_coords_bbox, dim3(blocks), dim3(TPB), 0, s, (const int4*)coords, n, n_dev, bbox);
+    }
+    AGB_CHECK_LAUNCH("agb_coords_bbox");
+    return AGB_OK;
+}
+
+static int fill_grid(int32_t* grid, const int32_t* desc, hipStream_t s) {
+    long long cells = desc_cells(desc);
+    if (cells <= 0 || cells > 0x7FFFFFFFLL) {
+        agb_set_error("dense grid of %lld cells is out of range (use the hash mode)", cells);
+        return AGB_ERANGE;
+    }
+    hipLaunchKernelGGL(k_fill_i32, dim3(agb_cdiv(cells, TPB)), dim3(TPB), 0, s, grid, (int)cells, INT_MAX);
+    return AGB_OK;
+}
+
+int agb_grid_insert(const int32_t* coords, int n, const int32_t* n_dev, const int32_t* desc, int32_t* grid,
+                    long long* cell_of_row, int32_t* status, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = fill_grid(grid, desc, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s, status, 4, 0);
+    if (n > 0) {
+        dim3 g(agb_cdiv(n, TPB)), b(TPB);
+        hipLaunchKernelGGL(k_grid_insert, g, b, 0, s, (const int4*)coords, n, n_dev, mk_desc(desc), grid, cell_of_row,
+                           status);
+        hipLaunchKernelGGL(k_grid_count_dups, g, b, 0, s, n, n_dev, grid, cell_of_row, status);
+    }
+    AGB_CHECK_LAUNCH("agb_grid_insert");
+    return AGB_OK;
+}
+
+// desc describes the OUTPUT level (ts = ts_out). status[1] counts rows that fall outside the grid.
+int agb_grid_stride(const int32_t* in_coords, int n, const int32_t* n_dev, const int32_t* desc, int32_t* grid,
+                    long long* cell_of_row, int32_t* flags, int32_t* excl, int32_t* scratch, int32_t* out_coords,
+                    int32_t* n_out_dev, int32_t* status, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = fill_grid(grid, desc, s);
+    if (rc) return rc;
+    if (n == 0) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s, n_out_dev, 1, 0);
+        AGB_CHECK_LAUNCH("agb_grid_stride");
+        return AGB_OK;
+    }
+    dim3 g(agb_cdiv(n, TPB)), b(TPB);
+    GridDesc gd = mk_desc(desc);
+    hipLaunchKernelGGL(k_grid_stride_insert, g, b, 0, s, (const int4*)in_coords, n, n_dev, gd, grid, cell_of_row,
+                       status);
+    hipLaunchKernelGGL(k_grid_stride_flag, g, b, 0, s, n, n_dev, grid, cell_of_row, flags);
+    int nb = agb_cdiv(n, SCAN_BLOCK);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), b, 0, s, flags, n, scratch);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, scratch, nb, n_out_dev);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), b, 0, s, flags, n, scratch, excl);
+    hipLaunchKernelGGL(k_grid_stride_emit, g, b, 0, s, (const int4*)in_coords, n, n_dev, gd.ts, flags, excl,
+                       cell_of_row, grid, (int4*)out_coords);
+    AGB_CHECK_LAUNCH("agb_grid_stride");
+    return AGB_OK;
+}
+
+// Same contract as agb_kernel_map, probing a dense grid (desc/grid of the PROBED level). The lattice check of the
+// transposed map is implied by the grid's own stride.
+int agb_grid_kernel_map(const int32_t* q_coords, int n, const int32_t* n_dev, int K, int step, int sign,
+                        const int32_t* desc, const int32_t* grid, int32_t* nbr, long long nbr_stride,
+                        unsigned long long* pair_count, void* stream) {
+    AGB_CHECK_ARG(K >= 1 && K <= 9, "agb_grid_kernel_map: kernel size %d unsupported", K);
+    AGB_CHECK_ARG(nbr_stride >= n, "agb_grid_kernel_map: nbr_stride < n");
+    if (n == 0) return AGB_OK;
+    hipLaunchKernelGGL(k_grid_kernel_map, dim3(agb_cdiv(n, TPB), K * K), dim3(TPB), 0, (hipStream_t)stream,
+                       (const int4*)q_coords, n, n_dev, K, step, sign, mk_desc(desc), grid, nbr, nbr_stride,
+                       pair_count);
+    AGB_CHECK_LAUNCH("agb_grid_kernel_map");
     return AGB_OK;
 }
 

@@ -60,18 +60,24 @@ __global__ void k_maxpool_bwd(const float* __restrict__ dY, int ldy, const int32
 }
 
 // ------------------------------------------------------------ segment reduce
-// grid (B, ceil(C/64)), block 256 = 4 row lanes x 64 channels.
+// grid (B, ceil(C/64), S), block 256 = 4 row lanes x 64 channels. Segment b is cut into S contiguous row
+// chunks so that long segments (6.8k rows/plot at 64 channels) still fill the chip; chunk partials go to
+// `part` [B*S, C] (and `part_arg`) and a second tiny kernel folds them in a fixed order (deterministic).
 // mode 0 sum, 1 average, 2 max (arg receives the winning row); optional second operand: reduce A*Bm.
 __global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict__ A, int lda,
                                                         const float* __restrict__ Bm, int ldb,
-                                                        const int32_t* __restrict__ ptr, int C, int mode,
+                                                        const int32_t* __restrict__ ptr, int C, int mode, int S,
                                                         float* __restrict__ Y, int32_t* __restrict__ arg) {
     __shared__ float s_val[4][64];
     __shared__ int s_arg[4][64];
     const int b = blockIdx.x;
     const int c = blockIdx.y * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
-    const int beg = ptr[b], end = ptr[b + 1];
+    const int seg_beg = ptr[b], seg_end = ptr[b + 1];
+    const int len = seg_end - seg_beg;
+    const int chunk = (len + S - 1) / S;
+    const int beg = seg_beg + blockIdx.z * chunk;
+    const int end = min(seg_end, beg + chunk);
     float acc = (mode == 2) ? -FLT_MAX : 0.f;
     int ai = -1;
     if (c < C) {
@@ -91,22 +97,45 @@ __global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict_
     if (rl == 0 && c < C) {
         int l = threadIdx.x & 63;
         if (mode == 2) {
-            // rows visited by lane j are j, j+4, ...; keep the smallest row on ties
             for (int j = 1; j < 4; ++j) {
                 float v = s_val[j][l];
                 int a = s_arg[j][l];
                 if (a >= 0 && (v > acc || (v == acc && a < ai))) { acc = v; ai = a; }
             }
-            if (ai < 0) acc = 0.f;
-            arg[(long long)b * C + c] = ai;
+            if (S == 1 && ai < 0) acc = 0.f;
+            arg[((long long)b * S + blockIdx.z) * C + c] = ai;
         } else {
             acc = ((s_val[0][l] + s_val[1][l]) + (s_val[2][l] + s_val[3][l]));
-            if (mode == 1) {
-                int n = end - beg;
-                acc = n > 0 ? acc / (float)n : 0.f;
-            }
+            if (mode == 1 && S == 1) acc = len > 0 ? acc / (float)len : 0.f;
         }
-        Y[(long long)b * C + c] = acc;
+        Y[((long long)b * S + blockIdx.z) * C + c] = acc;
+    }
+}
+
+__global__ void k_segment_fold(const float* __restrict__ part, const int32_t* __restrict__ part_arg,
+                               const int32_t* __restrict__ ptr, int B, int C, int mode, int S,
+                               float* __restrict__ Y, int32_t* __restrict__ arg) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    int b = t / C, c = t % C;
+    if (mode == 2) {
+        float best = -FLT_MAX;
+        int bi = -1;
+        for (int s = 0; s < S; ++s) {
+            int a = part_arg[((long long)b * S + s) * C + c];
+            float v = part[((long long)b * S + s) * C + c];
+            if (a >= 0 && (v > best || (v == best && a < bi) || bi < 0)) { best = v; bi = a; }
+        }
+        Y[t] = bi >= 0 ? best : 0.f;
+        arg[t] = bi;
+    } else {
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += part[((long long)b * S + s) * C + c];
+        if (mode == 1) {
+            int len = ptr[b + 1] - ptr[b];
+            acc = len > 0 ? acc / (float)len : 0.f;
+        }
+        Y[t] = acc;
     }
 }
 
@@ -165,13 +194,26 @@ int agb_maxpool_bwd(const float* dY, int ldy, const int32_t* argmax, const int32
     return AGB_OK;
 }
 
+// splits == 1: direct. splits > 1: `part` float[B*splits*C] (and `part_arg` int32[B*splits*C] for max) are
+// caller-provided scratch for the chunk partials.
 int agb_segment_reduce(const float* A, int lda, const float* Bm, int ldb, const int32_t* ptr, int B, int C, int mode,
-                       float* Y, int32_t* argmax, void* stream) {
+                       int splits, float* part, int32_t* part_arg, float* Y, int32_t* argmax, void* stream) {
     AGB_CHECK_ARG(mode >= 0 && mode <= 2, "agb_segment_reduce: mode %d", mode);
     AGB_CHECK_ARG(mode != 2 || argmax != nullptr, "agb_segment_reduce: max mode needs an argmax buffer");
+    AGB_CHECK_ARG(splits >= 1 && splits <= 1024, "agb_segment_reduce: splits %d", splits);
+    AGB_CHECK_ARG(splits == 1 || (part != nullptr && (mode != 2 || part_arg != nullptr)),
+                  "agb_segment_reduce: splits > 1 needs scratch buffers");
     if (B == 0 || C == 0) return AGB_OK;
-    hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, A, lda, Bm, ldb,
-                       ptr, C, mode, Y, argmax);
+    hipStream_t s = (hipStream_t)stream;
+    if (splits == 1) {
+        hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64), 1), dim3(256), 0, s, A, lda, Bm, ldb, ptr, C,
+                           mode, 1, Y, argmax);
+    } else {
+        hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64), splits), dim3(256), 0, s, A, lda, Bm, ldb, ptr,
+                           C, mode, splits, part, part_arg);
+        hipLaunchKernelGGL(k_segment_fold, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, s, part, part_arg,
+                           ptr, B, C, mode, splits, Y, argmax);
+    }
     AGB_CHECK_LAUNCH("agb_segment_reduce");
     return AGB_OK;
 }

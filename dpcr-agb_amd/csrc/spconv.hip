@@ -152,6 +152,127 @@ __global__ __launch_bounds__(256) void k_spconv_fwd(const float* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Generic path, software-pipelined: while the MFMAs of K-chunk i run, the gathers of chunk i+1 are in
+// flight into registers and the neighbour indices of chunk i+2 are being fetched (the index -> gather
+// dependency would otherwise expose two L2 latencies per chunk).  TM x 64 output tile:
+//   TM = 64 : 2x2 waves, each 32x32            (few-row layers: keeps enough workgroups to fill 256 CUs)
+//   TM = 128: 4x1 waves, each 32 rows x 64 cols (W tile reused by 128 rows: 21.8 FLOP per staged byte)
+template <int TM>
+__global__ __launch_bounds__(256) void k_spconv_fwd_pipe(const float* __restrict__ X, int ldx,
+                                                         const float* __restrict__ W,
+                                                         const int32_t* __restrict__ nbr, long long nbr_stride,
+                                                         int kflip, const float* __restrict__ bias,
+                                                         float* __restrict__ Y, int ldy, int n_out, int K3, int Cin,
+                                                         int Cout) {
+    constexpr int WAVES_M = TM / 32;       // 2 or 4
+    constexpr int WAVES_N = 4 / WAVES_M;   // 2 or 1
+    constexpr int NT = 2 / WAVES_N;        // 32-col accumulators per wave: 1 or 2
+    constexpr int AJ = TM / 32;            // float4 A gathers per thread per chunk
+    __shared__ __attribute__((aligned(16))) float As[TM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int row0 = blockIdx.x * TM;
+    const int n0 = blockIdx.y * BN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_r = tid >> 3, a_c = (tid & 7) * 4;     // A: row (+32j), channel offset in chunk
+    const int b_r = tid >> 4, b_c = (tid & 15) * 4;    // B: k row (+16j), output offset
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int cpk = (Cin + BK - 1) / BK;
+    const int nchunks = K3 * cpk;
+
+    int idx_cur[AJ], idx_nxt[AJ];
+    float4 a_reg[AJ], b_reg[2];
+
+    auto load_idx = [&](int ch, int* dst) {
+        int k = ch / cpk;
+        int kn = kflip ? (K3 - 1 - k) : k;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            int r = row0 + a_r + 32 * j;
+            dst[j] = (ch < nchunks && r < n_out) ? nbr[(long long)kn * nbr_stride + r] : -1;
+        }
+    };
+    auto load_data = [&](int ch, const int* idx) {
+        int k = ch / cpk;
+        int c0 = (ch - k * cpk) * BK;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx[j] >= 0 && c0 + a_c < Cin)
+                a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)idx[j] * ldx + c0 + a_c);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int kr = b_r + 16 * j;
+            b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + kr < Cin && n0 + b_c < Cout)
+                b_reg[j] = *reinterpret_cast<const float4*>(W + ((long long)k * Cin + c0 + kr) * Cout + n0 + b_c);
+        }
+    };
+
+    load_idx(0, idx_cur);
+    load_idx(1, idx_nxt);
+    load_data(0, idx_cur);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            *reinterpret_cast<float4*>(&As[(a_r + 32 * j) * LDA + a_c]) = a_reg[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&Bs[(b_r + 16 * j) * LDB + b_c]) = b_reg[j];
+        __syncthreads();
+        if (ch + 1 < nchunks) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) idx_cur[j] = idx_nxt[j];
+            load_data(ch + 1, idx_cur);   // in flight during the MFMAs below
+            load_idx(ch + 2, idx_nxt);
+        }
+        const float* arow = &As[(wm * 32 + li) * LDA + 4 * lh];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * t);
+            const int kb = 8 * t + 4 * lh;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float* bcol = &Bs[(wn * NT + nt) * 32 + li];
+                float b0 = bcol[(kb + 0) * LDB];
+                float b1 = bcol[(kb + 1) * LDB];
+                float b2 = bcol[(kb + 2) * LDB];
+                float b3 = bcol[(kb + 3) * LDB];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + (wn * NT + nt) * 32 + li;
+        if (col < Cout) {
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int row = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (row < n_out) Y[(long long)row * ldy + col] = acc[nt][reg] + bv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient. grid = (row_chunks, M_tiles, N_tiles); M = K3*Cin rows of the flattened weight.
 //   generic: M tile = 64 input channels of one offset      (Cin % 64 handled by bounds)
 //   CPAD   : M tile = 64/CPAD offsets x CPAD channels
@@ -294,9 +415,13 @@ int agb_spconv_fwd(const float* X, int ldx, const float* W, const int32_t* nbr, 
     else if (Cin == 8)
         hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out,
                            K3, Cin, Cout);
+    else if ((long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, BN) >= 1024)
+        // enough 128-row tiles to give every CU four workgroups: use the tile with the better W reuse
+        hipLaunchKernelGGL(k_spconv_fwd_pipe<128>, dim3(agb_cdiv(n_out, 128), agb_cdiv(Cout, BN)), block, 0, s, X, ldx,
+                           W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout);
     else
-        hipLaunchKernelGGL(k_spconv_fwd<0>, grid, block, 0, s, X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out,
-                           K3, Cin, Cout);
+        hipLaunchKernelGGL(k_spconv_fwd_pipe<64>, grid, block, 0, s, X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy,
+                           n_out, K3, Cin, Cout);
     AGB_CHECK_LAUNCH("agb_spconv_fwd");
     return AGB_OK;
 }

@@ -55,7 +55,12 @@ class MinkowskiBaselineModel(InstanceBase):
         features = data.x
         if self.add_pos:
             features = torch.cat([data.pos, features], 1)
-        self.input = ME.SparseTensor(features=features, coordinates=coords, device=device, batch_size=len(data))
+        self.input = ME.SparseTensor(features=features, coordinates=coords, device=device, batch_size=len(data),
+                                     bounds=getattr(data, "coord_bounds", None))
+        strides = getattr(self.model, "tensor_strides", None)
+        if strides:
+            # whole coordinate pyramid in one go: a single host read-back per batch instead of one per level
+            self.input.coordinate_manager.prefetch_strides(strides)
         if len(self.loss_fns) > 0:
             bs = len(data)
             if self.has_reg_targets and data.y_reg is not None:

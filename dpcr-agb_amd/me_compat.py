@@ -26,13 +26,13 @@ class SparseTensor:
     def __init__(self, features: torch.Tensor, coordinates: Optional[torch.Tensor] = None,
                  coordinate_map_key: Optional[CoordinateMapKey] = None,
                  coordinate_manager: Optional[CoordinateManager] = None, tensor_stride: int = 1, device=None,
-                 batch_size: Optional[int] = None, **kwargs):
+                 batch_size: Optional[int] = None, bounds=None, coordinate_mode: str = "auto", **kwargs):
         if coordinates is not None:
             if device is None:
                 device = features.device
             ts = _as_int(tensor_stride)
             coordinate_manager = CoordinateManager(coordinates, device=device, tensor_stride=ts,
-                                                   batch_size=batch_size)
+                                                   batch_size=batch_size, bounds=bounds, mode=coordinate_mode)
             coordinate_map_key = CoordinateMapKey(ts)
             features = features.to(device=coordinate_manager.device, dtype=torch.float32, non_blocking=True)
         if coordinate_manager is None or coordinate_map_key is None:

@@ -144,6 +144,22 @@ class MaxPoolFunction(torch.autograd.Function):
 _MODES = {"sum": 0, "avg": 1, "max": 2}
 
 
+def segment_reduce(a, bm, ptr, B, mode_id):
+    """[N, C] -> [B, C] per-batch reduction (optionally of a*bm); long segments are cut into row chunks so the
+    launch fills the chip, partials folded in a fixed order."""
+    n, c = a.shape
+    y = torch.empty(B, c, dtype=torch.float32, device=a.device)
+    arg = torch.empty(B, c, dtype=torch.int32, device=a.device) if mode_id == 2 else None
+    splits = max(1, min(64, (n // max(B, 1)) // 256))
+    part = part_arg = None
+    if splits > 1:
+        part = torch.empty(B * splits, c, dtype=torch.float32, device=a.device)
+        part_arg = torch.empty(B * splits, c, dtype=torch.int32, device=a.device) if mode_id == 2 else None
+    _lib.call("agb_segment_reduce", _P(a), a.stride(0), _P(bm), 0 if bm is None else bm.stride(0), _P(ptr), B, c,
+              mode_id, splits, _P(part), _P(part_arg), _P(y), _P(arg), _lib.stream())
+    return y, arg
+
+
 class GlobalPoolFunction(torch.autograd.Function):
     """Per-batch segment reduction of [N, C] rows -> [B, C]."""
 
@@ -152,9 +168,7 @@ class GlobalPoolFunction(torch.autograd.Function):
         x = feats.contiguous()
         n, c = x.shape
         m = _MODES[mode]
-        y = torch.empty(B, c, dtype=torch.float32, device=x.device)
-        arg = torch.empty(B, c, dtype=torch.int32, device=x.device) if m == 2 else None
-        _lib.call("agb_segment_reduce", _P(x), x.stride(0), None, 0, _P(ptr), B, c, m, _P(y), _P(arg), _lib.stream())
+        y, arg = segment_reduce(x, None, ptr, B, m)
         ctx.save_for_backward(coords, ptr, arg if arg is not None else torch.empty(0))
         ctx.dims = (n, c, B, m)
         return y
@@ -204,7 +218,5 @@ class BroadcastMulFunction(torch.autograd.Function):
             _lib.call("agb_segment_broadcast", _P(s), _P(coords), _P(ptr), _P(dout), dout.stride(0), _P(dx),
                       dx.stride(0), n, c, 0, _lib.stream())
         if ctx.needs_input_grad[1]:
-            ds = torch.empty(B, c, dtype=torch.float32, device=x.device)
-            _lib.call("agb_segment_reduce", _P(dout), dout.stride(0), _P(x), x.stride(0), _P(ptr), B, c, 0, _P(ds),
-                      None, _lib.stream())
+            ds, _ = segment_reduce(dout, x, ptr, B, 0)
         return dx, ds, None, None

@@ -77,10 +77,14 @@ def voxelize_host(pos: np.ndarray, perm: np.ndarray, size: float):
 class PlotBatch:
     """Stand-in for the torch_geometric ``Batch`` the reference feeds to ``model.set_input``."""
 
-    def __init__(self, batch, coords, x, pos, y_reg=None, y_reg_mask=None, num_plots=None):
+    def __init__(self, batch, coords, x, pos, y_reg=None, y_reg_mask=None, num_plots=None, coord_bounds=None):
         self.batch, self.coords, self.x, self.pos = batch, coords, x, pos
         self.y_reg, self.y_reg_mask = y_reg, y_reg_mask
         self._n = int(num_plots) if num_plots is not None else int(batch.max().item()) + 1
+        # (min_x, min_y, min_z, max_x, max_y, max_z) of the voxel coordinates: a by-product of voxelisation
+        if coord_bounds is None and coords is not None and len(coords) > 0:
+            coord_bounds = tuple(coords.min(0).values.tolist()) + tuple(coords.max(0).values.tolist())
+        self.coord_bounds = coord_bounds
 
     def __len__(self):
         return self._n
@@ -94,7 +98,7 @@ class PlotBatch:
     def to(self, device, non_blocking=True):
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)  # noqa: E731
         return PlotBatch(mv(self.batch), mv(self.coords), mv(self.x), mv(self.pos), mv(self.y_reg),
-                         mv(self.y_reg_mask), self._n)
+                         mv(self.y_reg_mask), self._n, self.coord_bounds)
 
     @property
     def ptr(self):

@@ -63,6 +63,20 @@ int agb_kernel_map(const int32_t* q_coords, int n, const int32_t* n_dev, int K, 
                    int require_multiple_of, const uint64_t* keys, const int32_t* vals, int cap, int32_t* nbr,
                    long long nbr_stride, unsigned long long* pair_count, void* stream);
 
+/* Dense-grid mode (small bounding volumes, e.g. LiDAR plots): every level keeps int32 grid[B][Z][Y][X]
+ * (x fastest, INT_MAX = empty) described by desc = {ox, oy, oz, X, Y, Z, ts, B} (HOST int32[8]; origin a multiple
+ * of ts).  Same results as the hash entry points above, one load per probe. */
+int agb_coords_bbox(const int32_t* coords, int n, const int32_t* n_dev, int32_t* bbox /* dev int32[8]:
+                    min x,y,z, max x,y,z, max batch */, void* stream);
+int agb_grid_insert(const int32_t* coords, int n, const int32_t* n_dev, const int32_t* desc, int32_t* grid,
+                    long long* cell_of_row /* [n] scratch */, int32_t* status, void* stream);
+int agb_grid_stride(const int32_t* in_coords, int n, const int32_t* n_dev, const int32_t* desc /* OUTPUT level */,
+                    int32_t* grid, long long* cell_of_row, int32_t* flags, int32_t* excl, int32_t* scratch,
+                    int32_t* out_coords, int32_t* n_out_dev, int32_t* status, void* stream);
+int agb_grid_kernel_map(const int32_t* q_coords, int n, const int32_t* n_dev, int K, int step, int sign,
+                        const int32_t* desc /* PROBED level */, const int32_t* grid, int32_t* nbr,
+                        long long nbr_stride, unsigned long long* pair_count, void* stream);
+
 /* Row range of every batch element: ptr int32[B+1]. */
 int agb_batch_ptr(const int32_t* coords, int n, const int32_t* n_dev, int B, int32_t* ptr, void* stream);
 
@@ -90,9 +104,11 @@ int agb_maxpool_fwd(const float* X, int ldx, const int32_t* nbr, long long nbr_s
                     int32_t* argmax /* [n_out, C] */, int n_out, int K3, int C, void* stream);
 int agb_maxpool_bwd(const float* dY, int ldy, const int32_t* argmax, const int32_t* nbrT, long long nbrT_stride,
                     float* dX, int ldx, int n_in, int K3, int C, void* stream);
-/* Y[b,:] = reduce over rows ptr[b]..ptr[b+1] of A (optionally A*Bm); mode 0 sum, 1 average, 2 max (+argmax rows) */
+/* Y[b,:] = reduce over rows ptr[b]..ptr[b+1] of A (optionally A*Bm); mode 0 sum, 1 average, 2 max (+argmax rows).
+ * splits > 1 cuts every segment into that many row chunks (scratch: part float[B*splits*C], part_arg
+ * int32[B*splits*C] for max) folded in a fixed order: deterministic, no float atomics. */
 int agb_segment_reduce(const float* A, int lda, const float* Bm, int ldb, const int32_t* ptr, int B, int C, int mode,
-                       float* Y, int32_t* argmax, void* stream);
+                       int splits, float* part, int32_t* part_arg, float* Y, int32_t* argmax, void* stream);
 /* out[r,:] = S[batch(r),:] (/ rows of the batch if average) (* M[r,:] if M) */
 int agb_segment_broadcast(const float* S, const int32_t* coords, const int32_t* ptr, const float* M, int ldm,
                           float* out, int ldo, int n, int C, int average, void* stream);

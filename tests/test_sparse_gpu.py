@@ -29,18 +29,21 @@ def random_coords(rng, B, n_per, extent, negative=False):
     return np.concatenate(rows).astype(np.int64)
 
 
-def _cm(coords, device):
+def _cm(coords, device, mode="auto", on_device=False):
     from dpcr_agb_amd.coords import CoordinateManager
-    cm = CoordinateManager(torch.from_numpy(coords).int(), device=device)
+    c = torch.from_numpy(coords).int()
+    cm = CoordinateManager(c.to(device) if on_device else c, device=device, mode=mode)
     cm.validate()
+    assert mode == "auto" or cm.mode == mode
     return cm
 
 
+@pytest.mark.parametrize("mode", ["grid", "hash"])
 @pytest.mark.parametrize("negative", [False, True])
-def test_levels_and_kernel_maps_exact(device, negative):
+def test_levels_and_kernel_maps_exact(device, negative, mode):
     rng = np.random.default_rng(0)
     coords = random_coords(rng, 3, 700, 12, negative)
-    cm = _cm(coords, device)
+    cm = _cm(coords, device, mode, on_device=negative)
     ref = R.Coords(coords, 3)
     for ts_in, K, s in [(1, 3, 1), (1, 7, 1), (1, 3, 2), (2, 3, 1), (2, 3, 2), (2, 1, 2), (4, 3, 1), (1, 2, 2)]:
         nbr = cm.kernel_map(ts_in, K, s).cpu().numpy()
@@ -56,10 +59,30 @@ def test_levels_and_kernel_maps_exact(device, negative):
         assert np.array_equal(np.diff(ptr), counts)
 
 
-def test_transposed_map_inverts_forward(device):
+@pytest.mark.parametrize("mode", ["grid", "hash"])
+def test_prefetched_pyramid_matches_lazy(device, mode):
+    """prefetch_strides (device-side counts, one read-back) gives the same levels as level-by-level creation."""
+    rng = np.random.default_rng(11)
+    coords = random_coords(rng, 4, 2500, 40)
+    lazy = _cm(coords, device, mode)
+    pre = _cm(coords, device, mode)
+    pre.prefetch_strides([1, 2, 2, 4, 8, 16])
+    ts = 1
+    for t in (2, 4, 8, 16):
+        lazy.stride(ts, 2)
+        ts = t
+        a, b = lazy.level(t), pre.level(t)
+        assert a.n == b.n and torch.equal(a.coords[:a.n], b.coords[:b.n])
+        assert torch.equal(lazy.batch_ptr(t), pre.batch_ptr(t))
+    assert torch.equal(lazy.kernel_map(4, 3, 2), pre.kernel_map(4, 3, 2))
+    assert torch.equal(lazy.transposed_map(8, 3, 2), pre.transposed_map(8, 3, 2))
+
+
+@pytest.mark.parametrize("mode", ["grid", "hash"])
+def test_transposed_map_inverts_forward(device, mode):
     rng = np.random.default_rng(1)
     coords = random_coords(rng, 2, 900, 14)
-    cm = _cm(coords, device)
+    cm = _cm(coords, device, mode)
     for ts_in, K, s in [(1, 3, 2), (2, 1, 2), (1, 2, 2), (1, 3, 1)]:
         nbr = cm.kernel_map(ts_in, K, s).cpu().numpy()
         nbrT = cm.transposed_map(ts_in, K, s).cpu().numpy()
@@ -73,11 +96,15 @@ def test_duplicate_and_order_checks(device):
     from dpcr_agb_amd._lib import AgbError
     from dpcr_agb_amd.coords import CoordinateManager
     dup = torch.tensor([[0, 1, 1, 1], [0, 2, 2, 2], [0, 1, 1, 1]], dtype=torch.int32)
-    with pytest.raises(AgbError):
-        CoordinateManager(dup, device=device).validate()
     unordered = torch.tensor([[1, 1, 1, 1], [0, 2, 2, 2]], dtype=torch.int32)
+    for mode in ("grid", "hash"):
+        with pytest.raises(AgbError):
+            CoordinateManager(dup, device=device, mode=mode).validate()
+        with pytest.raises(AgbError):
+            CoordinateManager(unordered, device=device, mode=mode).validate()
+    # declared bounds that do not contain the data are reported, not silently clipped
     with pytest.raises(AgbError):
-        CoordinateManager(unordered, device=device).validate()
+        CoordinateManager(unordered, device=device, bounds=(0, 0, 0, 1, 1, 1)).validate()
     with pytest.raises(AgbError):
         CoordinateManager(dup, device="cpu")
 
