@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated batches cycled per rank")
     ap.add_argument("--features", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="build each batch's coordinate plan inside set_input")
     ap.add_argument("--cpu-plots", type=int, default=1)
     return ap.parse_args()
 
@@ -62,7 +63,7 @@ def roofline_from_profile(prof):
             continue
         key = id(p)
         if key not in pair_cache:
-            pair_cache[key] = int(p.item())
+            pair_cache[key] = int(p.sum().item())
         pairs = pair_cache[key]
         byts, flops = conv_cost(rec, pairs)
         small = rec["cin"] in (4, 8)
@@ -72,6 +73,22 @@ def roofline_from_profile(prof):
         g["n"] += 1
         g["bytes"] += byts
         g["flops"] += flops
+    # per-layer table (stderr): where the conv time goes
+    layers = {}
+    for rec in prof:
+        if rec["pairs"] is None:
+            continue
+        key = (rec["kind"], rec["K3"], rec["cin"], rec["cout"], rec["rows"] // 1000)
+        pairs = pair_cache[id(rec["pairs"])]
+        e = layers.setdefault(key, [0, 0.0, 0.0, 0])
+        e[0] += 1
+        e[1] += rec["start"].elapsed_time(rec["end"])
+        e[2] += 2.0 * pairs * rec["cin"] * rec["cout"]
+        e[3] += pairs
+    for key, (cnt, ms, fl, pr) in sorted(layers.items(), key=lambda kv: -kv[1][1])[:40]:
+        kind, K3, cin, cout, krows = key
+        log(f"  {kind:5s} K3={K3:3d} {cin:4d}->{cout:4d} rows~{krows:4d}k  n={cnt:3d}  {ms / cnt * 1e3:8.1f} us/launch  "
+            f"{fl / (ms / 1e3) / 1e12:6.1f} TF  density={pr / cnt / (K3 * max(krows, 1) * 1000.0):.2f}")
     if not groups:
         return None, {}
     dom = max(groups, key=lambda k: groups[k]["ms"])
@@ -192,8 +209,12 @@ def main():
     steps_per_epoch = 133  # 4271 train plots / 32
 
     def step(i):
+        # software pipeline of the input path: this step's coordinate pyramid was built on a side stream while the
+        # previous step ran; the next one is built now, behind this step's already-enqueued kernels
         model.set_input(pool[i % len(pool)], dev)
         model.optimize_parameters(epoch=i // steps_per_epoch, batch_size=args.batch, num_batches=steps_per_epoch)
+        if not args.no_prefetch:
+            model.prefetch_input(pool[(i + 1) % len(pool)], dev)
 
     log(f"model + {len(pool)} batches resident ({voxels:.0f} voxels/plot); warmup")
     for i in range(args.warmup):

@@ -42,20 +42,42 @@ class MinkowskiDropPath(nn.Module):
         self.drop_prob = drop_prob
         self.scale_by_keep = scale_by_keep
 
-    def forward(self, x):
+    _RING, _ring, _slot = 64, None, 0  # pinned staging rows: the per-step H2D copies stay asynchronous
+
+    def scale_vector(self, x):
+        """float[B] on the device: keep/(1-p) per batch element, or None when nothing is to be applied."""
         if not self.training:
+            return None
+        B = x.coordinate_manager.batch_size
+        keep_prob = 1 - self.drop_prob
+        keep = [1.0 if random.uniform(0, 1) > self.drop_prob else 0.0 for _ in range(B)]
+        if keep_prob > 0.0 and self.scale_by_keep:
+            keep = [k / keep_prob for k in keep]
+        cls = MinkowskiDropPath
+        if cls._ring is None or cls._ring.shape[1] < B:
+            cls._ring = torch.empty(cls._RING, max(B, 256), dtype=torch.float32).pin_memory()
+        row = cls._ring[cls._slot % cls._RING, :B]
+        cls._slot += 1
+        row.copy_(torch.tensor(keep, dtype=torch.float32))
+        return row.to(x.device, non_blocking=True)
+
+    def forward(self, x):
+        scale = self.scale_vector(x)
+        if scale is None:
             return x
         cm = x.coordinate_manager
-        keep_prob = 1 - self.drop_prob
-        keep = [1.0 if random.uniform(0, 1) > self.drop_prob else 0.0 for _ in range(cm.batch_size)]
-        if all(k == 1.0 for k in keep) and not (keep_prob > 0.0 and self.scale_by_keep):
-            return x
-        scale = torch.tensor(keep, dtype=torch.float32)
-        if keep_prob > 0.0 and self.scale_by_keep:
-            scale = scale / keep_prob
-        scale = scale.to(x.device, non_blocking=True).view(-1, 1).expand(-1, x.F.shape[1]).contiguous()
-        glob = ME.SparseTensor(scale, coordinate_map_key=ME.CoordinateMapKey(0), coordinate_manager=cm)
+        s = scale.view(-1, 1).expand(-1, x.F.shape[1]).contiguous()
+        glob = ME.SparseTensor(s, coordinate_map_key=ME.CoordinateMapKey(0), coordinate_manager=cm)
         return ME.MinkowskiBroadcastMultiplication()(x, glob)
+
+
+def _residual_tail(block, out, residual):
+    """relu(drop_path(out) + residual) (resnet_block.py:70-73) as one fused kernel."""
+    dp = block.drop_path
+    scale = dp.scale_vector(out) if isinstance(dp, MinkowskiDropPath) else None
+    if not isinstance(dp, (MinkowskiDropPath, nn.Identity)):
+        out = dp(out)
+    return ME.fused_residual(out, residual, block.relu, scale)
 
 
 class ConvNormActivation(nn.Module):
@@ -67,7 +89,7 @@ class ConvNormActivation(nn.Module):
         self.act = nn.Identity() if activation_layer is None else activation_layer
 
     def forward(self, x):
-        return self.act(self.norm(self.conv(x)))
+        return ME.fused_norm_act(self.norm, self.act if not isinstance(self.act, nn.Identity) else None, self.conv(x))
 
 
 class BasicBlock(nn.Module):
@@ -88,13 +110,13 @@ class BasicBlock(nn.Module):
         self.drop_path = MinkowskiDropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def _main(self, x):
-        out = self.relu(self.norm1(self.conv1(x)))
+        out = ME.fused_norm_act(self.norm1, self.relu, self.conv1(x))
         return self.norm2(self.conv2(out))
 
     def forward(self, x):
         out = self._main(x)
         residual = self.downsample(x)
-        return self.relu(self.drop_path(out) + residual)
+        return _residual_tail(self, out, residual)
 
 
 class Bottleneck(nn.Module):
@@ -117,14 +139,14 @@ class Bottleneck(nn.Module):
         self.drop_path = MinkowskiDropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def _main(self, x):
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.relu(self.norm2(self.conv2(out)))
+        out = ME.fused_norm_act(self.norm1, self.relu, self.conv1(x))
+        out = ME.fused_norm_act(self.norm2, self.relu, self.conv2(out))
         return self.norm3(self.conv3(out))
 
     def forward(self, x):
         out = self._main(x)
         residual = self.downsample(x)
-        return self.relu(self.drop_path(out) + residual)
+        return _residual_tail(self, out, residual)
 
 
 class SELayer(nn.Module):
@@ -242,6 +264,32 @@ class ResNetBase(nn.Module):
             layers.append(block(self.inplanes, planes, self.act_fn, stride=1, dilation=dilation, dimension=self.D,
                                 drop_path=self.drop_path, bias=self.bias, norm_layer=self.norm_layer))
         return nn.Sequential(*layers)
+
+    def plan_spec(self, input_requires_grad=False):
+        """Kernel maps the forward/backward pass will ask for: (ts_in, K, stride, dilation, need_transposed).
+        Lets the input pipeline build them ahead of time (on a side stream) instead of lazily inside forward."""
+        specs = []
+
+        def visit(conv, ts, needs_dx):
+            if getattr(conv, "use_mm", False):
+                return ts
+            k, s, d = conv.kernel_size, conv.stride, conv.dilation
+            specs.append((ts, k, s, d, needs_dx and not (s == 1 and k % 2 == 1)))
+            return ts * s
+
+        stem, pool = self.blocks[0][0], self.blocks[0][1]
+        ts = visit(stem.conv, 1, input_requires_grad)
+        specs.append((ts, pool.kernel_size, pool.stride, pool.dilation, True))
+        ts *= pool.stride
+        for stage in list(self.blocks)[1:]:
+            for blk in stage:
+                ts_in = ts
+                convs = [blk.conv1, blk.conv2] + ([blk.conv3] if hasattr(blk, "conv3") else [])
+                for c in convs:
+                    ts = visit(c, ts, True)
+                if not isinstance(blk.downsample, nn.Identity):
+                    visit(blk.downsample[0], ts_in, True)
+        return specs
 
     def forward(self, x):
         for block in self.blocks:

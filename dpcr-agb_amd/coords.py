@@ -149,7 +149,10 @@ class CoordinateManager:
         """Host-side check of the insert status (duplicates / range / batch order). One device read."""
         if self._validated:
             return
-        dup, rng, order, _ = self.levels[self.origin_ts].status.tolist()
+        self._check_status(self.levels[self.origin_ts].status.tolist())
+
+    def _check_status(self, status):
+        dup, rng, order, _ = status
         if rng:
             raise _lib.AgbError(f"{rng} coordinates fall outside the supported range (packed 16-bit keys / the "
                                 "declared bounds)")
@@ -247,16 +250,46 @@ class CoordinateManager:
                 todo.append(self._make_level(ts, t))
             ts = t
         pending = [lv for lv in todo if lv.n is None]
-        if pending:
-            counts = torch.cat([lv.n_dev for lv in pending]).tolist()  # the single read-back
-            for lv, c in zip(pending, counts):
+        if pending or not self._validated:
+            # the single read-back: every new level's row count + the insert status (dup / range / order)
+            status = self.levels[self.origin_ts].status
+            vals = torch.cat([lv.n_dev for lv in pending] + [status]).tolist()
+            for lv, c in zip(pending, vals):
                 lv.n, lv.n_dev, lv.bound = int(c), None, int(c)
+            self._check_status(vals[len(pending):])
+
+    def prebuild(self, specs):
+        """Build kernel maps ahead of the forward pass. specs: iterable of (ts_in, K, stride, dilation, need_T)."""
+        for ts_in, K, s, d, need_t in specs:
+            self.kernel_map(ts_in, K, s, d)
+            if need_t:
+                self.transposed_map(ts_in, K, s, d)
+        for ts in list(self.levels):
+            self.batch_ptr(ts)
+
+    def tensors(self):
+        for lvl in self.levels.values():
+            for t in (lvl.coords, lvl.grid, lvl.keys, lvl.vals, lvl._ptr, lvl.status, lvl.n_dev):
+                if t is not None:
+                    yield t
+        for m in self.kernel_maps.values():
+            yield m
+            p = getattr(m, "agb_pairs", None)
+            if p is not None:
+                yield p
+
+    def record_stream(self, stream):
+        """Tell the caching allocator that `stream` uses every tensor of this manager (needed when the manager was
+        built on a side stream and is consumed on the compute stream)."""
+        for t in self.tensors():
+            t.record_stream(stream)
 
     # -------------------------------------------------------------- kernel maps
     def _lookup(self, q: _Level, table: _Level, K, step, sign, require_multiple_of, count_pairs):
         self._resolve(q)
         nbr = torch.empty(K ** 3, max(q.n, 1), dtype=torch.int32, device=self.device)
-        pairs = torch.zeros(1, dtype=torch.int64, device=self.device) if count_pairs else None
+        # sharded counter (64 slots on separate lines); the kernel-map size is the sum — read only by profiling code
+        pairs = torch.zeros(64 * 16, dtype=torch.int64, device=self.device) if count_pairs else None
         if self.mode == "grid":
             _lib.call("agb_grid_kernel_map", _lib.ptr(q.coords), q.n, None, K, step, sign, table.desc_host,
                       _lib.ptr(table.grid), _lib.ptr(nbr), nbr.stride(0), _lib.ptr(pairs), _lib.stream())

@@ -23,6 +23,7 @@ void agb_set_error(const char* fmt, ...) {
 }
 
 #define TPB 256
+#define AGB_PAIR_SHARDS 64  // pair_count buffers are uint64[AGB_PAIR_SHARDS * 16]; the total is the sum of all slots
 
 __device__ __forceinline__ int eff_n(int n_bound, const int32_t* n_dev) {
     if (n_dev) {
@@ -255,7 +256,10 @@ __global__ void k_kernel_map(const int4* __restrict__ q_coords, int n, const int
         unsigned long long m = __ballot(res >= 0);
         unsigned long long active = __ballot(1);
         int leader = __ffsll((long long)active) - 1;
-        if ((int)(threadIdx.x & 63) == leader && m) atomicAdd(pair_count, (unsigned long long)__popcll(m));
+        // AGB_PAIR_SHARDS counters on separate 128-B lines: one hot address saturates at ~90 atomics/us
+        if ((int)(threadIdx.x & 63) == leader && m)
+            atomicAdd(pair_count + 16 * ((blockIdx.x + blockIdx.y) & (AGB_PAIR_SHARDS - 1)),
+                      (unsigned long long)__popcll(m));
     }
 }
 
@@ -414,10 +418,10 @@ __global__ void k_grid_kernel_map(const int4* __restrict__ q_coords, int n, cons
                                   int sign, GridDesc g, const int32_t* __restrict__ grid, int32_t* nbr,
                                   long long nbr_stride, unsigned long long* pair_count) {
     int nn = eff_n(n, n_dev);
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y * blockDim.x + threadIdx.x;  // row block = slow grid axis: its K*K (iy,iz) slices run together (L2 reuse of the probed grid region)
     int cnt = 0;
     if (r < nn) {
-        int iy = blockIdx.y % K, iz = blockIdx.y / K;
+        int iy = blockIdx.x % K, iz = blockIdx.x / K;
         int half = (K & 1) ? K / 2 : 0;
         int4 c = q_coords[r];
         int y = c.z + sign * (iy - half) * step;
@@ -439,7 +443,9 @@ __global__ void k_grid_kernel_map(const int4* __restrict__ q_coords, int n, cons
         // every lane of the wave is active here (no early return above): plain butterfly reduction
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(pair_count, (unsigned long long)cnt);
+        if ((threadIdx.x & 63) == 0 && cnt)
+            atomicAdd(pair_count + 16 * ((blockIdx.x + blockIdx.y + (threadIdx.x >> 6)) & (AGB_PAIR_SHARDS - 1)),
+                      (unsigned long long)cnt);
     }
 }
 
@@ -621,7 +627,7 @@ int agb_grid_kernel_map(const int32_t* q_coords, int n, const int32_t* n_dev, in
     AGB_CHECK_ARG(K >= 1 && K <= 9, "agb_grid_kernel_map: kernel size %d unsupported", K);
     AGB_CHECK_ARG(nbr_stride >= n, "agb_grid_kernel_map: nbr_stride < n");
     if (n == 0) return AGB_OK;
-    hipLaunchKernelGGL(k_grid_kernel_map, dim3(agb_cdiv(n, TPB), K * K), dim3(TPB), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_grid_kernel_map, dim3(K * K, agb_cdiv(n, TPB)), dim3(TPB), 0, (hipStream_t)stream,
                        (const int4*)q_coords, n, n_dev, K, step, sign, mk_desc(desc), grid, nbr, nbr_stride,
                        pair_count);
     AGB_CHECK_LAUNCH("agb_grid_kernel_map");

@@ -1,0 +1,406 @@
+// norm.hip — training-mode BatchNorm over the rows of a [N, C] feature matrix fused with the activation that
+// follows it, plus the fused residual tail.  HBM-bound: every kernel streams rows as 16-B pieces.
+//
+// Replaces, on the reference's hot path,
+//   ME.MinkowskiBatchNorm (= nn.BatchNorm1d on .F) + MinkowskiGELU/ReLU
+//       torch_points3d/modules/MinkowskiEngine/common.py:215-226 (ConvNormActivation), resnet_block.py:62-72,
+//       senet_block.py:83-96, PointNet.py:16-39
+//   nn.BatchNorm1d(momentum 0.02) + ReLU of the KPConv blocks: modules/KPConv/blocks.py:460-535
+// Statistics are combined with Chan's parallel update (count, mean, M2) so that E[x^2]-E[x]^2 cancellation never
+// happens; partials are folded in a fixed order (bitwise reproducible).  The backward pass recomputes the
+// pre-activation from the saved conv output instead of storing it.
+#include "agb_common.h"
+
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_GELU 2
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+    return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == ACT_GELU) {
+        float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+        float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+        return cdf + z * pdf;
+    }
+    return 1.f;
+}
+
+// block = 256 threads = 16 row lanes x 16 column groups of 4 channels (one 64-channel slab, 16 rows / pass)
+#define NB_ROWS 16
+
+// ---------------------------------------------------------------- statistics
+// grid (chunks, ceil(C/64)); part[chunk][3][C] = (count, mean, M2) of the chunk's rows
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ X, int ldx, int n, int C,
+                                                          int rows_per_chunk, float* __restrict__ part) {
+    __shared__ float s_mean[NB_ROWS][64];
+    __shared__ float s_m2[NB_ROWS][64];
+    __shared__ float s_cnt[NB_ROWS];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cg * 4;
+    const int r_beg = blockIdx.x * rows_per_chunk;
+    const int r_end = min(n, r_beg + rows_per_chunk);
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+    float cnt = 0.f;
+    if (c < C) {
+        for (int r = r_beg + rl; r < r_end; r += NB_ROWS) {
+            float4 v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+            cnt += 1.f;
+            float inv = 1.f / cnt;
+            float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float d = x[j] - mean[j];
+                mean[j] += d * inv;
+                m2[j] += d * (x[j] - mean[j]);
+            }
+        }
+    } else {
+        for (int r = r_beg + rl; r < r_end; r += NB_ROWS) cnt += 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_mean[rl][cg * 4 + j] = mean[j];
+        s_m2[rl][cg * 4 + j] = m2[j];
+    }
+    if (cg == 0) s_cnt[rl] = cnt;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int cc = blockIdx.y * 64 + threadIdx.x;
+        float na = 0.f, ma = 0.f, qa = 0.f;
+        for (int j = 0; j < NB_ROWS; ++j) {  // fixed order
+            float nb = s_cnt[j];
+            if (nb == 0.f) continue;
+            float mb = s_mean[j][threadIdx.x], qb = s_m2[j][threadIdx.x];
+            float nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
+        }
+        if (cc < C) {
+            float* p = part + (long long)blockIdx.x * 3 * C;
+            p[cc] = na;
+            p[C + cc] = ma;
+            p[2 * C + cc] = qa;
+        }
+    }
+}
+
+// block = 16 channels x 16 chunk lanes: every lane folds chunks j, j+16, ... in order, the 16 lane results are
+// combined in lane order (fixed order -> bitwise reproducible); writes mean / rstd, updates the running stats
+__global__ __launch_bounds__(256) void k_bn_stats_fold(const float* __restrict__ part, int chunks, int C, float eps,
+                                                       float momentum, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, float* running_mean,
+                                                       float* running_var) {
+    __shared__ float s_n[16][16], s_m[16][16], s_q[16][16];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float na = 0.f, ma = 0.f, qa = 0.f;
+    if (c < C) {
+        for (int j = lane; j < chunks; j += 16) {
+            const float* p = part + (long long)j * 3 * C;
+            float nb = p[c];
+            if (nb == 0.f) continue;
+            float mb = p[C + c], qb = p[2 * C + c];
+            float nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
+        }
+    }
+    s_n[lane][cl] = na; s_m[lane][cl] = ma; s_q[lane][cl] = qa;
+    __syncthreads();
+    if (lane == 0 && c < C) {
+        na = 0.f; ma = 0.f; qa = 0.f;
+        for (int j = 0; j < 16; ++j) {
+            float nb = s_n[j][cl];
+            if (nb == 0.f) continue;
+            float mb = s_m[j][cl], qb = s_q[j][cl];
+            float nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
+        }
+        float var_b = na > 0.f ? qa / na : 0.f;
+        mean[c] = ma;
+        rstd[c] = rsqrtf(var_b + eps);
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ma;
+        if (running_var) {
+            float var_u = na > 1.f ? qa / (na - 1.f) : var_b;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * var_u;
+        }
+    }
+}
+
+// eval mode: mean/rstd from the running statistics
+__global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const float* __restrict__ running_var, int C,
+                                float eps, float* mean, float* rstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = running_mean[c];
+    rstd[c] = rsqrtf(running_var[c] + eps);
+}
+
+// ---------------------------------------------------------------- forward apply: y = act(gamma*(x-mean)*rstd+beta)
+__global__ void k_bn_act_fwd(const float* __restrict__ X, int ldx, int n, int C4, const float* __restrict__ mean,
+                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, int act, float* __restrict__ Y, int ldy) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4), c = (int)(t % C4) * 4;
+    if (r >= n) return;
+    float4 v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+    float4 m = *reinterpret_cast<const float4*>(mean + c);
+    float4 s = *reinterpret_cast<const float4*>(rstd + c);
+    float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 b = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o;
+    o.x = act_fwd((v.x - m.x) * s.x * g.x + b.x, act);
+    o.y = act_fwd((v.y - m.y) * s.y * g.y + b.y, act);
+    o.z = act_fwd((v.z - m.z) * s.z * g.z + b.z, act);
+    o.w = act_fwd((v.w - m.w) * s.w * g.w + b.w, act);
+    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = o;
+}
+
+// ---------------------------------------------------------------- backward
+// pass 1: per chunk, sum(dz) and sum(dz * xhat) with dz = dy * act'(z), z recomputed from x
+__global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restrict__ X, int ldx,
+                                                            const float* __restrict__ dY, int ldy, int n, int C,
+                                                            int rows_per_chunk, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int act,
+                                                            float* __restrict__ part) {
+    __shared__ float s_a[NB_ROWS][64];
+    __shared__ float s_b[NB_ROWS][64];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cg * 4;
+    const int r_beg = blockIdx.x * rows_per_chunk;
+    const int r_end = min(n, r_beg + rows_per_chunk);
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        float m[4], s[4], g[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m[j] = mean[c + j];
+            s[j] = rstd[c + j];
+            g[j] = gamma ? gamma[c + j] : 1.f;
+            b[j] = beta ? beta[c + j] : 0.f;
+        }
+        for (int r = r_beg + rl; r < r_end; r += NB_ROWS) {
+            float4 xv = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+            float4 dv = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+            float x[4] = {xv.x, xv.y, xv.z, xv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float xh = (x[j] - m[j]) * s[j];
+                float dz = d[j] * act_grad(xh * g[j] + b[j], act);
+                sa[j] += dz;
+                sb[j] += dz * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_a[rl][cg * 4 + j] = sa[j];
+        s_b[rl][cg * 4 + j] = sb[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int cc = blockIdx.y * 64 + threadIdx.x;
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < NB_ROWS; ++j) {
+            a += s_a[j][threadIdx.x];
+            b += s_b[j][threadIdx.x];
+        }
+        if (cc < C) {
+            float* p = part + (long long)blockIdx.x * 2 * C;
+            p[cc] = a;
+            p[C + cc] = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_fold(const float* __restrict__ part, int chunks, int C,
+                                                     float* dbeta, float* dgamma) {
+    __shared__ float s_a[16][16], s_b[16][16];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        for (int j = lane; j < chunks; j += 16) {
+            const float* p = part + (long long)j * 2 * C;
+            a += p[c];
+            b += p[C + c];
+        }
+    }
+    s_a[lane][cl] = a; s_b[lane][cl] = b;
+    __syncthreads();
+    if (lane == 0 && c < C) {
+        a = 0.f; b = 0.f;
+        for (int j = 0; j < 16; ++j) { a += s_a[j][cl]; b += s_b[j][cl]; }
+        dbeta[c] = a;
+        dgamma[c] = b;
+    }
+}
+
+// pass 2: dx = gamma*rstd*(dz - [training] (dbeta + xhat*dgamma)/n)
+__global__ void k_bn_act_bwd_apply(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy, int n,
+                                   int C4, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                   const float* __restrict__ dbeta, const float* __restrict__ dgamma, int training,
+                                   float* __restrict__ dX, int lddx) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4), c = (int)(t % C4) * 4;
+    if (r >= n) return;
+    float4 xv = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+    float4 dv = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+    float x[4] = {xv.x, xv.y, xv.z, xv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
+    const float inv_n = training ? 1.f / (float)n : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float m = mean[c + j], s = rstd[c + j];
+        float g = gamma ? gamma[c + j] : 1.f, b = beta ? beta[c + j] : 0.f;
+        float xh = (x[j] - m) * s;
+        float dz = d[j] * act_grad(xh * g + b, act);
+        o[j] = g * s * (dz - (dbeta[c + j] + xh * dgamma[c + j]) * inv_n);
+    }
+    *reinterpret_cast<float4*>(dX + (long long)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ---------------------------------------------------------------- residual tail: y = act(a * s[batch] + r)
+// (the drop-path scale s is optional; reference call sites resnet_block.py:70-73, senet_block.py:92-96)
+__global__ void k_add_act_fwd(const float* __restrict__ A, int lda, const float* __restrict__ R, int ldr,
+                              const float* __restrict__ scale, const int32_t* __restrict__ coords, int n, int C4,
+                              int act, float* __restrict__ Y, int ldy) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4), c = (int)(t % C4) * 4;
+    if (r >= n) return;
+    float s = scale ? scale[coords[4 * (long long)r]] : 1.f;
+    float4 a = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
+    float4 b = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+    float4 o;
+    o.x = act_fwd(a.x * s + b.x, act);
+    o.y = act_fwd(a.y * s + b.y, act);
+    o.z = act_fwd(a.z * s + b.z, act);
+    o.w = act_fwd(a.w * s + b.w, act);
+    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = o;
+}
+
+// dA = dz * s, dR = dz with dz = dY * act'(a*s + r)
+__global__ void k_add_act_bwd(const float* __restrict__ A, int lda, const float* __restrict__ R, int ldr,
+                              const float* __restrict__ scale, const int32_t* __restrict__ coords,
+                              const float* __restrict__ dY, int ldy, int n, int C4, int act, float* __restrict__ dA,
+                              float* __restrict__ dR) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4), c = (int)(t % C4) * 4;
+    if (r >= n) return;
+    float s = scale ? scale[coords[4 * (long long)r]] : 1.f;
+    float4 a = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
+    float4 b = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+    float4 d = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+    float4 dz;
+    dz.x = d.x * act_grad(a.x * s + b.x, act);
+    dz.y = d.y * act_grad(a.y * s + b.y, act);
+    dz.z = d.z * act_grad(a.z * s + b.z, act);
+    dz.w = d.w * act_grad(a.w * s + b.w, act);
+    long long o = (long long)r * (C4 * 4) + c;
+    if (dR) *reinterpret_cast<float4*>(dR + o) = dz;
+    if (dA) *reinterpret_cast<float4*>(dA + o) = make_float4(dz.x * s, dz.y * s, dz.z * s, dz.w * s);
+}
+
+// =============================================================== C ABI
+extern "C" {
+
+int agb_bn_chunks(int n) {
+    // ~512 rows per chunk, at most 512 chunks (x C/64 column slabs of workgroups)
+    int chunks = agb_cdiv(n > 0 ? n : 1, 512);
+    return chunks > 512 ? 512 : chunks;
+}
+
+static int rows_per_chunk(int n, int chunks) { return agb_cdiv(n > 0 ? n : 1, chunks); }
+
+// training != 0: batch statistics of X (and running-stat update if the pointers are given); else mean/rstd from the
+// running statistics.  part: float[agb_bn_chunks(n) * 3 * C] scratch.  mean, rstd: float[C] out.
+int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
+                 float* mean, float* rstd, float* running_mean, float* running_var, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0, "agb_bn_stats: C (%d) and ldx must be multiples of 4", C);
+    hipStream_t s = (hipStream_t)stream;
+    if (!training) {
+        AGB_CHECK_ARG(running_mean && running_var, "agb_bn_stats: eval mode needs running statistics");
+        hipLaunchKernelGGL(k_bn_eval_stats, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, C, eps,
+                           mean, rstd);
+    } else {
+        int chunks = agb_bn_chunks(n);
+        hipLaunchKernelGGL(k_bn_stats_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, n, C,
+                           rows_per_chunk(n, chunks), part);
+        hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, 16)), dim3(256), 0, s, part, chunks, C, eps, momentum,
+                           mean, rstd, running_mean, running_var);
+    }
+    AGB_CHECK_LAUNCH("agb_bn_stats");
+    return AGB_OK;
+}
+
+int agb_bn_act_fwd(const float* X, int ldx, int n, int C, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, int act, float* Y, int ldy, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_bn_act_fwd: C/ld must be multiples of 4");
+    AGB_CHECK_ARG(act >= 0 && act <= 2, "agb_bn_act_fwd: activation %d", act);
+    if (n == 0) return AGB_OK;
+    long long total = (long long)n * (C / 4);
+    hipLaunchKernelGGL(k_bn_act_fwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, n, C / 4,
+                       mean, rstd, gamma, beta, act, Y, ldy);
+    AGB_CHECK_LAUNCH("agb_bn_act_fwd");
+    return AGB_OK;
+}
+
+// part: float[agb_bn_chunks(n) * 2 * C] scratch; dgamma, dbeta: float[C] out (always written); dX: [n, C]
+int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
+                   float* dX, int lddx, float* dgamma, float* dbeta, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0,
+                  "agb_bn_act_bwd: C/ld must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    int chunks = agb_bn_chunks(n);
+    hipLaunchKernelGGL(k_bn_act_bwd_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY, ldy, n, C,
+                       rows_per_chunk(n, chunks), mean, rstd, gamma, beta, act, part);
+    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, 16)), dim3(256), 0, s, part, chunks, C, dbeta, dgamma);
+    if (n > 0 && dX) {
+        long long total = (long long)n * (C / 4);
+        hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, X, ldx, dY, ldy, n, C / 4,
+                           mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx);
+    }
+    AGB_CHECK_LAUNCH("agb_bn_act_bwd");
+    return AGB_OK;
+}
+
+// y = act(A * scale[batch(row)] + R); scale (float[B]) and coords may be NULL (no drop-path)
+int agb_add_act_fwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords, int n,
+                    int C, int act, float* Y, int ldy, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0,
+                  "agb_add_act_fwd: C/ld must be multiples of 4");
+    AGB_CHECK_ARG(scale == nullptr || coords != nullptr, "agb_add_act_fwd: a scale needs the coords (batch column)");
+    if (n == 0) return AGB_OK;
+    long long total = (long long)n * (C / 4);
+    hipLaunchKernelGGL(k_add_act_fwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, A, lda, R, ldr,
+                       scale, coords, n, C / 4, act, Y, ldy);
+    AGB_CHECK_LAUNCH("agb_add_act_fwd");
+    return AGB_OK;
+}
+
+// dA, dR: contiguous [n, C] (either may be NULL)
+int agb_add_act_bwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords,
+                    const float* dY, int ldy, int n, int C, int act, float* dA, float* dR, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0,
+                  "agb_add_act_bwd: C/ld must be multiples of 4");
+    if (n == 0) return AGB_OK;
+    long long total = (long long)n * (C / 4);
+    hipLaunchKernelGGL(k_add_act_bwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, A, lda, R, ldr,
+                       scale, coords, dY, ldy, n, C / 4, act, dA, dR);
+    AGB_CHECK_LAUNCH("agb_add_act_bwd");
+    return AGB_OK;
+}
+
+}  // extern "C"

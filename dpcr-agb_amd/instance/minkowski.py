@@ -48,23 +48,53 @@ class MinkowskiBaselineModel(InstanceBase):
             (head if self.head_namespace in name else backbone).append(p)
         return [{"params": head, **self.head_optim_settings}, {"params": backbone, **self.backbone_optim_settings}]
 
-    def set_input(self, data, device):
-        self.batch_idx = data.batch.squeeze()
+    def _build_input(self, data, device):
         coords = torch.cat([data.batch.unsqueeze(-1).int(), data.coords.int()], -1)
-        self.data_visual = data
         features = data.x
         if self.add_pos:
             features = torch.cat([data.pos, features], 1)
-        self.input = ME.SparseTensor(features=features, coordinates=coords, device=device, batch_size=len(data),
-                                     bounds=getattr(data, "coord_bounds", None))
+        inp = ME.SparseTensor(features=features, coordinates=coords, device=device, batch_size=len(data),
+                              bounds=getattr(data, "coord_bounds", None))
+        cm = inp.coordinate_manager
         strides = getattr(self.model, "tensor_strides", None)
         if strides:
             # whole coordinate pyramid in one go: a single host read-back per batch instead of one per level
-            self.input.coordinate_manager.prefetch_strides(strides)
+            cm.prefetch_strides(strides)
+        if hasattr(self.model, "plan_spec"):
+            cm.prebuild(self.model.plan_spec(input_requires_grad=False))
+        return inp
+
+    def prefetch_input(self, data, device):
+        """Build the NEXT batch's SparseTensor (coordinate levels, kernel maps) on a side stream while the current
+        step's kernels are still running; ``set_input`` picks the result up without a device-wide stall."""
+        if not hasattr(self, "_side_stream"):
+            self._side_stream = torch.cuda.Stream(device=device)
+        side = self._side_stream
+        # NOTE: no wait on the compute stream here (that would serialise the plan behind the whole running step):
+        # the batch tensors must already be materialised (data-loader output / device-resident pool).
+        with torch.cuda.stream(side):
+            inp = self._build_input(data, device)
+            ev = side.record_event()
+        data._prefetched = (inp, ev)
+
+    def set_input(self, data, device):
+        self.batch_idx = data.batch.squeeze()
+        self.data_visual = data
+        pre = getattr(data, "_prefetched", None)
+        if pre is not None:
+            self.input, ev = pre
+            data._prefetched = None
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(ev)
+            self.input.coordinate_manager.record_stream(cur)
+            self.input.F.record_stream(cur)
+        else:
+            self.input = self._build_input(data, device)
         if len(self.loss_fns) > 0:
             bs = len(data)
             if self.has_reg_targets and data.y_reg is not None:
-                self._reg_mask_all = bool(data.y_reg_mask.all())  # host-side: no device sync in the loss
+                mask_all = getattr(data, "y_reg_mask_all", None)  # host-side flag: no device sync in the loss
+                self._reg_mask_all = bool(data.y_reg_mask.all()) if mask_all is None else mask_all
                 self.reg_y_mask = data.y_reg_mask.to(device, non_blocking=True).view(bs, -1)
                 self.reg_y = data.y_reg.to(device, non_blocking=True).view(bs, -1)
 

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from .coords import CoordinateManager, CoordinateMapKey, _as_int
+from .norm_ops import ACT_IDS, AddActFunction, batch_norm_act
 from .sparse_ops import (BroadcastMulFunction, GlobalPoolFunction, MaxPoolFunction, SparseConvFunction)
 
 
@@ -269,6 +270,8 @@ class MinkowskiBatchNorm(nn.Module):
                                  track_running_stats=track_running_stats)
 
     def forward(self, input: SparseTensor) -> SparseTensor:
+        if input.F.shape[1] % 4 == 0:
+            return input._like(batch_norm_act(input.F, self.bn, None))
         return input._like(self.bn(input.F))
 
 
@@ -304,12 +307,14 @@ class MinkowskiDropout(nn.Module):
         return input._like(self.dropout(input.F))
 
 
-def _pointwise(name, torch_cls):
+def _pointwise(name, torch_cls, fused_name=None):
     class _Act(nn.Module):
         def __init__(self, *args, **kwargs):
             super().__init__()
             kwargs.pop("inplace", None)  # features may alias saved activations of the HIP ops
             self.module = torch_cls(*args, **kwargs)
+            # name understood by the fused BN/residual kernels (only for the plain default form)
+            self.act_name = fused_name if not args and not kwargs else None
 
         def forward(self, input: SparseTensor) -> SparseTensor:
             return input._like(self.module(input.F))
@@ -318,14 +323,39 @@ def _pointwise(name, torch_cls):
     return _Act
 
 
-MinkowskiReLU = _pointwise("MinkowskiReLU", nn.ReLU)
-MinkowskiGELU = _pointwise("MinkowskiGELU", nn.GELU)
+MinkowskiReLU = _pointwise("MinkowskiReLU", nn.ReLU, "relu")
+MinkowskiGELU = _pointwise("MinkowskiGELU", nn.GELU, "gelu")
 MinkowskiCELU = _pointwise("MinkowskiCELU", nn.CELU)
 MinkowskiSiLU = _pointwise("MinkowskiSiLU", nn.SiLU)
 MinkowskiELU = _pointwise("MinkowskiELU", nn.ELU)
 MinkowskiSigmoid = _pointwise("MinkowskiSigmoid", nn.Sigmoid)
 MinkowskiTanh = _pointwise("MinkowskiTanh", nn.Tanh)
 MinkowskiLeakyReLU = _pointwise("MinkowskiLeakyReLU", nn.LeakyReLU)
+
+
+def fused_norm_act(norm, act, x: SparseTensor) -> SparseTensor:
+    """act(norm(x)) in one fused BatchNorm+activation kernel pair when norm is a MinkowskiBatchNorm and act a plain
+    ReLU/GELU (the reference's ConvNormActivation / block wiring); otherwise the modules are applied one by one."""
+    name = getattr(act, "act_name", None) if act is not None else "none"
+    if isinstance(norm, MinkowskiBatchNorm) and name is not None and x.F.shape[1] % 4 == 0:
+        return x._like(batch_norm_act(x.F, norm.bn, name))
+    x = norm(x)
+    return act(x) if act is not None else x
+
+
+def fused_residual(out: SparseTensor, residual: SparseTensor, act, drop_scale=None) -> SparseTensor:
+    """act(out * drop_scale[batch] + residual): the tail of every residual block in one kernel."""
+    out._check_same_map(residual)
+    name = getattr(act, "act_name", None)
+    if name is not None and out.F.shape[1] % 4 == 0:
+        lvl = out.coordinate_manager.level(out._ts)
+        return out._like(AddActFunction.apply(out.F, residual.F, drop_scale, lvl.coords, ACT_IDS[name]))
+    if drop_scale is not None:
+        lvl = out.coordinate_manager.level(out._ts)
+        s = drop_scale.view(-1, 1).expand(-1, out.F.shape[1]).contiguous()
+        f = BroadcastMulFunction.apply(out.F, s, lvl.coords, out.coordinate_manager.batch_ptr(out._ts))
+        out = out._like(f)
+    return act(out + residual)
 
 
 class _Namespace:
@@ -340,4 +370,5 @@ MinkowskiNonlinearity = _Namespace()
 for _n in ("ReLU", "GELU", "CELU", "SiLU", "ELU", "Sigmoid", "Tanh", "LeakyReLU"):
     setattr(MinkowskiNonlinearity, "Minkowski" + _n, globals()["Minkowski" + _n])
 
-__all__ = [n for n in dir() if n.startswith("Minkowski")] + ["SparseTensor", "CoordinateManager", "CoordinateMapKey"]
+__all__ = [n for n in dir() if n.startswith("Minkowski")] + ["SparseTensor", "CoordinateManager", "CoordinateMapKey",
+                                                              "fused_norm_act", "fused_residual"]

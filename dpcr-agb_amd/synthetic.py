@@ -85,6 +85,8 @@ class PlotBatch:
         if coord_bounds is None and coords is not None and len(coords) > 0:
             coord_bounds = tuple(coords.min(0).values.tolist()) + tuple(coords.max(0).values.tolist())
         self.coord_bounds = coord_bounds
+        self.y_reg_mask_all = bool(y_reg_mask.all()) if y_reg_mask is not None else None
+        self._prefetched = None
 
     def __len__(self):
         return self._n
@@ -97,8 +99,10 @@ class PlotBatch:
 
     def to(self, device, non_blocking=True):
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)  # noqa: E731
-        return PlotBatch(mv(self.batch), mv(self.coords), mv(self.x), mv(self.pos), mv(self.y_reg),
-                         mv(self.y_reg_mask), self._n, self.coord_bounds)
+        out = PlotBatch(mv(self.batch), mv(self.coords), mv(self.x), mv(self.pos), None, None, self._n,
+                        self.coord_bounds)
+        out.y_reg, out.y_reg_mask, out.y_reg_mask_all = mv(self.y_reg), mv(self.y_reg_mask), self.y_reg_mask_all
+        return out
 
     @property
     def ptr(self):

@@ -58,7 +58,8 @@ int agb_coords_stride(const int32_t* in_coords, int n, const int32_t* n_dev, int
  * q_coords[r] + sign*offset_k*step, or -1.  offset_k, k = ix + K*(iy + K*iz): odd K -> (ix-K/2,..), even K -> (ix,..).
  * Forward map of a conv/pool in->out:  q = out coords, table = in level, sign=+1, require_multiple_of=0.
  * Transposed map (data gradients):     q = in coords, table = out level, sign=-1, require_multiple_of=ts_out.
- * pair_count (optional): device uint64 accumulating the number of non-empty entries (ME's kernel-map size). */
+ * pair_count (optional): device uint64[64*16], zero-filled by the caller: sharded counters (one per 128-B line) whose
+ * SUM is the number of non-empty entries (ME's kernel-map size). */
 int agb_kernel_map(const int32_t* q_coords, int n, const int32_t* n_dev, int K, int step, int sign,
                    int require_multiple_of, const uint64_t* keys, const int32_t* vals, int cap, int32_t* nbr,
                    long long nbr_stride, unsigned long long* pair_count, void* stream);

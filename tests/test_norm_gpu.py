@@ -1,0 +1,103 @@
+"""Fused BatchNorm(+activation) and residual-tail HIP kernels vs plain PyTorch (fp64 reference of the same op;
+reference semantics: nn.BatchNorm1d on .F, common.py:215-226 / resnet_block.py:62-73)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+ACTS = {"none": lambda z: z, "relu": F.relu, "gelu": F.gelu}
+
+
+@pytest.mark.parametrize("n,c", [(1, 64), (37, 4), (5000, 64), (70001, 128), (333, 1024)])
+@pytest.mark.parametrize("act", ["none", "relu", "gelu"])
+def test_bn_act_training(device, n, c, act):
+    from dpcr_agb_amd.norm_ops import batch_norm_act
+    torch.manual_seed(n + c)
+    # a large common offset makes single-pass E[x^2]-E[x]^2 statistics fail; Chan's combine must not
+    # ReLU's derivative jumps at z = 0: keep the offset small there so fp32-vs-fp64 sign flips of z cannot happen
+    x = (torch.randn(n, c) * 0.5 + (0.5 if act == "relu" else 30.0) * torch.randn(1, c)).float()
+    bn = torch.nn.BatchNorm1d(c, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = torch.nn.BatchNorm1d(c, momentum=0.1).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    bn = bn.to(device).train()
+    xg = x.to(device).requires_grad_(True)
+    g = torch.randn(n, c)
+    if n == 1:
+        ref.eval(), bn.eval()  # batch statistics of one row are degenerate: exercise the eval path instead
+    y = batch_norm_act(xg, bn, act)
+    y.backward(g.to(device))
+    xr = x.double().requires_grad_(True)
+    yr = ACTS[act](ref(xr))
+    yr.backward(g.double())
+    assert rel(y, yr) < 5e-5  # fp32 input with |mean| ~ 60 sigma: x - mean alone costs ~6 bits
+    if act == "relu":  # elements within rounding distance of the kink are excluded from the gradient check
+        z = ref(x.double()).detach()
+        keep = (z.abs() > 1e-4)
+        assert rel(xg.grad.cpu() * keep, xr.grad * keep) < 2e-4
+    else:
+        assert rel(xg.grad, xr.grad) < 2e-4
+    assert rel(bn.weight.grad, ref.weight.grad) < 2e-4
+    assert rel(bn.bias.grad, ref.bias.grad) < 2e-4
+    if n > 1:
+        assert rel(bn.running_mean, ref.running_mean) < 1e-5
+        assert rel(bn.running_var, ref.running_var) < 1e-4
+        assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu"])
+def test_add_act(device, act):
+    from dpcr_agb_amd.norm_ops import ACT_IDS, AddActFunction
+    torch.manual_seed(3)
+    n, c, B = 4097, 64, 5
+    a, r = torch.randn(n, c), torch.randn(n, c)
+    batch = torch.sort(torch.randint(0, B, (n,))).values
+    coords = torch.zeros(n, 4, dtype=torch.int32)
+    coords[:, 0] = batch.int()
+    scale = torch.tensor([1 / 0.9, 0.0, 1 / 0.9, 1 / 0.9, 0.0])
+    g = torch.randn(n, c)
+    for use_scale in (False, True):
+        ag, rg = a.to(device).requires_grad_(True), r.to(device).requires_grad_(True)
+        y = AddActFunction.apply(ag, rg, scale.to(device) if use_scale else None, coords.to(device), ACT_IDS[act])
+        y.backward(g.to(device))
+        ar, rr = a.double().requires_grad_(True), r.double().requires_grad_(True)
+        s = scale.double()[batch].unsqueeze(1) if use_scale else 1.0
+        yr = ACTS[act](ar * s + rr)
+        yr.backward(g.double())
+        assert rel(y, yr) < 1e-6
+        assert rel(ag.grad, ar.grad) < 1e-5
+        assert rel(rg.grad, rr.grad) < 1e-5
+
+
+def test_prefetched_input_gives_identical_step(device):
+    """Building the coordinate plan on a side stream ahead of time must not change a single bit of the step."""
+    import random
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_016))
+    batch = synthetic.make_sparse_batch([11, 12, 13], n_points=2000).to(device)
+    outs = []
+    for prefetch in (False, True):
+        torch.manual_seed(0)
+        random.seed(5)
+        model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS["SENet14"]), "minkowski", ds).to(device).train()
+        if prefetch:
+            model.prefetch_input(batch, device)
+        model.set_input(batch, device)
+        model.forward()
+        model.loss.backward()
+        torch.cuda.synchronize()
+        outs.append((model.output.detach().clone(), model.model.blocks[1][0].conv1.kernel.grad.detach().clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    # weight gradients use float atomics across row chunks: equal up to summation order
+    assert rel(outs[0][1], outs[1][1]) < 1e-5
