@@ -1,0 +1,261 @@
+"""KPConv index path on the GPU behind the reference's Python wrappers
+(torch_points3d/modules/KPConv/common.py:8-157):
+
+    batch_neighbors(queries, supports, q_batches, s_batches, radius)          -> int32 [Nq, max_count]
+    batch_grid_subsampling(points, batches_len, features=None, labels=None, sampleDl=0.1, max_p=0, verbose=0,
+                           random_grid_orient=True)                           -> (points, lengths[, features])
+
+numpy in -> numpy out (drop-in for the reference's call sites, models/instance/kpconv.py:184,200,210);
+device tensors in -> device tensors out (no host round trip: what the model wrapper uses).
+Results are bit-identical to the reference's C++ (same float32 operation order, no FMA), except that
+  * neighbours at EXACTLY equal distance are ordered by ascending index (unspecified in the reference), and
+  * subsampled points are emitted in canonical order (cell key ascending per cloud) instead of the iteration order
+    of the reference's unordered_map.
+Extra keyword ``rotations=`` injects the per-cloud grid orientation matrices that the reference draws from
+``np.random`` (common.py:59-66); when omitted they are drawn exactly like the reference does.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_P = _lib.ptr
+_V, _I, _F = _lib.c_void_p, _lib.c_int, _lib.c_float
+_lib.declare("agb_elem_bbox", [_V, _V, _I, _I, _V, _V, _V])
+_lib.declare("agb_elem_of_row", [_V, _I, _I, _V, _V])
+_lib.declare("agb_rotate_points", [_V, _V, _V, _I, _I, _V, _V])
+_lib.declare("agb_ball_grid_build", [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V])
+_lib.declare("agb_ball_query_count", [_V, _I, _V, _V, _V, _V, _V, _F, _V, _V, _V])
+_lib.declare("agb_ball_query_fill", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V])
+_lib.declare("agb_grid_subsample", [_V, _V, _I, _I, _V, _V, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V,
+                                    _V, _V, _V, _V, _V])
+
+MAX_CELLS = 1 << 27
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise _lib.AgbError("the KPConv index kernels need a HIP device (there is no CPU fallback in the product path)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(a, dtype):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=_dev() if not a.is_cuda else a.device, dtype=dtype).contiguous(), True
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=_dev(), dtype=dtype).contiguous(), False
+
+
+def _lengths(v):
+    if isinstance(v, torch.Tensor):
+        v = v.cpu().numpy()
+    return np.asarray(v, dtype=np.int64).reshape(-1)
+
+
+def _ptr_tensor(lens, device):
+    p = np.zeros(len(lens) + 1, dtype=np.int32)
+    np.cumsum(lens, out=p[1:])
+    return torch.from_numpy(p).to(device)
+
+
+def elem_bbox(points, ptr, B):
+    """Per-cloud bounding boxes (device): float [B, 6] = (min xyz, max xyz)."""
+    n = points.shape[0]
+    ordb = torch.empty(6 * B, dtype=torch.int32, device=points.device)
+    out = torch.empty(B, 6, dtype=torch.float32, device=points.device)
+    _lib.call("agb_elem_bbox", _P(points), _P(ptr), B, n, _P(ordb), _P(out), _lib.stream())
+    return out
+
+
+def _elem_of_row(ptr, B, n, device):
+    e = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    _lib.call("agb_elem_of_row", _P(ptr), B, n, _P(e), _lib.stream())
+    return e
+
+
+def _check_shapes(queries, supports, q_batches, s_batches):
+    # same checks (and messages) as cpp_neighbors/wrapper.cpp:127-171
+    if queries.dim() != 2 or queries.shape[1] != 3:
+        raise RuntimeError("Wrong dimensions : query.shape is not (N, 3)")
+    if supports.dim() != 2 or supports.shape[1] != 3:
+        raise RuntimeError("Wrong dimensions : support.shape is not (N, 3)")
+    if len(q_batches) != len(s_batches):
+        raise RuntimeError("Wrong number of batch elements")
+    if int(q_batches.sum()) != queries.shape[0] or int(s_batches.sum()) != supports.shape[0]:
+        raise RuntimeError("Wrong dimensions : batch lengths do not sum to the number of points")
+
+
+def batch_neighbors(queries, supports, q_batches, s_batches, radius, bounds=None):
+    """bounds: optional float (min_x, min_y, min_z, max_x, max_y, max_z) covering every support (saves the
+    bounding-box read-back)."""
+    q, q_is_t = _to_dev(queries, torch.float32)
+    s, _ = _to_dev(supports, torch.float32)
+    ql, sl = _lengths(q_batches), _lengths(s_batches)
+    _check_shapes(q, s, ql, sl)
+    dev = q.device
+    B, nq, ns = len(ql), q.shape[0], s.shape[0]
+    radius = float(np.float32(radius))
+    if nq == 0 or ns == 0:
+        raise RuntimeError("Error")  # the reference raises on an empty result (wrapper.cpp:201-205)
+    q_ptr, s_ptr = _ptr_tensor(ql, dev), _ptr_tensor(sl, dev)
+    if bounds is None:
+        bb = elem_bbox(s, s_ptr, B)
+        lo = bb[:, :3].min(0).values.tolist()   # one host read (pass `bounds` to avoid it)
+        hi = bb[:, 3:].max(0).values.tolist()
+    else:
+        lo, hi = list(bounds[:3]), list(bounds[3:])
+    cs = radius * 1.001
+    while True:
+        dims = [int(np.floor((h - l) / cs)) + 1 for l, h in zip(lo, hi)]
+        if B * dims[0] * dims[1] * dims[2] <= MAX_CELLS:
+            break
+        cs *= 2.0  # coarser cells stay correct for as long as cell >= radius
+    origin_cs = (ctypes.c_float * 4)(lo[0], lo[1], lo[2], cs)
+    dims_c = (ctypes.c_int32 * 4)(dims[0], dims[1], dims[2], B)
+    cells = B * dims[0] * dims[1] * dims[2]
+    cell_start = torch.empty(cells + 1, dtype=torch.int32, device=dev)
+    cell_fill = torch.empty(cells + 1, dtype=torch.int32, device=dev)
+    cell_of = torch.empty(ns, dtype=torch.int32, device=dev)
+    sorted_pts = torch.empty(ns, 4, dtype=torch.float32, device=dev)
+    scratch = torch.empty(_lib.scan_scratch_elems(cells + 1), dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.call("agb_ball_grid_build", _P(s), ns, _P(s_ptr), origin_cs, dims_c, _P(cell_start), _P(sorted_pts),
+              _P(cell_of), _P(cell_fill), _P(scratch), _P(total), _lib.stream())
+    q_elem = _elem_of_row(q_ptr, B, nq, dev)
+    counts = torch.empty(nq, dtype=torch.int32, device=dev)
+    mx = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.call("agb_ball_query_count", _P(q), nq, _P(q_elem), origin_cs, dims_c, _P(cell_start), _P(sorted_pts),
+              radius, _P(counts), _P(mx), _lib.stream())
+    width = int(mx.item())  # the padded matrix the reference returns is as wide as the fullest neighbourhood
+    if width == 0:
+        raise RuntimeError("Error")
+    out = torch.empty(nq, width, dtype=torch.int32, device=dev)
+    status = torch.empty(4, dtype=torch.int32, device=dev)
+    _lib.call("agb_ball_query_fill", _P(q), nq, _P(q_elem), origin_cs, dims_c, _P(cell_start), _P(sorted_pts), radius,
+              ns, width, _P(out), _P(status), _lib.stream())
+    if width > 1024 and int(status[0].item()):
+        raise _lib.AgbError("a neighbourhood holds more than 1024 points: beyond the kernel's LDS capacity")
+    return out if q_is_t else out.cpu().numpy()
+
+
+def create_3D_rotations(axis, angle):
+    """Rotation matrices from axes and angles (same formula and float64 evaluation order as
+    torch_points3d/modules/KPConv/kernel_points.py:38-69)."""
+    t1 = np.cos(angle)
+    t2 = 1 - t1
+    t3 = axis[:, 0] * axis[:, 0]
+    t6 = t2 * axis[:, 0]
+    t7 = t6 * axis[:, 1]
+    t8 = np.sin(angle)
+    t9 = t8 * axis[:, 2]
+    t11 = t6 * axis[:, 2]
+    t12 = t8 * axis[:, 1]
+    t15 = axis[:, 1] * axis[:, 1]
+    t19 = t2 * axis[:, 1] * axis[:, 2]
+    t20 = t8 * axis[:, 0]
+    t24 = axis[:, 2] * axis[:, 2]
+    R = np.stack([t1 + t2 * t3, t7 - t9, t11 + t12, t7 + t9, t1 + t2 * t15, t19 - t20, t11 - t12, t19 + t20,
+                  t1 + t2 * t24], axis=1)
+    return np.reshape(R, (-1, 3, 3))
+
+
+def random_grid_rotations(B):
+    """Draws from np.random in the reference's order (common.py:59-72): theta, phi, alpha, each rand(B)."""
+    theta = np.random.rand(B) * 2 * np.pi
+    phi = (np.random.rand(B) - 0.5) * np.pi
+    u = np.vstack([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
+    alpha = np.random.rand(B) * 2 * np.pi
+    return create_3D_rotations(u.T, alpha).astype(np.float32)
+
+
+def _rotate(points, elem, R_dev, transpose):
+    out = torch.empty_like(points)
+    _lib.call("agb_rotate_points", _P(points), _P(elem), _P(R_dev), points.shape[0], int(transpose), _P(out),
+              _lib.stream())
+    return out
+
+
+def _subsample_core(p, f, lens, dl, bounds_hint=None):
+    dev = p.device
+    B, n = len(lens), p.shape[0]
+    ptr = _ptr_tensor(lens, dev)
+    elem = _elem_of_row(ptr, B, n, dev)
+    if bounds_hint is None:
+        bb = elem_bbox(p, ptr, B)
+        ext = (bb[:, 3:] - bb[:, :3]).max(0).values.tolist()   # one host read
+    else:
+        ext = list(bounds_hint)
+    cap = 1
+    for e in ext:
+        cap *= int(np.floor(e / dl)) + 3
+    if B * cap > MAX_CELLS:
+        raise _lib.AgbError(f"grid subsampling would need {B * cap} cells: sampleDl too small for these clouds")
+    nc = B * cap + 1
+    i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
+    bbox_ord, dims = i32(6 * B), i32(3 * B)
+    origin = torch.empty(3 * B, dtype=torch.float32, device=dev)
+    cell_cnt, cell_start, slot, flag = i32(nc), i32(nc), i32(nc), i32(nc)
+    cell_of, members = i32(max(n, 1)), i32(max(n, 1))
+    scratch = i32(_lib.scan_scratch_elems(nc))
+    out_p = torch.empty(max(n, 1), 3, dtype=torch.float32, device=dev)
+    fdim = 0 if f is None else f.shape[1]
+    out_f = torch.empty(max(n, 1), fdim, dtype=torch.float32, device=dev) if f is not None else None
+    out_ptr, n_out, status = i32(B + 1), i32(1), i32(4)
+    _lib.call("agb_grid_subsample", _P(p), _P(f), fdim, n, _P(ptr), _P(elem), B, float(np.float32(dl)), cap,
+              _P(bbox_ord), _P(origin), _P(dims), _P(cell_cnt), _P(cell_start), _P(slot), _P(flag), _P(cell_of),
+              _P(members), _P(scratch), _P(out_p), _P(out_f), _P(out_ptr), _P(n_out), _P(status), _lib.stream())
+    host = torch.cat([out_ptr, status[:1]]).tolist()   # one host read: sizes of the subsampled clouds
+    if host[-1]:
+        raise _lib.AgbError("grid subsampling: a cloud exceeds the reserved cell capacity")
+    optr = np.asarray(host[:B + 1], dtype=np.int64)
+    m = int(optr[-1])
+    return out_p[:m], (None if out_f is None else out_f[:m]), np.diff(optr).astype(np.int32), elem
+
+
+def batch_grid_subsampling(points, batches_len, features=None, labels=None, sampleDl=0.1, max_p=0, verbose=0,
+                           random_grid_orient=True, rotations=None):
+    if labels is not None:
+        raise NotImplementedError("label voting is not on the AGB regression path (and is broken for ldim > 1 in "
+                                  "the reference, grid_subsampling.cpp:157-158)")
+    p, is_t = _to_dev(points, torch.float32)
+    f = None if features is None else _to_dev(features, torch.float32)[0]
+    lens = _lengths(batches_len)
+    if p.dim() != 2 or p.shape[1] != 3:
+        raise RuntimeError("Wrong dimensions : points.shape is not (N, 3)")
+    if int(lens.sum()) != p.shape[0]:
+        raise RuntimeError("Wrong dimensions : batch lengths do not sum to the number of points")
+    B = len(lens)
+    R = None
+    if random_grid_orient:
+        R = random_grid_rotations(B) if rotations is None else np.asarray(rotations, dtype=np.float32)
+        R_dev = torch.from_numpy(np.ascontiguousarray(R)).to(p.device)
+        ptr = _ptr_tensor(lens, p.device)
+        elem = _elem_of_row(ptr, B, p.shape[0], p.device)
+        p = _rotate(p, elem, R_dev, False)
+    sp, sf, slen, _ = _subsample_core(p, f, lens, sampleDl)
+    if max_p and max_p > 0:
+        keep, off = [], 0
+        for n_b in slen:
+            keep.append(torch.arange(off, off + min(int(n_b), int(max_p)), device=sp.device))
+            off += int(n_b)
+        keep = torch.cat(keep)
+        sp, sf = sp[keep], (None if sf is None else sf[keep])
+        slen = np.minimum(slen, int(max_p)).astype(np.int32)
+    if random_grid_orient:
+        optr = _ptr_tensor(slen, sp.device)
+        oelem = _elem_of_row(optr, B, sp.shape[0], sp.device)
+        sp = _rotate(sp.contiguous(), oelem, R_dev, True)
+    if is_t:
+        res = (sp, torch.from_numpy(slen)) + ((sf,) if sf is not None else ())
+    else:
+        res = (sp.cpu().numpy(), slen) + ((sf.cpu().numpy(),) if sf is not None else ())
+    return res
+
+
+def grid_subsampling(points, features=None, labels=None, sampleDl=0.1, verbose=0):
+    """Single cloud (common.py:8-36)."""
+    n = points.shape[0]
+    res = batch_grid_subsampling(points, [n], features=features, labels=labels, sampleDl=sampleDl,
+                                 random_grid_orient=False)
+    return res[0] if features is None else (res[0], res[2])

@@ -1,0 +1,120 @@
+"""GPU parity of the KPConv index kernels (csrc/kpindex.hip) through the reference's wrapper API against
+the golden vectors produced by the reference's own C++ and against the pinned CPU oracle: bit-exact indices
+(tie order excepted), bit-equal barycentres."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kpconv_index as K
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kpconv_index_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def test_neighbors_golden(device, gold):
+    from dpcr_agb_amd import kp_index
+    pts, lens = gold["A_points"], gold["A_lens"]
+    for r in (0.03125, 0.0625):
+        got = kp_index.batch_neighbors(pts, pts, lens, lens, r)
+        assert got.dtype == np.int32
+        assert np.array_equal(got, gold[f"A_neighbors_r{r}"])
+    for dl, r in ((0.025, 0.03125), (0.05, 0.0625)):
+        sp, sb = gold[f"B_sub_points_dl{dl}"], gold[f"B_sub_lens_dl{dl}"]
+        got = kp_index.batch_neighbors(sp, pts, sb, lens, r)
+        assert K.same_up_to_ties(got, gold[f"B_pool_neighbors_dl{dl}"], sp, pts)
+    pts, lens = gold["C_points"], gold["C_lens"]
+    got = kp_index.batch_neighbors(pts, pts, lens, lens, 0.05)
+    assert K.same_up_to_ties(got, gold["C_neighbors_r0.05"], pts, pts)
+    assert np.array_equal(got, K.batch_neighbors(pts, pts, lens, lens, 0.05))  # same tie rule as the oracle
+
+
+def test_grid_subsampling_golden(device, gold):
+    from dpcr_agb_amd import kp_index
+    pts, feats, lens = gold["A_points"], gold["A_feats"], gold["A_lens"]
+    for dl in (0.025, 0.05):
+        sp, sb, sf = kp_index.batch_grid_subsampling(pts, lens, features=feats, sampleDl=dl,
+                                                     random_grid_orient=False)
+        # canonical order: compare with the oracle's canonical order bit for bit, and as a set with the
+        # reference's emission order
+        op, ob, of = K.batch_grid_subsampling(pts, lens, features=feats, sampleDl=dl, order="canonical")
+        assert np.array_equal(sb, ob) and np.array_equal(sb, gold[f"B_sub_lens_dl{dl}"])
+        assert np.array_equal(sp, op) and np.array_equal(sf, of)
+        ref = np.concatenate([gold[f"B_sub_points_dl{dl}"], gold[f"B_sub_feats_dl{dl}"]], 1)
+        got = np.concatenate([sp, sf], 1)
+        off = 0
+        for n in sb:
+            assert {tuple(x) for x in ref[off:off + n].tolist()} == {tuple(x) for x in got[off:off + n].tolist()}
+            off += n
+    pts, lens = gold["C_points"], gold["C_lens"]
+    sp, sb = kp_index.batch_grid_subsampling(pts, lens, sampleDl=0.04, random_grid_orient=False)
+    assert {tuple(x) for x in sp.tolist()} == {tuple(x) for x in gold["C_sub_points_dl0.04"].tolist()}
+
+
+@pytest.mark.parametrize("n,B,r", [(6144, 4, 0.03125), (6144, 4, 0.125), (16000, 2, 0.03125), (300, 7, 0.5)])
+def test_neighbors_vs_oracle_full_size(device, n, B, r):
+    from dpcr_agb_amd import kp_index, synthetic
+    b = synthetic.make_point_batch(list(range(20, 20 + B)), n_points=n)
+    pts = b.pos.numpy()
+    lens = np.bincount(b.batch.numpy()).astype(np.int32)
+    got = kp_index.batch_neighbors(pts, pts, lens, lens, r)
+    assert np.array_equal(got, K.batch_neighbors(pts, pts, lens, lens, r))
+    # device tensors in -> device tensor out, same values
+    got_t = kp_index.batch_neighbors(torch.from_numpy(pts).to(device), torch.from_numpy(pts).to(device), lens, lens, r)
+    assert got_t.is_cuda and np.array_equal(got_t.cpu().numpy(), got)
+    # size-independent properties: self is the first neighbour (d2 = 0); rows sorted by distance; symmetric relation
+    assert np.array_equal(got[:, 0], np.arange(len(pts)))
+    d2 = K.neighbor_d2(pts, pts, got)
+    finite = np.where(np.isinf(d2), np.float32(3e38), d2)   # shadow entries sort last
+    assert (np.diff(finite, axis=1) >= 0).all()
+    rows, cols = np.nonzero(got < len(pts))
+    pairs = set(zip(rows.tolist(), got[rows, cols].tolist()))
+    assert all((j, i) in pairs for i, j in list(pairs)[:20000])
+
+
+def test_pyramid_with_rotations_matches_oracle(device):
+    """The reference's prepare_inputs chain (kpconv.py:145-264) for two levels, with injected grid orientations."""
+    from dpcr_agb_amd import kp_index, synthetic
+    b = synthetic.make_point_batch([5, 6, 7], n_points=4000)
+    pts = b.pos.numpy()
+    lens = np.bincount(b.batch.numpy()).astype(np.int32)
+    np.random.seed(0)
+    R = kp_index.random_grid_rotations(3)
+    dl, r = 0.025, 0.03125
+    sp, sb = kp_index.batch_grid_subsampling(pts, lens, sampleDl=dl, rotations=R)
+    # oracle: rotate on the host exactly like common.py:76-81, subsample canonically, rotate back (:93-97)
+    rot = pts.copy()
+    i0 = 0
+    for bi, n in enumerate(lens):
+        rot[i0:i0 + n] = np.sum(np.expand_dims(pts[i0:i0 + n], 2) * R[bi], axis=1)
+        i0 += n
+    op, ob = K.batch_grid_subsampling(rot, lens, sampleDl=dl, order="canonical")
+    i0 = 0
+    for bi, n in enumerate(ob):
+        op[i0:i0 + n] = np.sum(np.expand_dims(op[i0:i0 + n], 2) * R[bi].T, axis=1)
+        i0 += n
+    assert np.array_equal(sb, ob)
+    assert np.array_equal(sp, op)
+    pool = kp_index.batch_neighbors(sp, pts, sb, lens, r)
+    assert K.same_up_to_ties(pool, K.batch_neighbors(op, pts, ob, lens, r), op, pts)
+    # drawing the rotations inside consumes np.random exactly like the reference (3 x rand(B))
+    np.random.seed(0)
+    sp2, _ = kp_index.batch_grid_subsampling(pts, lens, sampleDl=dl)
+    assert np.array_equal(sp2, sp)
+
+
+def test_error_behaviour(device):
+    from dpcr_agb_amd import kp_index
+    pts = np.zeros((4, 3), dtype=np.float32)
+    with pytest.raises(RuntimeError):
+        kp_index.batch_neighbors(pts[:, :2], pts, [4], [4], 0.1)
+    with pytest.raises(RuntimeError):
+        kp_index.batch_neighbors(pts, pts, [4], [3], 0.1)
+    with pytest.raises(RuntimeError):
+        kp_index.batch_neighbors(pts[:0], pts, [0], [4], 0.1)
