@@ -4,6 +4,7 @@
 from . import sparse as _sparse
 from .sparse import *  # noqa: F401,F403
 from .pointnet import MinkowskiPointNet  # noqa: F401
+from .kpconv import KPCNN, KPConv  # noqa: F401
 
 _REGISTRY = {name: getattr(_sparse, name) for name in _sparse.__all__ if name[0].isupper()}
 _REGISTRY["MinkowskiPointNet"] = MinkowskiPointNet

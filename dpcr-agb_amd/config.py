@@ -52,3 +52,19 @@ NFI_TARGETS = Opt(
 )
 
 FIRST_SUBSAMPLING = 0.0125  # conf/data/instance/NFI/default.yaml:23 (normalised units)
+
+
+# torch-points3d/conf/models/instance/kpconv.yaml:15-75 (FEAT = dataset feature dimension)
+def kpconv_config(in_features_dim=3, first_subsampling_dl=FIRST_SUBSAMPLING):
+    return Opt(
+        in_points_dim=3, in_features_dim=in_features_dim, in_radius=1.0,
+        architecture=["simple", "resnetb", "resnetb_strided", "resnetb", "resnetb", "resnetb_strided", "resnetb",
+                      "resnetb", "resnetb_strided", "resnetb", "resnetb", "resnetb_strided", "resnetb", "resnetb",
+                      "global_sum"],
+        first_features_dim=64, use_batch_norm=True, batch_norm_momentum=0.02, activation="relu",
+        num_kernel_points=15, first_subsampling_dl=first_subsampling_dl, conv_radius=2.5, deform_radius=5.0,
+        KP_extent=1.0, KP_influence="linear", aggregation_mode="sum", fixed_kernel_points="center", modulated=False,
+        deform_fitting_mode="point2point", deform_fitting_power=1.0, deform_lr_factor=0.1, repulse_extent=1.2)
+
+
+MODEL_OPTIONS["KPConv"] = Opt(conv_type="PARTIAL_DENSE", config=kpconv_config())

@@ -1,0 +1,117 @@
+"""``KPConv`` model wrapper of the reference (torch_points3d/models/instance/kpconv.py:38-276) with the input
+pyramid built ON THE GPU: ``prepare_inputs`` (:145-264) runs 5 radius searches, 4 grid subsamplings and 4 pooled
+radius searches per batch — single-threaded C++ in the reference's training main loop (4.0 s per 32 x 6144-point
+batch measured in SURVEY.md), HIP kernels here (csrc/kpindex.hip), with the index matrices staying on the device
+as int32 instead of travelling host -> device as int64.
+
+Level radii / grid sizes follow the reference: r_0 = first_subsampling_dl * conv_radius, pool grid dl = 2 r / conv_radius,
+r doubles per level (:148,197,234).  Head: one Linear(1024, 1) per regression target (:17-35).
+The reference's ``has_mol_targets`` / ``has_cls_targets`` reads (:126,129) are defects (never defined): treated
+as False.
+"""
+from typing import List
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import kp_index
+from ..backbones.kpconv import KPCNN
+from ..config import Opt
+from .base import InstanceBase
+
+
+class SeparateLinear(nn.Module):
+    def __init__(self, in_channel, num_reg_classes):
+        super().__init__()
+        self.linears = nn.ModuleList([nn.Linear(in_channel, 1, bias=True) for _ in range(max(num_reg_classes, 0))])
+
+    def forward(self, x):
+        return torch.cat([lin(x) for lin in self.linears], 1)
+
+
+class KPConvModel(InstanceBase):
+    def __init__(self, option, model_type, dataset, modules=None):
+        super().__init__(option, model_type, dataset, modules)
+        self.config = config = option.config
+        self.model = KPCNN(config)
+        self.neighborhood_limits: List[int] = []
+        in_channel = self.model.head_mlp.mlp.weight.shape[0]
+        self.head = SeparateLinear(in_channel, self.num_reg_classes)
+        self.head_optim_settings = option.get("head_optim_settings", {})
+        self.backbone_optim_settings = option.get("backbone_optim_settings", {})
+        self.random_grid_orient = option.get("random_grid_orient", True)
+
+    def get_parameter_list(self) -> List[dict]:
+        return [{"params": list(self.head.parameters()), **self.head_optim_settings},
+                {"params": list(self.model.parameters()), **self.backbone_optim_settings}]
+
+    # ------------------------------------------------------------------ input pyramid (kpconv.py:145-264)
+    def _crop(self, mat, layer):
+        if len(self.neighborhood_limits) > 0:
+            return mat[:, :self.neighborhood_limits[layer]].contiguous()
+        return mat
+
+    def prepare_inputs(self, stacked_points, stacked_features, stack_lengths, device, rotations=None):
+        """stacked_points [N,3] / stacked_features [N,F] (numpy or tensors), stack_lengths int[B].
+        rotations: optional list (one float32 [B,3,3] per strided level) replacing the np.random grid orientations."""
+        cfg = self.config
+        pts = torch.as_tensor(stacked_points, dtype=torch.float32).to(device).contiguous()
+        feats = torch.as_tensor(stacked_features, dtype=torch.float32).to(device).contiguous()
+        lens = np.asarray(stack_lengths, dtype=np.int64).reshape(-1)
+        r_normal = cfg.first_subsampling_dl * cfg.conv_radius
+        layer_blocks, points, neighbors, pools, lengths = [], [], [], [], []
+        empty_i = torch.zeros(0, 1, dtype=torch.int32, device=device)
+        level = 0
+        for block in cfg.architecture:
+            if not ("pool" in block or "strided" in block or "global" in block or "upsample" in block):
+                layer_blocks.append(block)
+                continue
+            conv_i = kp_index.batch_neighbors(pts, pts, lens, lens, r_normal) if layer_blocks else empty_i
+            if "pool" in block or "strided" in block:
+                dl = 2 * r_normal / cfg.conv_radius
+                rot = None if rotations is None else rotations[level]
+                pool_p, pool_b = kp_index.batch_grid_subsampling(pts, lens, sampleDl=dl,
+                                                                 random_grid_orient=self.random_grid_orient,
+                                                                 rotations=rot)
+                pool_b = pool_b.numpy().astype(np.int64)
+                pool_i = kp_index.batch_neighbors(pool_p, pts, pool_b, lens, r_normal)
+            else:
+                pool_i, pool_p, pool_b = empty_i, torch.zeros(0, 3, device=device), np.zeros(0, dtype=np.int64)
+            points.append(pts)
+            neighbors.append(self._crop(conv_i, len(points) - 1))
+            pools.append(self._crop(pool_i, len(points) - 1))
+            lengths.append(torch.from_numpy(lens.copy()))
+            pts, lens = pool_p, pool_b
+            r_normal *= 2
+            layer_blocks = []
+            level += 1
+            if "global" in block or "upsample" in block:
+                break
+        ptr = np.zeros(len(lengths[-1]) + 1, dtype=np.int32)
+        np.cumsum(lengths[-1].numpy(), out=ptr[1:])
+        return dict(points=points, neighbors=neighbors, pools=pools, lengths=lengths, features=feats,
+                    last_ptr=torch.from_numpy(ptr).to(device))
+
+    def set_input(self, data, device):
+        self.data_visual = data
+        self.batch_idx = data.batch
+        ptr = data.ptr
+        lens = (ptr[1:] - ptr[:-1]).cpu().numpy().astype(np.int64)
+        self.input = Opt(self.prepare_inputs(data.pos.view(-1, 3), data.x.view(-1, data.x.shape[-1]), lens, device))
+        if len(self.loss_fns) > 0:
+            bs = len(data)
+            if self.has_reg_targets and data.y_reg is not None:
+                mask_all = getattr(data, "y_reg_mask_all", None)
+                self._reg_mask_all = bool(data.y_reg_mask.all()) if mask_all is None else mask_all
+                self.reg_y_mask = data.y_reg_mask.to(device, non_blocking=True).view(bs, -1)
+                self.reg_y = data.y_reg.to(device, non_blocking=True).view(bs, -1)
+
+    def forward(self, *args, **kwargs):
+        out = self.model(self.input)
+        self.output = self.head(out)
+        self.reg_out = self.convert_outputs(self.output)
+        self.compute_loss()
+
+
+KPConv = KPConvModel  # the reference's class name (models/instance/kpconv.py:38)

@@ -1,0 +1,73 @@
+"""autograd bindings of csrc/kpconv.hip (KPConv neighbourhood gather, max-pooled shortcut)."""
+import torch
+
+from . import _lib
+
+_P = _lib.ptr
+_V, _I, _F = _lib.c_void_p, _lib.c_int, _lib.c_float
+_lib.declare("agb_kpconv_gather_fwd", [_V, _V, _V, _I, _I, _V, _I, _V, _I, _F, _V, _I, _I, _V])
+_lib.declare("agb_kpconv_gather_bwd", [_V, _V, _V, _I, _I, _V, _V, _I, _F, _V, _I, _I, _I, _V])
+_lib.declare("agb_kp_maxpool_fwd", [_V, _I, _V, _I, _I, _V, _V, _I, _I, _V])
+_lib.declare("agb_kp_maxpool_bwd", [_V, _V, _V, _I, _I, _I, _V])
+
+
+def as_index(idx):
+    """Neighbour matrices are int32 on the device; the reference hands int64 (kpconv.py:224-225) — converted once."""
+    if idx.dtype != torch.int32:
+        idx = idx.to(torch.int32)
+    return idx.contiguous()
+
+
+class KPGatherFunction(torch.autograd.Function):
+    """wf[n,k,:] = sum_h infl(n,h,k) * x[idx[n,h],:]  (the neighbour-feature gather + kernel-weight correlation)."""
+
+    @staticmethod
+    def forward(ctx, x, q_pts, s_pts, idx, kernel_points, extent):
+        x = x.contiguous()
+        q_pts, s_pts, kernel_points = q_pts.contiguous(), s_pts.contiguous(), kernel_points.contiguous()
+        N, H = idx.shape
+        Ns, cin = x.shape
+        K = kernel_points.shape[0]
+        wf = torch.empty(N, K, cin, dtype=torch.float32, device=x.device)
+        _lib.call("agb_kpconv_gather_fwd", _P(q_pts), _P(s_pts), _P(idx), H, Ns, _P(x), x.stride(0),
+                  _P(kernel_points), K, float(extent), _P(wf), N, cin, _lib.stream())
+        ctx.save_for_backward(q_pts, s_pts, idx, kernel_points)
+        ctx.cfg = (float(extent), Ns, cin)
+        return wf
+
+    @staticmethod
+    def backward(ctx, dwf):
+        q_pts, s_pts, idx, kernel_points = ctx.saved_tensors
+        extent, Ns, cin = ctx.cfg
+        dwf = dwf.contiguous()
+        N, H = idx.shape
+        K = kernel_points.shape[0]
+        dx = torch.zeros(Ns, cin, dtype=torch.float32, device=dwf.device)
+        _lib.call("agb_kpconv_gather_bwd", _P(q_pts), _P(s_pts), _P(idx), H, Ns, _P(dwf), _P(kernel_points), K, extent,
+                  _P(dx), dx.stride(0), N, cin, _lib.stream())
+        return dx, None, None, None, None, None
+
+
+class KPMaxPoolFunction(torch.autograd.Function):
+    """max over the neighbour matrix with a zero shadow row (blocks.py:98-114)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = x.contiguous()
+        N, H = idx.shape
+        Ns, c = x.shape
+        y = torch.empty(N, c, dtype=torch.float32, device=x.device)
+        arg = torch.empty(N, c, dtype=torch.int32, device=x.device)
+        _lib.call("agb_kp_maxpool_fwd", _P(x), x.stride(0), _P(idx), H, Ns, _P(y), _P(arg), N, c, _lib.stream())
+        ctx.save_for_backward(arg)
+        ctx.cfg = (Ns, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        Ns, c = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.zeros(Ns, c, dtype=torch.float32, device=dy.device)
+        _lib.call("agb_kp_maxpool_bwd", _P(dy), _P(arg), _P(dx), dx.stride(0), dy.shape[0], c, _lib.stream())
+        return dx, None
