@@ -1,0 +1,101 @@
+"""GridSampling3D(size, quantize_coords=True, mode="last") on the GPU for a whole batch of clouds
+(reference: torch_points3d/core/data_transform/grid_transform.py:83-140, applied per sample in DataLoader workers).
+
+``voxelize_last(pos, lengths, size, perm=None)`` returns per-cloud voxel coordinates (int32, ascending voxel key:
+z-major / x fastest), the index of the representative point of every voxel in the ORIGINAL stacked order (every
+per-point attribute is then ``attr[keep]``), the new cloud lengths, and the integer bounding box that the sparse
+coordinate manager wants.  ``perm`` is the within-cloud shuffle the reference draws with ``torch.randperm``
+(grid_transform.py:24); pass it to be comparable, omit it to draw one per cloud the same way.
+Only mode="last" is implemented (the NFI sparse pipelines use it: sparse-xy.yaml:95-99).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .kp_index import _elem_of_row, _lengths, _ptr_tensor
+
+_P = _lib.ptr
+_V, _I, _F = _lib.c_void_p, _lib.c_int, _lib.c_float
+_lib.declare("agb_voxelize_last", [_V, _V, _V, _V, _I, _I, _F, _I] + [_V] * 14 + [_V])
+
+
+def draw_permutations(lengths):
+    """One torch.randperm per cloud, in batch order (what shuffle_data does when the transform runs per sample)."""
+    return torch.cat([torch.randperm(int(n)) for n in lengths]) if len(lengths) else torch.zeros(0, dtype=torch.int64)
+
+
+def voxelize_last(pos, lengths, size, perm=None, extent_hint=None):
+    """pos: float [N,3] stacked clouds (tensor, any device); lengths: int [B].
+    extent_hint: optional upper bound of (max - min) of pos/size per axis (saves the sizing read-back)."""
+    lens = _lengths(lengths)
+    B, n = len(lens), int(pos.shape[0])
+    if int(lens.sum()) != n:
+        raise ValueError("lengths do not sum to the number of points")
+    if not torch.cuda.is_available():
+        raise _lib.AgbError("voxelize_last needs a HIP device (no CPU fallback in the product path)")
+    dev = pos.device if pos.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    p = pos.to(device=dev, dtype=torch.float32).contiguous()
+    if perm is None:
+        perm = draw_permutations(lens)
+    perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+    ptr = _ptr_tensor(lens, dev)
+    elem = _elem_of_row(ptr, B, n, dev)
+    size32 = float(np.float32(size))
+    if extent_hint is None:
+        from .kp_index import elem_bbox
+        bb = elem_bbox(p, ptr, B)
+        ext = ((bb[:, 3:] - bb[:, :3]).max(0).values / size32).tolist()   # one host read
+    else:
+        ext = list(extent_hint)
+    cap = 1
+    for e in ext:
+        cap *= int(np.floor(e)) + 3
+    if B * cap >= (1 << 30):
+        raise _lib.AgbError(f"voxel grid of {B * cap} cells is too large: voxel size too small for these clouds")
+    nc = B * cap + 1
+    i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
+    bbox_ord, span, cells, slot, flag = i32(6 * B), i32(3 * B), i32(nc), i32(nc), i32(nc)
+    cell_of, scratch = i32(max(n, 1)), i32(_lib.scan_scratch_elems(nc))
+    lo = torch.empty(3 * B, dtype=torch.float32, device=dev)
+    coords = torch.empty(max(n, 1), 3, dtype=torch.int32, device=dev)
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    out_ptr, n_out, bounds, status = i32(B + 1), i32(1), i32(6), i32(4)
+    _lib.call("agb_voxelize_last", _P(p), _P(perm), _P(ptr), _P(elem), B, n, size32, cap, _P(bbox_ord), _P(lo),
+              _P(span), _P(cells), _P(slot), _P(flag), _P(cell_of), _P(scratch), _P(coords), _P(keep), _P(out_ptr),
+              _P(n_out), _P(bounds), _P(status), _lib.stream())
+    host = torch.cat([out_ptr, bounds, status[:1]]).tolist()   # one host read: new lengths + coordinate bounds
+    if host[-1]:
+        raise _lib.AgbError("voxelize_last: a cloud exceeds the reserved cell capacity (extent_hint too small)")
+    optr = np.asarray(host[:B + 1], dtype=np.int64)
+    m = int(optr[-1])
+    return coords[:m], keep[:m], np.diff(optr).astype(np.int64), tuple(host[B + 1:B + 7])
+
+
+class GridSampling3D:
+    """Batch-level drop-in for the reference transform: takes an object with ``pos`` [N,3], ``batch`` [N] (sorted)
+    and any per-point tensors, returns a PlotBatch-like object with ``coords``, per-point fields restricted to one
+    point per voxel, and ``coord_bounds``."""
+
+    def __init__(self, size, quantize_coords=True, mode="last", verbose=False):
+        if mode != "last":
+            raise NotImplementedError("only mode='last' is implemented (the NFI sparse pipelines use it)")
+        self._grid_size, self._quantize_coords, self._mode = size, quantize_coords, mode
+
+    def __call__(self, data, perm=None):
+        from .synthetic import PlotBatch
+        batch = data.batch
+        num = len(data)
+        lens = torch.bincount(batch.cpu(), minlength=num).numpy()
+        coords, keep, new_lens, bounds = voxelize_last(data.pos, lens, self._grid_size, perm=perm)
+        dev = coords.device
+        pick = lambda t: None if t is None else t.to(dev)[keep]  # noqa: E731
+        out = PlotBatch(pick(batch), coords if self._quantize_coords else None, pick(data.x), pick(data.pos),
+                        None, None, num, bounds)
+        out.y_reg = None if data.y_reg is None else data.y_reg.to(dev)
+        out.y_reg_mask = None if data.y_reg_mask is None else data.y_reg_mask.to(dev)
+        out.y_reg_mask_all = getattr(data, "y_reg_mask_all", None)
+        out.grid_size = torch.tensor([self._grid_size])
+        return out
+
+    def __repr__(self):
+        return f"GridSampling3D(grid_size={self._grid_size}, quantize_coords={self._quantize_coords}, mode={self._mode})"

@@ -303,3 +303,34 @@ def test_train_steps_track_oracle(device):
             sd[k] = v
         lg, lr_ = float(model.loss.detach()), float(loss.detach())
         assert abs(lg - lr_) < 1e-3 * max(1.0, abs(lr_)), (step, lg, lr_)
+
+
+@pytest.mark.parametrize("pool", ["sum", "max"])
+def test_mpointnet_matches_oracle(device, pool):
+    """MinkowskiPointNet (the reference's published 'PointNet', add_pos=True -> 6 input channels): shared MLP +
+    BN + GELU, per-plot pool, head — forward, loss and gradients vs the fp64 oracle."""
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_032))
+    opt = Opt(MODEL_OPTIONS["MPointNet"])
+    opt["global_pool"] = pool
+    model = MinkowskiBaselineModel(opt, "minkowski", ds)
+    batch = synthetic.make_sparse_batch([0, 1, 2, 3], n_points=1500)
+    sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    model.to(device).train()
+    model.set_input(batch, device)
+    model.forward()
+    model.loss.backward()
+    sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in sd32.items()}
+    feats = torch.cat([batch.pos, batch.x], 1).double()
+    out = R.pointnet_forward(sd, batch.batch, feats, 4, global_pool_mode=pool)
+    loss = R.reg_loss(out, batch.y_reg.double(), model.reg_center_targets.cpu().double(),
+                      model.reg_scale_targets.cpu().double(), model.reg_weights.cpu().double())
+    loss.backward()
+    assert rel_err(model.output, out) < RTOL
+    gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.model.named_parameters())
+    for k, p in model.model.named_parameters():
+        denom = max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
+        assert float((p.grad.detach().cpu().double() - sd[k].grad).abs().max()) / denom < 10 * RTOL, k
