@@ -116,6 +116,89 @@ int agb_segment_broadcast(const float* S, const int32_t* coords, const int32_t* 
 /* dX[argmax[b,c], c] = dY[b,c]; dX zero-filled by the caller */
 int agb_segment_max_bwd(const float* dY, const int32_t* argmax, float* dX, int ldx, int B, int C, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * BatchNorm over [n, C] rows fused with the following activation (0 none, 1 ReLU, 2 GELU-erf), and the residual
+ * tail.  Replaces ME.MinkowskiBatchNorm (= nn.BatchNorm1d on .F) + activation: modules/MinkowskiEngine/common.py:
+ * 215-226, resnet_block.py:62-73, senet_block.py:83-96, PointNet.py:16-39; KPConv blocks.py:460-535.
+ * --------------------------------------------------------------------------------------------------------- */
+int agb_bn_chunks(int n);  /* host helper: number of row chunks the statistics kernels use */
+/* training != 0: batch statistics (Chan-combined), running stats updated when given; else running stats.
+ * part: float[agb_bn_chunks(n)*3*C] scratch; mean, rstd: float[C] out. */
+int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
+                 float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
+int agb_bn_act_fwd(const float* X, int ldx, int n, int C, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, int act, float* Y, int ldy, void* stream);
+/* part: float[agb_bn_chunks(n)*2*C] scratch; dgamma, dbeta: float[C] out; dX may be NULL */
+int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
+                   float* dX, int lddx, float* dgamma, float* dbeta, void* stream);
+/* Y = act(A * scale[batch(row)] + R); scale float[B] (drop-path keep/(1-p)) and coords may be NULL */
+int agb_add_act_fwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords, int n,
+                    int C, int act, float* Y, int ldy, void* stream);
+int agb_add_act_bwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords,
+                    const float* dY, int ldy, int n, int C, int act, float* dA, float* dR, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * KPConv index path.  Replaces the CPython extensions behind modules/KPConv/common.py:
+ *   radius_neighbors.batch_query   cpp_wrappers/cpp_neighbors/wrapper.cpp:58-238 -> neighbors/neighbors.cpp:211-333
+ *   grid_subsampling.subsample_batch  cpp_wrappers/cpp_subsampling/wrapper.cpp:62-335 -> grid_subsampling.cpp:109-211
+ * Clouds are stacked; ptr int32[B+1] gives the row range of every cloud, elem int32[n] the cloud of every row.
+ * --------------------------------------------------------------------------------------------------------- */
+int agb_elem_bbox(const float* pts, const int32_t* ptr, int B, int n, int32_t* bbox_ord /* int32[6B] scratch */,
+                  float* bbox /* float[6B] out: min xyz, max xyz; may be NULL */, void* stream);
+int agb_elem_of_row(const int32_t* ptr, int B, int n, int32_t* elem, void* stream);
+/* out = pts @ R[elem] (transpose=0) or pts @ R[elem]^T (1), float32 products summed left to right (common.py:76-97) */
+int agb_rotate_points(const float* pts, const int32_t* elem, const float* R /* [B,3,3] */, int n, int transpose,
+                      float* out, void* stream);
+/* Support cell grid: origin_cs = HOST float[4] {ox, oy, oz, cell size >= radius}; dims = HOST int32[4] {X, Y, Z, B}.
+ * cell_start int32[cells+1] out; sorted float[ns*4] out (xyz + index bits, cell order); cell_of int32[ns],
+ * cell_fill int32[cells+1], scan_scratch int32[agb_scan_scratch_elems(cells+1)], total_scratch int32[1]: scratch. */
+int agb_ball_grid_build(const float* supports, int ns, const int32_t* s_ptr, const float* origin_cs,
+                        const int32_t* dims, int32_t* cell_start, float* sorted, int32_t* cell_of,
+                        int32_t* cell_fill, int32_t* scan_scratch, int32_t* total_scratch, void* stream);
+/* Phase 1: counts[nq] and *max_count (device). Phase 2: out int32[nq,width] sorted by (d2, index), padded with ns. */
+int agb_ball_query_count(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
+                         const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius,
+                         int32_t* counts, int32_t* max_count, void* stream);
+int agb_ball_query_fill(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
+                        const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
+                        int width, int32_t* out, int32_t* status, void* stream);
+/* Grid subsampling (barycentres, optional feature means), canonical order = cell key ascending per cloud.
+ * cap = cells reserved per cloud. Scratch int32: bbox_ord[6B], dims[3B], cell_cnt/cell_start/slot/flag[B*cap+1],
+ * cell_of[n], members[n], scan_scratch[agb_scan_scratch_elems(B*cap+1)]; origin float[3B].
+ * Out: out_pts float[n*3] (upper bound), out_feats float[n*fdim] or NULL, out_ptr int32[B+1], n_out_dev, status[4]. */
+int agb_grid_subsample(const float* pts, const float* feats, int fdim, int n, const int32_t* ptr,
+                       const int32_t* elem, int B, float dl, int cap, int32_t* bbox_ord, float* origin,
+                       int32_t* dims, int32_t* cell_cnt, int32_t* cell_start, int32_t* slot, int32_t* flag,
+                       int32_t* cell_of, int32_t* members, int32_t* scan_scratch, float* out_pts, float* out_feats,
+                       int32_t* out_ptr, int32_t* n_out_dev, int32_t* status, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * KPConv layer (replaces KPConv.forward modules/KPConv/blocks.py:264-400 and max_pool :98-114).
+ * idx int32[N,H], entries >= Ns are shadow neighbours.  wf[n,k,:] = sum_h infl(n,h,k) * x[idx[n,h],:],
+ * infl = max(0, 1 - |(s[idx]-q) - kp[k]| / extent); the layer output is wf[N,K*Cin] @ W[K*Cin,Cout] (plain GEMM).
+ * --------------------------------------------------------------------------------------------------------- */
+int agb_kpconv_gather_fwd(const float* q, const float* s, const int32_t* idx, int H, int Ns, const float* x, int ldx,
+                          const float* kp, int K, float extent, float* wf, int N, int Cin, void* stream);
+/* dx float[Ns,ldx] zero-filled by the caller (fp32 atomics) */
+int agb_kpconv_gather_bwd(const float* q, const float* s, const int32_t* idx, int H, int Ns, const float* dwf,
+                          const float* kp, int K, float extent, float* dx, int ldx, int N, int Cin, void* stream);
+int agb_kp_maxpool_fwd(const float* x, int ldx, const int32_t* idx, int H, int Ns, float* y, int32_t* argmax, int N,
+                       int C, void* stream);
+int agb_kp_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int ldx, int N, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * GridSampling3D(size, quantize_coords=True, mode="last") for a batch of clouds
+ * (replaces core/data_transform/grid_transform.py:112-128).  perm int64[n]: within-cloud shuffle.
+ * Out: coords int32[n,3] (upper bound), keep int64[n] (rows of the ORIGINAL stacked order), out_ptr int32[B+1],
+ * n_out_dev, bounds int32[6] (min/max of coords), status[4].  Scratch as documented in csrc/voxelize.hip.
+ * --------------------------------------------------------------------------------------------------------- */
+int agb_voxelize_last(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
+                      float size, int cap, int32_t* bbox_ord, float* lo, int32_t* span, int32_t* cells,
+                      int32_t* slot, int32_t* flag, int32_t* cell_of, int32_t* scan_scratch, int32_t* coords,
+                      long long* keep, int32_t* out_ptr, int32_t* n_out_dev, int32_t* bounds, int32_t* status,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif
