@@ -52,6 +52,34 @@ def conv_cost(rec, pairs):
     return byts, flops
 
 
+def kernel_of(rec):
+    """Name of the HIP kernel a recorded launch ran (mirrors the dispatch rule of csrc/spconv.hip:launch_conv)."""
+    small = rec["cin"] in (4, 8)
+    if rec["kind"] == "wgrad":
+        return f"k_spconv_dw<{rec['cin']}>" if small else "k_spconv_dw_pipe"
+    if small:
+        return f"k_spconv_fwd<{rec['cin']}>"
+    if rec.get("perm"):
+        return "k_spconv_pipe<64, true>"
+    col_tiles = -(-rec["cout"] // 64)
+    if rec.get("split", 1) == 1 and -(-rec["rows"] // 128) * col_tiles >= 1024:
+        return "k_spconv_pipe<128, false>"
+    return "k_spconv_pipe<64, false>"
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/collect_pmc.sh -> profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        data = json.load(open(path))["kernels"]
+    except Exception:
+        return None
+    for name, v in data.items():
+        if name.replace("void ", "").strip() == kernel:
+            return round(v["hbm_bytes_per_launch"])
+    return None
+
+
 def roofline_from_profile(prof):
     """Group launches by kernel flavour; the dominant one (largest total time) is reported."""
     groups = {}
@@ -66,8 +94,7 @@ def roofline_from_profile(prof):
             pair_cache[key] = int(p.sum().item())
         pairs = pair_cache[key]
         byts, flops = conv_cost(rec, pairs)
-        small = rec["cin"] in (4, 8)
-        name = ("k_spconv_dw" if rec["kind"] == "wgrad" else "k_spconv_fwd") + ("<small-Cin>" if small else "<generic>")
+        name = kernel_of(rec)
         g = groups.setdefault(name, dict(ms=0.0, n=0, bytes=0.0, flops=0.0))
         g["ms"] += ms
         g["n"] += 1
@@ -99,11 +126,11 @@ def roofline_from_profile(prof):
     if intensity >= ridge:
         ach = g["flops"] / secs / 1e12
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                    frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=None)
+                    frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=pmc_traffic(dom))
     else:
         ach = g["bytes"] / secs / 1e9
         roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None)
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom))
     roof.update(kernel=dom, launches=g["n"], avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2),
                 alg_bytes_per_launch=round(g["bytes"] / g["n"]), alg_flops_per_launch=round(g["flops"] / g["n"]))
     summary = {k: dict(total_ms=round(v["ms"], 3), launches=v["n"],
@@ -208,7 +235,14 @@ def main():
     voxels = sum(int(b.coords.shape[0]) for b in pool) / len(pool) / args.batch
     steps_per_epoch = 133  # 4271 train plots / 32
 
+    host_ms = []
+
     def step(i):
+        t_h = time.perf_counter()
+        _step(i)
+        host_ms.append((time.perf_counter() - t_h) * 1e3)
+
+    def _step(i):
         # software pipeline of the input path: this step's coordinate pyramid was built on a side stream while the
         # previous step ran; the next one is built now, behind this step's already-enqueued kernels
         model.set_input(pool[i % len(pool)], dev)
@@ -242,7 +276,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(model.loss.detach())
-    log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
+    hm = sorted(host_ms[-args.steps:])
+    log(f"timed region: {elapsed:.3f}s for {args.steps} steps; host enqueue time per step: median "
+        f"{hm[len(hm) // 2]:.2f} ms, min {hm[0]:.2f} ms (GPU-bound when well below ms_per_step)")
 
     if rank == 0:
         roof, summary = roofline_from_profile(prof or [])

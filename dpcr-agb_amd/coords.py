@@ -71,6 +71,30 @@ def _floor_to(v, ts):
     return (v // ts) * ts  # python floor division: correct for negatives
 
 
+_CLASS_TABLES = {}
+
+
+def _class_table(K, s, d, device):
+    """cls_tab[class] = (count, offsets k...) : kernel offsets through which an input row of that parity class can
+    be reached from the stride-s output lattice: (c/ts - o*d) = 0 (mod s) per axis."""
+    key = (K, s, d, str(device))
+    if key not in _CLASS_TABLES:
+        half = K // 2 if K % 2 == 1 else 0
+        K3 = K ** 3
+        tab = torch.zeros(s ** 3, 1 + K3, dtype=torch.int32)
+        for cls in range(s ** 3):
+            p = (cls % s, (cls // s) % s, cls // (s * s))
+            offs = []
+            for k in range(K3):
+                i = (k % K, (k // K) % K, k // (K * K))
+                if all(((p[a] - (i[a] - half) * d) % s) == 0 for a in range(3)):
+                    offs.append(k)
+            tab[cls, 0] = len(offs)
+            tab[cls, 1:1 + len(offs)] = torch.tensor(offs, dtype=torch.int32)
+        _CLASS_TABLES[key] = tab.to(device)
+    return _CLASS_TABLES[key]
+
+
 class CoordinateManager:
     def __init__(self, coordinates: torch.Tensor, device=None, tensor_stride: int = 1, batch_size: int = None,
                  bounds: Optional[Sequence[int]] = None, mode: str = "auto"):
@@ -264,6 +288,8 @@ class CoordinateManager:
             self.kernel_map(ts_in, K, s, d)
             if need_t:
                 self.transposed_map(ts_in, K, s, d)
+                if s > 1:
+                    self.transposed_plan(ts_in, K, s, d)
         for ts in list(self.levels):
             self.batch_ptr(ts)
 
@@ -273,6 +299,10 @@ class CoordinateManager:
                 if t is not None:
                     yield t
         for m in self.kernel_maps.values():
+            if isinstance(m, tuple):      # transposed plan: (perm, tile_cls, cls_tab, max_tiles)
+                yield m[0]
+                yield m[1]
+                continue
             yield m
             p = getattr(m, "agb_pairs", None)
             if p is not None:
@@ -309,6 +339,25 @@ class CoordinateManager:
             ts_out = self.stride(ts_in, s)
             self.kernel_maps[key] = self._lookup(self.levels[ts_out], self.levels[int(ts_in)], K, int(ts_in) * d, 1,
                                                  0, True)
+        return self.kernel_maps[key]
+
+    def transposed_plan(self, ts_in: int, kernel_size: int, stride: int, dilation: int = 1):
+        """Class-partitioned row order for the data gradient of a strided operator: rows of level ts_in grouped by
+        lattice parity (c/ts_in mod stride per axis); a row of a given class can only be reached through the few
+        kernel offsets o with o = c/ts_in (mod stride) — 1/2/4/8 of 27 for K=3, s=2.
+        Returns (perm int32[n + s^3*64], tile_cls int32[max_tiles], cls_tab int32[s^3, 1+K^3], max_tiles)."""
+        K, s, d = _as_int(kernel_size), _as_int(stride), _as_int(dilation)
+        key = ("plan", int(ts_in), K, s, d)
+        if key not in self.kernel_maps:
+            src = self._resolve(self.levels[int(ts_in)])
+            n, ncls = src.n, s ** 3
+            max_tiles = n // 64 + ncls + 1
+            perm = torch.empty(n + ncls * 64, dtype=torch.int32, device=self.device)
+            tile_cls = torch.empty(max_tiles, dtype=torch.int32, device=self.device)
+            scratch = torch.empty(256, dtype=torch.int32, device=self.device)
+            _lib.call("agb_parity_partition", _lib.ptr(src.coords), n, int(ts_in), s, _lib.ptr(perm),
+                      _lib.ptr(tile_cls), max_tiles, _lib.ptr(scratch), _lib.stream())
+            self.kernel_maps[key] = (perm, tile_cls, _class_table(K, s, d, self.device), max_tiles)
         return self.kernel_maps[key]
 
     def transposed_map(self, ts_in: int, kernel_size: int, stride: int = 1, dilation: int = 1) -> torch.Tensor:

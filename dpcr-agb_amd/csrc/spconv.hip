@@ -157,13 +157,25 @@ __global__ __launch_bounds__(256) void k_spconv_fwd(const float* __restrict__ X,
 // dependency would otherwise expose two L2 latencies per chunk).  TM x 64 output tile:
 //   TM = 64 : 2x2 waves, each 32x32            (few-row layers: keeps enough workgroups to fill 256 CUs)
 //   TM = 128: 4x1 waves, each 32 rows x 64 cols (W tile reused by 128 rows: 21.8 FLOP per staged byte)
-template <int TM>
-__global__ __launch_bounds__(256) void k_spconv_fwd_pipe(const float* __restrict__ X, int ldx,
-                                                         const float* __restrict__ W,
-                                                         const int32_t* __restrict__ nbr, long long nbr_stride,
-                                                         int kflip, const float* __restrict__ bias,
-                                                         float* __restrict__ Y, int ldy, int n_out, int K3, int Cin,
-                                                         int Cout) {
+// PERM: rows come from a class-partitioned permutation (agb_parity_partition): every tile holds rows of ONE
+//   lattice-parity class and visits only the kernel offsets that class can reach — the data gradient of a
+//   stride-2 convolution touches 1/2/4/8 of the 27 offsets per row instead of walking a map of density 0.11.
+// ksplit > 1 (gridDim.z): the offset/channel chunks are divided among gridDim.z workgroups per tile, partial
+//   tiles go to `partial` [ksplit][n_out][Cout] and k_split_reduce folds them in order (deterministic); used
+//   when a layer has too few rows to fill 256 CUs (2.8 k rows x 512 channels at tensor stride 16).
+struct ConvArgs {
+    const float* X; int ldx;
+    const float* W;
+    const int32_t* nbr; long long nbr_stride; int kflip;
+    const float* bias;
+    float* Y; int ldy;
+    int n_out, K3, Cin, Cout;
+    const int32_t* perm; const int32_t* tile_cls; const int32_t* cls_tab;
+    int ksplit; float* partial;
+};
+
+template <int TM, bool PERM>
+__global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
     constexpr int WAVES_M = TM / 32;       // 2 or 4
     constexpr int WAVES_N = 4 / WAVES_M;   // 2 or 1
     constexpr int NT = 2 / WAVES_N;        // 32-col accumulators per wave: 1 or 2
@@ -175,11 +187,22 @@ __global__ __launch_bounds__(256) void k_spconv_fwd_pipe(const float* __restrict
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int row0 = blockIdx.x * TM;
+    const int tile = blockIdx.x;
+    const int row0 = tile * TM;
     const int n0 = blockIdx.y * BN;
     const int li = lane & 31, lh = lane >> 5;
     const int a_r = tid >> 3, a_c = (tid & 7) * 4;     // A: row (+32j), channel offset in chunk
     const int b_r = tid >> 4, b_c = (tid & 15) * 4;    // B: k row (+16j), output offset
+    const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
+
+    int noff = K3;
+    const int32_t* offs = nullptr;
+    if (PERM) {
+        int cls = a.tile_cls[tile];
+        if (cls < 0) return;  // padding tile (uniform for the workgroup)
+        noff = a.cls_tab[cls * (1 + K3)];
+        offs = a.cls_tab + cls * (1 + K3) + 1;
+    }
 
     f32x16 acc[NT];
 #pragma unroll
@@ -188,50 +211,64 @@ __global__ __launch_bounds__(256) void k_spconv_fwd_pipe(const float* __restrict
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     const int cpk = (Cin + BK - 1) / BK;
-    const int nchunks = K3 * cpk;
+    const int nchunks = noff * cpk;
+    const int ch_beg = (int)((long long)nchunks * blockIdx.z / a.ksplit);
+    const int ch_end = (int)((long long)nchunks * (blockIdx.z + 1) / a.ksplit);
+
+    int grow[AJ];  // global output row of the A rows this thread gathers for
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        int r = row0 + a_r + 32 * j;
+        if (PERM) grow[j] = a.perm[r];
+        else grow[j] = r < a.n_out ? r : -1;
+    }
 
     int idx_cur[AJ], idx_nxt[AJ];
     float4 a_reg[AJ], b_reg[2];
 
+    auto offset_of = [&](int ch) {
+        int ko = ch / cpk;
+        return PERM ? offs[ko] : ko;
+    };
     auto load_idx = [&](int ch, int* dst) {
-        int k = ch / cpk;
-        int kn = kflip ? (K3 - 1 - k) : k;
+        int k = ch < ch_end ? offset_of(ch) : 0;
+        int kn = a.kflip ? (K3 - 1 - k) : k;
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            int r = row0 + a_r + 32 * j;
-            dst[j] = (ch < nchunks && r < n_out) ? nbr[(long long)kn * nbr_stride + r] : -1;
-        }
+        for (int j = 0; j < AJ; ++j)
+            dst[j] = (ch < ch_end && grow[j] >= 0) ? a.nbr[(long long)kn * a.nbr_stride + grow[j]] : -1;
     };
     auto load_data = [&](int ch, const int* idx) {
-        int k = ch / cpk;
-        int c0 = (ch - k * cpk) * BK;
+        int k = offset_of(ch);
+        int c0 = (ch % cpk) * BK;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx[j] >= 0 && c0 + a_c < Cin)
-                a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)idx[j] * ldx + c0 + a_c);
+                a_reg[j] = *reinterpret_cast<const float4*>(a.X + (long long)idx[j] * a.ldx + c0 + a_c);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int kr = b_r + 16 * j;
             b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c0 + kr < Cin && n0 + b_c < Cout)
-                b_reg[j] = *reinterpret_cast<const float4*>(W + ((long long)k * Cin + c0 + kr) * Cout + n0 + b_c);
+                b_reg[j] = *reinterpret_cast<const float4*>(a.W + ((long long)k * Cin + c0 + kr) * Cout + n0 + b_c);
         }
     };
 
-    load_idx(0, idx_cur);
-    load_idx(1, idx_nxt);
-    load_data(0, idx_cur);
+    if (ch_beg < ch_end) {
+        load_idx(ch_beg, idx_cur);
+        load_idx(ch_beg + 1, idx_nxt);
+        load_data(ch_beg, idx_cur);
+    }
 
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = ch_beg; ch < ch_end; ++ch) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
             *reinterpret_cast<float4*>(&As[(a_r + 32 * j) * LDA + a_c]) = a_reg[j];
 #pragma unroll
         for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&Bs[(b_r + 16 * j) * LDB + b_c]) = b_reg[j];
         __syncthreads();
-        if (ch + 1 < nchunks) {
+        if (ch + 1 < ch_end) {
 #pragma unroll
             for (int j = 0; j < AJ; ++j) idx_cur[j] = idx_nxt[j];
             load_data(ch + 1, idx_cur);   // in flight during the MFMAs below
@@ -258,18 +295,96 @@ __global__ __launch_bounds__(256) void k_spconv_fwd_pipe(const float* __restrict
         __syncthreads();
     }
 
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* out = a.ksplit > 1 ? a.partial + (long long)blockIdx.z * a.n_out * Cout : a.Y;
+    const int ldo = a.ksplit > 1 ? Cout : a.ldy;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + (wn * NT + nt) * 32 + li;
-        if (col < Cout) {
-            const float bv = bias ? bias[col] : 0.f;
+    for (int reg = 0; reg < 16; ++reg) {
+        int rt = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        int row = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
+        if (row < 0) continue;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                int row = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                if (row < n_out) Y[(long long)row * ldy + col] = acc[nt][reg] + bv;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + (wn * NT + nt) * 32 + li;
+            if (col < Cout) {
+                float bv = (a.bias && a.ksplit == 1) ? a.bias[col] : 0.f;
+                out[(long long)row * ldo + col] = acc[nt][reg] + bv;
             }
         }
     }
+}
+
+// Y[r, :] = bias + sum_s partial[s][r, :]   (fixed order)
+__global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_out, int C4,
+                               const float* __restrict__ bias, float* __restrict__ Y, int ldy) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4), c = (int)(t % C4) * 4;
+    if (r >= n_out) return;
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+        float4 v = *reinterpret_cast<const float4*>(partial + ((long long)s * n_out + r) * (C4 * 4) + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lattice-parity partition of the rows of a level for a stride-s operator: class = (c/ts mod s) per axis.
+// perm [n + ncls*TM] receives the rows grouped by class, every class padded with -1 to a multiple of TM;
+// tile_cls[t] = class of tile t (or -1).  Order inside a class is arbitrary (results do not depend on it).
+__device__ __forceinline__ int parity_class(int4 c, int ts, int s) {
+    int px = ((c.y / ts) % s + s) % s, py = ((c.z / ts) % s + s) % s, pz = ((c.w / ts) % s + s) % s;
+    return px + s * (py + s * pz);
+}
+
+__global__ void k_parity_count(const int4* __restrict__ coords, int n, int ts, int s, int32_t* counts) {
+    __shared__ int h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&h[parity_class(coords[i], ts, s)], 1);
+    __syncthreads();
+    if (threadIdx.x < s * s * s && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+
+// counts[0..ncls) -> start[0..ncls] (padded to TM), cursor[c] = start[c]; tile classes
+__global__ void k_parity_layout(int32_t* counts, int ncls, int TM, int32_t* start, int32_t* cursor, int32_t* tile_cls,
+                                int max_tiles) {
+    __shared__ int s_start[65];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < ncls; ++c) {
+            s_start[c] = acc;
+            acc += (counts[c] + TM - 1) / TM * TM;
+        }
+        s_start[ncls] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x <= ncls) start[threadIdx.x] = s_start[threadIdx.x];
+    if (threadIdx.x < ncls) cursor[threadIdx.x] = s_start[threadIdx.x];
+    for (int t = threadIdx.x; t < max_tiles; t += blockDim.x) {
+        int r = t * TM, cls = -1;
+        for (int c = 0; c < ncls; ++c)
+            if (r >= s_start[c] && r < s_start[c + 1]) cls = c;
+        tile_cls[t] = cls;
+    }
+}
+
+__global__ void k_parity_scatter(const int4* __restrict__ coords, int n, int ts, int s, int32_t* cursor,
+                                 int32_t* perm) {
+    __shared__ int h[64], base[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1, rank = 0;
+    if (i < n) {
+        cls = parity_class(coords[i], ts, s);
+        rank = atomicAdd(&h[cls], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < s * s * s && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (i < n) perm[base[cls] + rank] = i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,33 +511,184 @@ __global__ __launch_bounds__(256) void k_spconv_dw(const float* __restrict__ X, 
     }
 }
 
+// Weight gradient, generic path, software-pipelined like k_spconv_pipe: gathers of the next 32-row step are in
+// flight during the MFMAs of the current one, neighbour indices are fetched two steps ahead.
+__global__ __launch_bounds__(256) void k_spconv_dw_pipe(const float* __restrict__ X, int ldx,
+                                                        const float* __restrict__ dY, int ldy,
+                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
+                                                        float* __restrict__ dW, int n_out, int K3, int Cin, int Cout,
+                                                        int rows_per_wg, int cin_tiles) {
+    __shared__ __attribute__((aligned(16))) float As[BK * 64];  // [r][m]
+    __shared__ __attribute__((aligned(16))) float Bs[BK * 64];  // [r][n]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.z * 64;
+    const int r_begin = blockIdx.x * rows_per_wg;
+    const int r_end = min(n_out, r_begin + rows_per_wg);
+    const int k = blockIdx.y / cin_tiles;
+    const int c0 = (blockIdx.y % cin_tiles) * 64;
+    const int t_r = tid >> 4, t_c = (tid & 15) * 4;
+    const int32_t* nrow = nbr + (long long)k * nbr_stride;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    int idx_cur[2], idx_nxt[2];
+    float4 a_reg[2], b_reg[2];
+    auto load_idx = [&](int rb, int* dst) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int r = rb + t_r + 16 * j;
+            dst[j] = r < r_end ? nrow[r] : -1;
+        }
+    };
+    auto load_data = [&](int rb, const int* idx) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int r = rb + t_r + 16 * j;
+            a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx[j] >= 0) {
+                if (c0 + t_c < Cin) a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)idx[j] * ldx + c0 + t_c);
+                if (n0 + t_c < Cout) b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + n0 + t_c);
+            }
+        }
+    };
+    if (r_begin < r_end) {
+        load_idx(r_begin, idx_cur);
+        load_idx(r_begin + BK, idx_nxt);
+        load_data(r_begin, idx_cur);
+    }
+    for (int rb = r_begin; rb < r_end; rb += BK) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<float4*>(&As[(t_r + 16 * j) * 64 + t_c]) = a_reg[j];
+            *reinterpret_cast<float4*>(&Bs[(t_r + 16 * j) * 64 + t_c]) = b_reg[j];
+        }
+        __syncthreads();
+        if (rb + BK < r_end) {
+            idx_cur[0] = idx_nxt[0];
+            idx_cur[1] = idx_nxt[1];
+            load_data(rb + BK, idx_cur);
+            load_idx(rb + 2 * BK, idx_nxt);
+        }
+        const float* ap = &As[wr * 32 + li];
+        const float* bp = &Bs[wc * 32 + li];
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 2; ++s2) {
+            float av = ap[(2 * s2 + lh) * 64];
+            float bv = bp[(2 * s2 + lh) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + li;
+    if (col < Cout) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int m = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (c0 + m < Cin) atomicAdd(&dW[((long long)k * Cin + c0 + m) * Cout + col], acc[reg]);
+        }
+    }
+}
+
 // =============================================================== C ABI
 extern "C" {
 
-int agb_spconv_fwd(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
-                   const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, void* stream) {
+static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
+    const bool small = (a.Cin == 4 || a.Cin == 8);
+    dim3 block(256);
+    if (a.perm) {
+        if (small) {
+            agb_set_error("agb_spconv_fwd_ex: the class-partitioned path needs Cin >= 12");
+            return AGB_EUNSUPPORTED;
+        }
+        dim3 grid(n_tiles_perm, agb_cdiv(a.Cout, BN), a.ksplit);
+        hipLaunchKernelGGL((k_spconv_pipe<64, true>), grid, block, 0, s, a);
+    } else if (small) {
+        dim3 grid(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN));
+        if (a.Cin == 4)
+            hipLaunchKernelGGL(k_spconv_fwd<4>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
+                               a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
+        else
+            hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
+                               a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
+    } else if (a.ksplit == 1 && (long long)agb_cdiv(a.n_out, 128) * agb_cdiv(a.Cout, BN) >= 1024) {
+        // enough 128-row tiles to give every CU four workgroups: use the tile with the better W reuse
+        hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), 1), block, 0,
+                           s, a);
+    } else {
+        hipLaunchKernelGGL((k_spconv_pipe<64, false>), dim3(agb_cdiv(a.n_out, 64), agb_cdiv(a.Cout, BN), a.ksplit),
+                           block, 0, s, a);
+    }
+    if (a.ksplit > 1) {
+        long long total = (long long)a.n_out * (a.Cout / 4);
+        hipLaunchKernelGGL(k_split_reduce, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, a.partial, a.ksplit, a.n_out,
+                           a.Cout / 4, a.bias, a.Y, a.ldy);
+    }
+    return AGB_OK;
+}
+
+// How many offset splits a layer of n_out rows wants (1 = none): host helper for sizing `partial`.
+int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
+    if (Cin == 4 || Cin == 8 || K3 < 8) return 1;
+    long long tiles = (long long)agb_cdiv(n_out, 64) * agb_cdiv(Cout, BN);
+    if (tiles >= 768) return 1;
+    long long s = (1024 + tiles - 1) / tiles;
+    if (s > 8) s = 8;
+    return (int)(s < 1 ? 1 : s);
+}
+
+int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                      const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                      const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                      float* partial, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_fwd: bad sizes");
     AGB_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout,
                   "agb_spconv_fwd: Cin (%d), Cout (%d), ldx (%d) must be multiples of 4 (pad small inputs)", Cin,
                   Cout, ldx);
     AGB_CHECK_ARG(nbr_stride >= n_out, "agb_spconv_fwd: nbr_stride < n_out");
+    AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_ex: ksplit needs `partial`");
+    AGB_CHECK_ARG(perm == nullptr || (tile_cls != nullptr && cls_tab != nullptr && n_tiles > 0),
+                  "agb_spconv_fwd_ex: perm needs tile_cls, cls_tab and n_tiles");
     if (n_out == 0) return AGB_OK;
-    dim3 grid(agb_cdiv(n_out, BM), agb_cdiv(Cout, BN)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    if (Cin == 4)
-        hipLaunchKernelGGL(k_spconv_fwd<4>, grid, block, 0, s, X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out,
-                           K3, Cin, Cout);
-    else if (Cin == 8)
-        hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out,
-                           K3, Cin, Cout);
-    else if ((long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, BN) >= 1024)
-        // enough 128-row tiles to give every CU four workgroups: use the tile with the better W reuse
-        hipLaunchKernelGGL(k_spconv_fwd_pipe<128>, dim3(agb_cdiv(n_out, 128), agb_cdiv(Cout, BN)), block, 0, s, X, ldx,
-                           W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout);
-    else
-        hipLaunchKernelGGL(k_spconv_fwd_pipe<64>, grid, block, 0, s, X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy,
-                           n_out, K3, Cin, Cout);
+    ConvArgs a{X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit,
+               partial};
+    int rc = launch_conv(a, n_tiles, (hipStream_t)stream);
+    if (rc) return rc;
     AGB_CHECK_LAUNCH("agb_spconv_fwd");
+    return AGB_OK;
+}
+
+int agb_spconv_fwd(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                   const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, void* stream) {
+    return agb_spconv_fwd_ex(X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, nullptr, nullptr,
+                             nullptr, 0, 1, nullptr, stream);
+}
+
+// Rows of a level grouped by lattice-parity class for a stride-`stride` operator (see k_spconv_pipe<.., PERM>).
+// perm: int32[n + stride^3 * 64] out (filled with -1 padding); tile_cls: int32[max_tiles] out with
+// max_tiles = n/64 + stride^3 + 1; scratch: int32[256].  Tile size 64.
+int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, int32_t* perm, int32_t* tile_cls,
+                         int max_tiles, int32_t* scratch, void* stream) {
+    AGB_CHECK_ARG(stride >= 1 && stride <= 4, "agb_parity_partition: stride %d", stride);
+    hipStream_t s = (hipStream_t)stream;
+    const int ncls = stride * stride * stride, TMR = 64;
+    (void)hipMemsetAsync(scratch, 0, sizeof(int32_t) * 256, s);
+    (void)hipMemsetAsync(perm, 0xFF, sizeof(int32_t) * ((size_t)n + (size_t)ncls * TMR), s);
+    if (n > 0)
+        hipLaunchKernelGGL(k_parity_count, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, (const int4*)coords, n, ts_in,
+                           stride, scratch);
+    hipLaunchKernelGGL(k_parity_layout, dim3(1), dim3(256), 0, s, scratch, ncls, TMR, scratch + 64, scratch + 160,
+                       tile_cls, max_tiles);
+    if (n > 0)
+        hipLaunchKernelGGL(k_parity_scatter, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, (const int4*)coords, n, ts_in,
+                           stride, scratch + 160, perm);
+    AGB_CHECK_LAUNCH("agb_parity_partition");
     return AGB_OK;
 }
 
@@ -457,7 +723,7 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
         hipLaunchKernelGGL(k_spconv_dw<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
                            Cout, (int)rows, cin_tiles);
     else
-        hipLaunchKernelGGL(k_spconv_dw<0>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
+        hipLaunchKernelGGL(k_spconv_dw_pipe, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
                            Cout, (int)rows, cin_tiles);
     AGB_CHECK_LAUNCH("agb_spconv_bwd_weight");
     return AGB_OK;

@@ -173,12 +173,14 @@ class MinkowskiConvolution(nn.Module):
             return input._like(out)
         nbr = cm.kernel_map(ts, self.kernel_size, self.stride, self.dilation)
         ts_out = ts * self.stride
-        nbrT = None
+        nbrT = plan = None
         needs_dx = input.F.requires_grad and torch.is_grad_enabled()
         if needs_dx and not (self.stride == 1 and self.kernel_size % 2 == 1):
             nbrT = cm.transposed_map(ts, self.kernel_size, self.stride, self.dilation)
+            if self.stride > 1:
+                plan = cm.transposed_plan(ts, self.kernel_size, self.stride, self.dilation)
         n_in, n_out = cm.level(ts).n, cm.level(ts_out).n
-        out = SparseConvFunction.apply(input.F, self.kernel, self.bias, nbr, nbrT, n_in, n_out)
+        out = SparseConvFunction.apply(input.F, self.kernel, self.bias, nbr, nbrT, n_in, n_out, plan)
         return SparseTensor(out, coordinate_map_key=CoordinateMapKey(ts_out), coordinate_manager=cm)
 
     def extra_repr(self):

@@ -24,12 +24,13 @@ def _prof_begin():
     return ev
 
 
-def _prof_end(ev0, kind, K3, cin, cout, rows, pairs):
+def _prof_end(ev0, kind, K3, cin, cout, rows, pairs, perm=False, split=1):
     if ev0 is None:
         return
     ev1 = torch.cuda.Event(enable_timing=True)
     ev1.record()
-    PROFILE.append(dict(kind=kind, K3=K3, cin=cin, cout=cout, rows=rows, pairs=pairs, start=ev0, end=ev1))
+    PROFILE.append(dict(kind=kind, K3=K3, cin=cin, cout=cout, rows=rows, pairs=pairs, start=ev0, end=ev1, perm=perm,
+                        split=split))
 
 
 def _pad_cols(x, mult):
@@ -49,13 +50,21 @@ def _small_cin_pad(cin):
     return (cin + 3) // 4 * 4
 
 
-def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None):
-    """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout]."""
+def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None, plan=None):
+    """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout].
+    plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad)."""
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+    split = _lib.load().agb_spconv_split_hint(n_out, K3, cin, cout) if plan is None else 1
+    partial = torch.empty(split, n_out, cout, dtype=torch.float32, device=x.device) if split > 1 else None
+    perm = tile_cls = cls_tab = None
+    n_tiles = 0
+    if plan is not None:
+        perm, tile_cls, cls_tab, n_tiles = plan
     ev = _prof_begin()
-    _lib.call("agb_spconv_fwd", _P(x), x.stride(0), _P(w2d), _P(nbr), nbr.stride(0), int(kflip), _P(bias), _P(y),
-              y.stride(0), n_out, K3, cin, cout, _lib.stream())
-    _prof_end(ev, kind, K3, cin, cout, n_out, pairs)
+    _lib.call("agb_spconv_fwd_ex", _P(x), x.stride(0), _P(w2d), _P(nbr), nbr.stride(0), int(kflip), _P(bias), _P(y),
+              y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles, split, _P(partial),
+              _lib.stream())
+    _prof_end(ev, kind, K3, cin, cout, n_out, pairs, plan is not None, split)
     return y
 
 
@@ -64,7 +73,7 @@ class SparseConvFunction(torch.autograd.Function):
     nbrT: transposed map [K3, N_in] or None when the k-flipped forward map serves (stride 1, odd kernel)."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, bias, nbr, nbrT, n_in, n_out):
+    def forward(ctx, feats, kernel, bias, nbr, nbrT, n_in, n_out, plan=None):
         K3, cin, cout = kernel.shape
         cin_p = _small_cin_pad(cin)
         cout_p = (cout + 3) // 4 * 4
@@ -82,6 +91,7 @@ class SparseConvFunction(torch.autograd.Function):
         pairs = getattr(nbr, "agb_pairs", None)
         y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs)
         ctx.pairs = pairs
+        ctx.plan = plan
         ctx.save_for_backward(x, w, nbr, nbrT if nbrT is not None else torch.empty(0))
         ctx.dims = (K3, cin, cout, cin_p, cout_p, n_in, n_out, nbrT is not None, bias is not None,
                     None if bias is None else bias.shape)
@@ -99,7 +109,8 @@ class SparseConvFunction(torch.autograd.Function):
             # dX[q] = sum_k dY[nbrT[k][q]] @ W[k]^T : same implicit GEMM with the transposed weights
             wt2d = w.transpose(1, 2).contiguous().view(K3 * cout_p, cin_p)
             if has_T:
-                dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs)
+                plan = ctx.plan if cout_p >= 12 else None
+                dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, plan)
             else:
                 dxp = spconv_forward_raw(dy, wt2d, nbr, 1, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs)
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
@@ -112,7 +123,7 @@ class SparseConvFunction(torch.autograd.Function):
             dk = dwp if (cin_p == cin and cout_p == cout) else dwp[:, :cin, :cout].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy[:, :cout].sum(0).reshape(bias_shape)
-        return dx, dk, db, None, None, None, None
+        return dx, dk, db, None, None, None, None, None
 
 
 class MaxPoolFunction(torch.autograd.Function):

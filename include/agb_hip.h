@@ -93,6 +93,21 @@ int agb_batch_ptr(const int32_t* coords, int n, const int32_t* n_dev, int B, int
 int agb_spconv_fwd(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
                    const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, void* stream);
 
+/* Extended form.  perm/tile_cls/cls_tab/n_tiles (all or none): class-partitioned output rows from
+ * agb_parity_partition — every 64-row tile holds rows of one lattice-parity class and visits only the kernel offsets
+ * listed for it in cls_tab int32[classes][1+K3] (count, offsets...): the data gradient of a stride-s operator.
+ * ksplit > 1: the offset/channel chunks are split over ksplit workgroups per tile, partials in
+ * `partial` float[ksplit][n_out][Cout], folded in order (deterministic); agb_spconv_split_hint suggests ksplit. */
+int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                      const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                      const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                      float* partial, void* stream);
+int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper */
+/* perm int32[n + stride^3*64] (rows grouped by class, -1 padding), tile_cls int32[max_tiles] with
+ * max_tiles = n/64 + stride^3 + 1, scratch int32[256].  class = (c/ts_in mod stride) per axis, x fastest. */
+int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, int32_t* perm, int32_t* tile_cls,
+                         int max_tiles, int32_t* scratch, void* stream);
+
 /* dW[k] += sum_r X[nbr[k][r],:]^T @ dY[r,:]; dW ([K3*Cin, Cout]) must be zero-filled by the caller. */
 int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                           long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, void* stream);
