@@ -38,9 +38,17 @@ class MinkowskiPointNet(nn.Module):
         self.dp1 = ME.MinkowskiDropout(dropout)
         self.final = ME.MinkowskiLinear(256, out_channels, bias=True)
 
+    @staticmethod
+    def _run(seq, x):
+        """(Linear, BatchNorm, act) triples of the Sequential with BatchNorm+activation in one fused kernel pair."""
+        mods = list(seq)
+        for i in range(0, len(mods), 3):
+            x = ME.fused_norm_act(mods[i + 1], mods[i + 2], mods[i](x))
+        return x
+
     def forward(self, x):
-        x = self.blocks(x)
+        x = self._run(self.blocks, x)
         x = self.global_pool(x)
-        x = self.mlp(x)
+        x = self._run(self.mlp, x)
         x = self.dp1(x)
         return self.final(x)
