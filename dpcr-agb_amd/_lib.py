@@ -49,6 +49,9 @@ _SIGNATURES = {
     "agb_segment_broadcast": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                               c_void_p],
     "agb_segment_max_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "agb_adabelief_chunk": [],
+    "agb_adabelief_step": [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_float,
+                           c_float, c_float, c_int, c_float, c_void_p],
 }
 
 _lib = None

@@ -599,6 +599,16 @@ __global__ __launch_bounds__(256) void k_spconv_dw_pipe(const float* __restrict_
 // =============================================================== C ABI
 extern "C" {
 
+// tile height of the generic kernel: 128 rows when there are plenty of tiles anyway, or when the layer is W-heavy
+// (Cin >= 256: every workgroup streams Cin x 64 weights per offset, so halving the number of row tiles halves the
+// dominant L2 traffic); else 64
+static int conv_tile_rows(int n_out, int Cin, int Cout) {
+    long long t128 = (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, BN);
+    if (t128 >= 1024) return 128;
+    if (Cin >= 256 && n_out >= 1024) return 128;
+    return 64;
+}
+
 static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
     const bool small = (a.Cin == 4 || a.Cin == 8);
     dim3 block(256);
@@ -617,10 +627,10 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
         else
             hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
                                a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
-    } else if (a.ksplit == 1 && (long long)agb_cdiv(a.n_out, 128) * agb_cdiv(a.Cout, BN) >= 1024) {
-        // enough 128-row tiles to give every CU four workgroups: use the tile with the better W reuse
-        hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), 1), block, 0,
-                           s, a);
+    } else if (conv_tile_rows(a.n_out, a.Cin, a.Cout) == 128) {
+        // 128-row tiles: the W tile is reused by twice as many rows (layers with many rows, or W-heavy layers)
+        hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
+                           block, 0, s, a);
     } else {
         hipLaunchKernelGGL((k_spconv_pipe<64, false>), dim3(agb_cdiv(a.n_out, 64), agb_cdiv(a.Cout, BN), a.ksplit),
                            block, 0, s, a);
@@ -636,7 +646,7 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
 // How many offset splits a layer of n_out rows wants (1 = none): host helper for sizing `partial`.
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
     if (Cin == 4 || Cin == 8 || K3 < 8) return 1;
-    long long tiles = (long long)agb_cdiv(n_out, 64) * agb_cdiv(Cout, BN);
+    long long tiles = (long long)agb_cdiv(n_out, conv_tile_rows(n_out, Cin, Cout)) * agb_cdiv(Cout, BN);
     if (tiles >= 768) return 1;
     long long s = (1024 + tiles - 1) / tiles;
     if (s > 8) s = 8;

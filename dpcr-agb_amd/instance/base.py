@@ -140,6 +140,10 @@ class InstanceBase(torch.nn.Module):
         name = opt.get("name", opt.get("class", "AdaBelief"))
         params = dict(opt.get("params", {}))
         cls = AdaBelief if name == "AdaBelief" else getattr(torch.optim, name)
+        self._grad_clip = training.get("grad_clip", -1)
+        if cls is AdaBelief and torch.cuda.is_available() and next(self.parameters()).is_cuda:
+            # one fused HIP launch per parameter group, gradient clip folded in
+            params.update(fused=True, clip_value=self._grad_clip if self._grad_clip > 0 else None)
         self._optimizer = cls(self.get_parameter_list(), **params)
         sch = training.get("lr_scheduler", None)
         if sch:
@@ -172,7 +176,7 @@ class InstanceBase(torch.nn.Module):
         self.loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()
-        if self._grad_clip > 0:
+        if self._grad_clip > 0 and not getattr(self._optimizer, "fused", False):
             torch.nn.utils.clip_grad_value_(self.parameters(), self._grad_clip)
         self._optimizer.step()
         self._step_scheduler(epoch, batch_size, num_batches)

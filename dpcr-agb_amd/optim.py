@@ -14,7 +14,10 @@ from torch.optim.optimizer import Optimizer
 
 class AdaBelief(Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-16, weight_decay=0, amsgrad=False,
-                 decoupled_decay=True, fixed_decay=False, rectify=True, degenerated_to_sgd=True):
+                 decoupled_decay=True, fixed_decay=False, rectify=True, degenerated_to_sgd=True, fused=False,
+                 clip_value=None):
+        """fused=True: one HIP launch per parameter group (csrc/optim.hip) instead of ~12 multi-tensor launches;
+        clip_value: clip_grad_value_ folded into that launch (the gradients themselves are left untouched)."""
         if lr < 0.0:
             raise ValueError(f"Invalid learning rate: {lr}")
         if eps < 0.0:
@@ -27,6 +30,8 @@ class AdaBelief(Optimizer):
                         degenerated_to_sgd=degenerated_to_sgd, decoupled_decay=decoupled_decay, rectify=rectify,
                         fixed_decay=fixed_decay)
         super().__init__(params, defaults)
+        self.fused, self.clip_value = bool(fused), clip_value
+        self._fused_cache = {}
 
     @staticmethod
     def _rectified_step(step, beta1, beta2, degenerated_to_sgd):
@@ -73,6 +78,9 @@ class AdaBelief(Optimizer):
             step = steps.pop()
             beta1, beta2 = group["betas"]
             lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+            if self.fused and params[0].is_cuda and group["decoupled_decay"]:
+                self._fused_step(group, params, grads, m, v, step)
+                continue
 
             if group["decoupled_decay"]:
                 torch._foreach_mul_(params, 1.0 - (wd if group["fixed_decay"] else lr * wd))
@@ -103,3 +111,56 @@ class AdaBelief(Optimizer):
                 elif step_size > 0:
                     torch._foreach_add_(params, m, alpha=-step_size * lr)
         return loss
+
+    # ------------------------------------------------------------------ fused HIP path
+    def _fused_step(self, group, params, grads, m, v, step):
+        from . import _lib
+        _V, _I, _F = _lib.c_void_p, _lib.c_int, _lib.c_float
+        if "agb_adabelief_step" not in _lib._SIGNATURES:
+            _lib.declare("agb_adabelief_chunk", [])
+            _lib.declare("agb_adabelief_step", [_V, _V, _V, _I, _F, _F, _F, _F, _F, _F, _F, _F, _I, _F, _V])
+        dev = params[0].device
+        key = (id(group), tuple(p.numel() for p in params))
+        cache = self._fused_cache.get(key)
+        if cache is None:
+            chunk = _lib.load().agb_adabelief_chunk()
+            ct, ci = [], []
+            for t, p in enumerate(params):
+                nck = (p.numel() + chunk - 1) // chunk
+                ct += [t] * nck
+                ci += list(range(nck))
+            cache = dict(ct=torch.tensor(ct, dtype=torch.int32, device=dev),
+                         ci=torch.tensor(ci, dtype=torch.int32, device=dev), n=len(ct),
+                         # ring of pinned staging tables: the host may run a step ahead of the device
+                         host=[torch.empty(len(params), 5, dtype=torch.int64).pin_memory() for _ in range(4)],
+                         dev=[torch.empty(len(params), 5, dtype=torch.int64, device=dev) for _ in range(4)], it=0)
+            self._fused_cache[key] = cache
+        slot = cache["it"] % 4
+        cache["it"] += 1
+        table = []
+        for p, g, mm, vv in zip(params, grads, m, v):
+            if not (p.is_contiguous() and g.is_contiguous()):
+                raise RuntimeError("fused AdaBelief needs contiguous parameters and gradients")
+            table.append((p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel()))
+        cache["host"][slot].numpy()[:] = table
+        descs = cache["dev"][slot]
+        descs.copy_(cache["host"][slot], non_blocking=True)
+        beta1, beta2 = group["betas"]
+        lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+        decay = 1.0 - (wd if group["fixed_decay"] else lr * wd)
+        inv_sqrt_bc2 = 1.0
+        if not group["rectify"]:
+            mode, stepv = 3, lr / (1 - beta1 ** step)
+            inv_sqrt_bc2 = 1.0 / math.sqrt(1 - beta2 ** step)
+        else:
+            num_sma, step_size = self._rectified_step(step, beta1, beta2, group["degenerated_to_sgd"])
+            if num_sma >= 5:
+                mode, stepv = 0, step_size * lr
+            elif step_size > 0:
+                mode, stepv = 1, step_size * lr
+            else:
+                mode, stepv = 2, 0.0
+        clip = float(self.clip_value) if self.clip_value else 0.0
+        _lib.call("agb_adabelief_step", _lib.ptr(descs), _lib.ptr(cache["ct"]), _lib.ptr(cache["ci"]),
+                  cache["n"], decay, beta1, beta2, 1 - beta1, 1 - beta2, eps, stepv, inv_sqrt_bc2, mode, clip,
+                  _lib.stream())

@@ -214,6 +214,17 @@ int agb_voxelize_last(const float* pos, const long long* perm, const int32_t* pt
                       long long* keep, int32_t* out_ptr, int32_t* n_out_dev, int32_t* bounds, int32_t* status,
                       void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdaBelief step with clip_grad_value_ (replaces core/optimizer/adabelief.py:89-201 +
+ * models/base_model.py:241-245).  descs: device array of {float* p; const float* g; float* m; float* v; int64 n}
+ * per tensor; chunk_tensor / chunk_index: int32[n_chunks] (tensor of every agb_adabelief_chunk()-element block and
+ * its chunk number).  mode 0 rectified-adaptive, 1 SGD-like, 2 no update, 3 non-rectified.  clip <= 0: no clip.
+ * --------------------------------------------------------------------------------------------------------- */
+int agb_adabelief_chunk(void);
+int agb_adabelief_step(const void* descs, const int32_t* chunk_tensor, const int32_t* chunk_index, int n_chunks,
+                       float decay, float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps,
+                       float step, float inv_sqrt_bc2, int mode, float clip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
