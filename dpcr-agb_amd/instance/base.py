@@ -168,6 +168,37 @@ class InstanceBase(torch.nn.Module):
             for _ in range(batch_size):
                 self._lr_scheduler.step(epoch)
 
+    @torch.no_grad()
+    def calibrate_bn(self, batches, device, epochs=1):
+        """Forward-only passes in train mode to refresh the BatchNorm running statistics — the reference's
+        calibrate_bn.py flow (trainer.py:230-283: model.train() under torch.no_grad())."""
+        was_training = self.training
+        self.train()
+        for _ in range(epochs):
+            for data in batches:
+                self.set_input(data, device)
+                self.forward()
+        self.train(was_training)
+
+    @torch.no_grad()
+    def evaluate(self, batches, device, target_mean=None):
+        """eval.py flow (trainer.py:361-418): no-grad forward in eval mode, RMSE / MAE / R2 as the InstanceTracker
+        defines them (metrics.py).  target_mean: mean of the stage's targets (default: of these batches)."""
+        from ..metrics import RegressionMeter
+        was_training = self.training
+        self.eval()
+        outs, ys = [], []
+        for data in batches:
+            self.set_input(data, device)
+            self.forward()
+            outs.append(self.get_reg_output().detach().cpu())
+            ys.append(self.get_reg_input().detach().cpu())
+        self.train(was_training)
+        outs, ys = torch.cat(outs), torch.cat(ys)
+        meter = RegressionMeter(ys.double().mean(0) if target_mean is None else target_mean)
+        meter.add(outs, ys)
+        return meter.value()
+
     def optimize_parameters(self, epoch, batch_size, num_batches):
         self(epoch=epoch)
         # data-parallel: gradients accumulate in place into the flat all-reduce buckets; single GPU: let autograd

@@ -1,0 +1,117 @@
+"""Size-independent properties of the sparse-voxel HIP path at BASELINE.json's full size (B = 32 plots x 16 000
+points, ~411 k voxels, voxel 0.0125) — where the CPU oracle is too slow to be the checker:
+uniqueness/ordering of levels, kernel-map symmetry, centre-tap convolution == Linear, linearity, adjointness of
+forward and data-gradient, weight-gradient against a dense contraction over an explicit pair list, pooling identities."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full(device):
+    from dpcr_agb_amd import synthetic
+    import dpcr_agb_amd.me_compat as ME
+    batch = synthetic.make_sparse_batch(list(range(32)), n_points=16000)
+    coords = torch.cat([batch.batch[:, None].int(), batch.coords.int()], 1)
+    st = ME.SparseTensor(batch.x, coordinates=coords, device=device, batch_size=32, bounds=batch.coord_bounds)
+    cm = st.coordinate_manager
+    cm.prefetch_strides([1, 2, 2, 4, 8, 16])
+    return st, cm, batch
+
+
+def test_levels_unique_batch_ordered(full):
+    st, cm, batch = full
+    assert cm.mode == "grid"
+    prev = None
+    for ts in (1, 2, 4, 8, 16):
+        lvl = cm.level(ts)
+        c = lvl.coords[:lvl.n].long()
+        key = ((c[:, 0] * 4096 + c[:, 3] + 2048) * 4096 + c[:, 2] + 2048) * 4096 + c[:, 1] + 2048
+        assert torch.unique(key).numel() == lvl.n                       # no duplicate coordinates
+        assert bool((c[1:, 0] >= c[:-1, 0]).all())                      # rows stay batch-contiguous
+        assert bool(((c[:, 1:] % ts) == 0).all())                       # coordinates on the level's lattice
+        ptr = cm.batch_ptr(ts).long()
+        assert int(ptr[-1]) == lvl.n and torch.equal(ptr[1:] - ptr[:-1], torch.bincount(c[:, 0], minlength=32))
+        if prev is not None:
+            assert lvl.n < prev
+        prev = lvl.n
+    assert 380_000 < cm.level(1).n < 450_000
+
+
+def test_kernel_map_symmetry_and_pair_count(full):
+    st, cm, _ = full
+    for ts, K in ((1, 7), (2, 3), (4, 3)):
+        nbr = cm.kernel_map(ts, K, 1).long()
+        K3, n = nbr.shape
+        assert int((nbr >= 0).sum()) == int(nbr.agb_pairs.sum()) if hasattr(nbr, "agb_pairs") else True
+        rows = torch.arange(n, device=nbr.device)
+        assert torch.equal(nbr[K3 // 2], rows)                          # centre tap is the identity
+        for k in (0, 5, K3 // 2 + 3, K3 - 1):
+            q = nbr[k]
+            ok = q >= 0
+            assert torch.equal(nbr[K3 - 1 - k][q[ok]], rows[ok])        # nbr[k][r] = q  <=>  nbr[K3-1-k][q] = r
+    pairs = int(cm.kernel_map(1, 7, 1).agb_pairs.sum())
+    assert int((cm.kernel_map(1, 7, 1) >= 0).sum()) == pairs
+
+
+@pytest.mark.parametrize("ts,cin,cout", [(2, 64, 64), (4, 128, 128), (16, 512, 512)])
+def test_conv_identities(full, device, ts, cin, cout):
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd.sparse_ops import SparseConvFunction
+    st, cm, _ = full
+    torch.manual_seed(ts)
+    n = cm.level(ts).n
+    nbr = cm.kernel_map(ts, 3, 1)
+    x = torch.randn(n, cin, device=device)
+    y2 = torch.randn(n, cin, device=device)
+    w = torch.randn(27, cin, cout, device=device) * 0.05
+    f = lambda a, ww: SparseConvFunction.apply(a, ww, None, nbr, None, n, n)  # noqa: E731
+    # centre tap only == Linear
+    wc = torch.zeros_like(w)
+    wc[13] = w[13]
+    ref = x @ w[13]
+    assert float((f(x, wc) - ref).abs().max() / ref.abs().max()) < 1e-5
+    # linearity
+    a, b = 0.7, -1.3
+    lhs, rhs = f(a * x + b * y2, w), a * f(x, w) + b * f(y2, w)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max()) < 1e-4
+    # adjointness of forward and data gradient: <conv(x), g> == <x, conv^T(g)>; weight gradient vs explicit pairs
+    xg = x.clone().requires_grad_(True)
+    wg = w.clone().requires_grad_(True)
+    out = f(xg, wg)
+    g = torch.randn_like(out)
+    out.backward(g)
+    lhs, rhs = float((out.detach().double() * g.double()).sum()), float((x.double() * xg.grad.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs), 1.0)
+    k = 5
+    q = nbr[k].long()
+    ok = q >= 0
+    dw_ref = x[q[ok]].double().t() @ g[ok].double()
+    assert float((wg.grad[k].double() - dw_ref).abs().max() / dw_ref.abs().max()) < 1e-4
+
+
+def test_strided_conv_adjointness_and_pools(full, device):
+    import dpcr_agb_amd.me_compat as ME
+    st, cm, _ = full
+    torch.manual_seed(0)
+    n_in = cm.level(2).n
+    conv = ME.MinkowskiConvolution(64, 128, kernel_size=3, stride=2, bias=False, dimension=3).to(device)
+    x = torch.randn(n_in, 64, device=device, requires_grad=True)
+    inp = ME.SparseTensor(x, coordinate_map_key=ME.CoordinateMapKey(2), coordinate_manager=cm)
+    out = conv(inp).F
+    g = torch.randn_like(out)
+    out.backward(g)     # goes through the class-partitioned data gradient
+    lhs, rhs = float((out.detach().double() * g.double()).sum()), float((x.detach().double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs), 1.0)
+    # pooling identities
+    ones = ME.SparseTensor(torch.ones(n_in, 64, device=device), coordinate_map_key=ME.CoordinateMapKey(2),
+                           coordinate_manager=cm)
+    counts = torch.bincount(cm.level(2).coords[:n_in, 0].long(), minlength=32).float()
+    assert torch.equal(ME.MinkowskiGlobalSumPooling()(ones).F[:, 0], counts)
+    assert torch.allclose(ME.MinkowskiGlobalAvgPooling()(ones).F, torch.ones(32, 64, device=device))
+    mp = ME.MinkowskiMaxPooling(3, 2, dimension=3)(ones)
+    assert mp.F.shape[0] == cm.level(4).n and bool((mp.F == 1).all())
+    xs = ME.SparseTensor(x.detach(), coordinate_map_key=ME.CoordinateMapKey(2), coordinate_manager=cm)
+    assert bool((ME.MinkowskiGlobalMaxPooling()(xs).F >= ME.MinkowskiGlobalAvgPooling()(xs).F).all())
