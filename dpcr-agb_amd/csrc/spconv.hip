@@ -314,6 +314,172 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Low-precision-operand variant of k_spconv_pipe: fp32 features/weights in HBM are rounded to bf16 while being staged
+// into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the fp32 MFMA rate).
+//   X3 = false : plain bf16 operands (BASELINE.json config 5: "bf16 with fp32 index kernels")
+//   X3 = true  : split-bf16: a = a_hi + a_lo, acc += a_hi*b_hi + a_hi*b_lo + a_lo*b_hi — relative error ~2^-16 per
+//                product, i.e. fp32-level accuracy for this network (1e-4 bar) at 3/16 of the fp32 MFMA cost
+// W is taken K-major: Wt[K3][Cout][Cin] (the k index contiguous) so that both MFMA operands are staged as plain 16-B
+// row pieces: forward passes the transposed kernel, the data gradient passes the kernel itself.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define LBK 64        // K elements per chunk
+#define LLD 72        // LDS row stride in bf16 (144 B = 36 dwords: conflict-free ds_read_b128, as LDA)
+
+__device__ __forceinline__ unsigned short f2bf(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);   // round to nearest even (NaN payloads are not preserved: features are finite)
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <bool X3>
+__device__ __forceinline__ void stage_bf16(unsigned short* hi, unsigned short* lo, int off, float4 v) {
+    unsigned short h0 = f2bf(v.x), h1 = f2bf(v.y), h2 = f2bf(v.z), h3 = f2bf(v.w);
+    *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+    if (X3) {
+        unsigned short l0 = f2bf(v.x - bf2f(h0)), l1 = f2bf(v.y - bf2f(h1)), l2 = f2bf(v.z - bf2f(h2)),
+                       l3 = f2bf(v.w - bf2f(h3));
+        *reinterpret_cast<uint2*>(lo + off) =
+            make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+    }
+}
+
+template <int TM, bool PERM, bool X3>
+__global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
+    constexpr int WAVES_M = TM / 32;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int NT = 2 / WAVES_N;
+    constexpr int AJ = TM / 16;            // float4 A gathers per thread per chunk (16 rows per pass)
+    constexpr int NP = X3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short As[NP][TM * LLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][64 * LLD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tile = blockIdx.x;
+    const int row0 = tile * TM;
+    const int n0 = blockIdx.y * BN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int t_r = tid >> 4, t_c = (tid & 15) * 4;   // staging: row (+16j), k offset inside the chunk
+    const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
+
+    int noff = K3;
+    const int32_t* offs = nullptr;
+    if (PERM) {
+        int cls = a.tile_cls[tile];
+        if (cls < 0) return;
+        noff = a.cls_tab[cls * (1 + K3)];
+        offs = a.cls_tab + cls * (1 + K3) + 1;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int cpk = (Cin + LBK - 1) / LBK;
+    const int nchunks = noff * cpk;
+    const int ch_beg = (int)((long long)nchunks * blockIdx.z / a.ksplit);
+    const int ch_end = (int)((long long)nchunks * (blockIdx.z + 1) / a.ksplit);
+
+    int grow[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        int r = row0 + t_r + 16 * j;
+        if (PERM) grow[j] = a.perm[r];
+        else grow[j] = r < a.n_out ? r : -1;
+    }
+    int idx_cur[AJ], idx_nxt[AJ];
+    float4 a_reg[AJ], b_reg[4];
+
+    auto offset_of = [&](int ch) {
+        int ko = ch / cpk;
+        return PERM ? offs[ko] : ko;
+    };
+    auto load_idx = [&](int ch, int* dst) {
+        int k = ch < ch_end ? offset_of(ch) : 0;
+        int kn = a.kflip ? (K3 - 1 - k) : k;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            dst[j] = (ch < ch_end && grow[j] >= 0) ? a.nbr[(long long)kn * a.nbr_stride + grow[j]] : -1;
+    };
+    auto load_data = [&](int ch, const int* idx) {
+        int k = offset_of(ch);
+        int c0 = (ch % cpk) * LBK;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx[j] >= 0 && c0 + t_c < Cin)
+                a_reg[j] = *reinterpret_cast<const float4*>(a.X + (long long)idx[j] * a.ldx + c0 + t_c);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + t_r + 16 * j;
+            b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < Cout && c0 + t_c < Cin)
+                b_reg[j] = *reinterpret_cast<const float4*>(a.W + ((long long)k * Cout + n) * Cin + c0 + t_c);
+        }
+    };
+
+    if (ch_beg < ch_end) {
+        load_idx(ch_beg, idx_cur);
+        load_idx(ch_beg + 1, idx_nxt);
+        load_data(ch_beg, idx_cur);
+    }
+    for (int ch = ch_beg; ch < ch_end; ++ch) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) stage_bf16<X3>(As[0], As[NP - 1], (t_r + 16 * j) * LLD + t_c, a_reg[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_bf16<X3>(Bs[0], Bs[NP - 1], (t_r + 16 * j) * LLD + t_c, b_reg[j]);
+        __syncthreads();
+        if (ch + 1 < ch_end) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) idx_cur[j] = idx_nxt[j];
+            load_data(ch + 1, idx_cur);
+            load_idx(ch + 2, idx_nxt);
+        }
+        // fragments: lane (r = lane&31, h = lane>>5) holds A[row r][k = 16 s + 8 h + j] and B[same k][col r], j = 0..7
+        const int aoff = (wm * 32 + li) * LLD + 8 * lh;
+#pragma unroll
+        for (int s2 = 0; s2 < LBK / 16; ++s2) {
+            bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][aoff + 16 * s2]);
+            bf16x8 al;
+            if (X3) al = *reinterpret_cast<const bf16x8*>(&As[NP - 1][aoff + 16 * s2]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int boff = ((wn * NT + nt) * 32 + li) * LLD + 8 * lh + 16 * s2;
+                bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][boff]);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+                if (X3) {
+                    bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[NP - 1][boff]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = a.ksplit > 1 ? a.partial + (long long)blockIdx.z * a.n_out * Cout : a.Y;
+    const int ldo = a.ksplit > 1 ? Cout : a.ldy;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        int rt = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        int row = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
+        if (row < 0) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + (wn * NT + nt) * 32 + li;
+            if (col < Cout) {
+                float bv = (a.bias && a.ksplit == 1) ? a.bias[col] : 0.f;
+                out[(long long)row * ldo + col] = acc[nt][reg] + bv;
+            }
+        }
+    }
+}
+
 // Y[r, :] = bias + sum_s partial[s][r, :]   (fixed order)
 __global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_out, int C4,
                                const float* __restrict__ bias, float* __restrict__ Y, int ldy) {
@@ -671,6 +837,44 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
     int rc = launch_conv(a, n_tiles, (hipStream_t)stream);
     if (rc) return rc;
     AGB_CHECK_LAUNCH("agb_spconv_fwd");
+    return AGB_OK;
+}
+
+// Low-precision operands (precision 1 = bf16, 2 = split-bf16 x3), fp32 accumulate and fp32 I/O.  Same contract as
+// agb_spconv_fwd_ex except that the weights are K-major: Wt float[K3][Cout][Cin].
+int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* nbr, long long nbr_stride, int kflip,
+                      const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                      const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                      float* partial, int precision, void* stream) {
+    AGB_CHECK_ARG(precision == 1 || precision == 2, "agb_spconv_fwd_lp: precision %d (1 = bf16, 2 = bf16x3)", precision);
+    AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 4 && Cout >= 4 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0,
+                  "agb_spconv_fwd_lp: Cin (%d), Cout (%d), ldx must be multiples of 4", Cin, Cout);
+    AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_lp: ksplit needs `partial`");
+    if (n_out == 0) return AGB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ConvArgs a{X, ldx, Wt, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit,
+               partial};
+    dim3 block(256);
+    const bool x3 = precision == 2;
+    if (perm) {
+        dim3 grid(n_tiles, agb_cdiv(Cout, BN), ksplit);
+        if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<64, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_spconv_pipe_bf16<64, true, false>), grid, block, 0, s, a);
+    } else if (conv_tile_rows(n_out, Cin, Cout) == 128) {
+        dim3 grid(agb_cdiv(n_out, 128), agb_cdiv(Cout, BN), ksplit);
+        if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, false>), grid, block, 0, s, a);
+    } else {
+        dim3 grid(agb_cdiv(n_out, 64), agb_cdiv(Cout, BN), ksplit);
+        if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<64, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_spconv_pipe_bf16<64, false, false>), grid, block, 0, s, a);
+    }
+    if (ksplit > 1) {
+        long long total = (long long)n_out * (Cout / 4);
+        hipLaunchKernelGGL(k_split_reduce, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, partial, ksplit, n_out, Cout / 4,
+                           bias, Y, ldy);
+    }
+    AGB_CHECK_LAUNCH("agb_spconv_fwd_lp");
     return AGB_OK;
 }
 

@@ -10,6 +10,18 @@ from . import _lib
 
 _P = _lib.ptr
 
+# Operand precision of the sparse-conv forward / data-gradient MFMAs (weight gradient and all I/O stay fp32):
+#   "fp32"   exact fp32 MFMA (default; what bench.py's headline number uses)
+#   "bf16"   bf16 operands, fp32 accumulate (BASELINE.json config 5)
+#   "bf16x3" split-bf16 (hi+lo) operands, three MFMAs per product: fp32-level accuracy at 3/16 of the fp32 MFMA cost
+import os as _os
+CONV_PRECISION = _os.environ.get("AGB_CONV_PRECISION", "fp32")
+_PREC_ID = {"bf16": 1, "bf16x3": 2}
+_lib.declare("agb_spconv_fwd_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
+                                   _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
+                                   _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
+                                   _lib.c_void_p, _lib.c_int, _lib.c_void_p])
+
 # When set to a list, every sparse-conv launch appends
 #   dict(kind, K3, cin, cout, rows, pairs (device int64 tensor or None), start, end (torch.cuda.Event))
 # bench.py uses this to time the dominant kernel with HIP events on the launch stream.
@@ -50,9 +62,11 @@ def _small_cin_pad(cin):
     return (cin + 3) // 4 * 4
 
 
-def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None, plan=None):
+def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None, plan=None,
+                       w_kmajor=None):
     """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout].
-    plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad)."""
+    plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
+    w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes."""
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
     split = _lib.load().agb_spconv_split_hint(n_out, K3, cin, cout) if plan is None else 1
     partial = torch.empty(split, n_out, cout, dtype=torch.float32, device=x.device) if split > 1 else None
@@ -61,9 +75,15 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     if plan is not None:
         perm, tile_cls, cls_tab, n_tiles = plan
     ev = _prof_begin()
-    _lib.call("agb_spconv_fwd_ex", _P(x), x.stride(0), _P(w2d), _P(nbr), nbr.stride(0), int(kflip), _P(bias), _P(y),
-              y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles, split, _P(partial),
-              _lib.stream())
+    prec = _PREC_ID.get(CONV_PRECISION, 0) if (w_kmajor is not None and cin >= 12) else 0
+    if prec:
+        _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), nbr.stride(0), int(kflip),
+                  _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
+                  split, _P(partial), prec, _lib.stream())
+    else:
+        _lib.call("agb_spconv_fwd_ex", _P(x), x.stride(0), _P(w2d), _P(nbr), nbr.stride(0), int(kflip), _P(bias),
+                  _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles, split,
+                  _P(partial), _lib.stream())
     _prof_end(ev, kind, K3, cin, cout, n_out, pairs, plan is not None, split)
     return y
 
@@ -89,7 +109,8 @@ class SparseConvFunction(torch.autograd.Function):
                 b = F.pad(b, (0, cout_p - cout))
             b = b.contiguous()
         pairs = getattr(nbr, "agb_pairs", None)
-        y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs)
+        wkm = w.transpose(1, 2).contiguous() if (CONV_PRECISION in _PREC_ID and cin_p >= 12) else None
+        y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs, None, wkm)
         ctx.pairs = pairs
         ctx.plan = plan
         ctx.save_for_backward(x, w, nbr, nbrT if nbrT is not None else torch.empty(0))
@@ -107,12 +128,17 @@ class SparseConvFunction(torch.autograd.Function):
         dx = dk = db = None
         if ctx.needs_input_grad[0]:
             # dX[q] = sum_k dY[nbrT[k][q]] @ W[k]^T : same implicit GEMM with the transposed weights
-            wt2d = w.transpose(1, 2).contiguous().view(K3 * cout_p, cin_p)
+            lp = CONV_PRECISION in _PREC_ID and cout_p >= 12
+            # the data gradient multiplies by W[k]^T: its K-major form is the kernel itself ([K3, cin, cout])
+            wkm = w.contiguous() if lp else None
+            wt2d = None if lp else w.transpose(1, 2).contiguous().view(K3 * cout_p, cin_p)
             if has_T:
                 plan = ctx.plan if cout_p >= 12 else None
-                dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, plan)
+                dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, plan,
+                                         wkm)
             else:
-                dxp = spconv_forward_raw(dy, wt2d, nbr, 1, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs)
+                dxp = spconv_forward_raw(dy, wt2d, nbr, 1, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, None,
+                                         wkm)
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)

@@ -103,6 +103,14 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                       float* partial, void* stream);
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper */
+/* Low-precision MFMA operands, fp32 accumulate and I/O: precision 1 = bf16 (BASELINE config 5), 2 = split-bf16 x3
+ * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi: fp32-level accuracy at 3/16 of the fp32 MFMA cost).  Same contract as
+ * agb_spconv_fwd_ex but the weights are K-major: Wt float[K3][Cout][Cin] (forward: the transposed kernel; data
+ * gradient: the kernel itself).  Cin >= 12. */
+int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* nbr, long long nbr_stride, int kflip,
+                      const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                      const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                      float* partial, int precision, void* stream);
 /* perm int32[n + stride^3*64] (rows grouped by class, -1 padding), tile_cls int32[max_tiles] with
  * max_tiles = n/64 + stride^3 + 1, scratch int32[256].  class = (c/ts_in mod stride) per axis, x fastest. */
 int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, int32_t* perm, int32_t* tile_cls,

@@ -334,3 +334,44 @@ def test_mpointnet_matches_oracle(device, pool):
     for k, p in model.model.named_parameters():
         denom = max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
         assert float((p.grad.detach().cpu().double() - sd[k].grad).abs().max()) / denom < 10 * RTOL, k
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16", 2e-2), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("cin,cout,K,stride,ts_in", [(64, 64, 3, 1, 2), (64, 128, 3, 2, 2), (96, 80, 3, 1, 1),
+                                                      (128, 128, 3, 1, 4), (16, 32, 3, 1, 1)])
+def test_conv_low_precision_operands(device, precision, tol, cin, cout, K, stride, ts_in):
+    """bf16 / split-bf16x3 MFMA operands (fp32 accumulate): forward and data gradient vs the fp64 oracle.
+    bf16x3 must meet the fp32 bar (1e-4); plain bf16 is the config-5 mode."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import sparse_ops
+    rng = np.random.default_rng(cin + cout)
+    torch.manual_seed(cin * 7 + cout)
+    coords = random_coords(rng, 2, 1500, 16)
+    ref = R.Coords(coords, 2)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    ts = 1
+    while ts < ts_in:
+        cm.stride(ts, 2)
+        ref.level(ts, 2)
+        ts *= 2
+    n_in = cm.level(ts_in).n
+    x = torch.randn(n_in, cin)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=K, stride=stride, bias=True, dimension=3).to(device)
+    old = sparse_ops.CONV_PRECISION
+    sparse_ops.CONV_PRECISION = precision
+    try:
+        xg = x.to(device).requires_grad_(True)
+        out = conv(ME.SparseTensor(xg, coordinate_map_key=ME.CoordinateMapKey(ts_in), coordinate_manager=cm))
+        g = torch.randn(out.F.shape[0], cout)
+        out.F.backward(g.to(device))
+    finally:
+        sparse_ops.CONV_PRECISION = old
+    xr = x.double().requires_grad_(True)
+    wr = conv.kernel.detach().cpu().double().requires_grad_(True)
+    br = conv.bias.detach().cpu().double().requires_grad_(True)
+    outr = R.conv(xr, ref.map(ts_in, K, stride), wr, br)
+    outr.backward(g.double())
+    assert rel_err(out.F, outr) < tol
+    assert rel_err(xg.grad, xr.grad) < tol
+    assert rel_err(conv.kernel.grad, wr.grad) < RTOL      # the weight gradient stays fp32
