@@ -56,12 +56,14 @@ def kernel_of(rec):
     """Name of the HIP kernel a recorded launch ran (mirrors the dispatch rule of csrc/spconv.hip:launch_conv)."""
     small = rec["cin"] in (4, 8)
     if rec["kind"] == "wgrad":
-        return f"k_spconv_dw<{rec['cin']}>" if small else "k_spconv_dw_pipe"
+        return f"k_spconv_dw<{rec['cin']}>" if small else "k_spconv_dw_cmp"
     if small:
         return f"k_spconv_fwd<{rec['cin']}>"
     if rec.get("perm"):
         return "k_spconv_pipe<64, true>"
     col_tiles = -(-rec["cout"] // 64)
+    if rec["cin"] % 64 == 0 and rec.get("split", 1) == 1 and -(-rec["rows"] // 128) * col_tiles >= 384:
+        return "k_spconv_cmp<128>"
     if -(-rec["rows"] // 128) * col_tiles >= 1024 or (rec["cin"] >= 256 and rec["rows"] >= 1024):
         return "k_spconv_pipe<128, false>"
     return "k_spconv_pipe<64, false>"

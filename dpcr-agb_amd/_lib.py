@@ -39,6 +39,7 @@ _SIGNATURES = {
     "agb_spconv_fwd_ex": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "agb_spconv_split_hint": [c_int, c_int, c_int, c_int],
+    "agb_spconv_set_cmp_mode": [c_int],
     "agb_parity_partition": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "agb_spconv_bwd_weight": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int,
                               c_void_p],

@@ -14,6 +14,7 @@
 // kernel offsets, gathering the 64 neighbour rows of each offset into LDS (coalesced 16-B row pieces).
 // Results are run-to-run deterministic for fwd/data-grad.
 #include "agb_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -480,6 +481,206 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PAIR-COMPACTED output-stationary kernel (Cin a multiple of 64).
+// The register-accumulator kernels above multiply zero rows wherever a neighbour is absent (3^3 maps are 50-70 %
+// dense).  Here every WAVE (= workgroup) owns up to R consecutive output rows x 64 output channels whose running sums
+// live in LDS (wave-private: no barriers, no atomics, fixed offset / group order -> deterministic).  Per kernel
+// offset the wave compacts its neighbour indices (ballot + prefix) into a pair list and multiplies only the present
+// pairs, 16 at a time, on v_mfma_f32_16x16x4_f32 (exact fp32, same peak as 32x32x2):
+//   A fragment  lane (m, q) = row m of the group, channels 4q..4q+3 of each 16-channel block: one 16-B gather
+//               straight from global memory into registers, prefetched one group ahead (across offsets too);
+//   B fragment  MFMA column j of accumulator ct stands for output column 4j+ct, so lane m reads W[k][c][4m..4m+3]
+//               as ONE float4 and the 16x64 product block leaves as float4 read-add-writes on the LDS rows;
+//               the fragments of a 64-channel step stay in registers for all groups, those of the next step are
+//               loaded while the current one multiplies (two register sets, loop unrolled by two).
+// MFMA work = pairs rounded up to 16 per (wave, offset) instead of the tile height per offset.
+// 1-D grid, XCD-aware: every XCD (workgroup id % 8) walks one contiguous range of row tiles, so the gathers of
+// neighbouring tiles share that XCD's L2.  rows_per_tile <= R is chosen by the host so that the number of workgroups is
+// a multiple of the resident-wave capacity (tiles of equal cost: no half-empty last round).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CMP_YS 68   // LDS row stride of the running sums (floats): 16-B aligned rows, 4-bank skew per row
+#define CMP_CB 4    // 16-channel blocks per step (64 input channels)
+
+template <int R>
+__global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int nct, int rows_per_tile) {
+    constexpr int NJ = R / 64;
+    constexpr int CB = CMP_CB;
+    // row R of Ys is a sink: list padding (up to 15 entries per offset) multiplies input row 0 into it
+    __shared__ __attribute__((aligned(16))) float Ys[(R + 1) * CMP_YS];
+    __shared__ __attribute__((aligned(16))) int pl_in[2][R + 16];
+    __shared__ __attribute__((aligned(16))) int pl_out[2][R + 16];
+    const int lane = threadIdx.x;
+    const int m = lane & 15, q = lane >> 4;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int ct0 = jx % nct;
+    const int tile = xcd * per_xcd + jx / nct;
+    if (tile >= ntiles) return;
+    const int row0 = tile * rows_per_tile;
+    const int row_end = min(a.n_out, row0 + rows_per_tile);
+    const int n0 = ct0 * 64;
+    const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
+    const int NSB = Cin / (CB * 16);
+    const int nsteps = K3 * NSB;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const bool colok = (n0 + 4 * m) < Cout;
+    // clamped column: the weight loads are unconditional; columns past Cout hold sums that the epilogue never stores
+    const int coff = colok ? 4 * m : 0;
+
+    for (int i = lane; i < (R + 1) * CMP_YS / 4; i += 64)
+        reinterpret_cast<float4*>(Ys)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int nv[NJ];
+    auto load_nbr = [&](int k) {
+        const int kn = a.kflip ? (K3 - 1 - k) : k;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int r = row0 + 64 * j + lane;
+            nv[j] = r < row_end ? a.nbr[(long long)kn * a.nbr_stride + r] : -1;
+        }
+    };
+    // pairs of offset k (whose neighbour indices are in nv) -> list k&1, padded to a multiple of 16; returns groups
+    auto compact = [&](int k) {
+        int* li = pl_in[k & 1];
+        int* lo = pl_out[k & 1];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool p = nv[j] >= 0;
+            const unsigned long long bal = __ballot(p);
+            if (p) {
+                int pos = cnt + __popcll(bal & lt_mask);
+                li[pos] = nv[j];
+                lo[pos] = 64 * j + lane;
+            }
+            cnt += __popcll(bal);
+        }
+        const int cpad = (cnt + 15) & ~15;
+        if (lane < cpad - cnt) {
+            li[cnt + lane] = 0;
+            lo[cnt + lane] = R;
+        }
+        __threadfence_block();
+        return cpad >> 4;
+    };
+    auto load_b = [&](int step, float4 (&b)[CB][4]) {
+        const int k = step / NSB, cbase = (step % NSB) * (CB * 16);
+        const float* Wk = a.W + ((long long)k * Cin + cbase + 4 * q) * Cout + n0 + coff;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                b[cb][s2] = *reinterpret_cast<const float4*>(Wk + (cb * 16 + s2) * Cout);
+            }
+    };
+    float4 an[CB];
+    // A fragment of one 16-channel block of group g of `step` (list padding points at input row 0)
+    auto gather_cb = [&](int step, int g, int cb) {
+        const int k = step / NSB, cbase = (step % NSB) * (CB * 16);
+        const float* xr = a.X + (long long)pl_in[k & 1][16 * g + m] * a.ldx + cbase + 4 * q;
+        an[cb] = *reinterpret_cast<const float4*>(xr + cb * 16);
+    };
+    auto gather = [&](int step, int g) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) gather_cb(step, g, cb);
+    };
+
+    int ng_cur, ng_nxt = 0;
+    // one step = 64 input channels of one offset.  bcur: this step's weights; bnxt: filled for the next step
+    auto body = [&](int step, float4 (&bcur)[CB][4], float4 (&bnxt)[CB][4]) {
+        const int k = step / NSB;
+        const int nstep = step + 1;
+        if (nstep < nsteps) {
+            const int nk = nstep / NSB;
+            if (nk != k) {
+                ng_nxt = compact(nk);
+                if (nk + 1 < K3) load_nbr(nk + 1);   // in flight during this offset's MFMAs
+            } else {
+                ng_nxt = ng_cur;
+            }
+            load_b(nstep, bnxt);
+        } else {
+            ng_nxt = 0;
+        }
+        const int* lo = pl_out[k & 1];
+        if (ng_cur == 0 && ng_nxt > 0) gather(nstep, 0);
+        // list / channel offset of this step and of the next one (for the refills)
+        const int* li_cur = pl_in[k & 1];
+        const int* li_nxt = pl_in[(nstep / NSB) & 1];
+        const int xoff_cur = (step % NSB) * (CB * 16) + 4 * q, xoff_nxt = (nstep % NSB) * (CB * 16) + 4 * q;
+
+        for (int g = 0; g < ng_cur; ++g) {
+            // D layout: MFMA col = lane & 15 (-> output column 4m + ct), row = 4 * (lane >> 4) + v.  The four rows of a
+            // lane group are distinct (a row occurs once per offset) or the sink row.
+            const int4 o4 = *reinterpret_cast<const int4*>(&lo[16 * g + 4 * q]);
+            const int ov[4] = {o4.x, o4.y, o4.z, o4.w};
+            float4 yv[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) yv[v] = *reinterpret_cast<const float4*>(&Ys[ov[v] * CMP_YS + 4 * m]);
+            // where the registers of a 16-channel block are refilled from once its MFMAs are issued: the next group of
+            // this step, or the first group of the next step (three quarters of a group of MFMAs ahead of use); with
+            // no next group at all, group 0 of this step is re-read: the loads stay unconditional so that the
+            // compiler's wait counts are exact instead of "everything outstanding"
+            const bool last = g + 1 == ng_cur;
+            const bool tonext = last && ng_nxt > 0;
+            const int pg = last ? 0 : g + 1;
+            const float* xnext = a.X + (long long)(tonext ? li_nxt : li_cur)[16 * pg + m] * a.ldx +
+                                 (tonext ? xoff_nxt : xoff_cur);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const float av[4] = {an[cb].x, an[cb].y, an[cb].z, an[cb].w};
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bcur[cb][s2].x, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bcur[cb][s2].y, c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bcur[cb][s2].z, c2, 0, 0, 0);
+                    c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bcur[cb][s2].w, c3, 0, 0, 0);
+                }
+                // Pin the refill of this block right behind its MFMAs: left alone, instruction selection and the
+                // scheduler sink all four loads to the end of the group, where their latency is exposed.  The empty
+                // asm ties the accumulators (the MFMAs stay above it) and clobbers memory (the load stays between).
+                asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : : "memory");
+                const float4 ld = *reinterpret_cast<const float4*>(xnext + cb * 16);
+                asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : : "memory");
+                an[cb] = ld;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float4 y = yv[v];
+                y.x += c0[v]; y.y += c1[v]; y.z += c2[v]; y.w += c3[v];
+                *reinterpret_cast<float4*>(&Ys[ov[v] * CMP_YS + 4 * m]) = y;
+            }
+        }
+        ng_cur = ng_nxt;
+    };
+
+    float4 bA[CB][4], bB[CB][4];
+    load_nbr(0);
+    ng_cur = compact(0);
+    if (K3 > 1) load_nbr(1);
+    load_b(0, bA);
+    if (ng_cur > 0) gather(0, 0);
+    for (int step = 0; step < nsteps; step += 2) {
+        body(step, bA, bB);
+        if (step + 1 < nsteps) body(step + 1, bB, bA);
+    }
+    __threadfence_block();
+    // ---- epilogue: tile -> global (4 rows per instruction, float4 per lane)
+    const int c4 = (lane & 15) * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias && n0 + c4 < Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + c4);
+    for (int r = lane >> 4; r < rows_per_tile; r += 4) {
+        const int row = row0 + r;
+        if (row < row_end && n0 + c4 < Cout) {
+            float4 y = *reinterpret_cast<const float4*>(&Ys[r * CMP_YS + c4]);
+            y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+            *reinterpret_cast<float4*>(a.Y + (long long)row * a.ldy + n0 + c4) = y;
+        }
+    }
+}
+
 // Y[r, :] = bias + sum_s partial[s][r, :]   (fixed order)
 __global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_out, int C4,
                                const float* __restrict__ bias, float* __restrict__ Y, int ldy) {
@@ -762,6 +963,121 @@ __global__ __launch_bounds__(256) void k_spconv_dw_pipe(const float* __restrict_
     }
 }
 
+// Weight gradient, generic path, PAIR-COMPACTED: the reduction runs over rows, so rows whose neighbour at offset k is
+// absent need not be multiplied at all.  Every workgroup first compacts its row chunk of nbr[k] into an (in, out) pair
+// list in LDS (row order kept: deterministic inside the workgroup), then walks that list 64 pairs at a time with the
+// same register-prefetch pipeline — MFMA work falls by the map density (0.5-0.8 on the 3^3 maps).
+// 1-D grid, XCD-aware: consecutive workgroups of one XCD (id % 8) walk the m-tiles (offset x cin tile) of ONE row
+// chunk, so the chunk's dY / X rows are re-read from that XCD's L2 instead of crossing to HBM/MALL 27 times.
+#define DW_KS 64
+#define DW_MAXROWS 2048
+__global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__ X, int ldx,
+                                                       const float* __restrict__ dY, int ldy,
+                                                       const int32_t* __restrict__ nbr, long long nbr_stride,
+                                                       float* __restrict__ dW, int n_out, int K3, int Cin, int Cout,
+                                                       int rows_per_wg, int cin_tiles, int chunks, int m_tiles) {
+    __shared__ __attribute__((aligned(16))) float As[DW_KS * 64];  // [pair][m]
+    __shared__ __attribute__((aligned(16))) float Bs[DW_KS * 64];  // [pair][n]
+    __shared__ int p_in[DW_MAXROWS], p_out[DW_MAXROWS];
+    __shared__ int s_wcnt[2][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int mt, chunk;
+    if (chunks >= 16) {  // XCD-aware: the m-tiles of one row chunk run back to back on one XCD
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        mt = jx % m_tiles;
+        chunk = (jx / m_tiles) * 8 + xcd;
+        if (chunk >= chunks) return;
+    } else {             // few row chunks: spread the m-tiles over the XCDs
+        chunk = blockIdx.x % chunks;
+        mt = blockIdx.x / chunks;
+    }
+    const int n0 = blockIdx.y * 64;
+    const int r_begin = chunk * rows_per_wg;
+    const int r_end = min(n_out, r_begin + rows_per_wg);
+    const int k = mt / cin_tiles;
+    const int c0 = (mt % cin_tiles) * 64;
+    const int t_r = tid >> 4, t_c = (tid & 15) * 4;
+    const int32_t* nrow = nbr + (long long)k * nbr_stride;
+
+    // ---- phase 1: ordered compaction of the present pairs
+    int total = 0;
+    const int nrows = r_end - r_begin;
+    for (int base = 0, it = 0; base < nrows; base += 256, ++it) {
+        const int i = base + tid;
+        int idx = -1;
+        if (i < nrows) idx = nrow[r_begin + i];
+        const unsigned long long bal = __ballot(idx >= 0);
+        if (lane == 0) s_wcnt[it & 1][wave] = __popcll(bal);
+        __syncthreads();
+        int off = total, round = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            int c = s_wcnt[it & 1][w];
+            if (w < wave) off += c;
+            round += c;
+        }
+        if (idx >= 0) {
+            int p = off + __popcll(bal & ((1ull << lane) - 1ull));
+            p_in[p] = idx;
+            p_out[p] = r_begin + i;
+        }
+        total += round;
+    }
+    __syncthreads();
+    if (total == 0) return;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    constexpr int LJ = DW_KS / 16;
+    float4 a_reg[LJ], b_reg[LJ];
+    auto load_data = [&](int pb) {
+#pragma unroll
+        for (int j = 0; j < LJ; ++j) {
+            int p = pb + t_r + 16 * j;
+            a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < total) {
+                int in = p_in[p], out = p_out[p];
+                if (c0 + t_c < Cin) a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)in * ldx + c0 + t_c);
+                if (n0 + t_c < Cout) b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)out * ldy + n0 + t_c);
+            }
+        }
+    };
+    load_data(0);
+    for (int pb = 0; pb < total; pb += DW_KS) {
+#pragma unroll
+        for (int j = 0; j < LJ; ++j) {
+            *reinterpret_cast<float4*>(&As[(t_r + 16 * j) * 64 + t_c]) = a_reg[j];
+            *reinterpret_cast<float4*>(&Bs[(t_r + 16 * j) * 64 + t_c]) = b_reg[j];
+        }
+        __syncthreads();
+        if (pb + DW_KS < total) load_data(pb + DW_KS);   // in flight during the MFMAs below
+        const float* ap = &As[wr * 32 + li];
+        const float* bp = &Bs[wc * 32 + li];
+#pragma unroll
+        for (int s2 = 0; s2 < DW_KS / 2; ++s2) {
+            float av = ap[(2 * s2 + lh) * 64];
+            float bv = bp[(2 * s2 + lh) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + li;
+    if (col < Cout) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int m = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (c0 + m < Cin) atomicAdd(&dW[((long long)k * Cin + c0 + m) * Cout + col], acc[reg]);
+        }
+    }
+}
+
 // =============================================================== C ABI
 extern "C" {
 
@@ -773,6 +1089,26 @@ static int conv_tile_rows(int n_out, int Cin, int Cout) {
     if (t128 >= 1024) return 128;
     if (Cin >= 256 && n_out >= 1024) return 128;
     return 64;
+}
+
+// Rows per wave of the pair-compacted kernel, or 0 when the layer should take the register-accumulator kernels.
+// Mode (agb_spconv_set_cmp_mode, or the AGB_CONV_CMP environment variable at first use): 1 = automatic (default),
+// 0 = never, 64 / 128 = always with that tile height (tests, tuning).
+static int g_cmp_mode = -1;
+static int cmp_rows(const ConvArgs& a) {
+    if (g_cmp_mode < 0) {
+        const char* e = getenv("AGB_CONV_CMP");
+        g_cmp_mode = e ? atoi(e) : 1;
+    }
+    const int mode = g_cmp_mode;
+    if (mode == 0 || a.perm || a.ksplit > 1 || a.Cin % 64 != 0 || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Cout % 4 != 0)
+        return 0;
+    if (mode == 64 || mode == 128) return mode;
+    // measured on the SENet14 pyramid (tools/bench_conv.py): 128-row tiles win from ~400 waves up (64->64 at 210 k rows
+    // 351 vs 497 us, 128->128 at 61 k rows 438 vs 566 us, 256->256 at 14 k rows 477 vs 519 us); below that the
+    // offset-split register-accumulator kernel fills the chip better (512->512 at 2.9 k rows 439 vs 497 us)
+    const long long waves128 = (long long)agb_cdiv(a.n_out, 128) * agb_cdiv(a.Cout, 64);
+    return waves128 >= 384 ? 128 : 0;
 }
 
 static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
@@ -793,6 +1129,20 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
         else
             hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
                                a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
+    } else if (cmp_rows(a) > 0) {
+        const int R = cmp_rows(a), nct = agb_cdiv(a.Cout, 64);
+        // equal-cost tiles, workgroup count a multiple of the resident-wave capacity (LDS: 4 / 8 waves per CU)
+        const long long slots = (R == 128 ? 4 : 8) * 256;
+        const long long rounds = ((long long)agb_cdiv(a.n_out, R) * nct + slots - 1) / slots;
+        long long want_tiles = rounds * slots / nct;
+        if (want_tiles < 1) want_tiles = 1;
+        int rpt = agb_cdiv(a.n_out, want_tiles);
+        if (rpt > R) rpt = R;
+        if (rpt < 16) rpt = 16;
+        const int ntiles = agb_cdiv(a.n_out, rpt);
+        dim3 grid(8 * agb_cdiv(ntiles, 8) * nct), blk(64);
+        if (R == 128) hipLaunchKernelGGL((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt);
+        else hipLaunchKernelGGL((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt);
     } else if (conv_tile_rows(a.n_out, a.Cin, a.Cout) == 128) {
         // 128-row tiles: the W tile is reused by twice as many rows (layers with many rows, or W-heavy layers)
         hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
@@ -809,9 +1159,29 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
     return AGB_OK;
 }
 
+// Resident workgroups per CU of the pair-compacted kernel (R = 64 / 128), as the runtime computes it (tuning aid).
+int agb_spconv_cmp_occupancy(int R) {
+    int n = -1;
+    hipError_t e = R == 128
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_spconv_cmp<128>, 64, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_spconv_cmp<64>, 64, 0);
+    return e == hipSuccess ? n : -1;
+}
+
+int agb_spconv_set_cmp_mode(int mode) {
+    AGB_CHECK_ARG(mode == 0 || mode == 1 || mode == 64 || mode == 128, "agb_spconv_set_cmp_mode: mode %d", mode);
+    g_cmp_mode = mode;
+    return AGB_OK;
+}
+
 // How many offset splits a layer of n_out rows wants (1 = none): host helper for sizing `partial`.
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
     if (Cin == 4 || Cin == 8 || K3 < 8) return 1;
+    {
+        ConvArgs probe{};
+        probe.n_out = n_out; probe.K3 = K3; probe.Cin = Cin; probe.Cout = Cout; probe.ksplit = 1;
+        if (cmp_rows(probe) > 0) return 1;   // the pair-compacted kernel takes the layer unsplit
+    }
     long long tiles = (long long)agb_cdiv(n_out, conv_tile_rows(n_out, Cin, Cout)) * agb_cdiv(Cout, BN);
     if (tiles >= 768) return 1;
     long long s = (1024 + tiles - 1) / tiles;
@@ -936,9 +1306,14 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
     else if (Cin == 8)
         hipLaunchKernelGGL(k_spconv_dw<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
                            Cout, (int)rows, cin_tiles);
-    else
-        hipLaunchKernelGGL(k_spconv_dw_pipe, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
-                           Cout, (int)rows, cin_tiles);
+    else {
+        // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
+        if (rows > DW_MAXROWS) rows = DW_MAXROWS;
+        chunks = agb_cdiv(n_out, rows);
+        dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
+        hipLaunchKernelGGL(k_spconv_dw_cmp, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
+                           Cout, (int)rows, cin_tiles, chunks, m_tiles);
+    }
     AGB_CHECK_LAUNCH("agb_spconv_bwd_weight");
     return AGB_OK;
 }

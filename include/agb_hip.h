@@ -103,6 +103,11 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                       float* partial, void* stream);
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper */
+/* Kernel selection of agb_spconv_fwd(_ex) for layers with Cin % 64 == 0 (host state, tests and tuning):
+ * 1 = automatic (default: the pair-compacted LDS-accumulating kernel for many-row layers with Cin <= 128, the
+ * register-accumulator kernels otherwise), 0 = never the pair-compacted kernel, 64 / 128 = always, with that many rows
+ * per wave.  All choices compute the same sums; only the fp32 summation order differs. */
+int agb_spconv_set_cmp_mode(int mode);
 /* Low-precision MFMA operands, fp32 accumulate and I/O: precision 1 = bf16 (BASELINE config 5), 2 = split-bf16 x3
  * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi: fp32-level accuracy at 3/16 of the fp32 MFMA cost).  Same contract as
  * agb_spconv_fwd_ex but the weights are K-major: Wt float[K3][Cout][Cin] (forward: the transposed kernel; data

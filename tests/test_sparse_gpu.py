@@ -126,6 +126,25 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("cin,cout,K,stride,ts_in", CONV_CASES)
 def test_conv_forward_backward(device, cin, cout, K, stride, ts_in):
+    _conv_case(device, cin, cout, K, stride, ts_in)
+
+
+@pytest.mark.parametrize("rows_per_wave", [64, 128])
+@pytest.mark.parametrize("cin,cout,K,stride,ts_in", [(64, 64, 3, 1, 2), (64, 128, 3, 2, 2), (64, 128, 1, 2, 2),
+                                                      (128, 128, 3, 1, 4), (64, 80, 3, 1, 1), (256, 64, 3, 1, 2),
+                                                      (128, 36, 2, 2, 1)])
+def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride, ts_in):
+    """The pair-compacted LDS-accumulating kernel (k_spconv_cmp; picked automatically only for many-row layers) forced
+    on the small parity cases: forward and stride-1 data gradient run through it."""
+    from dpcr_agb_amd import _lib
+    _lib.call("agb_spconv_set_cmp_mode", rows_per_wave)
+    try:
+        _conv_case(device, cin, cout, K, stride, ts_in)
+    finally:
+        _lib.call("agb_spconv_set_cmp_mode", 1)
+
+
+def _conv_case(device, cin, cout, K, stride, ts_in):
     import dpcr_agb_amd.me_compat as ME
     rng = np.random.default_rng(cin * 131 + cout + K)
     torch.manual_seed(cin + cout + K + stride)

@@ -1,0 +1,76 @@
+"""Micro-benchmark of the sparse-conv kernels on the real SENet14 pyramid of a synthetic batch (tuning aid).
+
+  python tools/bench_conv.py [--modes 0,64,128] [--reps 20]
+For every (level, Cin, Cout) of the stride-1 3^3 layers it times agb_spconv_fwd_ex per kernel-selection mode
+(agb_spconv_set_cmp_mode) and the weight gradient, and prints us/launch and algorithmic TFLOP/s (2*pairs*Cin*Cout)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--modes", default="0,64,128")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--wgrad", action="store_true")
+    args = ap.parse_args()
+    from dpcr_agb_amd import _lib, synthetic
+    from dpcr_agb_amd.coords import CoordinateManager
+    from dpcr_agb_amd.sparse_ops import spconv_forward_raw
+    dev = torch.device("cuda", 0)
+    b = synthetic.make_sparse_batch(list(range(args.batch)))
+    coords = torch.cat([b.batch[:, None].int(), b.coords.int()], 1).to(dev)
+    cm = CoordinateManager(coords, device=dev, batch_size=args.batch, bounds=b.coord_bounds)
+    ts = 1
+    cases = []
+    for ts_in, c in ((2, 64), (4, 128), (8, 256), (16, 512)):
+        while ts < ts_in:
+            cm.stride(ts, 2)
+            ts *= 2
+        n = cm.level(ts_in).n
+        nbr = cm.kernel_map(ts_in, 3, 1)
+        pairs = int((nbr[:, :n] >= 0).sum())
+        cases.append((ts_in, c, c, n, nbr, pairs))
+    for ts_in, cin, cout, n, nbr, pairs in cases:
+        x = torch.randn(n, cin, device=dev)
+        w = torch.randn(27 * cin, cout, device=dev) * 0.05
+        ref = None
+        for mode in [int(m) for m in args.modes.split(",")]:
+            _lib.call("agb_spconv_set_cmp_mode", mode)
+            y = spconv_forward_raw(x, w, nbr, 0, None, n, 27, cin, cout)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = y
+            err = float((y - ref).abs().max() / ref.abs().max())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                spconv_forward_raw(x, w, nbr, 0, None, n, 27, cin, cout)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / args.reps * 1e3
+            print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} rows {n:7d} density {pairs / (27 * n):.2f} mode {mode:3d}: "
+                  f"{us:8.1f} us  {2.0 * pairs * cin * cout / us / 1e6:6.1f} TF  (max rel diff vs first mode {err:.1e})",
+                  flush=True)
+        if args.wgrad:
+            dy = torch.randn(n, cout, device=dev)
+            dw = torch.zeros(27, cin, cout, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                _lib.call("agb_spconv_bwd_weight", x.data_ptr(), cin, dy.data_ptr(), cout, nbr.data_ptr(),
+                          nbr.stride(0), dw.data_ptr(), n, 27, cin, cout, _lib.stream())
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / args.reps * 1e3
+            print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} wgrad: {us:8.1f} us  {2.0 * pairs * cin * cout / us / 1e6:6.1f} TF")
+    _lib.call("agb_spconv_set_cmp_mode", 1)
+
+
+if __name__ == "__main__":
+    main()
