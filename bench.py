@@ -56,7 +56,7 @@ def kernel_of(rec):
     """Name of the HIP kernel a recorded launch ran (mirrors the dispatch rule of csrc/spconv.hip:launch_conv)."""
     small = rec["cin"] in (4, 8)
     if rec["kind"] == "wgrad":
-        return f"k_spconv_dw<{rec['cin']}>" if small else "k_spconv_dw_cmp"
+        return f"k_spconv_dw_small_cmp<{rec['cin']}>" if small else "k_spconv_dw_cmp"
     if small:
         return f"k_spconv_fwd<{rec['cin']}>"
     if rec.get("perm"):

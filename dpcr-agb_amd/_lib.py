@@ -40,6 +40,7 @@ _SIGNATURES = {
                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "agb_spconv_split_hint": [c_int, c_int, c_int, c_int],
     "agb_spconv_set_cmp_mode": [c_int],
+    "agb_spconv_cmp_occupancy": [c_int],
     "agb_parity_partition": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "agb_spconv_bwd_weight": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int,
                               c_void_p],

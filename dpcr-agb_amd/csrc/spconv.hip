@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw(const float* __restrict__ X, 
                                                    const float* __restrict__ dY, int ldy,
                                                    const int32_t* __restrict__ nbr, long long nbr_stride,
                                                    float* __restrict__ dW, int n_out, int K3, int Cin, int Cout,
-                                                   int rows_per_wg, int cin_tiles) {
+                                                   int rows_per_wg, int cin_tiles, int chunks, int m_tiles) {
     __shared__ __attribute__((aligned(16))) float As[BK * 64];  // [r][m]
     __shared__ __attribute__((aligned(16))) float Bs[BK * 64];  // [r][n]
 
@@ -773,16 +773,29 @@ __global__ __launch_bounds__(256) void k_spconv_dw(const float* __restrict__ X, 
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.z * 64;
-    const int r_begin = blockIdx.x * rows_per_wg;
+    const int n0 = blockIdx.y * 64;
+    // 1-D grid, XCD-aware (as k_spconv_dw_cmp): the m-tiles of one row chunk run back to back on one XCD, so the
+    // chunk's dY rows (573 KB for the stem) are read from HBM once instead of once per m-tile (PMC: 2.4 GB -> per
+    // launch for the 22 m-tiles of the 7^3 stem before this mapping)
+    int mt, chunk;
+    if (chunks >= 16) {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        mt = jx % m_tiles;
+        chunk = (jx / m_tiles) * 8 + xcd;
+        if (chunk >= chunks) return;
+    } else {
+        chunk = blockIdx.x % chunks;
+        mt = blockIdx.x / chunks;
+    }
+    const int r_begin = chunk * rows_per_wg;
     const int r_end = min(n_out, r_begin + rows_per_wg);
 
     int k = 0, c0 = 0, k0 = 0;
     if constexpr (CPAD == 0) {
-        k = blockIdx.y / cin_tiles;
-        c0 = (blockIdx.y % cin_tiles) * 64;
+        k = mt / cin_tiles;
+        c0 = (mt % cin_tiles) * 64;
     } else {
-        k0 = blockIdx.y * (64 / CPAD);
+        k0 = mt * (64 / CPAD);
     }
 
     f32x16 acc;
@@ -874,91 +887,6 @@ __global__ __launch_bounds__(256) void k_spconv_dw(const float* __restrict__ X, 
                 ok = wrow < (long long)K3 * CPAD;
             }
             if (ok) atomicAdd(&dW[wrow * Cout + col], acc[reg]);
-        }
-    }
-}
-
-// Weight gradient, generic path, software-pipelined like k_spconv_pipe: gathers of the next 32-row step are in
-// flight during the MFMAs of the current one, neighbour indices are fetched two steps ahead.
-__global__ __launch_bounds__(256) void k_spconv_dw_pipe(const float* __restrict__ X, int ldx,
-                                                        const float* __restrict__ dY, int ldy,
-                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
-                                                        float* __restrict__ dW, int n_out, int K3, int Cin, int Cout,
-                                                        int rows_per_wg, int cin_tiles) {
-    __shared__ __attribute__((aligned(16))) float As[BK * 64];  // [r][m]
-    __shared__ __attribute__((aligned(16))) float Bs[BK * 64];  // [r][n]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.z * 64;
-    const int r_begin = blockIdx.x * rows_per_wg;
-    const int r_end = min(n_out, r_begin + rows_per_wg);
-    const int k = blockIdx.y / cin_tiles;
-    const int c0 = (blockIdx.y % cin_tiles) * 64;
-    const int t_r = tid >> 4, t_c = (tid & 15) * 4;
-    const int32_t* nrow = nbr + (long long)k * nbr_stride;
-
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    int idx_cur[2], idx_nxt[2];
-    float4 a_reg[2], b_reg[2];
-    auto load_idx = [&](int rb, int* dst) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int r = rb + t_r + 16 * j;
-            dst[j] = r < r_end ? nrow[r] : -1;
-        }
-    };
-    auto load_data = [&](int rb, const int* idx) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int r = rb + t_r + 16 * j;
-            a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx[j] >= 0) {
-                if (c0 + t_c < Cin) a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)idx[j] * ldx + c0 + t_c);
-                if (n0 + t_c < Cout) b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + n0 + t_c);
-            }
-        }
-    };
-    if (r_begin < r_end) {
-        load_idx(r_begin, idx_cur);
-        load_idx(r_begin + BK, idx_nxt);
-        load_data(r_begin, idx_cur);
-    }
-    for (int rb = r_begin; rb < r_end; rb += BK) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4*>(&As[(t_r + 16 * j) * 64 + t_c]) = a_reg[j];
-            *reinterpret_cast<float4*>(&Bs[(t_r + 16 * j) * 64 + t_c]) = b_reg[j];
-        }
-        __syncthreads();
-        if (rb + BK < r_end) {
-            idx_cur[0] = idx_nxt[0];
-            idx_cur[1] = idx_nxt[1];
-            load_data(rb + BK, idx_cur);
-            load_idx(rb + 2 * BK, idx_nxt);
-        }
-        const float* ap = &As[wr * 32 + li];
-        const float* bp = &Bs[wc * 32 + li];
-#pragma unroll
-        for (int s2 = 0; s2 < BK / 2; ++s2) {
-            float av = ap[(2 * s2 + lh) * 64];
-            float bv = bp[(2 * s2 + lh) * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int col = n0 + wc * 32 + li;
-    if (col < Cout) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            int m = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            if (c0 + m < Cin) atomicAdd(&dW[((long long)k * Cin + c0 + m) * Cout + col], acc[reg]);
         }
     }
 }
@@ -1074,6 +1002,123 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
         for (int reg = 0; reg < 16; ++reg) {
             int m = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             if (c0 + m < Cin) atomicAdd(&dW[((long long)k * Cin + c0 + m) * Cout + col], acc[reg]);
+        }
+    }
+}
+
+// Weight gradient of the small-Cin (stem) path, ROW-COMPACTED: an M tile covers 64/CPAD kernel offsets; a row whose
+// neighbours at ALL of those offsets are absent contributes nothing (7^3 stem map: 35 % of the rows of a 16-offset
+// tile).  The workgroup compacts its row chunk to the rows with at least one present neighbour, then walks them 32 at a
+// time.  Same XCD-aware 1-D grid as k_spconv_dw_cmp.
+template <int CPAD>
+__global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __restrict__ X, int ldx,
+                                                             const float* __restrict__ dY, int ldy,
+                                                             const int32_t* __restrict__ nbr, long long nbr_stride,
+                                                             float* __restrict__ dW, int n_out, int K3, int Cout,
+                                                             int rows_per_wg, int chunks, int m_tiles) {
+    constexpr int OPT = 64 / CPAD;   // offsets per M tile
+    constexpr int F4 = CPAD / 4;     // float4 per (row, offset)
+    __shared__ __attribute__((aligned(16))) float As[BK * 64];  // [r][m]
+    __shared__ __attribute__((aligned(16))) float Bs[BK * 64];  // [r][n]
+    __shared__ int p_row[DW_MAXROWS];
+    __shared__ int s_wcnt[2][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.y * 64;
+    int mt, chunk;
+    if (chunks >= 16) {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        mt = jx % m_tiles;
+        chunk = (jx / m_tiles) * 8 + xcd;
+        if (chunk >= chunks) return;
+    } else {
+        chunk = blockIdx.x % chunks;
+        mt = blockIdx.x / chunks;
+    }
+    const int r_begin = chunk * rows_per_wg;
+    const int r_end = min(n_out, r_begin + rows_per_wg);
+    const int k0 = mt * OPT;
+    const int nk = min(OPT, K3 - k0);
+
+    // ---- phase 1: rows with at least one present neighbour among the tile's offsets (order kept)
+    int total = 0;
+    const int nrows = r_end - r_begin;
+    for (int base = 0, it = 0; base < nrows; base += 256, ++it) {
+        const int i = base + tid;
+        bool any = false;
+        if (i < nrows)
+            for (int o = 0; o < nk; ++o) any |= nbr[(long long)(k0 + o) * nbr_stride + r_begin + i] >= 0;
+        const unsigned long long bal = __ballot(any);
+        if (lane == 0) s_wcnt[it & 1][wave] = __popcll(bal);
+        __syncthreads();
+        int off = total, round = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            int c = s_wcnt[it & 1][w];
+            if (w < wave) off += c;
+            round += c;
+        }
+        if (any) p_row[off + __popcll(bal & ((1ull << lane) - 1ull))] = r_begin + i;
+        total += round;
+    }
+    __syncthreads();
+    if (total == 0) return;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    float4 a_reg[2], b_reg[2];
+    auto load_data = [&](int pb) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // A: 32 rows x 16 float4 columns (offset, channel quad)
+            int e = tid + 256 * j;
+            int p = pb + (e & 31);
+            int m4 = e >> 5;
+            int o = m4 / F4, f = m4 % F4;
+            a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < total && o < nk) {
+                int idx = nbr[(long long)(k0 + o) * nbr_stride + p_row[p]];
+                if (idx >= 0) a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)idx * ldx + f * 4);
+            }
+            // B: 32 rows x 64 output channels
+            int pr = pb + (tid >> 4) + 16 * j;
+            int n = n0 + (tid & 15) * 4;
+            b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr < total && n < Cout) b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)p_row[pr] * ldy + n);
+        }
+    };
+    load_data(0);
+    for (int pb = 0; pb < total; pb += BK) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int e = tid + 256 * j;
+            *reinterpret_cast<float4*>(&As[(e & 31) * 64 + (e >> 5) * 4]) = a_reg[j];
+            *reinterpret_cast<float4*>(&Bs[((tid >> 4) + 16 * j) * 64 + (tid & 15) * 4]) = b_reg[j];
+        }
+        __syncthreads();
+        if (pb + BK < total) load_data(pb + BK);   // in flight during the MFMAs below
+        const float* ap = &As[wr * 32 + li];
+        const float* bp = &Bs[wc * 32 + li];
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 2; ++s2) {
+            float av = ap[(2 * s2 + lh) * 64];
+            float bv = bp[(2 * s2 + lh) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + li;
+    if (col < Cout) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int m = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            long long wrow = (long long)k0 * CPAD + m;
+            if (wrow < (long long)K3 * CPAD) atomicAdd(&dW[wrow * Cout + col], acc[reg]);
         }
     }
 }
@@ -1299,13 +1344,17 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
     if (rows < 256) rows = 256;
     rows = (rows + 31) / 32 * 32;
     int chunks = agb_cdiv(n_out, rows);
-    dim3 grid(chunks, m_tiles, n_tiles), block(256);
+    if (Cin == 4 || Cin == 8) {
+        if (rows > DW_MAXROWS) rows = DW_MAXROWS;
+        chunks = agb_cdiv(n_out, rows);
+    }
+    dim3 grid((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles), block(256);
     if (Cin == 4)
-        hipLaunchKernelGGL(k_spconv_dw<4>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
-                           Cout, (int)rows, cin_tiles);
+        hipLaunchKernelGGL(k_spconv_dw_small_cmp<4>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                           Cout, (int)rows, chunks, m_tiles);
     else if (Cin == 8)
-        hipLaunchKernelGGL(k_spconv_dw<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
-                           Cout, (int)rows, cin_tiles);
+        hipLaunchKernelGGL(k_spconv_dw_small_cmp<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                           Cout, (int)rows, chunks, m_tiles);
     else {
         // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
         if (rows > DW_MAXROWS) rows = DW_MAXROWS;

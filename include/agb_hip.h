@@ -108,6 +108,7 @@ int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper
  * register-accumulator kernels otherwise), 0 = never the pair-compacted kernel, 64 / 128 = always, with that many rows
  * per wave.  All choices compute the same sums; only the fp32 summation order differs. */
 int agb_spconv_set_cmp_mode(int mode);
+int agb_spconv_cmp_occupancy(int rows_per_wave);  /* resident workgroups per CU of that kernel (tuning aid) */
 /* Low-precision MFMA operands, fp32 accumulate and I/O: precision 1 = bf16 (BASELINE config 5), 2 = split-bf16 x3
  * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi: fp32-level accuracy at 3/16 of the fp32 MFMA cost).  Same contract as
  * agb_spconv_fwd_ex but the weights are K-major: Wt float[K3][Cout][Cin] (forward: the transposed kernel; data
