@@ -1,0 +1,176 @@
+// transform.hip — the per-point part of the NFI sparse transform chain on the device, for a whole batch of plots.
+//
+// The reference runs these transforms one sample at a time in DataLoader workers on the CPU
+// (torch-points3d/conf/data/instance/NFI/transforms/sparse-xy.yaml:106-150, test_transform):
+//   ScalePos(op=div)                 core/data_transform/transforms.py:590-598   pos = pos / (sx, sy, sz)
+//   MoveCenterPosPerSample           transforms.py:722-739                       pos += (cx, cy, cz)
+//   StartZFromZero                   transforms.py:766-769                       pos.z -= min(pos.z)  (per plot)
+//   Polygon2dExtend                  transforms.py:1461-1496                     keep points inside the polygon:
+//                                    matplotlib.path.Path.contains_points (crossing test, in double)
+//   XYZFeature(z) / AddOnes / AddXYDistanceToCenter / AddFeatsByKeys
+//                                    core/data_transform/features.py:307-334,353-383
+//                                    x = [1, pos.z, || (pos.xy - c) + 1e-6 ||_2]   (torch PairwiseDistance, eps 1e-6)
+// and, after GridSampling3D (voxelize.hip), the train-time coordinate augmentation
+//   RandomCoordsFlip                 core/data_transform/sparse_transforms.py:49-55   c[:, ax] = max(c[:, ax]) - c[:, ax]
+//   ShiftVoxels                      transforms.py:1046-1054                          c += shift (per plot)
+// Random decisions (flip flags, shifts) are drawn on the host in the reference's order and passed in.
+// Arithmetic is fp32 in the reference's operation order (no contraction), the polygon test runs in double on the
+// fp32 coordinates like matplotlib does: results are bit-identical to the CPU chain except for points lying exactly on
+// a polygon edge.  HBM-bound, a few bytes per point: N*(12 read + 12+12+8+4 written).
+#include "agb_common.h"
+#include "scan.cuh"
+
+struct PlotXform {
+    float sx, sy, sz;     // ScalePos
+    float cx, cy, cz;     // MoveCenterPosPerSample
+    float fcx, fcy;       // AddXYDistanceToCenter
+    int div;              // ScalePos op: 1 = div, 0 = mul
+    int z0;               // StartZFromZero on/off
+};
+
+__device__ __forceinline__ float xf_scale(float v, float s, int div) { return div ? v / s : v * s; }
+
+// zmin[b] = min over the plot of (scale(z) + cz)
+__global__ void k_plot_zmin(const float* __restrict__ pos, const int32_t* __restrict__ ptr, PlotXform t,
+                            float* __restrict__ zmin) {
+    __shared__ float s_min[4];
+    const int b = blockIdx.x;
+    float m = INFINITY;
+    for (int i = ptr[b] + threadIdx.x; i < ptr[b + 1]; i += blockDim.x)
+        m = fminf(m, xf_scale(pos[3LL * i + 2], t.sz, t.div) + t.cz);
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) zmin[b] = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+}
+
+// matplotlib's point_in_path (src/_path.h, point_in_path_impl): crossing test over the implicitly closed polygon
+__device__ __forceinline__ int point_in_polygon(double tx, double ty, const double* __restrict__ poly, int nv) {
+    double vtx0 = poly[2 * (nv - 1)], vty0 = poly[2 * (nv - 1) + 1];
+    int yflag0 = vty0 >= ty;
+    int inside = 0;
+    for (int j = 0; j < nv; ++j) {
+        const double vtx1 = poly[2 * j], vty1 = poly[2 * j + 1];
+        const int yflag1 = vty1 >= ty;
+        if (yflag0 != yflag1) {
+            if (((vty1 - ty) * (vtx0 - vtx1) >= (vtx1 - tx) * (vty0 - vty1)) == yflag1) inside ^= 1;
+        }
+        yflag0 = yflag1;
+        vtx0 = vtx1;
+        vty0 = vty1;
+    }
+    return inside;
+}
+
+__global__ void k_plot_transform(const float* __restrict__ pos, const int32_t* __restrict__ elem, int n, PlotXform t,
+                                 const float* __restrict__ zmin, const double* __restrict__ poly, int nv,
+                                 float* __restrict__ pos_t, int32_t* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = xf_scale(pos[3LL * i], t.sx, t.div) + t.cx;
+    float y = xf_scale(pos[3LL * i + 1], t.sy, t.div) + t.cy;
+    float z = xf_scale(pos[3LL * i + 2], t.sz, t.div) + t.cz;
+    if (t.z0) z -= zmin[elem[i]];
+    pos_t[3LL * i] = x;
+    pos_t[3LL * i + 1] = y;
+    pos_t[3LL * i + 2] = z;
+    flag[i] = nv > 0 ? point_in_polygon((double)x, (double)y, poly, nv) : 1;
+}
+
+// kept rows, order preserved: pos, features [1, z, xy distance], source row; new plot offsets
+__global__ void k_plot_emit(const float* __restrict__ pos_t, const int32_t* __restrict__ flag,
+                            const int32_t* __restrict__ slot, int n, PlotXform t, float* __restrict__ pos_out,
+                            float* __restrict__ x_out, long long* __restrict__ src) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const long long o = slot[i];
+    const float x = pos_t[3LL * i], y = pos_t[3LL * i + 1], z = pos_t[3LL * i + 2];
+    pos_out[3 * o] = x;
+    pos_out[3 * o + 1] = y;
+    pos_out[3 * o + 2] = z;
+    const float dx = (x - t.fcx) + 1e-6f, dy = (y - t.fcy) + 1e-6f;
+    x_out[3 * o] = 1.f;
+    x_out[3 * o + 1] = z;
+    x_out[3 * o + 2] = sqrtf(dx * dx + dy * dy);
+    src[o] = i;
+}
+
+__global__ void k_plot_out_ptr(const int32_t* __restrict__ slot, const int32_t* __restrict__ ptr,
+                               const int32_t* __restrict__ total, int B, int n, int32_t* __restrict__ out_ptr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out_ptr[b] = ptr[b] < n ? slot[ptr[b]] : *total;
+    if (b == B) out_ptr[b] = *total;
+}
+
+__global__ void k_coords_max(const int32_t* __restrict__ coords, const int32_t* __restrict__ elem, int n,
+                             int32_t* __restrict__ cmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = elem[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) atomicMax(&cmax[3 * b + a], coords[3LL * i + a]);
+}
+
+__global__ void k_coords_augment(int32_t* __restrict__ coords, const int32_t* __restrict__ elem, int n,
+                                 const int32_t* __restrict__ flip, const int32_t* __restrict__ shift,
+                                 const int32_t* __restrict__ cmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = elem[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int c = coords[3LL * i + a];
+        if (flip[3 * b + a]) c = cmax[3 * b + a] - c;
+        coords[3LL * i + a] = c + shift[3 * b + a];
+    }
+}
+
+extern "C" {
+
+// pos float[n,3]: stacked raw plots; ptr int32[B+1], elem int32[n] (plot of every row).
+// xform float[8] = (sx, sy, sz, cx, cy, cz, fcx, fcy); scale_div: ScalePos op (1 = div); z_from_zero: StartZFromZero.
+// poly double[2*nv]: polygon vertices (nv = 0: no crop).
+// Scratch: zmin float[B], pos_t float[n,3], flag int32[n], slot int32[n], scan_scratch int32[agb_scan_scratch_elems(n)].
+// Out (upper bound n rows): pos_out float[n,3], x_out float[n,3], src int64[n] (row in the input), out_ptr int32[B+1],
+// n_out_dev int32[1].  No host synchronisation.
+int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
+                     int scale_div, int z_from_zero, const double* poly, int nv, float* zmin, float* pos_t,
+                     int32_t* flag, int32_t* slot, int32_t* scan_scratch, float* pos_out, float* x_out, long long* src,
+                     int32_t* out_ptr, int32_t* n_out_dev, void* stream) {
+    AGB_CHECK_ARG(B >= 1 && n >= 0 && nv >= 0 && nv != 1 && nv != 2, "agb_plot_prepare: bad sizes (B %d, n %d, nv %d)",
+                  B, n, nv);
+    AGB_CHECK_ARG(xform != nullptr, "agb_plot_prepare: xform is a HOST array of 8 floats");
+    hipStream_t s = (hipStream_t)stream;
+    PlotXform t{xform[0], xform[1], xform[2], xform[3], xform[4], xform[5], xform[6], xform[7], scale_div, z_from_zero};
+    AGB_CHECK_ARG(!scale_div || (t.sx != 0.f && t.sy != 0.f && t.sz != 0.f), "agb_plot_prepare: zero scale divisor");
+    if (n == 0) {
+        (void)hipMemsetAsync(out_ptr, 0, sizeof(int32_t) * (B + 1), s);
+        (void)hipMemsetAsync(n_out_dev, 0, sizeof(int32_t), s);
+        return AGB_OK;
+    }
+    hipLaunchKernelGGL(k_plot_zmin, dim3(B), dim3(256), 0, s, pos, ptr, t, zmin);
+    hipLaunchKernelGGL(k_plot_transform, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, pos, elem, n, t, zmin, poly, nv, pos_t,
+                       flag);
+    agb_launch_exclusive_scan(flag, n, slot, scan_scratch, n_out_dev, s);
+    hipLaunchKernelGGL(k_plot_emit, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, pos_t, flag, slot, n, t, pos_out, x_out,
+                       src);
+    hipLaunchKernelGGL(k_plot_out_ptr, dim3(agb_cdiv(B + 1, 64)), dim3(64), 0, s, slot, ptr, n_out_dev, B, n, out_ptr);
+    AGB_CHECK_LAUNCH("agb_plot_prepare");
+    return AGB_OK;
+}
+
+// RandomCoordsFlip + ShiftVoxels on voxel coordinates int32[n,3] (in place): flip int32[B,3] (0/1 per plot and axis),
+// shift int32[B,3]; cmax int32[B,3] scratch.
+int agb_coords_augment(int32_t* coords, const int32_t* elem, int B, int n, const int32_t* flip, const int32_t* shift,
+                       int32_t* cmax, void* stream) {
+    AGB_CHECK_ARG(B >= 1 && n >= 0, "agb_coords_augment: bad sizes");
+    if (n == 0) return AGB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(cmax, 0x80, sizeof(int32_t) * 3 * B, s);   // 0x80808080: below any voxel coordinate
+    hipLaunchKernelGGL(k_coords_max, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, coords, elem, n, cmax);
+    hipLaunchKernelGGL(k_coords_augment, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, coords, elem, n, flip, shift, cmax);
+    AGB_CHECK_LAUNCH("agb_coords_augment");
+    return AGB_OK;
+}
+
+}  // extern "C"

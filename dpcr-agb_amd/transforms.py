@@ -1,0 +1,253 @@
+"""The NFI sparse transform chain on the device, for a whole batch of plots at once.
+
+The reference applies its transforms per sample on the CPU inside DataLoader workers
+(torch-points3d/conf/data/instance/NFI/transforms/sparse-xy.yaml; classes in
+torch_points3d/core/data_transform/{transforms,features,sparse_transforms,grid_transform}.py).  Here the same classes
+(same names, same constructor arguments) are descriptors; ``SparsePlotPipeline`` fuses the per-point ones into
+``agb_plot_prepare`` (csrc/transform.hip: scale, centre, z from zero, polygon crop, features) followed by
+``agb_voxelize_last`` (GridSampling3D, csrc/voxelize.hip) and ``agb_coords_augment`` (RandomCoordsFlip, ShiftVoxels),
+and returns the ``PlotBatch`` that ``MinkowskiBaselineModel.set_input`` consumes.
+
+Randomness is drawn on the host with the same generators, in the same per-sample order as the reference
+(``torch.randperm`` for MaxPoints / MinPoints / the GridSampling3D shuffle, ``random.random`` / ``torch.rand`` for the
+coordinate flips and shifts), so a seeded run picks the same points and flips.  The float augmentations of the training
+chain (ground removal, dropout, jitter, z-rotation, random points, random polygon) are not part of this module.
+"""
+import math
+import random
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .kp_index import _elem_of_row, _ptr_tensor
+from .voxelize import draw_permutations, voxelize_last
+
+_P = _lib.ptr
+_V, _I = _lib.c_void_p, _lib.c_int
+_lib.declare("agb_plot_prepare", [_V, _V, _V, _I, _I, _V, _I, _I, _V, _I] + [_V] * 10 + [_V])
+_lib.declare("agb_coords_augment", [_V, _V, _I, _I, _V, _V, _V, _V])
+
+HEXAGON = [[0.0, 0.5], [0.25, 0.9330127], [0.75, 0.9330127], [1.0, 0.5], [0.75, 0.0669873], [0.25, 0.0669873]]
+
+
+# ------------------------------------------------------------------------------------------------ descriptors
+class ScalePos:
+    def __init__(self, scale_x=1.0, scale_y=1.0, scale_z=1.0, op="mul"):
+        self.scale, self.op_str = (float(scale_x), float(scale_y), float(scale_z)), op
+
+
+class MoveCenterPosPerSample:
+    def __init__(self, center_x: float = 0.5, center_y: float = 0.5, center_z: float = 0.5):
+        self.center = (float(center_x), float(center_y), float(center_z))
+
+
+class StartZFromZero:
+    pass
+
+
+class Polygon2dExtend:
+    def __init__(self, polygon, skip_list: Optional[list] = None):
+        self.polygon = [[float(a), float(b)] for a, b in polygon]
+        self.skip_list = list(skip_list or [])
+
+
+class MaxPoints:
+    def __init__(self, num, skip_list: Optional[list] = None):
+        self.num = int(num)
+
+
+class MinPoints:
+    def __init__(self, num, skip_list: Optional[list] = None):
+        self.num = int(num)
+
+
+class XYZFeature:
+    def __init__(self, add_x=False, add_y=False, add_z=True):
+        if add_x or add_y or not add_z:
+            raise NotImplementedError("the NFI chains add pos_z only")
+
+
+class AddOnes:
+    pass
+
+
+class AddXYDistanceToCenter:
+    def __init__(self, center_x: float, center_y: float):
+        self.center = (float(center_x), float(center_y))
+
+
+class AddFeatsByKeys:
+    def __init__(self, list_add_to_x, feat_names, input_nc_feats=None, stricts=None, delete_feats=None):
+        if list(feat_names) != ["ones", "pos_z", "xy_distance"] or not all(list_add_to_x):
+            raise NotImplementedError("the NFI chains build x = [ones, pos_z, xy_distance]")
+
+
+class GridSampling3D:
+    def __init__(self, size, quantize_coords=True, mode="last", verbose=False):
+        if mode != "last" or not quantize_coords:
+            raise NotImplementedError("only GridSampling3D(quantize_coords=True, mode='last') is implemented")
+        self.size = float(size)
+
+
+class RandomCoordsFlip:
+    def __init__(self, ignored_axis, is_temporal=False, p=0.95):
+        assert 0 <= p <= 1
+        mapping = {"x": 0, "y": 1, "z": 2}
+        self.axes = sorted(set(range(3)) - {mapping[a] for a in ignored_axis})   # CPython iterates {0,1,2} ascending
+        self.p = p
+
+
+class ShiftVoxels:
+    def __init__(self, apply_shift=True, p=0.5):
+        self.apply_shift, self.p = apply_shift, p
+
+
+def nfi_test_transform(scale=(30.0, 30.0, 40.0), center=(0.5, 0.5), size=0.0125):
+    """sparse-xy.yaml test_transform with the values of conf/data/instance/NFI/default.yaml:18-23."""
+    return [ScalePos(*scale, op="div"), MoveCenterPosPerSample(*center), StartZFromZero(), Polygon2dExtend(HEXAGON),
+            MaxPoints(16000), MinPoints(500), XYZFeature(False, False, True), AddOnes(),
+            AddXYDistanceToCenter(*center), AddFeatsByKeys([True] * 3, ["ones", "pos_z", "xy_distance"]),
+            GridSampling3D(size, quantize_coords=True, mode="last")]
+
+
+def nfi_coord_augmentation():
+    """The two coordinate augmentations that end sparse-xy.yaml train_transform (:100-104)."""
+    return [RandomCoordsFlip("z", p=0.5), ShiftVoxels()]
+
+
+# ------------------------------------------------------------------------------------------------ pipeline
+class SparsePlotPipeline:
+    """Executes a transform list of the classes above on a batch of raw plots with fused device kernels."""
+
+    def __init__(self, transforms: Sequence):
+        self.scale, self.div = (1.0, 1.0, 1.0), 0
+        self.center = (0.0, 0.0, 0.0)
+        self.z0, self.polygon = False, None
+        self.max_points = self.min_points = None
+        self.feat_center, self.grid = None, None
+        self.flip, self.shift = None, None
+        stage = 0
+        order = [ScalePos, MoveCenterPosPerSample, StartZFromZero, Polygon2dExtend, MaxPoints, MinPoints, XYZFeature,
+                 AddOnes, AddXYDistanceToCenter, AddFeatsByKeys, GridSampling3D, RandomCoordsFlip, ShiftVoxels]
+        for t in transforms:
+            if type(t) not in order:
+                raise NotImplementedError(f"{type(t).__name__} has no device implementation in this pipeline")
+            if order.index(type(t)) < stage:
+                raise NotImplementedError("transforms must come in the order of the NFI sparse chains")
+            stage = order.index(type(t))
+            if isinstance(t, ScalePos):
+                self.scale, self.div = t.scale, int(t.op_str == "div")
+            elif isinstance(t, MoveCenterPosPerSample):
+                self.center = t.center
+            elif isinstance(t, StartZFromZero):
+                self.z0 = True
+            elif isinstance(t, Polygon2dExtend):
+                self.polygon = t.polygon
+            elif isinstance(t, MaxPoints):
+                self.max_points = t.num
+            elif isinstance(t, MinPoints):
+                self.min_points = t.num
+            elif isinstance(t, AddXYDistanceToCenter):
+                self.feat_center = t.center
+            elif isinstance(t, GridSampling3D):
+                self.grid = t
+            elif isinstance(t, RandomCoordsFlip):
+                self.flip = t
+            elif isinstance(t, ShiftVoxels):
+                self.shift = t
+        if self.feat_center is None:
+            raise NotImplementedError("the pipeline builds x = [ones, pos_z, xy_distance]: AddXYDistanceToCenter missing")
+
+    # -- per-point stage -----------------------------------------------------------------------------------------
+    def prepare(self, plots: List, device):
+        """plots: list of float [n_i, 3] (numpy or torch).  Returns (pos [M,3], x [M,3], src int64 [M] rows of the
+        stacked input, lengths int64 [B]) on the device, after the crop and MaxPoints / MinPoints."""
+        lens = np.asarray([int(p.shape[0]) for p in plots], dtype=np.int64)
+        B, n = len(plots), int(lens.sum())
+        dev = torch.device(device)
+        stacked = torch.cat([torch.as_tensor(p, dtype=torch.float32).reshape(-1, 3) for p in plots]).to(dev)
+        ptr = _ptr_tensor(lens, dev)
+        elem = _elem_of_row(ptr, B, n, dev)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
+        i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)      # noqa: E731
+        nn_ = max(n, 1)
+        zmin, pos_t, pos_o, x_o = f32(B), f32(nn_, 3), f32(nn_, 3), f32(nn_, 3)
+        flag, slot, scratch = i32(nn_), i32(nn_), i32(_lib.scan_scratch_elems(nn_))
+        src = torch.empty(nn_, dtype=torch.int64, device=dev)
+        out_ptr, n_out = i32(B + 1), i32(1)
+        xform = (_lib.c_float * 8)(*self.scale, *self.center, *self.feat_center)
+        poly = None
+        nv = 0
+        if self.polygon is not None:
+            poly = torch.tensor(self.polygon, dtype=torch.float64).reshape(-1).to(dev)
+            nv = len(self.polygon)
+        _lib.call("agb_plot_prepare", _P(stacked), _P(ptr), _P(elem), B, n, xform, self.div, int(self.z0), _P(poly), nv,
+                  _P(zmin), _P(pos_t), _P(flag), _P(slot), _P(scratch), _P(pos_o), _P(x_o), _P(src), _P(out_ptr),
+                  _P(n_out), _lib.stream())
+        optr = np.asarray(out_ptr.tolist(), dtype=np.int64)       # one host read: the lengths after the crop
+        new_lens = np.diff(optr)
+        m = int(optr[-1])
+        pos_o, x_o, src = pos_o[:m], x_o[:m], src[:m]
+        # MaxPoints / MinPoints: per plot, only when a plot is out of range (torch.randperm like FixedPointsOwn)
+        need = [(self.max_points is not None and c > self.max_points) or
+                (self.min_points is not None and 0 < c < self.min_points) for c in new_lens]
+        if any(need):
+            choice, out_lens = [], []
+            for b, c in enumerate(new_lens):
+                c = int(c)
+                idx = torch.arange(c)
+                if self.max_points is not None and c > self.max_points:
+                    idx = torch.randperm(c)[:self.max_points]
+                if self.min_points is not None and 0 < len(idx) < self.min_points:
+                    k = len(idx)
+                    idx = idx[torch.cat([torch.randperm(k) for _ in range(math.ceil(self.min_points / k))])
+                              [:self.min_points]]
+                choice.append(idx + int(optr[b]))
+                out_lens.append(len(idx))
+            choice = torch.cat(choice).to(dev)
+            pos_o, x_o, src = pos_o[choice], x_o[choice], src[choice]
+            new_lens = np.asarray(out_lens, dtype=np.int64)
+        return pos_o, x_o, src, new_lens
+
+    # -- whole chain ---------------------------------------------------------------------------------------------
+    def __call__(self, plots: List, device, y_reg=None, perms=None):
+        """Returns a PlotBatch (batch, coords, x, pos, y_reg, ...) resident on `device`."""
+        from .synthetic import PlotBatch
+        pos, x, src, lens = self.prepare(plots, device)
+        B = len(plots)
+        dev = pos.device
+        if self.grid is None:
+            batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(lens)).to(dev)
+            out = PlotBatch(batch, None, x, pos, None, None, B, None)
+        else:
+            perm = draw_permutations(lens) if perms is None else perms
+            coords, keep, vlens, bounds = voxelize_last(pos, lens, self.grid.size, perm=perm)
+            coords = coords.contiguous()
+            batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(vlens)).to(dev)
+            if self.flip is not None or self.shift is not None:
+                flips, shifts = np.zeros((B, 3), np.int32), np.zeros((B, 3), np.int32)
+                for b in range(B):   # the reference draws per sample: flip axes first, then the shift
+                    if self.flip is not None:
+                        for ax in self.flip.axes:
+                            if random.random() < self.flip.p:
+                                flips[b, ax] = 1
+                    if self.shift is not None and self.shift.apply_shift and random.random() < self.shift.p:
+                        shifts[b] = (torch.rand(3) * 100).to(torch.int32).numpy()
+                ptr = _ptr_tensor(vlens, dev)
+                m = int(coords.shape[0])
+                elem = _elem_of_row(ptr, B, m, dev)
+                cmax = torch.empty(3 * B, dtype=torch.int32, device=dev)
+                # named tensors: a temporary would be freed (and its block reused) as soon as its pointer is taken
+                flips_d, shifts_d = torch.from_numpy(flips).to(dev), torch.from_numpy(shifts).to(dev)
+                _lib.call("agb_coords_augment", _P(coords), _P(elem), B, m, _P(flips_d), _P(shifts_d), _P(cmax),
+                          _lib.stream())
+                bounds = None   # recomputed from the coordinates by PlotBatch
+            out = PlotBatch(batch, coords, x[keep], pos[keep], None, None, B, bounds)
+            out.src = src[keep]
+        if y_reg is not None:
+            out.y_reg = torch.as_tensor(y_reg, dtype=torch.float32).to(dev)
+            out.y_reg_mask = torch.ones_like(out.y_reg, dtype=torch.bool)
+            out.y_reg_mask_all = True
+        return out

@@ -239,6 +239,24 @@ int agb_adabelief_step(const void* descs, const int32_t* chunk_tensor, const int
                        float decay, float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps,
                        float step, float inv_sqrt_bc2, int mode, float clip, void* stream);
 
+/* ---- NFI transform chain on the device (dpcr-agb_amd/csrc/transform.hip) -------------------------------------------
+ * Replaces, for a whole batch, the per-sample CPU transforms of conf/data/instance/NFI/transforms/sparse-xy.yaml:
+ * ScalePos, MoveCenterPosPerSample, StartZFromZero (core/data_transform/transforms.py:590-598,722-739,766-769),
+ * Polygon2dExtend (:1461-1496, matplotlib Path.contains_points restated in double) and the feature build
+ * x = [1, pos.z, ||pos.xy - c + 1e-6||] (features.py:307-334,353-383).  xform: HOST float[8] = (sx, sy, sz, cx, cy, cz,
+ * fcx, fcy); poly: device double[2*nv] (nv = 0: no crop).  Scratch: zmin float[B], pos_t float[n,3], flag / slot
+ * int32[n], scan_scratch int32[agb_scan_scratch_elems(n)].  Out (n rows reserved): pos_out, x_out float[n,3], src
+ * int64[n] (input row of every kept point, order preserved), out_ptr int32[B+1], n_out_dev int32[1]. */
+int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
+                     int scale_div, int z_from_zero, const double* poly, int nv, float* zmin, float* pos_t,
+                     int32_t* flag, int32_t* slot, int32_t* scan_scratch, float* pos_out, float* x_out, long long* src,
+                     int32_t* out_ptr, int32_t* n_out_dev, void* stream);
+/* RandomCoordsFlip (core/data_transform/sparse_transforms.py:49-55) + ShiftVoxels (transforms.py:1046-1054) on voxel
+ * coordinates int32[n,3], in place: flip int32[B,3] (0/1), shift int32[B,3], both drawn by the host; cmax int32[B,3]
+ * scratch. */
+int agb_coords_augment(int32_t* coords, const int32_t* elem, int B, int n, const int32_t* flip, const int32_t* shift,
+                       int32_t* cmax, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,157 @@
+"""NFI sparse transform chain: the CPU restatement (oracle/transforms_ref.py) against known answers and against the real
+third-party calls the reference makes (matplotlib Path.contains_points, torch PairwiseDistance); the device pipeline
+(dpcr_agb_amd.transforms -> agb_plot_prepare / agb_voxelize_last / agb_coords_augment) against the oracle, bit-exact
+for positions, kept points, voxel coordinates and flips."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transforms_ref as T
+from oracle import voxelize_ref as V
+
+
+def point_in_polygon_np(x, y, poly):
+    """numpy copy of csrc/transform.hip:point_in_polygon (matplotlib's crossing test), vectorised over points."""
+    poly = np.asarray(poly, dtype=np.float64)
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    vx0, vy0 = poly[-1]
+    yflag0 = vy0 >= y
+    inside = np.zeros(len(x), dtype=bool)
+    for vx1, vy1 in poly:
+        yflag1 = vy1 >= y
+        cross = ((vy1 - y) * (vx0 - vx1) >= (vx1 - x) * (vy0 - vy1)) == yflag1
+        inside ^= (yflag0 != yflag1) & cross
+        yflag0, vx0, vy0 = yflag1, vx1, vy1
+    return inside
+
+
+def raw_plot(seed, n):
+    """A synthetic plot in the raw frame of the reference (metres, centred on the plot centre)."""
+    from dpcr_agb_amd import synthetic
+    rng = np.random.default_rng(seed)
+    pos, _, y = synthetic.make_plot(seed, n)
+    # undo the normalisation and spill some points outside the hexagon / below the lowest return
+    raw = np.stack([(pos[:, 0] - 0.5) * 30.0, (pos[:, 1] - 0.5) * 30.0, pos[:, 2] * 40.0 + 3.25], 1)
+    raw[:, :2] *= rng.uniform(1.0, 1.25)
+    return raw.astype(np.float32), y
+
+
+# ------------------------------------------------------------------------------------------------------------- CPU
+def test_known_answers():
+    pos = torch.tensor([[15.0, -15.0, 44.0], [0.0, 0.0, 4.0], [30.0, 0.0, 24.0]])
+    p = T.start_z_from_zero(T.move_center(T.scale_pos(pos, (30.0, 30.0, 40.0), "div"), 0.5, 0.5))
+    assert torch.equal(p, torch.tensor([[1.0, 0.0, 1.0], [0.5, 0.5, 0.0], [1.5, 0.5, 0.5]]))
+    m = T.polygon_mask(p)
+    assert m.tolist() == [False, True, False]
+    x = T.features(p[m])
+    assert x.shape == (1, 3) and x[0, 0] == 1 and x[0, 1] == 0
+    assert abs(float(x[0, 2]) - np.sqrt(2) * 1e-6) < 1e-9          # PairwiseDistance adds eps before the norm
+
+
+def test_crossing_test_is_matplotlibs():
+    from matplotlib.path import Path
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-0.2, 1.2, size=(200_000, 2))
+    # plus points hugging the edges (1e-9 .. 1e-4 away)
+    poly = np.asarray(T.HEXAGON)
+    a, b = poly, np.roll(poly, -1, 0)
+    t = rng.uniform(0, 1, size=(6, 2000, 1))
+    on = a[:, None] + t * (b - a)[:, None]
+    nrm = np.stack([(b - a)[:, 1], -(b - a)[:, 0]], 1)[:, None]
+    near = (on + nrm * rng.choice([-1, 1], size=(6, 2000, 1)) * 10 ** rng.uniform(-9, -4, size=(6, 2000, 1))).reshape(-1, 2)
+    pts = np.concatenate([pts, near]).astype(np.float32).astype(np.float64)   # the kernel sees fp32 coordinates
+    assert np.array_equal(point_in_polygon_np(pts[:, 0], pts[:, 1], T.HEXAGON), Path(T.HEXAGON).contains_points(pts))
+
+
+def test_coordinate_augmentations_known_answers():
+    c = torch.tensor([[0, 1, 2], [3, 0, 2], [1, 5, 0]], dtype=torch.int32)
+    random.seed(4)
+    draws = [random.random() for _ in range(3)]
+    random.seed(4)
+    torch.manual_seed(1)
+    flags = T.random_coords_flip(c, p=0.5)
+    assert flags == [int(draws[0] < 0.5), int(draws[1] < 0.5), 0]
+    exp = torch.tensor([[0, 1, 2], [3, 0, 2], [1, 5, 0]], dtype=torch.int32)
+    if flags[0]:
+        exp[:, 0] = 3 - exp[:, 0]
+    if flags[1]:
+        exp[:, 1] = 5 - exp[:, 1]
+    assert torch.equal(c, exp)
+    shift = T.shift_voxels(c, p=0.5)
+    torch.manual_seed(1)
+    want = (torch.rand(3) * 100).to(torch.int32) if draws[2] < 0.5 else torch.zeros(3, dtype=torch.int32)
+    assert torch.equal(shift, want) and torch.equal(c, exp + want)
+
+
+# ------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_device_prepare_matches_oracle(device):
+    from dpcr_agb_amd.transforms import SparsePlotPipeline, nfi_test_transform
+    sizes = [16000, 30000, 300, 9000, 1]      # one plot above MaxPoints after the crop, one below MinPoints, one point
+    plots = [raw_plot(200 + i, n)[0] for i, n in enumerate(sizes)]
+    plots[4] = np.array([[0.1, -0.2, 7.0]], np.float32)
+    pipe = SparsePlotPipeline(nfi_test_transform()[:-1])     # everything before GridSampling3D
+    torch.manual_seed(11)
+    pos, x, src, lens = pipe.prepare(plots, device)
+    torch.manual_seed(11)
+    off, o_off = 0, 0
+    for b, raw in enumerate(plots):
+        op, ox, osrc = T.test_transform_sample(torch.from_numpy(raw))
+        n = len(op)
+        assert lens[b] == n, (b, lens[b], n)
+        sl = slice(o_off, o_off + n)
+        assert torch.equal(pos[sl].cpu(), op), b
+        assert torch.equal(src[sl].cpu() - off, osrc), b
+        assert torch.equal(x[sl, :2].cpu(), ox[:, :2]), b
+        assert torch.allclose(x[sl, 2].cpu(), ox[:, 2], rtol=2e-7, atol=0), b   # sqrt of a 2-term sum: 1 ulp
+        off += len(raw)
+        o_off += n
+    assert lens.tolist()[1] == 16000 and lens.tolist()[2] in (500, 0) and o_off == len(pos)
+
+
+@pytest.mark.gpu
+def test_device_chain_with_voxelisation_and_coord_augmentation(device):
+    from dpcr_agb_amd.transforms import SparsePlotPipeline, nfi_coord_augmentation, nfi_test_transform
+    sizes = [12000, 16000, 7000]
+    plots = [raw_plot(300 + i, n)[0] for i, n in enumerate(sizes)]
+    # oracle: per sample
+    torch.manual_seed(3)
+    ops = [T.test_transform_sample(torch.from_numpy(r)) for r in plots]
+    lens = [len(o[0]) for o in ops]
+    rng = np.random.default_rng(9)
+    perms = [rng.permutation(n) for n in lens]
+    oc, ok, ol = V.batch_grid_sampling_last(np.concatenate([o[0].numpy() for o in ops]), lens, perms, 0.0125)
+    random.seed(1)
+    torch.manual_seed(22)
+    ocs, o0 = [], 0
+    for n in ol:
+        c = torch.from_numpy(oc[o0:o0 + n].copy())
+        T.random_coords_flip(c, p=0.5)
+        T.shift_voxels(c, p=0.5)
+        ocs.append(c)
+        o0 += n
+    # device
+    pipe = SparsePlotPipeline(nfi_test_transform() + nfi_coord_augmentation())
+    torch.manual_seed(3)
+    random.seed(1)
+    # the flips/shifts are drawn after the voxelisation: re-seed torch there through the perms argument path
+    pos, x, src, plens = pipe.prepare(plots, device)
+    assert plens.tolist() == lens
+    torch.manual_seed(22)
+    out = pipe(plots, device, y_reg=np.ones((3, 2), np.float32), perms=torch.from_numpy(np.concatenate(perms)))
+    assert torch.equal(out.coords.cpu(), torch.cat(ocs))
+    assert np.array_equal(np.bincount(out.batch.cpu().numpy(), minlength=3), ol)
+    ox = torch.cat([o[1] for o in ops])[torch.from_numpy(ok)]
+    assert torch.equal(out.x[:, :2].cpu(), ox[:, :2])
+    # the batch feeds the model
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_016))
+    model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS["SENet14"]), "minkowski", ds).to(device).eval()
+    with torch.no_grad():
+        model.set_input(out, device)
+        model.forward()
+    assert model.output.shape == (3, 2) and torch.isfinite(model.output).all()
