@@ -146,23 +146,39 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
 }
 
 // ---------------------------------------------------------------- forward apply: y = act(gamma*(x-mean)*rstd+beta)
-__global__ void k_bn_act_fwd(const float* __restrict__ X, int ldx, int n, int C4, const float* __restrict__ mean,
-                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                             const float* __restrict__ beta, int act, float* __restrict__ Y, int ldy) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int r = (int)(t / C4), c = (int)(t % C4) * 4;
-    if (r >= n) return;
-    float4 v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
-    float4 m = *reinterpret_cast<const float4*>(mean + c);
-    float4 s = *reinterpret_cast<const float4*>(rstd + c);
-    float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-    float4 b = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 o;
-    o.x = act_fwd((v.x - m.x) * s.x * g.x + b.x, act);
-    o.y = act_fwd((v.y - m.y) * s.y * g.y + b.y, act);
-    o.z = act_fwd((v.z - m.z) * s.z * g.z + b.z, act);
-    o.w = act_fwd((v.w - m.w) * s.w * g.w + b.w, act);
-    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = o;
+// Elementwise kernels: block = 16 column groups (one 64-channel slab) x 16 row lanes, EW_ROWS rows per workgroup; every
+// thread keeps the per-channel parameters of its 4 channels in registers and streams EW_ROWS/16 rows (independent
+// 16-B loads in flight) — no per-element 64-bit index division, no per-element parameter reloads.
+#define EW_ROWS 128
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ X, int ldx, int n, int C,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    int act, float* __restrict__ Y, int ldy) {
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cg * 4;
+    if (c >= C) return;
+    const float4 m = *reinterpret_cast<const float4*>(mean + c);
+    const float4 s = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 b = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r0 = blockIdx.x * EW_ROWS + rl;
+    float4 v[EW_ROWS / 16];
+#pragma unroll
+    for (int j = 0; j < EW_ROWS / 16; ++j) {
+        const int r = r0 + 16 * j;
+        if (r < n) v[j] = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+    }
+#pragma unroll
+    for (int j = 0; j < EW_ROWS / 16; ++j) {
+        const int r = r0 + 16 * j;
+        if (r >= n) continue;
+        float4 o;
+        o.x = act_fwd((v[j].x - m.x) * s.x * g.x + b.x, act);
+        o.y = act_fwd((v[j].y - m.y) * s.y * g.y + b.y, act);
+        o.z = act_fwd((v[j].z - m.z) * s.z * g.z + b.z, act);
+        o.w = act_fwd((v[j].w - m.w) * s.w * g.w + b.w, act);
+        *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = o;
+    }
 }
 
 // ---------------------------------------------------------------- backward
@@ -225,7 +241,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_fold(const float* __restrict__ part, int chunks, int C,
-                                                     float* dbeta, float* dgamma) {
+                                                     float* dbeta, float* dgamma, float* colsum) {
     __shared__ float s_a[16][16], s_b[16][16];
     const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -244,81 +260,164 @@ __global__ __launch_bounds__(256) void k_bn_bwd_fold(const float* __restrict__ p
         for (int j = 0; j < 16; ++j) { a += s_a[j][cl]; b += s_b[j][cl]; }
         dbeta[c] = a;
         dgamma[c] = b;
+        if (colsum) colsum[c] = 0.f;   // accumulated by the apply pass that follows
     }
 }
 
 // pass 2: dx = gamma*rstd*(dz - [training] (dbeta + xhat*dgamma)/n)
-__global__ void k_bn_act_bwd_apply(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy, int n,
-                                   int C4, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                   const float* __restrict__ dbeta, const float* __restrict__ dgamma, int training,
-                                   float* __restrict__ dX, int lddx) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int r = (int)(t / C4), c = (int)(t % C4) * 4;
-    if (r >= n) return;
-    float4 xv = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
-    float4 dv = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
-    float x[4] = {xv.x, xv.y, xv.z, xv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
-    const float inv_n = training ? 1.f / (float)n : 0.f;
+__global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restrict__ X, int ldx,
+                                                          const float* __restrict__ dY, int ldy, int n, int C,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int act, const float* __restrict__ dbeta,
+                                                          const float* __restrict__ dgamma, int training,
+                                                          float* __restrict__ dX, int lddx,
+                                                          float* __restrict__ colsum) {
+    __shared__ float s_cs[16][64];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = min(blockIdx.y * 64 + cg * 4, C - 4);   // a partial last slab recomputes its last group (C % 4 == 0)
+    float m[4], s[4], g[4], b[4], db[4], dg[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float m = mean[c + j], s = rstd[c + j];
-        float g = gamma ? gamma[c + j] : 1.f, b = beta ? beta[c + j] : 0.f;
-        float xh = (x[j] - m) * s;
-        float dz = d[j] * act_grad(xh * g + b, act);
-        o[j] = g * s * (dz - (dbeta[c + j] + xh * dgamma[c + j]) * inv_n);
+        m[j] = mean[c + j];
+        s[j] = rstd[c + j];
+        g[j] = gamma ? gamma[c + j] : 1.f;
+        b[j] = beta ? beta[c + j] : 0.f;
+        db[j] = dbeta[c + j];
+        dg[j] = dgamma[c + j];
     }
-    *reinterpret_cast<float4*>(dX + (long long)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    const float inv_n = training ? 1.f / (float)n : 0.f;
+    const int r0 = blockIdx.x * EW_ROWS + rl;
+    constexpr int NR = EW_ROWS / 16, HALF = NR / 2;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 xv[HALF], dv[HALF];
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int r = r0 + 16 * (h * HALF + j);
+            if (r < n) {
+                xv[j] = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+                dv[j] = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int r = r0 + 16 * (h * HALF + j);
+            if (r >= n) continue;
+            const float x[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, d[4] = {dv[j].x, dv[j].y, dv[j].z, dv[j].w};
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float xh = (x[q] - m[q]) * s[q];
+                float dz = d[q] * act_grad(xh * g[q] + b[q], act);
+                o[q] = g[q] * s[q] * (dz - (db[q] + xh * dg[q]) * inv_n);
+                cs[q] += o[q];
+            }
+            *reinterpret_cast<float4*>(dX + (long long)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    // column sums of dX = the bias gradient of the convolution that feeds this BatchNorm (mathematically zero in
+    // training mode: what is left is rounding noise, which the reference also feeds to its optimiser); one float
+    // atomic per column and workgroup
+    if (colsum) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_cs[rl][cg * 4 + q] = cs[q];
+        __syncthreads();
+        if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < C) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a += s_cs[j][threadIdx.x];
+            atomicAdd(&colsum[blockIdx.y * 64 + threadIdx.x], a);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- residual tail: y = act(a * s[batch] + r)
 // (the drop-path scale s is optional; reference call sites resnet_block.py:70-73, senet_block.py:92-96)
-__global__ void k_add_act_fwd(const float* __restrict__ A, int lda, const float* __restrict__ R, int ldr,
-                              const float* __restrict__ scale, const int32_t* __restrict__ coords, int n, int C4,
-                              int act, float* __restrict__ Y, int ldy) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int r = (int)(t / C4), c = (int)(t % C4) * 4;
-    if (r >= n) return;
-    float s = scale ? scale[coords[4 * (long long)r]] : 1.f;
-    float4 a = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
-    float4 b = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
-    float4 o;
-    o.x = act_fwd(a.x * s + b.x, act);
-    o.y = act_fwd(a.y * s + b.y, act);
-    o.z = act_fwd(a.z * s + b.z, act);
-    o.w = act_fwd(a.w * s + b.w, act);
-    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = o;
+__global__ __launch_bounds__(256) void k_add_act_fwd(const float* __restrict__ A, int lda, const float* __restrict__ R,
+                                                     int ldr, const float* __restrict__ scale,
+                                                     const int32_t* __restrict__ coords, int n, int C, int act,
+                                                     float* __restrict__ Y, int ldy) {
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cg * 4;
+    if (c >= C) return;
+    const int r0 = blockIdx.x * EW_ROWS + rl;
+    constexpr int NR = EW_ROWS / 16;
+    float4 av[NR], bv[NR];
+    float sv[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + 16 * j;
+        if (r < n) {
+            av[j] = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
+            bv[j] = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+            sv[j] = scale ? scale[coords[4 * (long long)r]] : 1.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + 16 * j;
+        if (r >= n) continue;
+        float4 o;
+        o.x = act_fwd(av[j].x * sv[j] + bv[j].x, act);
+        o.y = act_fwd(av[j].y * sv[j] + bv[j].y, act);
+        o.z = act_fwd(av[j].z * sv[j] + bv[j].z, act);
+        o.w = act_fwd(av[j].w * sv[j] + bv[j].w, act);
+        *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = o;
+    }
 }
 
 // dA = dz * s, dR = dz with dz = dY * act'(a*s + r)
-__global__ void k_add_act_bwd(const float* __restrict__ A, int lda, const float* __restrict__ R, int ldr,
-                              const float* __restrict__ scale, const int32_t* __restrict__ coords,
-                              const float* __restrict__ dY, int ldy, int n, int C4, int act, float* __restrict__ dA,
-                              float* __restrict__ dR) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int r = (int)(t / C4), c = (int)(t % C4) * 4;
-    if (r >= n) return;
-    float s = scale ? scale[coords[4 * (long long)r]] : 1.f;
-    float4 a = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
-    float4 b = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
-    float4 d = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
-    float4 dz;
-    dz.x = d.x * act_grad(a.x * s + b.x, act);
-    dz.y = d.y * act_grad(a.y * s + b.y, act);
-    dz.z = d.z * act_grad(a.z * s + b.z, act);
-    dz.w = d.w * act_grad(a.w * s + b.w, act);
-    long long o = (long long)r * (C4 * 4) + c;
-    if (dR) *reinterpret_cast<float4*>(dR + o) = dz;
-    if (dA) *reinterpret_cast<float4*>(dA + o) = make_float4(dz.x * s, dz.y * s, dz.z * s, dz.w * s);
+__global__ __launch_bounds__(256) void k_add_act_bwd(const float* __restrict__ A, int lda, const float* __restrict__ R,
+                                                     int ldr, const float* __restrict__ scale,
+                                                     const int32_t* __restrict__ coords, const float* __restrict__ dY,
+                                                     int ldy, int n, int C, int act, float* __restrict__ dA,
+                                                     float* __restrict__ dR) {
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cg * 4;
+    if (c >= C) return;
+    const int r0 = blockIdx.x * EW_ROWS + rl;
+    constexpr int NR = EW_ROWS / 16, HALF = NR / 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 av[HALF], bv[HALF], dv[HALF];
+        float sv[HALF];
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int r = r0 + 16 * (h * HALF + j);
+            if (r < n) {
+                av[j] = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
+                bv[j] = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+                dv[j] = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+                sv[j] = scale ? scale[coords[4 * (long long)r]] : 1.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int r = r0 + 16 * (h * HALF + j);
+            if (r >= n) continue;
+            const float s = sv[j];
+            float4 dz;
+            dz.x = dv[j].x * act_grad(av[j].x * s + bv[j].x, act);
+            dz.y = dv[j].y * act_grad(av[j].y * s + bv[j].y, act);
+            dz.z = dv[j].z * act_grad(av[j].z * s + bv[j].z, act);
+            dz.w = dv[j].w * act_grad(av[j].w * s + bv[j].w, act);
+            const long long o = (long long)r * C + c;
+            if (dR) *reinterpret_cast<float4*>(dR + o) = dz;
+            if (dA) *reinterpret_cast<float4*>(dA + o) = make_float4(dz.x * s, dz.y * s, dz.z * s, dz.w * s);
+        }
+    }
 }
 
 // =============================================================== C ABI
 extern "C" {
 
 int agb_bn_chunks(int n) {
-    // ~512 rows per chunk, at most 512 chunks (x C/64 column slabs of workgroups)
-    int chunks = agb_cdiv(n > 0 ? n : 1, 512);
-    return chunks > 512 ? 512 : chunks;
+    // ~128 rows per chunk, at most 2048 chunks (x C/64 column slabs of workgroups): enough workgroups to keep every
+    // CU's load queue full on the 64-channel levels (512 chunks left 2 workgroups per CU: latency-bound at ~2.5 TB/s)
+    int chunks = agb_cdiv(n > 0 ? n : 1, 128);
+    return chunks > 2048 ? 2048 : chunks;
 }
 
 static int rows_per_chunk(int n, int chunks) { return agb_cdiv(n > 0 ? n : 1, chunks); }
@@ -349,31 +448,39 @@ int agb_bn_act_fwd(const float* X, int ldx, int n, int C, const float* mean, con
     AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_bn_act_fwd: C/ld must be multiples of 4");
     AGB_CHECK_ARG(act >= 0 && act <= 2, "agb_bn_act_fwd: activation %d", act);
     if (n == 0) return AGB_OK;
-    long long total = (long long)n * (C / 4);
-    hipLaunchKernelGGL(k_bn_act_fwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, n, C / 4,
-                       mean, rstd, gamma, beta, act, Y, ldy);
+    hipLaunchKernelGGL(k_bn_act_fwd, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, X,
+                       ldx, n, C, mean, rstd, gamma, beta, act, Y, ldy);
     AGB_CHECK_LAUNCH("agb_bn_act_fwd");
     return AGB_OK;
 }
 
-// part: float[agb_bn_chunks(n) * 2 * C] scratch; dgamma, dbeta: float[C] out (always written); dX: [n, C]
-int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
-                   const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
-                   float* dX, int lddx, float* dgamma, float* dbeta, void* stream) {
+// part: float[agb_bn_chunks(n) * 2 * C] scratch; dgamma, dbeta: float[C] out (always written); dX: [n, C];
+// colsum (optional, float[C] out): column sums of dX — the bias gradient of the convolution feeding this BatchNorm,
+// produced while dX is written instead of by a separate reduction pass over it.
+int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
+                          float* dX, int lddx, float* dgamma, float* dbeta, float* colsum, void* stream) {
     AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0,
                   "agb_bn_act_bwd: C/ld must be multiples of 4");
+    AGB_CHECK_ARG(colsum == nullptr || dX != nullptr, "agb_bn_act_bwd: colsum needs dX");
     hipStream_t s = (hipStream_t)stream;
     int chunks = agb_bn_chunks(n);
     hipLaunchKernelGGL(k_bn_act_bwd_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY, ldy, n, C,
                        rows_per_chunk(n, chunks), mean, rstd, gamma, beta, act, part);
-    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, 16)), dim3(256), 0, s, part, chunks, C, dbeta, dgamma);
+    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, 16)), dim3(256), 0, s, part, chunks, C, dbeta, dgamma, colsum);
     if (n > 0 && dX) {
-        long long total = (long long)n * (C / 4);
-        hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, X, ldx, dY, ldy, n, C / 4,
-                           mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx);
+        hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY,
+                           ldy, n, C, mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx, colsum);
     }
     AGB_CHECK_LAUNCH("agb_bn_act_bwd");
     return AGB_OK;
+}
+
+int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
+                   float* dX, int lddx, float* dgamma, float* dbeta, void* stream) {
+    return agb_bn_act_bwd_colsum(X, ldx, dY, ldy, n, C, mean, rstd, gamma, beta, act, training, part, dX, lddx, dgamma,
+                                 dbeta, nullptr, stream);
 }
 
 // y = act(A * scale[batch(row)] + R); scale (float[B]) and coords may be NULL (no drop-path)
@@ -383,9 +490,8 @@ int agb_add_act_fwd(const float* A, int lda, const float* R, int ldr, const floa
                   "agb_add_act_fwd: C/ld must be multiples of 4");
     AGB_CHECK_ARG(scale == nullptr || coords != nullptr, "agb_add_act_fwd: a scale needs the coords (batch column)");
     if (n == 0) return AGB_OK;
-    long long total = (long long)n * (C / 4);
-    hipLaunchKernelGGL(k_add_act_fwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, A, lda, R, ldr,
-                       scale, coords, n, C / 4, act, Y, ldy);
+    hipLaunchKernelGGL(k_add_act_fwd, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, A,
+                       lda, R, ldr, scale, coords, n, C, act, Y, ldy);
     AGB_CHECK_LAUNCH("agb_add_act_fwd");
     return AGB_OK;
 }
@@ -396,9 +502,8 @@ int agb_add_act_bwd(const float* A, int lda, const float* R, int ldr, const floa
     AGB_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0,
                   "agb_add_act_bwd: C/ld must be multiples of 4");
     if (n == 0) return AGB_OK;
-    long long total = (long long)n * (C / 4);
-    hipLaunchKernelGGL(k_add_act_bwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, A, lda, R, ldr,
-                       scale, coords, dY, ldy, n, C / 4, act, dA, dR);
+    hipLaunchKernelGGL(k_add_act_bwd, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, A,
+                       lda, R, ldr, scale, coords, dY, ldy, n, C, act, dA, dR);
     AGB_CHECK_LAUNCH("agb_add_act_bwd");
     return AGB_OK;
 }

@@ -112,6 +112,73 @@ __global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict_
     }
 }
 
+// Same reduction with 16-B loads: block 256 = 16 column groups (one 64-channel slab) x 16 row lanes; every thread
+// folds rows r, r+16, ... of its 4 channels, the 16 lane partials are combined in lane order (fixed order).
+// Used when C, lda (and ldb) are multiples of 4: 4x fewer load instructions than the scalar kernel above
+// (the SE squeeze of 206 k x 64 rows ran at 0.9 TB/s with 4-byte loads).
+__global__ __launch_bounds__(256) void k_segment_reduce4(const float* __restrict__ A, int lda,
+                                                         const float* __restrict__ Bm, int ldb,
+                                                         const int32_t* __restrict__ ptr, int C, int mode, int S,
+                                                         float* __restrict__ Y, int32_t* __restrict__ arg) {
+    __shared__ float s_val[16][64];
+    __shared__ int s_arg[16][64];
+    const int b = blockIdx.x;
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cg * 4;
+    const int seg_beg = ptr[b], seg_end = ptr[b + 1];
+    const int len = seg_end - seg_beg;
+    const int chunk = (len + S - 1) / S;
+    const int beg = seg_beg + blockIdx.z * chunk;
+    const int end = min(seg_end, beg + chunk);
+    float acc[4];
+    int ai[4] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (mode == 2) ? -FLT_MAX : 0.f;
+    if (c < C) {
+        for (int r = beg + rl; r < end; r += 16) {
+            float4 v4 = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
+            if (Bm) {
+                float4 m4 = *reinterpret_cast<const float4*>(Bm + (long long)r * ldb + c);
+                v4.x *= m4.x; v4.y *= m4.y; v4.z *= m4.z; v4.w *= m4.w;
+            }
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mode == 2) {
+                    if (v[j] > acc[j]) { acc[j] = v[j]; ai[j] = r; }
+                } else {
+                    acc[j] += v[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_val[rl][cg * 4 + j] = acc[j];
+        s_arg[rl][cg * 4 + j] = ai[j];
+    }
+    __syncthreads();
+    const int l = threadIdx.x;
+    const int cc = blockIdx.y * 64 + l;
+    if (l < 64 && cc < C) {
+        float a = s_val[0][l];
+        int bi = s_arg[0][l];
+        if (mode == 2) {
+            for (int j = 1; j < 16; ++j) {
+                float v = s_val[j][l];
+                int q = s_arg[j][l];
+                if (q >= 0 && (bi < 0 || v > a || (v == a && q < bi))) { a = v; bi = q; }
+            }
+            if (S == 1 && bi < 0) a = 0.f;
+            arg[((long long)b * S + blockIdx.z) * C + cc] = bi;
+        } else {
+            for (int j = 1; j < 16; ++j) a += s_val[j][l];
+            if (mode == 1 && S == 1) a = len > 0 ? a / (float)len : 0.f;
+        }
+        Y[((long long)b * S + blockIdx.z) * C + cc] = a;
+    }
+}
+
 __global__ void k_segment_fold(const float* __restrict__ part, const int32_t* __restrict__ part_arg,
                                const int32_t* __restrict__ ptr, int B, int C, int mode, int S,
                                float* __restrict__ Y, int32_t* __restrict__ arg) {
@@ -205,11 +272,20 @@ int agb_segment_reduce(const float* A, int lda, const float* Bm, int ldb, const 
                   "agb_segment_reduce: splits > 1 needs scratch buffers");
     if (B == 0 || C == 0) return AGB_OK;
     hipStream_t s = (hipStream_t)stream;
+    const bool vec = C % 4 == 0 && lda % 4 == 0 && (Bm == nullptr || ldb % 4 == 0);
     if (splits == 1) {
-        hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64), 1), dim3(256), 0, s, A, lda, Bm, ldb, ptr, C,
-                           mode, 1, Y, argmax);
+        if (vec)
+            hipLaunchKernelGGL(k_segment_reduce4, dim3(B, agb_cdiv(C, 64), 1), dim3(256), 0, s, A, lda, Bm, ldb, ptr, C,
+                               mode, 1, Y, argmax);
+        else
+            hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64), 1), dim3(256), 0, s, A, lda, Bm, ldb, ptr, C,
+                               mode, 1, Y, argmax);
     } else {
-        hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64), splits), dim3(256), 0, s, A, lda, Bm, ldb, ptr,
+        if (vec)
+            hipLaunchKernelGGL(k_segment_reduce4, dim3(B, agb_cdiv(C, 64), splits), dim3(256), 0, s, A, lda, Bm, ldb,
+                               ptr, C, mode, splits, part, part_arg);
+        else
+            hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64), splits), dim3(256), 0, s, A, lda, Bm, ldb, ptr,
                            C, mode, splits, part, part_arg);
         hipLaunchKernelGGL(k_segment_fold, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, s, part, part_arg,
                            ptr, B, C, mode, splits, Y, argmax);

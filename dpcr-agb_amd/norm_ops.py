@@ -17,6 +17,10 @@ _lib.declare("agb_bn_act_bwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c
                                 _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
                                 _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
                                 _lib.c_void_p])
+_lib.declare("agb_bn_act_bwd_colsum", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int,
+                                       _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int,
+                                       _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_void_p,
+                                       _lib.c_void_p, _lib.c_void_p, _lib.c_void_p])
 _lib.declare("agb_add_act_fwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
                                  _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p])
 _lib.declare("agb_add_act_bwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
@@ -58,11 +62,16 @@ class BatchNormActFunction(torch.autograd.Function):
         n, c = x.shape
         dev = x.device
         part = torch.empty(bn_chunks(n) * 2 * c, dtype=torch.float32, device=dev)
-        dgb = torch.empty(2, c, dtype=torch.float32, device=dev)
+        dgb = torch.empty(3, c, dtype=torch.float32, device=dev)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        _lib.call("agb_bn_act_bwd", _P(x), x.stride(0), _P(dy), dy.stride(0), n, c, _P(stats[0]), _P(stats[1]),
+        _lib.call("agb_bn_act_bwd_colsum", _P(x), x.stride(0), _P(dy), dy.stride(0), n, c, _P(stats[0]), _P(stats[1]),
                   _P(gamma) if has_g else None, _P(beta) if has_b else None, act_id, int(training), _P(part), _P(dx),
-                  0 if dx is None else dx.stride(0), _P(dgb[0]), _P(dgb[1]), _lib.stream())
+                  0 if dx is None else dx.stride(0), _P(dgb[0]), _P(dgb[1]), _P(dgb[2]) if dx is not None else None,
+                  _lib.stream())
+        if dx is not None:
+            # column sums of dx, a by-product of the apply pass: the convolution that produced x (its backward node
+            # receives this very tensor) takes them as its bias gradient instead of reducing dx again
+            dx.agb_colsum = dgb[2]
         return dx, (dgb[0] if has_g else None), (dgb[1] if has_b else None), None, None, None, None, None, None
 
 

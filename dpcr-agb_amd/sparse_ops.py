@@ -122,6 +122,7 @@ class SparseConvFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, nbr, nbrT = ctx.saved_tensors
         K3, cin, cout, cin_p, cout_p, n_in, n_out, has_T, has_bias, bias_shape = ctx.dims
+        colsum = getattr(dy, "agb_colsum", None)   # left by the BatchNorm backward that produced dy (norm_ops.py)
         dy = dy.contiguous()
         if cout_p != cout:
             dy = F.pad(dy, (0, cout_p - cout)).contiguous()
@@ -148,7 +149,10 @@ class SparseConvFunction(torch.autograd.Function):
             _prof_end(ev, "wgrad", K3, cin_p, cout_p, n_out, ctx.pairs)
             dk = dwp if (cin_p == cin and cout_p == cout) else dwp[:, :cin, :cout].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy[:, :cout].sum(0).reshape(bias_shape)
+            if colsum is not None and colsum.numel() == cout and cout_p == cout:
+                db = colsum.reshape(bias_shape)
+            else:
+                db = dy[:, :cout].sum(0).reshape(bias_shape)
         return dx, dk, db, None, None, None, None, None
 
 

@@ -161,6 +161,11 @@ int agb_bn_act_fwd(const float* X, int ldx, int n, int C, const float* mean, con
 int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
                    const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
                    float* dX, int lddx, float* dgamma, float* dbeta, void* stream);
+/* Same, plus colsum float[C] (optional): the column sums of dX — the bias gradient of the convolution feeding the
+ * BatchNorm (common.py:215-226 ConvNormActivation, resnet_block.py:62-69) — accumulated while dX is written. */
+int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
+                          float* dX, int lddx, float* dgamma, float* dbeta, float* colsum, void* stream);
 /* Y = act(A * scale[batch(row)] + R); scale float[B] (drop-path keep/(1-p)) and coords may be NULL */
 int agb_add_act_fwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords, int n,
                     int C, int act, float* Y, int ldy, void* stream);

@@ -47,8 +47,17 @@ def test_bn_act_training(device, n, c, act):
         assert rel(xg.grad.cpu() * keep, xr.grad * keep) < 2e-4
     else:
         assert rel(xg.grad, xr.grad) < 2e-4
-    assert rel(bn.weight.grad, ref.weight.grad) < 2e-4
-    assert rel(bn.bias.grad, ref.bias.grad) < 2e-4
+    if act == "relu":
+        # a kink element whose sign differs between fp32 and fp64 moves dbeta by its |g| and dgamma by |g * xhat|:
+        # allow that per channel for the elements within rounding distance of z = 0 (about two expected in 9 M)
+        near = (z.abs() <= 1e-4).sum(0).double()
+        slack = near * float(g.abs().max())
+        db, dw = bn.bias.grad.detach().double().cpu(), bn.weight.grad.detach().double().cpu()
+        assert ((db - ref.bias.grad).abs() <= 2e-4 * ref.bias.grad.abs().max() + slack).all()
+        assert ((dw - ref.weight.grad).abs() <= 2e-4 * ref.weight.grad.abs().max() + 6 * slack).all()
+    else:
+        assert rel(bn.weight.grad, ref.weight.grad) < 2e-4
+        assert rel(bn.bias.grad, ref.bias.grad) < 2e-4
     if n > 1:
         assert rel(bn.running_mean, ref.running_mean) < 1e-5
         assert rel(bn.running_var, ref.running_var) < 1e-4
