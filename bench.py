@@ -28,8 +28,8 @@ MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="plots per GPU")
     ap.add_argument("--points", type=int, default=16000)
     ap.add_argument("--model", default="SENet14")
@@ -251,8 +251,13 @@ def main():
         model.set_input(pool[i % len(pool)], dev)
         model.optimize_parameters(epoch=i // steps_per_epoch, batch_size=args.batch, num_batches=steps_per_epoch)
         if not args.no_prefetch:
-            model.prefetch_input(pool[(i + 1) % len(pool)], dev)
+            # two batches deep: this call builds the kernel maps of batch i+1 (its coordinate levels were staged one
+            # step ago) and stages the levels of batch i+2 — the host never waits for a device read-back
+            model.prefetch_input(pool[(i + 2) % len(pool)], dev)
 
+    if not args.no_prefetch and len(pool) >= 3:
+        model.prefetch_input(pool[0], dev)
+        model.prefetch_input(pool[1], dev)
     log(f"model + {len(pool)} batches resident ({voxels:.0f} voxels/plot); warmup")
     for i in range(args.warmup):
         step(i)

@@ -263,9 +263,11 @@ class CoordinateManager:
         self._make_level(ts_in, ts_out)
         return ts_out
 
-    def prefetch_strides(self, tensor_strides: Sequence[int]):
+    def prefetch_strides(self, tensor_strides: Sequence[int], defer: bool = False):
         """Build the levels ts0 -> tensor_strides[0] -> tensor_strides[1] ... without any host synchronisation in
-        between, then read every row count back at once."""
+        between, then read every row count back at once.  defer=True: the read-back is only STARTED (asynchronous copy
+        into pinned memory + an event); ``finish_prefetch`` completes it later, by which time the copy has long landed
+        — the host never waits for the device (two-deep input pipeline of MinkowskiBaselineModel.prefetch_input)."""
         ts = self.origin_ts
         todo = []
         for t in tensor_strides:
@@ -277,10 +279,30 @@ class CoordinateManager:
         if pending or not self._validated:
             # the single read-back: every new level's row count + the insert status (dup / range / order)
             status = self.levels[self.origin_ts].status
-            vals = torch.cat([lv.n_dev for lv in pending] + [status]).tolist()
-            for lv, c in zip(pending, vals):
-                lv.n, lv.n_dev, lv.bound = int(c), None, int(c)
-            self._check_status(vals[len(pending):])
+            vals_dev = torch.cat([lv.n_dev for lv in pending] + [status])
+            if defer:
+                host = torch.empty(vals_dev.shape, dtype=vals_dev.dtype, pin_memory=True)
+                host.copy_(vals_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._deferred = (pending, host, ev, vals_dev)
+                return
+            self._apply_counts(pending, vals_dev.tolist())
+
+    def _apply_counts(self, pending, vals):
+        for lv, c in zip(pending, vals):
+            lv.n, lv.n_dev, lv.bound = int(c), None, int(c)
+        self._check_status(vals[len(pending):])
+
+    def finish_prefetch(self):
+        """Complete a deferred ``prefetch_strides`` (no-op otherwise)."""
+        d = getattr(self, "_deferred", None)
+        if d is None:
+            return
+        pending, host, ev, _keep = d
+        self._deferred = None
+        ev.synchronize()
+        self._apply_counts(pending, host.tolist())
 
     def prebuild(self, specs):
         """Build kernel maps ahead of the forward pass. specs: iterable of (ts_in, K, stride, dilation, need_T)."""

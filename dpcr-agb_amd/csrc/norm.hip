@@ -90,18 +90,21 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
     }
 }
 
-// block = 16 channels x 16 chunk lanes: every lane folds chunks j, j+16, ... in order, the 16 lane results are
-// combined in lane order (fixed order -> bitwise reproducible); writes mean / rstd, updates the running stats
+// block = 4 channels x 64 chunk lanes: every lane folds chunks j, j+64, ... in order, the 64 lane results are combined
+// in lane order (fixed order -> bitwise reproducible); writes mean / rstd, updates the running stats.  (64 lanes per
+// channel: with up to 2048 chunk partials the serial chain per lane stays at 32 combines.)
+#define FOLD_LANES 64
+#define FOLD_CH 4
 __global__ __launch_bounds__(256) void k_bn_stats_fold(const float* __restrict__ part, int chunks, int C, float eps,
                                                        float momentum, float* __restrict__ mean,
                                                        float* __restrict__ rstd, float* running_mean,
                                                        float* running_var) {
-    __shared__ float s_n[16][16], s_m[16][16], s_q[16][16];
-    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ float s_n[FOLD_LANES][FOLD_CH], s_m[FOLD_LANES][FOLD_CH], s_q[FOLD_LANES][FOLD_CH];
+    const int cl = threadIdx.x & (FOLD_CH - 1), lane = threadIdx.x / FOLD_CH;
+    const int c = blockIdx.x * FOLD_CH + cl;
     float na = 0.f, ma = 0.f, qa = 0.f;
     if (c < C) {
-        for (int j = lane; j < chunks; j += 16) {
+        for (int j = lane; j < chunks; j += FOLD_LANES) {
             const float* p = part + (long long)j * 3 * C;
             float nb = p[c];
             if (nb == 0.f) continue;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void k_bn_stats_fold(const float* __restrict__
     __syncthreads();
     if (lane == 0 && c < C) {
         na = 0.f; ma = 0.f; qa = 0.f;
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < FOLD_LANES; ++j) {
             float nb = s_n[j][cl];
             if (nb == 0.f) continue;
             float mb = s_m[j][cl], qb = s_q[j][cl];
@@ -242,12 +245,12 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
 
 __global__ __launch_bounds__(256) void k_bn_bwd_fold(const float* __restrict__ part, int chunks, int C,
                                                      float* dbeta, float* dgamma, float* colsum) {
-    __shared__ float s_a[16][16], s_b[16][16];
-    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ float s_a[FOLD_LANES][FOLD_CH], s_b[FOLD_LANES][FOLD_CH];
+    const int cl = threadIdx.x & (FOLD_CH - 1), lane = threadIdx.x / FOLD_CH;
+    const int c = blockIdx.x * FOLD_CH + cl;
     float a = 0.f, b = 0.f;
     if (c < C) {
-        for (int j = lane; j < chunks; j += 16) {
+        for (int j = lane; j < chunks; j += FOLD_LANES) {
             const float* p = part + (long long)j * 2 * C;
             a += p[c];
             b += p[C + c];
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_fold(const float* __restrict__ p
     __syncthreads();
     if (lane == 0 && c < C) {
         a = 0.f; b = 0.f;
-        for (int j = 0; j < 16; ++j) { a += s_a[j][cl]; b += s_b[j][cl]; }
+        for (int j = 0; j < FOLD_LANES; ++j) { a += s_a[j][cl]; b += s_b[j][cl]; }
         dbeta[c] = a;
         dgamma[c] = b;
         if (colsum) colsum[c] = 0.f;   // accumulated by the apply pass that follows
@@ -436,7 +439,7 @@ int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentu
         int chunks = agb_bn_chunks(n);
         hipLaunchKernelGGL(k_bn_stats_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, n, C,
                            rows_per_chunk(n, chunks), part);
-        hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, 16)), dim3(256), 0, s, part, chunks, C, eps, momentum,
+        hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(256), 0, s, part, chunks, C, eps, momentum,
                            mean, rstd, running_mean, running_var);
     }
     AGB_CHECK_LAUNCH("agb_bn_stats");
@@ -467,7 +470,7 @@ int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int
     int chunks = agb_bn_chunks(n);
     hipLaunchKernelGGL(k_bn_act_bwd_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY, ldy, n, C,
                        rows_per_chunk(n, chunks), mean, rstd, gamma, beta, act, part);
-    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, 16)), dim3(256), 0, s, part, chunks, C, dbeta, dgamma, colsum);
+    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(256), 0, s, part, chunks, C, dbeta, dgamma, colsum);
     if (n > 0 && dX) {
         hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY,
                            ldy, n, C, mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx, colsum);

@@ -48,42 +48,67 @@ class MinkowskiBaselineModel(InstanceBase):
             (head if self.head_namespace in name else backbone).append(p)
         return [{"params": head, **self.head_optim_settings}, {"params": backbone, **self.backbone_optim_settings}]
 
-    def _build_input(self, data, device):
+    def _stage_a(self, data, device, defer):
+        """SparseTensor + coordinate levels of a batch (device-side counts; host read-back deferred if asked)."""
         coords = torch.cat([data.batch.unsqueeze(-1).int(), data.coords.int()], -1)
         features = data.x
         if self.add_pos:
             features = torch.cat([data.pos, features], 1)
         inp = ME.SparseTensor(features=features, coordinates=coords, device=device, batch_size=len(data),
                               bounds=getattr(data, "coord_bounds", None))
-        cm = inp.coordinate_manager
         strides = getattr(self.model, "tensor_strides", None)
         if strides:
             # whole coordinate pyramid in one go: a single host read-back per batch instead of one per level
-            cm.prefetch_strides(strides)
+            inp.coordinate_manager.prefetch_strides(strides, defer=defer)
+        return inp
+
+    def _stage_b(self, inp):
+        """Kernel maps of every layer of the model for a staged batch."""
+        cm = inp.coordinate_manager
+        cm.finish_prefetch()
         if hasattr(self.model, "plan_spec"):
             cm.prebuild(self.model.plan_spec(input_requires_grad=False))
         return inp
 
+    def _build_input(self, data, device):
+        return self._stage_b(self._stage_a(data, device, defer=False))
+
     def prefetch_input(self, data, device):
-        """Build the NEXT batch's SparseTensor (coordinate levels, kernel maps) on a side stream while the current
-        step's kernels are still running; ``set_input`` picks the result up without a device-wide stall."""
+        """Input pipeline on a side stream, two batches deep, with no host wait: this call enqueues stage A of `data`
+        (coordinate levels; the row counts travel to pinned memory asynchronously) and stage B (kernel maps) of the
+        batch staged by the PREVIOUS call, whose counts landed a whole step ago.  ``set_input`` picks a batch up at
+        whatever stage it is in.  Call it after ``optimize_parameters`` with the batch two steps ahead (or one step
+        ahead: stage B then runs inside ``set_input``, still on the side stream)."""
         if not hasattr(self, "_side_stream"):
             self._side_stream = torch.cuda.Stream(device=device)
+            self._staged = None
         side = self._side_stream
         # NOTE: no wait on the compute stream here (that would serialise the plan behind the whole running step):
         # the batch tensors must already be materialised (data-loader output / device-resident pool).
         with torch.cuda.stream(side):
-            inp = self._build_input(data, device)
-            ev = side.record_event()
-        data._prefetched = (inp, ev)
+            prev = self._staged
+            if prev is not None and prev is not data and getattr(prev, "_prefetched", None) is not None \
+                    and prev._prefetched[2] == "A":
+                inp_prev = self._stage_b(prev._prefetched[0])
+                prev._prefetched = (inp_prev, side.record_event(), "B")
+            inp = self._stage_a(data, device, defer=True)
+            data._prefetched = (inp, side.record_event(), "A")
+            self._staged = data
 
     def set_input(self, data, device):
         self.batch_idx = data.batch.squeeze()
         self.data_visual = data
         pre = getattr(data, "_prefetched", None)
         if pre is not None:
-            self.input, ev = pre
+            inp, ev, stage = pre
             data._prefetched = None
+            if getattr(self, "_staged", None) is data:
+                self._staged = None
+            if stage == "A":   # staged only one step ahead: finish on the side stream now
+                with torch.cuda.stream(self._side_stream):
+                    inp = self._stage_b(inp)
+                    ev = self._side_stream.record_event()
+            self.input = inp
             cur = torch.cuda.current_stream(device)
             cur.wait_event(ev)
             self.input.coordinate_manager.record_stream(cur)
