@@ -224,7 +224,7 @@ def main():
     broadcast_parameters(model)
     model.init_train_objects(TRAINING_NFI)
     sync = None
-    if world > 1:
+    if world > 1 or os.environ.get("AGB_FORCE_GRAD_SYNC"):   # the env switch exercises the bucket path on one GPU
         sync = GradAllReduce(model.parameters())
         model.grad_sync = sync
 

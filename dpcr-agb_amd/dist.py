@@ -15,7 +15,12 @@ import torch.distributed as dist
 
 
 class GradAllReduce:
-    """Flat gradient buckets + async all-reduce per bucket as soon as all of its gradients are accumulated.
+    """Flat gradient buckets + async all-reduce per bucket as soon as all of its gradients are produced.
+
+    Gradients are left to autograd as fresh tensors (``zero_grad(set_to_none=True)``: assignment, no accumulate
+    kernel per parameter); when the last gradient of a bucket has arrived, ONE multi-tensor copy packs them into the
+    bucket's flat buffer, the all-reduce is launched on it and every ``param.grad`` is re-pointed at its slice of the
+    buffer, so the optimiser reads the averaged values once ``__call__`` has waited for the exchange.
 
     Usage:  sync = GradAllReduce(model.parameters()); model.grad_sync = sync   (called after backward)
     """
@@ -46,12 +51,12 @@ class GradAllReduce:
     def _make_bucket(self, params):
         total = sum(p.numel() for p in params)
         flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
-        off = 0
+        views, off = [], 0
         for p in params:
             n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)  # gradients accumulate straight into the bucket
+            views.append(flat[off:off + n].view_as(p))
             off += n
-        return dict(params=params, flat=flat, ready=0, launched=False)
+        return dict(params=params, flat=flat, views=views, ready=0, launched=False)
 
     def _make_hook(self, bi):
         def hook(param):
@@ -63,6 +68,18 @@ class GradAllReduce:
 
     def _launch(self, b):
         b["launched"] = True
+        with torch.no_grad():
+            src, dst = [], []
+            for p, v in zip(b["params"], b["views"]):
+                if p.grad is None:
+                    v.zero_()                      # parameter unused in this step
+                elif p.grad.data_ptr() != v.data_ptr():
+                    src.append(p.grad)
+                    dst.append(v)
+            if src:
+                torch._foreach_copy_(dst, src)      # one multi-tensor launch per bucket
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
         if self.world == 1:
             return
         backend = dist.get_backend(self.pg)

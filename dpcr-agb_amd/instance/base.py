@@ -201,9 +201,9 @@ class InstanceBase(torch.nn.Module):
 
     def optimize_parameters(self, epoch, batch_size, num_batches):
         self(epoch=epoch)
-        # data-parallel: gradients accumulate in place into the flat all-reduce buckets; single GPU: let autograd
-        # assign fresh gradient tensors (saves one zero-fill and one add per parameter per step)
-        self._optimizer.zero_grad(set_to_none=self.grad_sync is None)
+        # autograd assigns fresh gradient tensors (no zero-fill, no accumulate kernel per parameter); the data-parallel
+        # hook packs them into its flat buckets with one multi-tensor copy per bucket (dist.GradAllReduce)
+        self._optimizer.zero_grad(set_to_none=True)
         self.loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()

@@ -30,7 +30,7 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(seeds[0])
     x, y = torch.randn(4, 6, generator=g), torch.randn(4, 2, generator=g)
     for _ in range(3):
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=True)
         loss = torch.nn.functional.smooth_l1_loss(model(x), y)
         loss.backward()
         sync()
