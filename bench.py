@@ -258,6 +258,12 @@ def main():
     if not args.no_prefetch and len(pool) >= 3:
         model.prefetch_input(pool[0], dev)
         model.prefetch_input(pool[1], dev)
+    # manual garbage collection, as large training loops do: a generation-2 sweep over the module / autograd object
+    # graph costs ~80 ms of host time and stalls the device queue when it happens to fall inside a step
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     log(f"model + {len(pool)} batches resident ({voxels:.0f} voxels/plot); warmup")
     for i in range(args.warmup):
         step(i)
@@ -271,8 +277,12 @@ def main():
     if rank == 0:
         sparse_ops.PROFILE = []
     t0 = time.perf_counter()
+    step_events = []
     for i in range(args.steps):
         step(args.warmup + i)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        step_events.append(ev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -284,6 +294,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(model.loss.detach())
+    if len(step_events) > 1:
+        gaps = [step_events[j].elapsed_time(step_events[j + 1]) for j in range(len(step_events) - 1)]
+        log("device time between step ends (ms): " + " ".join(f"{g:.2f}" for g in gaps))
+        log("host enqueue per step (ms): " + " ".join(f"{h:.2f}" for h in host_ms[-args.steps:]))
     hm = sorted(host_ms[-args.steps:])
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps; host enqueue time per step: median "
         f"{hm[len(hm) // 2]:.2f} ms, min {hm[0]:.2f} ms (GPU-bound when well below ms_per_step)")

@@ -42,6 +42,10 @@ def main():
     print(f"data ready in {time.time() - t0:.1f}s: {len(train)} train / {len(val)} val batches", flush=True)
     nb = len(train)
     hist = []
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()      # manual GC (once per epoch below): a gen-2 sweep inside a step stalls the device queue for ~80 ms
     for epoch in range(a.epochs):
         model.train()
         t1 = time.time()
@@ -51,6 +55,7 @@ def main():
             model.optimize_parameters(epoch, a.batch, nb)
         torch.cuda.synchronize()
         dt = time.time() - t1
+        gc.collect()
         model.eval()
         meter = RegressionMeter(torch.cat([b.y_reg for b in val]).cpu().double().mean(0))
         with torch.no_grad():
