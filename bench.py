@@ -62,7 +62,8 @@ def kernel_of(rec):
     if rec.get("perm"):
         return "k_spconv_pipe<64, true>"
     col_tiles = -(-rec["cout"] // 64)
-    if rec["cin"] % 64 == 0 and rec.get("split", 1) == 1 and -(-rec["rows"] // 128) * col_tiles >= 384:
+    split = rec.get("split", 1)
+    if rec["cin"] % 64 == 0 and (rec["cin"] // 64) % split == 0 and -(-rec["rows"] // 128) * col_tiles * split >= 384:
         return "k_spconv_cmp<128>"
     if -(-rec["rows"] // 128) * col_tiles >= 1024 or (rec["cin"] >= 256 and rec["rows"] >= 1024):
         return "k_spconv_pipe<128, false>"

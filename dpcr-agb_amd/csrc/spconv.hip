@@ -503,7 +503,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CMP_CB 4    // 16-channel blocks per step (64 input channels)
 
 template <int R>
-__global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int nct, int rows_per_tile) {
+__global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int nct, int rows_per_tile, int csplit) {
     constexpr int NJ = R / 64;
     constexpr int CB = CMP_CB;
     // row R of Ys is a sink: list padding (up to 15 entries per offset) multiplies input row 0 into it
@@ -512,16 +512,21 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     __shared__ __attribute__((aligned(16))) int pl_out[2][R + 16];
     const int lane = threadIdx.x;
     const int m = lane & 15, q = lane >> 4;
+    // workgroup id -> (XCD, row tile, input-channel split, column tile); csplit > 1: the 64-channel steps of every
+    // offset are divided among csplit workgroups per tile, partial tiles go to a.partial [csplit][n_out][Cout] and
+    // k_split_reduce folds them in order (few-row, wide layers: 2.9 k rows x 512 channels would otherwise give 184 waves)
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int per_xcd = (ntiles + 7) >> 3;
     const int ct0 = jx % nct;
-    const int tile = xcd * per_xcd + jx / nct;
-    if (tile >= ntiles) return;
+    const int sp = (jx / nct) % csplit;
+    const int tile = xcd * per_xcd + jx / (nct * csplit);
+    if (tile >= ntiles || jx / (nct * csplit) >= per_xcd) return;
     const int row0 = tile * rows_per_tile;
     const int row_end = min(a.n_out, row0 + rows_per_tile);
     const int n0 = ct0 * 64;
     const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
-    const int NSB = Cin / (CB * 16);
+    const int NSB = Cin / (CB * 16) / csplit;            // 64-channel steps per offset handled here
+    const int c_first = sp * NSB * (CB * 16);            // first input channel of this split
     const int nsteps = K3 * NSB;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool colok = (n0 + 4 * m) < Cout;
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
         return cpad >> 4;
     };
     auto load_b = [&](int step, float4 (&b)[CB][4]) {
-        const int k = step / NSB, cbase = (step % NSB) * (CB * 16);
+        const int k = step / NSB, cbase = c_first + (step % NSB) * (CB * 16);
         const float* Wk = a.W + ((long long)k * Cin + cbase + 4 * q) * Cout + n0 + coff;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     float4 an[CB];
     // A fragment of one 16-channel block of group g of `step` (list padding points at input row 0)
     auto gather_cb = [&](int step, int g, int cb) {
-        const int k = step / NSB, cbase = (step % NSB) * (CB * 16);
+        const int k = step / NSB, cbase = c_first + (step % NSB) * (CB * 16);
         const float* xr = a.X + (long long)pl_in[k & 1][16 * g + m] * a.ldx + cbase + 4 * q;
         an[cb] = *reinterpret_cast<const float4*>(xr + cb * 16);
     };
@@ -608,7 +613,8 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
         // list / channel offset of this step and of the next one (for the refills)
         const int* li_cur = pl_in[k & 1];
         const int* li_nxt = pl_in[(nstep / NSB) & 1];
-        const int xoff_cur = (step % NSB) * (CB * 16) + 4 * q, xoff_nxt = (nstep % NSB) * (CB * 16) + 4 * q;
+        const int xoff_cur = c_first + (step % NSB) * (CB * 16) + 4 * q;
+        const int xoff_nxt = c_first + (nstep % NSB) * (CB * 16) + 4 * q;
 
         for (int g = 0; g < ng_cur; ++g) {
             // D layout: MFMA col = lane & 15 (-> output column 4m + ct), row = 4 * (lane >> 4) + v.  The four rows of a
@@ -670,13 +676,15 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     // ---- epilogue: tile -> global (4 rows per instruction, float4 per lane)
     const int c4 = (lane & 15) * 4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias && n0 + c4 < Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + c4);
+    if (a.bias && csplit == 1 && n0 + c4 < Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + c4);
+    float* out = csplit > 1 ? a.partial + (long long)sp * a.n_out * Cout : a.Y;
+    const int ldo = csplit > 1 ? Cout : a.ldy;
     for (int r = lane >> 4; r < rows_per_tile; r += 4) {
         const int row = row0 + r;
         if (row < row_end && n0 + c4 < Cout) {
             float4 y = *reinterpret_cast<const float4*>(&Ys[r * CMP_YS + c4]);
             y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
-            *reinterpret_cast<float4*>(a.Y + (long long)row * a.ldy + n0 + c4) = y;
+            *reinterpret_cast<float4*>(out + (long long)row * ldo + n0 + c4) = y;
         }
     }
 }
@@ -1140,20 +1148,46 @@ static int conv_tile_rows(int n_out, int Cin, int Cout) {
 // Mode (agb_spconv_set_cmp_mode, or the AGB_CONV_CMP environment variable at first use): 1 = automatic (default),
 // 0 = never, 64 / 128 = always with that tile height (tests, tuning).
 static int g_cmp_mode = -1;
+// Input-channel split the pair-compacted kernel wants for this shape (1, 2, 4, ... dividing Cin/64), 0 when the layer
+// should take the register-accumulator kernels: enough waves to fill the 1024 resident-wave slots.
+static int cmp_want_split(int n_out, int Cin, int Cout) {
+    if (Cin % 64 != 0 || Cout % 4 != 0 || n_out <= 0) return 0;
+    const long long waves128 = (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, 64);
+    const int nsb = Cin / 64;
+    int sp = 1;
+    while (waves128 * sp < 768 && sp * 2 <= nsb && nsb % (sp * 2) == 0) sp *= 2;
+    return waves128 * sp >= 384 ? sp : 0;
+}
+
 static int cmp_rows(const ConvArgs& a) {
     if (g_cmp_mode < 0) {
         const char* e = getenv("AGB_CONV_CMP");
         g_cmp_mode = e ? atoi(e) : 1;
     }
     const int mode = g_cmp_mode;
-    if (mode == 0 || a.perm || a.ksplit > 1 || a.Cin % 64 != 0 || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Cout % 4 != 0)
-        return 0;
+    if (mode == 0 || a.perm || a.Cin % 64 != 0 || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Cout % 4 != 0) return 0;
+    if (a.ksplit < 1 || (a.Cin / 64) % a.ksplit != 0 || (a.ksplit > 1 && a.partial == nullptr)) return 0;
     if (mode == 64 || mode == 128) return mode;
     // measured on the SENet14 pyramid (tools/bench_conv.py): 128-row tiles win from ~400 waves up (64->64 at 210 k rows
-    // 351 vs 497 us, 128->128 at 61 k rows 438 vs 566 us, 256->256 at 14 k rows 477 vs 519 us); below that the
-    // offset-split register-accumulator kernel fills the chip better (512->512 at 2.9 k rows 439 vs 497 us)
-    const long long waves128 = (long long)agb_cdiv(a.n_out, 128) * agb_cdiv(a.Cout, 64);
-    return waves128 >= 384 ? 128 : 0;
+    // 351 vs 497 us, 128->128 at 61 k rows 438 vs 566 us, 256->256 at 14 k rows 477 vs 519 us); few-row wide layers
+    // reach that by splitting the input channels (the caller sizes `partial` from agb_spconv_split_hint)
+    const long long waves = (long long)agb_cdiv(a.n_out, 128) * agb_cdiv(a.Cout, 64) * a.ksplit;
+    return waves >= 384 ? 128 : 0;
+}
+
+// Tile geometry of the pair-compacted kernel: equal-cost tiles, workgroup count a multiple of the resident-wave
+// capacity (LDS: 4 / 8 waves per CU) so that the last round of workgroups is not half empty.
+static void cmp_geometry(const ConvArgs& a, int* R_out, int* rpt_out, int* ntiles_out, int* nct_out) {
+    const int R = cmp_rows(a), nct = agb_cdiv(a.Cout, 64) * 1;
+    const long long per_tile = (long long)nct * a.ksplit;
+    const long long slots = (R == 128 ? 4 : 8) * 256;
+    const long long rounds = ((long long)agb_cdiv(a.n_out, R) * per_tile + slots - 1) / slots;
+    long long want_tiles = rounds * slots / per_tile;
+    if (want_tiles < 1) want_tiles = 1;
+    int rpt = agb_cdiv(a.n_out, want_tiles);
+    if (rpt > R) rpt = R;
+    if (rpt < 16) rpt = 16;
+    *R_out = R; *rpt_out = rpt; *ntiles_out = agb_cdiv(a.n_out, rpt); *nct_out = nct;
 }
 
 static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
@@ -1175,19 +1209,11 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
                                a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
     } else if (cmp_rows(a) > 0) {
-        const int R = cmp_rows(a), nct = agb_cdiv(a.Cout, 64);
-        // equal-cost tiles, workgroup count a multiple of the resident-wave capacity (LDS: 4 / 8 waves per CU)
-        const long long slots = (R == 128 ? 4 : 8) * 256;
-        const long long rounds = ((long long)agb_cdiv(a.n_out, R) * nct + slots - 1) / slots;
-        long long want_tiles = rounds * slots / nct;
-        if (want_tiles < 1) want_tiles = 1;
-        int rpt = agb_cdiv(a.n_out, want_tiles);
-        if (rpt > R) rpt = R;
-        if (rpt < 16) rpt = 16;
-        const int ntiles = agb_cdiv(a.n_out, rpt);
-        dim3 grid(8 * agb_cdiv(ntiles, 8) * nct), blk(64);
-        if (R == 128) hipLaunchKernelGGL((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt);
-        else hipLaunchKernelGGL((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt);
+        int R, rpt, ntiles, nct;
+        cmp_geometry(a, &R, &rpt, &ntiles, &nct);
+        dim3 grid(8 * agb_cdiv(ntiles, 8) * nct * a.ksplit), blk(64);
+        if (R == 128) hipLaunchKernelGGL((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit);
+        else hipLaunchKernelGGL((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit);
     } else if (conv_tile_rows(a.n_out, a.Cin, a.Cout) == 128) {
         // 128-row tiles: the W tile is reused by twice as many rows (layers with many rows, or W-heavy layers)
         hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
@@ -1223,9 +1249,13 @@ int agb_spconv_set_cmp_mode(int mode) {
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
     if (Cin == 4 || Cin == 8 || K3 < 8) return 1;
     {
-        ConvArgs probe{};
-        probe.n_out = n_out; probe.K3 = K3; probe.Cin = Cin; probe.Cout = Cout; probe.ksplit = 1;
-        if (cmp_rows(probe) > 0) return 1;   // the pair-compacted kernel takes the layer unsplit
+        if (g_cmp_mode < 0) {
+            const char* e = getenv("AGB_CONV_CMP");
+            g_cmp_mode = e ? atoi(e) : 1;
+        }
+        const int sp = g_cmp_mode == 0 ? 0 : cmp_want_split(n_out, Cin, Cout);
+        if (sp > 0) return sp;   // the pair-compacted kernel takes the layer, input channels split sp ways
+        if (g_cmp_mode == 64 || g_cmp_mode == 128) return 1;
     }
     long long tiles = (long long)agb_cdiv(n_out, conv_tile_rows(n_out, Cin, Cout)) * agb_cdiv(Cout, BN);
     if (tiles >= 768) return 1;

@@ -144,6 +144,38 @@ def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride,
         _lib.call("agb_spconv_set_cmp_mode", 1)
 
 
+@pytest.mark.parametrize("split", [2, 4])
+def test_conv_pair_compacted_channel_split(device, split):
+    """Input-channel split of the pair-compacted kernel (few-row wide layers): partial tiles + ordered fold must give
+    the unsplit sums up to fp32 summation order."""
+    from dpcr_agb_amd import _lib
+    import dpcr_agb_amd.me_compat as ME
+    rng = np.random.default_rng(3)
+    torch.manual_seed(5)
+    coords = random_coords(rng, 2, 1500, 16)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    n = cm.level(1).n
+    nbr = cm.kernel_map(1, 3, 1)
+    cin, cout = 256, 96
+    x = torch.randn(n, cin, device=device)
+    w = torch.randn(27 * cin, cout, device=device) * 0.05
+    b = torch.randn(cout, device=device)
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    outs = []
+    _lib.call("agb_spconv_set_cmp_mode", 128)
+    try:
+        for sp in (1, split):
+            y = torch.empty(n, cout, device=device)
+            part = torch.empty(sp, n, cout, device=device) if sp > 1 else None
+            _lib.call("agb_spconv_fwd_ex", P(x), cin, P(w), P(nbr), nbr.stride(0), 0, P(b), P(y), cout, n, 27, cin, cout,
+                      None, None, None, 0, sp, P(part), _lib.stream())
+            outs.append(y)
+    finally:
+        _lib.call("agb_spconv_set_cmp_mode", 1)
+    assert rel_err(outs[1], outs[0]) < 1e-5
+
+
 def _conv_case(device, cin, cout, K, stride, ts_in):
     import dpcr_agb_amd.me_compat as ME
     rng = np.random.default_rng(cin * 131 + cout + K)
