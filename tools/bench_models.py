@@ -41,6 +41,12 @@ def run(name, steps):
         if prefetch:
             model.prefetch_input(pool[(i + 1) % 2], dev)
 
+    import gc
+    gc.unfreeze()
+    gc.collect()
+    torch.cuda.empty_cache()
+    gc.freeze()
+    gc.disable()   # manual GC as in bench.py (a gen-2 sweep inside a step stalls the device queue)
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
@@ -49,6 +55,7 @@ def run(name, steps):
         step(3 + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     print(f"{name:10s} B={B:3d}  {dt / steps * 1e3:8.2f} ms/step  {B * steps / dt:9.1f} plots/s  "
           f"loss={float(model.loss.detach()):.4f}  params={sum(p.numel() for p in model.parameters()) / 1e6:.2f}M",
           flush=True)
@@ -60,5 +67,10 @@ if __name__ == "__main__":
     if "--steps" in sys.argv:
         steps = int(sys.argv[sys.argv.index("--steps") + 1])
         args = [a for a in args if a != str(steps)]
-    for n in (args or ["pointnet", "kpconv", "kpconv16k", "senet50"]):
-        run(n, steps)
+    names = args or ["pointnet", "kpconv", "kpconv16k", "senet50"]
+    if len(names) == 1:
+        run(names[0], steps)
+    else:   # one process per model: allocator / stream state left by one model must not colour the next one's number
+        import subprocess
+        for n in names:
+            subprocess.run([sys.executable, os.path.abspath(__file__), n, "--steps", str(steps)], check=False)
