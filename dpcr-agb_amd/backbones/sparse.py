@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import me_compat as ME
+from ..se_ops import MAX_HIDDEN as MAX_SE_HIDDEN, se_excite
 
 ACTIVATIONS = {
     "relu": ME.MinkowskiReLU,
@@ -164,7 +165,16 @@ class SELayer(nn.Module):
         self.broadcast_mul = ME.MinkowskiBroadcastMultiplication()
 
     def forward(self, x):
-        return self.broadcast_mul(x, self.fc(self.pooling(x)))
+        pooled = self.pooling(x)
+        lin1, act, lin2, gate = self.fc[0], self.fc[1], self.fc[2], self.fc[3]
+        name = getattr(act, "act_name", None)
+        if (name in ("relu", "gelu") and isinstance(gate, ME.MinkowskiSigmoid) and pooled.F.is_cuda
+                and lin1.linear.out_features <= MAX_SE_HIDDEN):
+            # the excitation MLP on [B, C] as one fused launch (two in the backward pass): csrc/se.hip
+            s = pooled._like(se_excite(pooled.F, lin1.linear, name, lin2.linear))
+        else:
+            s = self.fc(pooled)
+        return self.broadcast_mul(x, s)
 
 
 class SEBasicBlock(BasicBlock):

@@ -262,6 +262,17 @@ int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, 
 int agb_coords_augment(int32_t* coords, const int32_t* elem, int B, int n, const int32_t* flip, const int32_t* shift,
                        int32_t* cmax, void* stream);
 
+/* ---- squeeze-excite excitation MLP (dpcr-agb_amd/csrc/se.hip) -------------------------------------------------------
+ * SELayer.fc of modules/MinkowskiEngine/senet_block.py:35-42 on the pooled features P [B,C]:
+ * S = sigmoid(W2 act(W1 P + b1) + b2), W1 [H,C], W2 [C,H] (nn.Linear layout), H <= 256, act 0 none / 1 relu / 2 gelu.
+ * fwd writes h_pre [B,H] (kept for bwd) and S [B,C]; bwd: scratch dz2 [B,C], dh [B,H]; out dP [B,C], dW1, db1, dW2, db2
+ * (biases may be NULL).  Sums over the batch run in batch order (deterministic). */
+int agb_se_mlp_fwd(const float* P, const float* W1, const float* b1, const float* W2, const float* b2, int B, int C,
+                   int H, int act, float* h_pre, float* S, void* stream);
+int agb_se_mlp_bwd(const float* P, const float* W1, const float* W2, int B, int C, int H, int act, const float* h_pre,
+                   const float* S, const float* dS, float* dz2, float* dh, float* dP, float* dW1, float* db1,
+                   float* dW2, float* db2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
