@@ -1079,20 +1079,25 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    // software pipeline: the neighbour indices of step i+2 and the gathers of step i+1 are in flight during the MFMAs
+    // of step i (index -> gather is a dependent pair of L2 latencies; one step of MFMAs is only ~0.4 us)
     float4 a_reg[2], b_reg[2];
-    auto load_data = [&](int pb) {
+    int idx_cur[2], idx_nxt[2];
+    auto load_idx = [&](int pb, int* idx) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            // A: 32 rows x 16 float4 columns (offset, channel quad)
-            int e = tid + 256 * j;
+            int e = tid + 256 * j;          // A: 32 rows x 16 float4 columns (offset, channel quad)
             int p = pb + (e & 31);
-            int m4 = e >> 5;
-            int o = m4 / F4, f = m4 % F4;
+            int o = (e >> 5) / F4;
+            idx[j] = (p < total && o < nk) ? nbr[(long long)(k0 + o) * nbr_stride + p_row[p]] : -1;
+        }
+    };
+    auto load_data = [&](int pb, const int* idx) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int f = ((tid + 256 * j) >> 5) % F4;
             a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < total && o < nk) {
-                int idx = nbr[(long long)(k0 + o) * nbr_stride + p_row[p]];
-                if (idx >= 0) a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)idx * ldx + f * 4);
-            }
+            if (idx[j] >= 0) a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)idx[j] * ldx + f * 4);
             // B: 32 rows x 64 output channels
             int pr = pb + (tid >> 4) + 16 * j;
             int n = n0 + (tid & 15) * 4;
@@ -1100,7 +1105,9 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
             if (pr < total && n < Cout) b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)p_row[pr] * ldy + n);
         }
     };
-    load_data(0);
+    load_idx(0, idx_cur);
+    load_idx(BK, idx_nxt);
+    load_data(0, idx_cur);
     for (int pb = 0; pb < total; pb += BK) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1109,7 +1116,12 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
             *reinterpret_cast<float4*>(&Bs[((tid >> 4) + 16 * j) * 64 + (tid & 15) * 4]) = b_reg[j];
         }
         __syncthreads();
-        if (pb + BK < total) load_data(pb + BK);   // in flight during the MFMAs below
+        if (pb + BK < total) {
+            idx_cur[0] = idx_nxt[0];
+            idx_cur[1] = idx_nxt[1];
+            load_data(pb + BK, idx_cur);
+            load_idx(pb + 2 * BK, idx_nxt);
+        }
         const float* ap = &As[wr * 32 + li];
         const float* bp = &Bs[wc * 32 + li];
 #pragma unroll
@@ -1375,7 +1387,9 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
     rows = (rows + 31) / 32 * 32;
     int chunks = agb_cdiv(n_out, rows);
     if (Cin == 4 || Cin == 8) {
-        if (rows > DW_MAXROWS) rows = DW_MAXROWS;
+        // 1024-row chunks: the kernel is latency-bound (index -> gather), more resident workgroups hide more of it;
+        // 512 / 1024 / 2048 rows measured within 5 % of each other on the 7^3 stem, 4096+ clearly slower
+        if (rows > 1024) rows = 1024;
         chunks = agb_cdiv(n_out, rows);
     }
     dim3 grid((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles), block(256);
