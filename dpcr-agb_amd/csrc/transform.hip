@@ -174,3 +174,181 @@ int agb_coords_augment(int32_t* coords, const int32_t* elem, int B, int n, const
 }
 
 }  // extern "C"
+
+// ================================================================================================================
+// Train-time float augmentations of sparse-xy.yaml:4-69 on the device.  All random draws are made by the host in the
+// reference's per-sample order (dpcr-agb_amd/train_transforms.py) and arrive as per-plot parameters / per-point noise:
+//   RandomGroundRemoval   transforms.py:1131-1150   z -= remove_v for every point, then keep z > remove_v (host: index list)
+//   RandomDropout         transforms.py:1060-1087   keep a torch.randperm prefix                      (host: index list)
+//   ScalePos (div)        :590-598      RandomNoise  :482-505 (sigma * randn clamped, from the host)
+//   Random3AxisRotation   features.py:12-60  pos @ M^T      RandomShiftPos :747-759     MoveCenterPosPerSample :722-739
+//   StartZFromZero        :766-769
+//   AddRandomPoints       :775-815  (as committed upstream max_ == min_: every added point is the per-axis minimum)
+//   CopyJitterRandomPoints :818-873 (np.random.choice indices + clamped noise from the host)
+//   RandomPolygon2dExtend :1502-1552 (per-plot transformed polygon from matplotlib's Affine2D on the host; points are
+//                                     kept unfiltered when none falls inside)
+struct PlotAug {        // one per plot, 24 floats
+    float zsub;         // RandomGroundRemoval: subtracted from the raw z (0 when not applied)
+    float sx, sy, sz;   // ScalePos divisors
+    float M[9];         // rotation (row-major); pos_out[j] = sum_k pos[k] * M[j][k]
+    float tx, ty, tz;   // RandomShiftPos (0 when not applied)
+    float cx, cy, cz;   // MoveCenterPosPerSample
+    float pad[5];
+};
+
+// pos1[i] = ((raw[sel[i]] - (0,0,zsub)) / scale + noise[i]) @ M^T + shift + centre
+__global__ void k_plot_augment(const float* __restrict__ raw, const long long* __restrict__ sel,
+                               const int32_t* __restrict__ elem, int n, const PlotAug* __restrict__ aug,
+                               const float* __restrict__ noise, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PlotAug a = aug[elem[i]];
+    const long long s = sel[i];
+    float x = raw[3 * s], y = raw[3 * s + 1], z = raw[3 * s + 2];
+    z = z - a.zsub;
+    x = x / a.sx; y = y / a.sy; z = z / a.sz;
+    if (noise) { x += noise[3LL * i]; y += noise[3LL * i + 1]; z += noise[3LL * i + 2]; }
+    float rx = x * a.M[0] + y * a.M[1] + z * a.M[2];
+    float ry = x * a.M[3] + y * a.M[4] + z * a.M[5];
+    float rz = x * a.M[6] + y * a.M[7] + z * a.M[8];
+    out[3LL * i] = (rx + a.tx) + a.cx;
+    out[3LL * i + 1] = (ry + a.ty) + a.cy;
+    out[3LL * i + 2] = (rz + a.tz) + a.cz;
+}
+
+// per-plot minimum of x, y, z (grid B, block 256): mins[3b..3b+2]
+__global__ void k_plot_min3(const float* __restrict__ pos, const int32_t* __restrict__ ptr, float* __restrict__ mins) {
+    __shared__ float s_m[3][4];
+    const int b = blockIdx.x;
+    float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY;
+    for (int i = ptr[b] + threadIdx.x; i < ptr[b + 1]; i += blockDim.x) {
+        m0 = fminf(m0, pos[3LL * i]);
+        m1 = fminf(m1, pos[3LL * i + 1]);
+        m2 = fminf(m2, pos[3LL * i + 2]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m0 = fminf(m0, __shfl_down(m0, o));
+        m1 = fminf(m1, __shfl_down(m1, o));
+        m2 = fminf(m2, __shfl_down(m2, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_m[0][threadIdx.x >> 6] = m0;
+        s_m[1][threadIdx.x >> 6] = m1;
+        s_m[2][threadIdx.x >> 6] = m2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        mins[3 * b + threadIdx.x] = fminf(fminf(s_m[threadIdx.x][0], s_m[threadIdx.x][1]),
+                                          fminf(s_m[threadIdx.x][2], s_m[threadIdx.x][3]));
+}
+
+// StartZFromZero + AddRandomPoints + CopyJitterRandomPoints: output plot b = [its n1 points with z - zmin]
+// ++ [n_add copies of the per-axis minimum] ++ [n_cj jittered copies pos_prev[cj_idx] + cj_noise].
+// ptr1 / ptr2: offsets of the plots in the input / output; cj_ptr: offsets into cj_idx / cj_noise; n_add int32[B].
+__global__ void k_plot_extend(const float* __restrict__ pos1, const int32_t* __restrict__ ptr1,
+                              const float* __restrict__ mins, const int32_t* __restrict__ ptr2,
+                              const int32_t* __restrict__ elem2, int n2, const int32_t* __restrict__ n_add,
+                              const int32_t* __restrict__ cj_ptr, const long long* __restrict__ cj_idx,
+                              const float* __restrict__ cj_noise, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const int b = elem2[i];
+    const int n1 = ptr1[b + 1] - ptr1[b];
+    const int local = i - ptr2[b];
+    const float zmin = mins[3 * b + 2];
+    // the per-axis minimum AFTER StartZFromZero: z minimum is zmin - zmin
+    const float mx = mins[3 * b], my = mins[3 * b + 1], mz = zmin - zmin;
+    float x, y, z;
+    if (local < n1) {
+        const long long s = ptr1[b] + local;
+        x = pos1[3 * s]; y = pos1[3 * s + 1]; z = pos1[3 * s + 2] - zmin;
+    } else if (local < n1 + n_add[b]) {
+        x = mx; y = my; z = mz;
+    } else {
+        const int j = cj_ptr[b] + (local - n1 - n_add[b]);
+        const long long src = cj_idx[j];
+        if (src < n1) {
+            const long long s = ptr1[b] + src;
+            x = pos1[3 * s]; y = pos1[3 * s + 1]; z = pos1[3 * s + 2] - zmin;
+        } else {
+            x = mx; y = my; z = mz;
+        }
+        x += cj_noise[3LL * j]; y += cj_noise[3LL * j + 1]; z += cj_noise[3LL * j + 2];
+    }
+    out[3LL * i] = x; out[3LL * i + 1] = y; out[3LL * i + 2] = z;
+}
+
+// RandomPolygon2dExtend: inside test against the plot's own polygon (double [B][2*nv]); per-plot inside counts
+__global__ void k_plot_inside(const float* __restrict__ pos, const int32_t* __restrict__ elem, int n,
+                              const double* __restrict__ polys, int nv, int32_t* __restrict__ flag,
+                              int32_t* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = elem[i];
+    const int in = point_in_polygon((double)pos[3LL * i], (double)pos[3LL * i + 1], polys + 2LL * nv * b, nv);
+    flag[i] = in;
+    if (in) atomicAdd(&cnt[b], 1);
+}
+
+__global__ void k_plot_keep_all_if_none(int32_t* __restrict__ flag, const int32_t* __restrict__ elem, int n,
+                                        const int32_t* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && cnt[elem[i]] == 0) flag[i] = 1;
+}
+
+extern "C" {
+
+// raw float[n_raw,3] stacked plots; sel int64[n]: rows of raw kept after RandomGroundRemoval / RandomDropout, grouped by
+// plot (elem int32[n], ptr int32[B+1]); aug: device array of B PlotAug records (24 floats each); noise float[n,3] or
+// NULL.  Out: pos1 float[n,3]; mins float[3B] = per-plot minimum of pos1 (x, y, z) — StartZFromZero itself is applied by
+// agb_plot_extend.
+int agb_plot_augment(const float* raw, const long long* sel, const int32_t* elem, const int32_t* ptr, int B, int n,
+                     const float* aug, const float* noise, float* pos1, float* mins, void* stream) {
+    AGB_CHECK_ARG(B >= 1 && n >= 0, "agb_plot_augment: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (n > 0)
+        hipLaunchKernelGGL(k_plot_augment, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, raw, sel, elem, n,
+                           (const PlotAug*)aug, noise, pos1);
+    hipLaunchKernelGGL(k_plot_min3, dim3(B), dim3(256), 0, s, pos1, ptr, mins);
+    AGB_CHECK_LAUNCH("agb_plot_augment");
+    return AGB_OK;
+}
+
+// pos2 float[n2,3] = per plot [pos1 rows with z - zmin] ++ [n_add x per-axis minimum] ++ [jittered copies] (see
+// k_plot_extend); ptr2 / elem2 describe the output layout (host-computed: all counts are known to the host).
+int agb_plot_extend(const float* pos1, const int32_t* ptr1, const float* mins, const int32_t* ptr2,
+                    const int32_t* elem2, int B, int n2, const int32_t* n_add, const int32_t* cj_ptr,
+                    const long long* cj_idx, const float* cj_noise, float* pos2, void* stream) {
+    AGB_CHECK_ARG(B >= 1 && n2 >= 0, "agb_plot_extend: bad sizes");
+    if (n2 == 0) return AGB_OK;
+    hipLaunchKernelGGL(k_plot_extend, dim3(agb_cdiv(n2, 256)), dim3(256), 0, (hipStream_t)stream, pos1, ptr1, mins, ptr2,
+                       elem2, n2, n_add, cj_ptr, cj_idx, cj_noise, pos2);
+    AGB_CHECK_LAUNCH("agb_plot_extend");
+    return AGB_OK;
+}
+
+// Crop with one polygon per plot (polys double[B][2*nv]); a plot none of whose points falls inside is left whole
+// (transforms.py:1541-1543).  Features x = [1, z, ||xy - (fcx, fcy) + 1e-6||].  Scratch: flag / slot int32[n], cnt int32[B],
+// scan_scratch int32[agb_scan_scratch_elems(n)].  Out as agb_plot_prepare.
+int agb_plot_crop(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const double* polys, int nv,
+                  float fcx, float fcy, int32_t* flag, int32_t* slot, int32_t* cnt, int32_t* scan_scratch,
+                  float* pos_out, float* x_out, long long* src, int32_t* out_ptr, int32_t* n_out_dev, void* stream) {
+    AGB_CHECK_ARG(B >= 1 && n >= 0 && nv >= 3, "agb_plot_crop: bad sizes (B %d, n %d, nv %d)", B, n, nv);
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        (void)hipMemsetAsync(out_ptr, 0, sizeof(int32_t) * (B + 1), s);
+        (void)hipMemsetAsync(n_out_dev, 0, sizeof(int32_t), s);
+        return AGB_OK;
+    }
+    (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * B, s);
+    hipLaunchKernelGGL(k_plot_inside, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, pos, elem, n, polys, nv, flag, cnt);
+    hipLaunchKernelGGL(k_plot_keep_all_if_none, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, flag, elem, n, cnt);
+    agb_launch_exclusive_scan(flag, n, slot, scan_scratch, n_out_dev, s);
+    PlotXform t{1.f, 1.f, 1.f, 0.f, 0.f, 0.f, fcx, fcy, 0, 0};
+    hipLaunchKernelGGL(k_plot_emit, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, pos, flag, slot, n, t, pos_out, x_out, src);
+    hipLaunchKernelGGL(k_plot_out_ptr, dim3(agb_cdiv(B + 1, 64)), dim3(64), 0, s, slot, ptr, n_out_dev, B, n, out_ptr);
+    AGB_CHECK_LAUNCH("agb_plot_crop");
+    return AGB_OK;
+}
+
+}  // extern "C"

@@ -186,6 +186,11 @@ class SparsePlotPipeline:
         _lib.call("agb_plot_prepare", _P(stacked), _P(ptr), _P(elem), B, n, xform, self.div, int(self.z0), _P(poly), nv,
                   _P(zmin), _P(pos_t), _P(flag), _P(slot), _P(scratch), _P(pos_o), _P(x_o), _P(src), _P(out_ptr),
                   _P(n_out), _lib.stream())
+        return self.fix_counts(pos_o, x_o, src, out_ptr)
+
+    def fix_counts(self, pos_o, x_o, src, out_ptr):
+        """MaxPoints / MinPoints on the cropped rows (out_ptr: device int32 [B+1] offsets)."""
+        dev = pos_o.device
         optr = np.asarray(out_ptr.tolist(), dtype=np.int64)       # one host read: the lengths after the crop
         new_lens = np.diff(optr)
         m = int(optr[-1])
@@ -214,9 +219,12 @@ class SparsePlotPipeline:
     # -- whole chain ---------------------------------------------------------------------------------------------
     def __call__(self, plots: List, device, y_reg=None, perms=None):
         """Returns a PlotBatch (batch, coords, x, pos, y_reg, ...) resident on `device`."""
-        from .synthetic import PlotBatch
         pos, x, src, lens = self.prepare(plots, device)
-        B = len(plots)
+        return self.finish(pos, x, src, lens, len(plots), y_reg=y_reg, perms=perms)
+
+    def finish(self, pos, x, src, lens, B, y_reg=None, perms=None):
+        """GridSampling3D + coordinate augmentation + batch assembly on prepared rows."""
+        from .synthetic import PlotBatch
         dev = pos.device
         if self.grid is None:
             batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(lens)).to(dev)

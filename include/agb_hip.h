@@ -262,6 +262,27 @@ int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, 
 int agb_coords_augment(int32_t* coords, const int32_t* elem, int B, int n, const int32_t* flip, const int32_t* shift,
                        int32_t* cmax, void* stream);
 
+/* Train-time float augmentations of sparse-xy.yaml:4-69, applied to a whole batch from host-drawn parameters
+ * (dpcr-agb_amd/train_transforms.py draws them in the reference's per-sample order):
+ * agb_plot_augment: pos1 = ((raw[sel] - (0,0,zsub)) / scale + noise) @ M^T + shift + centre — RandomGroundRemoval's
+ *   z shift, ScalePos, RandomNoise, Random3AxisRotation, RandomShiftPos, MoveCenterPosPerSample
+ *   (transforms.py:1140-1150,590-598,482-505,747-759,722-739; features.py:44-60); sel int64[n] = rows kept by the ground
+ *   removal / RandomDropout (:1060-1087); aug: B records of 24 floats (zsub, sx,sy,sz, M[9] row-major, tx,ty,tz, cx,cy,cz,
+ *   5 pad); also writes mins float[3B] = per-plot minimum of pos1.
+ * agb_plot_extend: StartZFromZero (:766-769) + AddRandomPoints (:775-815, as upstream every added point equals the
+ *   per-axis minimum) + CopyJitterRandomPoints (:818-873): pos2 = per plot [pos1 with z - zmin] ++ [n_add x minimum] ++
+ *   [pos_prev[cj_idx] + cj_noise]; ptr2 / elem2 = output layout (host-known counts).
+ * agb_plot_crop: RandomPolygon2dExtend (:1502-1552) with one transformed polygon per plot (polys double[B][2*nv]); a plot
+ *   with no point inside is left whole; emits positions, features [1, z, xy distance], source rows like agb_plot_prepare. */
+int agb_plot_augment(const float* raw, const long long* sel, const int32_t* elem, const int32_t* ptr, int B, int n,
+                     const float* aug, const float* noise, float* pos1, float* mins, void* stream);
+int agb_plot_extend(const float* pos1, const int32_t* ptr1, const float* mins, const int32_t* ptr2,
+                    const int32_t* elem2, int B, int n2, const int32_t* n_add, const int32_t* cj_ptr,
+                    const long long* cj_idx, const float* cj_noise, float* pos2, void* stream);
+int agb_plot_crop(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const double* polys, int nv,
+                  float fcx, float fcy, int32_t* flag, int32_t* slot, int32_t* cnt, int32_t* scan_scratch,
+                  float* pos_out, float* x_out, long long* src, int32_t* out_ptr, int32_t* n_out_dev, void* stream);
+
 /* ---- squeeze-excite excitation MLP (dpcr-agb_amd/csrc/se.hip) -------------------------------------------------------
  * SELayer.fc of modules/MinkowskiEngine/senet_block.py:35-42 on the pooled features P [B,C]:
  * S = sigmoid(W2 act(W1 P + b1) + b2), W1 [H,C], W2 [C,H] (nn.Linear layout), H <= 256, act 0 none / 1 relu / 2 gelu.

@@ -155,3 +155,78 @@ def test_device_chain_with_voxelisation_and_coord_augmentation(device):
         model.set_input(out, device)
         model.forward()
     assert model.output.shape == (3, 2) and torch.isfinite(model.output).all()
+
+
+# ------------------------------------------------------------------------------------------------------- train chain
+def _seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def test_train_draws_follow_the_oracles_generator_order():
+    """The product's host-side draw function consumes random / numpy.random / torch exactly like the sequential oracle
+    (which applies the transforms while drawing, as the reference does): same selections, noise, rotation, polygon."""
+    import importlib.util
+    import os
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, draw_sample
+    raws = [torch.from_numpy(raw_plot(400 + i, n)[0]) for i, n in enumerate([9000, 16000, 700, 300])]
+    for seed in (0, 1, 2, 3, 4, 5):      # different seeds hit different branches (ground removal p = 0.1 ...)
+        _seed_all(seed)
+        ora = [T.train_transform_sample(r) for r in raws]
+        after = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+        _seed_all(seed)
+        drs = [draw_sample(r, NFITrainConfig()) for r in raws]
+        assert after == (random.random(), float(np.random.rand()), float(torch.rand(1))), seed
+        for (pos, src, pre, orig), d in zip(ora, drs):
+            assert torch.equal(d["sel"], orig)
+            n_cj = 0 if d["cj_idx"] is None else len(d["cj_idx"])
+            assert len(pre) == len(d["sel"]) + d["n_add"] + n_cj
+    # the rotation helper is the reference's (when the reference tree is mounted: never on the GPU box)
+    geo = "/root/reference/torch-points3d/torch_points3d/utils/geometry.py"
+    if os.path.exists(geo):
+        spec = importlib.util.spec_from_file_location("ref_geometry", geo)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        th = torch.tensor([0.3, -1.1, 2.0])
+        random.seed(9)
+        a = mod.euler_angles_to_rotation_matrix(th, random_order=True)
+        random.seed(9)
+        b = T.euler_angles_to_rotation_matrix(th, random_order=True)
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_device_train_chain_matches_oracle(device):
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, SparseTrainPipeline, draw_sample
+    raws = [raw_plot(500 + i, n)[0] for i, n in enumerate([9000, 16000, 700, 11000, 5000, 300])]
+    pipe = SparseTrainPipeline()
+    hit = dict(ground=0, drop=0, add=0, cj=0, shift=0)
+    for seed in range(6):
+        _seed_all(seed)
+        ora = [T.train_transform_sample(torch.from_numpy(r)) for r in raws]
+        _seed_all(seed)
+        draws = [draw_sample(torch.from_numpy(r), NFITrainConfig()) for r in raws]
+        pos, x, src, out_ptr = pipe.augment(raws, draws, device)
+        optr = out_ptr.cpu().numpy()
+        pos, src = pos.cpu(), src.cpu()
+        pre_off = 0
+        for b, ((opos, osrc, pre, orig), d) in enumerate(zip(ora, draws)):
+            dp, ds = pos[optr[b]:optr[b + 1]], src[optr[b]:optr[b + 1]] - pre_off
+            pre_off += len(pre)
+            # the rotation is a 3x3 torch.mm on the CPU and three multiply-adds on the device: positions agree to a few
+            # ulp, so a point within that distance of a polygon edge may be classified differently
+            common, ia, ib = np.intersect1d(ds.numpy(), osrc.numpy(), return_indices=True)
+            assert len(ds) + len(osrc) - 2 * len(common) <= 2, (seed, b)
+            assert torch.allclose(dp[ia], opos[ib], rtol=0, atol=2e-6), (seed, b)
+            hit["ground"] += d["zsub"] > 0
+            hit["drop"] += len(d["sel"]) < len(raws[b])
+            hit["add"] += d["n_add"] > 0
+            hit["cj"] += d["cj_idx"] is not None
+            hit["shift"] += d["shift"] is not None
+    assert all(v > 0 for v in hit.values()), hit      # every branch of the chain was exercised
+    # end to end: a voxelised, coordinate-augmented batch that the model accepts
+    _seed_all(11)
+    out = pipe(raws, device, y_reg=np.ones((len(raws), 2), np.float32))
+    assert out.coords.shape[0] == out.x.shape[0] == out.batch.shape[0] and out.coords.dtype == torch.int32
+    assert int(out.batch.max()) == len(raws) - 1
