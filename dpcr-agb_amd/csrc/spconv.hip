@@ -566,7 +566,10 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
             li[cnt + lane] = 0;
             lo[cnt + lane] = R;
         }
-        __threadfence_block();
+        // The lists are wave-private and one wave's LDS operations execute in order: a compiler barrier is all that is
+        // needed.  (A __threadfence_block() here also waits for every outstanding global load — the refills in
+        // flight — once per step.)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         return cpad >> 4;
     };
     auto load_b = [&](int step, float4 (&b)[CB][4]) {

@@ -1,0 +1,34 @@
+#!/bin/bash
+# MFMA utilisation / wait counters of the sparse-conv kernels (rocprofv3 --pmc, kernel-trace only, one small group of SQ
+# counters per pass) on the conv micro-benchmark.  Usage (GPU box): tools/collect_mfma_pmc.sh <tag>
+TAG=${1:-r01}
+export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/mfma_$TAG
+mkdir -p $OUT
+cd /tmp
+i=0
+for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pass$i -- python3 $ROOT/tools/bench_conv.py --modes 1 --reps 2 --wgrad > $OUT/pass$i.log 2>&1
+  echo "pass $i ($C) rc=$?"
+done
+cd $ROOT
+python3 - $OUT <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].strip()
+        if "spconv" not in name:
+            continue
+        a = acc[name][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+with open(sys.argv[1] + "_summary.txt", "w") as out:
+    for k, cs in sorted(acc.items()):
+        line = k + ": " + ", ".join(f"{c}={v[0] / max(v[1], 1):.4g}" for c, v in sorted(cs.items()))
+        mf, bz = cs.get("SQ_VALU_MFMA_BUSY_CYCLES"), cs.get("SQ_BUSY_CU_CYCLES")
+        if mf and bz and bz[0] > 0:
+            line += f"  -> MFMA busy / CU busy = {mf[0] / bz[0]:.3f}"
+        print(line); out.write(line + "\n")
+PY
