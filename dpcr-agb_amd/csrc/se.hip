@@ -51,12 +51,14 @@ __global__ __launch_bounds__(256) void k_se_fwd(const float* __restrict__ P, con
         acc = wave_sum(acc);
         if (lane == 0) {
             float h = acc + (b1 ? b1[j] : 0.f);
-            h_pre[(long long)b * H + j] = h;
+            if (blockIdx.y == 0) h_pre[(long long)b * H + j] = h;
             s_a[j] = se_act(h, act);
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    // the columns are divided among gridDim.y workgroups per plot (every one of them recomputes the small hidden layer):
+    // wide layers (C = 2048 in SENet50) would otherwise run on 32 CUs only
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {
         const float* w = W2 + (long long)c * H;
         float acc = b2 ? b2[c] : 0.f;
         for (int j = 0; j < H; ++j) acc += w[j] * s_a[j];
@@ -72,24 +74,27 @@ __global__ __launch_bounds__(256) void k_se_bwd_a(const float* __restrict__ W1, 
                                                   float* __restrict__ dP) {
     __shared__ float s_dh[SE_MAX_H];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every workgroup of the plot needs the whole dz2 vector for the hidden-layer gradient: each keeps a private copy in
+    // the scratch slice dz2[blockIdx.y][b] (slice 0 is the one pass B reads)
+    float* zw = dz2 + ((long long)blockIdx.y * gridDim.x + b) * C;
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = S[(long long)b * C + c];
-        dz2[(long long)b * C + c] = dS[(long long)b * C + c] * s * (1.f - s);
+        zw[c] = dS[(long long)b * C + c] * s * (1.f - s);
     }
-    __syncthreads();   // dz2 of this plot is read back below by other threads of the workgroup
-    const float* z = dz2 + (long long)b * C;
+    __syncthreads();   // read back below by other threads of the workgroup
+    const float* z = zw;
     for (int j = wave; j < H; j += 4) {
         float acc = 0.f;
         for (int c = lane; c < C; c += 64) acc += z[c] * W2[(long long)c * H + j];
         acc = wave_sum(acc);
         if (lane == 0) {
             float g = acc * se_act_grad(h_pre[(long long)b * H + j], act);
-            dh[(long long)b * H + j] = g;
+            if (blockIdx.y == 0) dh[(long long)b * H + j] = g;
             s_dh[j] = g;
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {
         float acc = 0.f;
         for (int j = 0; j < H; ++j) acc += s_dh[j] * W1[(long long)j * C + c];
         dP[(long long)b * C + c] = acc;
@@ -136,12 +141,13 @@ int agb_se_mlp_fwd(const float* P, const float* W1, const float* b1, const float
                   SE_MAX_H);
     AGB_CHECK_ARG(act >= 0 && act <= 2, "agb_se_mlp_fwd: activation %d", act);
     if (B == 0) return AGB_OK;
-    hipLaunchKernelGGL(k_se_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, P, W1, b1, W2, b2, C, H, act, h_pre, S);
+    hipLaunchKernelGGL(k_se_fwd, dim3(B, agb_cdiv(C, 512)), dim3(256), 0, (hipStream_t)stream, P, W1, b1, W2, b2, C, H, act,
+                       h_pre, S);
     AGB_CHECK_LAUNCH("agb_se_mlp_fwd");
     return AGB_OK;
 }
 
-// dS [B,C] in; scratch dz2 [B,C], dh [B,H]; out dP [B,C], dW1 [H,C], db1 [H] (or NULL), dW2 [C,H], db2 [C] (or NULL).
+// dS [B,C] in; scratch dz2 [ceil(C/512)][B,C] (slice 0 = the values), dh [B,H]; out dP [B,C], dW1 [H,C], db1 [H] (or NULL), dW2 [C,H], db2 [C] (or NULL).
 int agb_se_mlp_bwd(const float* P, const float* W1, const float* W2, int B, int C, int H, int act, const float* h_pre,
                    const float* S, const float* dS, float* dz2, float* dh, float* dP, float* dW1, float* db1,
                    float* dW2, float* db2, void* stream) {
@@ -149,7 +155,8 @@ int agb_se_mlp_bwd(const float* P, const float* W1, const float* W2, int B, int 
                   SE_MAX_H);
     hipStream_t s = (hipStream_t)stream;
     if (B > 0)
-        hipLaunchKernelGGL(k_se_bwd_a, dim3(B), dim3(256), 0, s, W1, W2, C, H, act, h_pre, S, dS, dz2, dh, dP);
+        hipLaunchKernelGGL(k_se_bwd_a, dim3(B, agb_cdiv(C, 512)), dim3(256), 0, s, W1, W2, C, H, act, h_pre, S, dS, dz2, dh,
+                           dP);
     const long long total = 2LL * C * H + C + H;
     hipLaunchKernelGGL(k_se_bwd_b, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, P, C, H, B, act, h_pre, dz2, dh, dW1,
                        db1, dW2, db2);

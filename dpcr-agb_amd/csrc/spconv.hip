@@ -942,13 +942,23 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     const int t_r = tid >> 4, t_c = (tid & 15) * 4;
     const int32_t* nrow = nbr + (long long)k * nbr_stride;
 
-    // ---- phase 1: ordered compaction of the present pairs
+    // ---- phase 1: ordered compaction of the present pairs.  All index loads are issued up front (one exposed memory
+    // latency per workgroup instead of one per 256 rows: the prologue was ~30 % of a workgroup's time)
     int total = 0;
     const int nrows = r_end - r_begin;
-    for (int base = 0, it = 0; base < nrows; base += 256, ++it) {
+    constexpr int NIT = DW_MAXROWS / 256;
+    int idxs[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        idxs[it] = i < nrows ? nrow[r_begin + i] : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int base = it * 256;
+        if (base >= nrows) break;
         const int i = base + tid;
-        int idx = -1;
-        if (i < nrows) idx = nrow[r_begin + i];
+        const int idx = idxs[it];
         const unsigned long long bal = __ballot(idx >= 0);
         if (lane == 0) s_wcnt[it & 1][wave] = __popcll(bal);
         __syncthreads();

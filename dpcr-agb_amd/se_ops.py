@@ -38,7 +38,7 @@ class SEExciteFunction(torch.autograd.Function):
         H = w1.shape[0]
         dev = p.device
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # noqa: E731
-        dz2, dh, dp = f32(B, C), f32(B, H), f32(B, C)
+        dz2, dh, dp = f32((C + 511) // 512, B, C), f32(B, H), f32(B, C)
         dw1, dw2 = f32(H, C), f32(C, H)
         db1 = f32(H) if has_b1 else None
         db2 = f32(C) if has_b2 else None

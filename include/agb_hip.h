@@ -286,7 +286,7 @@ int agb_plot_crop(const float* pos, const int32_t* ptr, const int32_t* elem, int
 /* ---- squeeze-excite excitation MLP (dpcr-agb_amd/csrc/se.hip) -------------------------------------------------------
  * SELayer.fc of modules/MinkowskiEngine/senet_block.py:35-42 on the pooled features P [B,C]:
  * S = sigmoid(W2 act(W1 P + b1) + b2), W1 [H,C], W2 [C,H] (nn.Linear layout), H <= 256, act 0 none / 1 relu / 2 gelu.
- * fwd writes h_pre [B,H] (kept for bwd) and S [B,C]; bwd: scratch dz2 [B,C], dh [B,H]; out dP [B,C], dW1, db1, dW2, db2
+ * fwd writes h_pre [B,H] (kept for bwd) and S [B,C]; bwd: scratch dz2 [ceil(C/512)][B,C], dh [B,H]; out dP [B,C], dW1, db1, dW2, db2
  * (biases may be NULL).  Sums over the batch run in batch order (deterministic). */
 int agb_se_mlp_fwd(const float* P, const float* W1, const float* b1, const float* W2, const float* b2, int B, int C,
                    int H, int act, float* h_pre, float* S, void* stream);
