@@ -299,6 +299,8 @@ def main():
         gaps = [step_events[j].elapsed_time(step_events[j + 1]) for j in range(len(step_events) - 1)]
         log("device time between step ends (ms): " + " ".join(f"{g:.2f}" for g in gaps))
         log("host enqueue per step (ms): " + " ".join(f"{h:.2f}" for h in host_ms[-args.steps:]))
+    log(f"device memory: {torch.cuda.memory_allocated() / 2**30:.2f} GiB allocated now, "
+        f"{torch.cuda.max_memory_allocated() / 2**30:.2f} GiB peak, {torch.cuda.memory_reserved() / 2**30:.2f} GiB reserved")
     hm = sorted(host_ms[-args.steps:])
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps; host enqueue time per step: median "
         f"{hm[len(hm) // 2]:.2f} ms, min {hm[0]:.2f} ms (GPU-bound when well below ms_per_step)")
