@@ -104,15 +104,27 @@ __global__ __launch_bounds__(256) void k_bn_stats_fold(const float* __restrict__
     const int c = blockIdx.x * FOLD_CH + cl;
     float na = 0.f, ma = 0.f, qa = 0.f;
     if (c < C) {
-        for (int j = lane; j < chunks; j += FOLD_LANES) {
-            const float* p = part + (long long)j * 3 * C;
-            float nb = p[c];
-            if (nb == 0.f) continue;
-            float mb = p[C + c], qb = p[2 * C + c];
-            float nt = na + nb, d = mb - ma;
-            ma += d * (nb / nt);
-            qa += qb + d * d * (na * nb / nt);
-            na = nt;
+        // batches of 8 chunk partials: 24 independent loads in flight, then the (serial) Chan combines — a dependent
+        // load per combine made this tiny kernel take 17 us
+        for (int j0 = lane; j0 < chunks; j0 += 8 * FOLD_LANES) {
+            float nb[8], mb[8], qb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * FOLD_LANES;
+                nb[u] = 0.f; mb[u] = 0.f; qb[u] = 0.f;
+                if (j < chunks) {
+                    const float* p = part + (long long)j * 3 * C;
+                    nb[u] = p[c]; mb[u] = p[C + c]; qb[u] = p[2 * C + c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (nb[u] == 0.f) continue;
+                float nt = na + nb[u], d = mb[u] - ma;
+                ma += d * (nb[u] / nt);
+                qa += qb[u] + d * d * (na * nb[u] / nt);
+                na = nt;
+            }
         }
     }
     s_n[lane][cl] = na; s_m[lane][cl] = ma; s_q[lane][cl] = qa;
