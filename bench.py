@@ -55,6 +55,8 @@ def conv_cost(rec, pairs):
 def kernel_of(rec):
     """Name of the HIP kernel a recorded launch ran (mirrors the dispatch rule of csrc/spconv.hip:launch_conv)."""
     small = rec["cin"] in (4, 8)
+    if rec["cin"] == 3:
+        return "k_spconv_fwd3"
     if rec["kind"] == "wgrad":
         return f"k_spconv_dw_small_cmp<{rec['cin']}>" if small else "k_spconv_dw_cmp"
     if small:

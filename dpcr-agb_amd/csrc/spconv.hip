@@ -153,6 +153,90 @@ __global__ __launch_bounds__(256) void k_spconv_fwd(const float* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Three input channels (the 7^3 x 3 -> 64 stem of the NFI models), PACKED: a K-chunk of 32 holds 10 offsets x 3 channels
+// (+ 2 zero rows) instead of 8 offsets x 4 padded channels: 35 chunks instead of 43 for the 343 offsets, a fifth less
+// MFMA work in an MFMA-bound kernel.  X rows are still 4 floats wide (one aligned 16-B gather per pair), W is the layer's
+// own [K3*3, Cout] matrix.
+__global__ __launch_bounds__(256) void k_spconv_fwd3(const float* __restrict__ X, int ldx,
+                                                     const float* __restrict__ W,  // [K3*3, Cout]
+                                                     const int32_t* __restrict__ nbr, long long nbr_stride, int kflip,
+                                                     const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                     int n_out, int K3, int Cout) {
+    constexpr int OPC = 10;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int row0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // K rows 30 and 31 of the A tile stay zero for the whole kernel
+    if (tid < BM) { As[tid * LDA + 30] = 0.f; As[tid * LDA + 31] = 0.f; }
+
+    const int nchunks = (K3 + OPC - 1) / OPC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = ch * OPC;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = tid + 256 * j;          // 64 rows x 10 offsets = 640 (row, offset) pairs per chunk
+            if (e < BM * OPC) {
+                const int r = e & (BM - 1), off = e >> 6;
+                const int k = k0 + off;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K3 && row0 + r < n_out) {
+                    const int kn = kflip ? (K3 - 1 - k) : k;
+                    const int idx = nbr[(long long)kn * nbr_stride + row0 + r];
+                    if (idx >= 0) v = *reinterpret_cast<const float4*>(X + (long long)idx * ldx);
+                }
+                float* dst = &As[r * LDA + off * 3];
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kr = (tid >> 4) + 16 * j;
+            const int n = n0 + (tid & 15) * 4;
+            const long long wrow = (long long)k0 * 3 + kr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kr < 3 * OPC && wrow < (long long)K3 * 3 && n < Cout) v = *reinterpret_cast<const float4*>(W + wrow * Cout + n);
+            *reinterpret_cast<float4*>(&Bs[kr * LDB + (tid & 15) * 4]) = v;
+        }
+        __syncthreads();
+        const float* arow = &As[(wr * 32 + li) * LDA + 4 * lh];
+        const float* bcol = &Bs[wc * 32 + li];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * t);
+            const int kb = 8 * t + 4 * lh;
+            float b0 = bcol[(kb + 0) * LDB];
+            float b1 = bcol[(kb + 1) * LDB];
+            float b2 = bcol[(kb + 2) * LDB];
+            float b3 = bcol[(kb + 3) * LDB];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + li;
+    if (col < Cout) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int row = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (row < n_out) Y[(long long)row * ldy + col] = acc[reg] + bv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic path, software-pipelined: while the MFMAs of K-chunk i run, the gathers of chunk i+1 are in
 // flight into registers and the neighbour indices of chunk i+2 are being fetched (the index -> gather
 // dependency would otherwise expose two L2 latencies per chunk).  TM x 64 output tile:
@@ -1218,6 +1302,15 @@ static void cmp_geometry(const ConvArgs& a, int* R_out, int* rpt_out, int* ntile
 static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
     const bool small = (a.Cin == 4 || a.Cin == 8);
     dim3 block(256);
+    if (a.Cin == 3) {
+        if (a.perm || a.ksplit > 1) {
+            agb_set_error("agb_spconv_fwd_ex: the packed 3-channel path takes neither a class partition nor a split");
+            return AGB_EUNSUPPORTED;
+        }
+        hipLaunchKernelGGL(k_spconv_fwd3, dim3(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN)), block, 0, s, a.X, a.ldx, a.W,
+                           a.nbr, a.nbr_stride, a.kflip, a.bias, a.Y, a.ldy, a.n_out, a.K3, a.Cout);
+        return AGB_OK;
+    }
     if (a.perm) {
         if (small) {
             agb_set_error("agb_spconv_fwd_ex: the class-partitioned path needs Cin >= 12");
@@ -1272,7 +1365,7 @@ int agb_spconv_set_cmp_mode(int mode) {
 
 // How many offset splits a layer of n_out rows wants (1 = none): host helper for sizing `partial`.
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
-    if (Cin == 4 || Cin == 8 || K3 < 8) return 1;
+    if (Cin == 3 || Cin == 4 || Cin == 8 || K3 < 8) return 1;
     {
         if (g_cmp_mode < 0) {
             const char* e = getenv("AGB_CONV_CMP");
@@ -1294,9 +1387,9 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                       float* partial, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_fwd: bad sizes");
-    AGB_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout,
-                  "agb_spconv_fwd: Cin (%d), Cout (%d), ldx (%d) must be multiples of 4 (pad small inputs)", Cin,
-                  Cout, ldx);
+    AGB_CHECK_ARG((Cin % 4 == 0 || Cin == 3) && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout,
+                  "agb_spconv_fwd: Cin (%d: a multiple of 4, or 3 with 4-float rows), Cout (%d), ldx (%d) must be "
+                  "multiples of 4 (pad small inputs)", Cin, Cout, ldx);
     AGB_CHECK_ARG(nbr_stride >= n_out, "agb_spconv_fwd: nbr_stride < n_out");
     AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_ex: ksplit needs `partial`");
     AGB_CHECK_ARG(perm == nullptr || (tile_cls != nullptr && cls_tab != nullptr && n_tiles > 0),

@@ -110,7 +110,12 @@ class SparseConvFunction(torch.autograd.Function):
             b = b.contiguous()
         pairs = getattr(nbr, "agb_pairs", None)
         wkm = w.transpose(1, 2).contiguous() if (CONV_PRECISION in _PREC_ID and cin_p >= 12) else None
-        y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs, None, wkm)
+        if cin == 3 and cout_p == cout:
+            # three input channels (the stem): rows stay 4 floats wide, the weights go in unpadded — the kernel packs
+            # 10 offsets x 3 channels per K-chunk instead of 8 x 4
+            y = spconv_forward_raw(x, kernel.contiguous().view(K3 * 3, cout), nbr, 0, b, n_out, K3, 3, cout_p, "fwd", pairs)
+        else:
+            y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs, None, wkm)
         ctx.pairs = pairs
         ctx.plan = plan
         ctx.save_for_backward(x, w, nbr, nbrT if nbrT is not None else torch.empty(0))
