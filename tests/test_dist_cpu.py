@@ -75,3 +75,26 @@ def test_single_process_matches_manual_average():
     for a, b in zip(m.parameters(), ref.parameters()):
         assert torch.allclose(a.grad, b.grad)
     sync.remove()
+
+
+def test_unused_parameter_and_repacking():
+    """A parameter that receives no gradient is exchanged as zeros; gradients are fresh tensors every step and end up as
+    slices of the bucket's flat buffer (what the optimiser reads after the exchange)."""
+    from dpcr_agb_amd.dist import GradAllReduce
+    torch.manual_seed(1)
+    used, unused = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+    params = list(used.parameters()) + list(unused.parameters())
+    sync = GradAllReduce(params, bucket_bytes=1 << 20)
+    x = torch.randn(5, 4)
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        used(x).sum().backward()
+        sync()
+        flat = sync.buckets[0]["flat"]
+        for p in params:
+            assert p.grad is not None and p.grad.data_ptr() >= flat.data_ptr()
+            assert p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
+        assert float(unused.weight.grad.abs().sum()) == 0.0
+        assert torch.allclose(used.weight.grad, x.sum(0).expand(3, 4))
+    sync.remove()
