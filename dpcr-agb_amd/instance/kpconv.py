@@ -93,12 +93,41 @@ class KPConvModel(InstanceBase):
         return dict(points=points, neighbors=neighbors, pools=pools, lengths=lengths, features=feats,
                     last_ptr=torch.from_numpy(ptr).to(device))
 
+    def _pyramid(self, data, device):
+        ptr = data.ptr
+        lens = (ptr[1:] - ptr[:-1]).cpu().numpy().astype(np.int64)
+        return self.prepare_inputs(data.pos.view(-1, 3), data.x.view(-1, data.x.shape[-1]), lens, device)
+
+    def prefetch_input(self, data, device):
+        """Build the NEXT batch's input pyramid on a side stream.  ``prepare_inputs`` reads counts back to the host after
+        every radius search and subsampling (two per level); called right after ``optimize_parameters`` those waits
+        fall on the side stream while the device works through the step that is already enqueued, instead of stalling
+        the training loop at the next ``set_input``.  (Grid orientations are still drawn from ``np.random`` in batch
+        order.)"""
+        if not hasattr(self, "_side_stream"):
+            self._side_stream = torch.cuda.Stream(device=device)
+        side = self._side_stream
+        with torch.cuda.stream(side):
+            inp = self._pyramid(data, device)
+            ev = side.record_event()
+        data._prefetched = (inp, ev)
+
     def set_input(self, data, device):
         self.data_visual = data
         self.batch_idx = data.batch
-        ptr = data.ptr
-        lens = (ptr[1:] - ptr[:-1]).cpu().numpy().astype(np.int64)
-        self.input = Opt(self.prepare_inputs(data.pos.view(-1, 3), data.x.view(-1, data.x.shape[-1]), lens, device))
+        pre = getattr(data, "_prefetched", None)
+        if pre is not None:
+            inp, ev = pre
+            data._prefetched = None
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(ev)
+            for v in inp.values():      # built on the side stream, consumed on the compute stream
+                for t in (v if isinstance(v, (list, tuple)) else [v]):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(cur)
+            self.input = Opt(inp)
+        else:
+            self.input = Opt(self._pyramid(data, device))
         if len(self.loss_fns) > 0:
             bs = len(data)
             if self.has_reg_targets and data.y_reg is not None:

@@ -31,7 +31,7 @@ def run(name, steps):
         pool = [synthetic.make_point_batch(list(range(i * B, (i + 1) * B)), n_points=npts) for i in range(2)]
         for b in pool:
             b.pos, b.x = b.pos.to(dev), b.x.to(dev)
-        prefetch = False
+        prefetch = True
     model.to(dev).train()
     model.init_train_objects(TRAINING_NFI)
 
