@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
 __global__ __launch_bounds__(256) void k_bn_stats_fold(const float* __restrict__ part, int chunks, int C, float eps,
                                                        float momentum, float* __restrict__ mean,
                                                        float* __restrict__ rstd, float* running_mean,
-                                                       float* running_var) {
+                                                       float* running_var, long long* num_batches_tracked) {
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     __shared__ float s_n[FOLD_LANES][FOLD_CH], s_m[FOLD_LANES][FOLD_CH], s_q[FOLD_LANES][FOLD_CH];
     const int cl = threadIdx.x & (FOLD_CH - 1), lane = threadIdx.x / FOLD_CH;
     const int c = blockIdx.x * FOLD_CH + cl;
@@ -439,8 +440,10 @@ static int rows_per_chunk(int n, int chunks) { return agb_cdiv(n > 0 ? n : 1, ch
 
 // training != 0: batch statistics of X (and running-stat update if the pointers are given); else mean/rstd from the
 // running statistics.  part: float[agb_bn_chunks(n) * 3 * C] scratch.  mean, rstd: float[C] out.
-int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
-                 float* mean, float* rstd, float* running_mean, float* running_var, void* stream) {
+// num_batches_tracked: the layer's int64 counter (device), incremented by the fold kernel in training mode; or NULL.
+int agb_bn_stats_tracked(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
+                         float* mean, float* rstd, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, void* stream) {
     AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0, "agb_bn_stats: C (%d) and ldx must be multiples of 4", C);
     hipStream_t s = (hipStream_t)stream;
     if (!training) {
@@ -452,10 +455,16 @@ int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentu
         hipLaunchKernelGGL(k_bn_stats_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, n, C,
                            rows_per_chunk(n, chunks), part);
         hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(256), 0, s, part, chunks, C, eps, momentum,
-                           mean, rstd, running_mean, running_var);
+                           mean, rstd, running_mean, running_var, num_batches_tracked);
     }
     AGB_CHECK_LAUNCH("agb_bn_stats");
     return AGB_OK;
+}
+
+int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
+                 float* mean, float* rstd, float* running_mean, float* running_var, void* stream) {
+    return agb_bn_stats_tracked(X, ldx, n, C, eps, momentum, training, part, mean, rstd, running_mean, running_var,
+                                nullptr, stream);
 }
 
 int agb_bn_act_fwd(const float* X, int ldx, int n, int C, const float* mean, const float* rstd, const float* gamma,

@@ -790,6 +790,34 @@ __global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_o
     *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = acc;
 }
 
+// WT[k][c][r] = W[k][r][c]: the data gradient multiplies by W[k]^T, and the weights change every step, so this runs
+// once per layer per step.  64x64 tiles through LDS, float4 on both sides (R, C multiples of 4).
+__global__ __launch_bounds__(256) void k_weight_transpose(const float* __restrict__ W, float* __restrict__ WT, int R,
+                                                          int C) {
+    __shared__ float tile[64][65];
+    const float* w = W + (long long)blockIdx.z * R * C;
+    float* wt = WT + (long long)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int g = threadIdx.x & 15, h = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = h + 16 * p;
+        if (r0 + r < R && c0 + 4 * g < C) {
+            float4 v = *reinterpret_cast<const float4*>(w + (long long)(r0 + r) * C + c0 + 4 * g);
+            tile[r][4 * g + 0] = v.x; tile[r][4 * g + 1] = v.y; tile[r][4 * g + 2] = v.z; tile[r][4 * g + 3] = v.w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = h + 16 * p;
+        if (c0 + c < C && r0 + 4 * g < R) {
+            float4 v = make_float4(tile[4 * g + 0][c], tile[4 * g + 1][c], tile[4 * g + 2][c], tile[4 * g + 3][c]);
+            *reinterpret_cast<float4*>(wt + (long long)(c0 + c) * R + r0 + 4 * g) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Lattice-parity partition of the rows of a level for a stride-s operator: class = (c/ts mod s) per axis.
 // perm [n + ncls*TM] receives the rows grouped by class, every class padded with -1 to a multiple of TM;
@@ -1299,6 +1327,11 @@ static void cmp_geometry(const ConvArgs& a, int* R_out, int* rpt_out, int* ntile
     *R_out = R; *rpt_out = rpt; *ntiles_out = agb_cdiv(a.n_out, rpt); *nct_out = nct;
 }
 
+// stem.hip (internal: not part of include/agb_hip.h)
+extern "C" int agb_stem_sparse_enabled();
+extern "C" int agb_stem_fwd_sparse_launch(const float* X, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                               const float* bias, float* Y, int ldy, int n_out, int K3, hipStream_t s);
+
 static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
     const bool small = (a.Cin == 4 || a.Cin == 8);
     dim3 block(256);
@@ -1307,6 +1340,8 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             agb_set_error("agb_spconv_fwd_ex: the packed 3-channel path takes neither a class partition nor a split");
             return AGB_EUNSUPPORTED;
         }
+        if (a.Cout == 64 && a.ldx == 4 && agb_stem_sparse_enabled())   // pair-sparse vector kernel (stem.hip)
+            return agb_stem_fwd_sparse_launch(a.X, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias, a.Y, a.ldy, a.n_out, a.K3, s);
         hipLaunchKernelGGL(k_spconv_fwd3, dim3(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN)), block, 0, s, a.X, a.ldx, a.W,
                            a.nbr, a.nbr_stride, a.kflip, a.bias, a.Y, a.ldy, a.n_out, a.K3, a.Cout);
         return AGB_OK;
@@ -1355,6 +1390,16 @@ int agb_spconv_cmp_occupancy(int R) {
         ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_spconv_cmp<128>, 64, 0)
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_spconv_cmp<64>, 64, 0);
     return e == hipSuccess ? n : -1;
+}
+
+// WT [K3][C][R] = transpose of W [K3][R][C] per offset (the weights the data gradient multiplies by); R, C % 4 == 0.
+int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C, void* stream) {
+    AGB_CHECK_ARG(K3 >= 1 && R >= 4 && C >= 4 && R % 4 == 0 && C % 4 == 0 && K3 <= 65535,
+                  "agb_spconv_weight_transpose: K3 %d, R %d, C %d (multiples of 4)", K3, R, C);
+    hipLaunchKernelGGL(k_weight_transpose, dim3(agb_cdiv(C, 64), agb_cdiv(R, 64), K3), dim3(256), 0,
+                       (hipStream_t)stream, W, WT, R, C);
+    AGB_CHECK_LAUNCH("agb_spconv_weight_transpose");
+    return AGB_OK;
 }
 
 int agb_spconv_set_cmp_mode(int mode) {

@@ -11,6 +11,9 @@ _lib.declare("agb_bn_chunks", [_lib.c_int])
 _lib.declare("agb_bn_stats", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_float, _lib.c_float,
                               _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p,
                               _lib.c_void_p])
+_lib.declare("agb_bn_stats_tracked", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_float, _lib.c_float,
+                                      _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p,
+                                      _lib.c_void_p, _lib.c_void_p, _lib.c_void_p])
 _lib.declare("agb_bn_act_fwd", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
                                 _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p])
 _lib.declare("agb_bn_act_bwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int,
@@ -36,7 +39,7 @@ class BatchNormActFunction(torch.autograd.Function):
     """y = act(gamma * (x - mean) * rstd + beta) over the rows of x [N, C] (C % 4 == 0)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act_id, training):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act_id, training, counter=None):
         x = x.contiguous()
         n, c = x.shape
         if c % 4 != 0:
@@ -44,8 +47,8 @@ class BatchNormActFunction(torch.autograd.Function):
         dev = x.device
         stats = torch.empty(2, c, dtype=torch.float32, device=dev)
         part = torch.empty(bn_chunks(n) * 3 * c, dtype=torch.float32, device=dev) if training else None
-        _lib.call("agb_bn_stats", _P(x), x.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
-                  _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _lib.stream())
+        _lib.call("agb_bn_stats_tracked", _P(x), x.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
+                  _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter), _lib.stream())
         y = torch.empty_like(x)
         _lib.call("agb_bn_act_fwd", _P(x), x.stride(0), n, c, _P(stats[0]), _P(stats[1]), _P(gamma), _P(beta),
                   act_id, _P(y), y.stride(0), _lib.stream())
@@ -72,7 +75,7 @@ class BatchNormActFunction(torch.autograd.Function):
             # column sums of dx, a by-product of the apply pass: the convolution that produced x (its backward node
             # receives this very tensor) takes them as its bias gradient instead of reducing dx again
             dx.agb_colsum = dgb[2]
-        return dx, (dgb[0] if has_g else None), (dgb[1] if has_b else None), None, None, None, None, None, None
+        return dx, (dgb[0] if has_g else None), (dgb[1] if has_b else None), None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, bn: torch.nn.BatchNorm1d, act=None):
@@ -80,12 +83,18 @@ def batch_norm_act(x, bn: torch.nn.BatchNorm1d, act=None):
     rm, rv = bn.running_mean, bn.running_var  # None when track_running_stats is off
     use_batch_stats = bn.training or rm is None
     momentum = 0.0
+    counter = None
     if bn.training and rm is not None:
-        bn.num_batches_tracked.add_(1)
-        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        if bn.momentum is not None:
+            # the int64 num_batches_tracked counter is bumped by the statistics fold kernel (one launch less per layer)
+            momentum, counter = bn.momentum, bn.num_batches_tracked
+        else:   # cumulative moving average: the factor needs the count on the host
+            bn.num_batches_tracked.add_(1)
+            momentum = 1.0 / float(bn.num_batches_tracked)
     # training + tracked: batch stats, running stats updated in the fold kernel; eval + tracked: running stats;
     # untracked: batch stats, nothing to update
-    return BatchNormActFunction.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, ACT_IDS[act], use_batch_stats)
+    return BatchNormActFunction.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, ACT_IDS[act], use_batch_stats,
+                                      counter)
 
 
 class AddActFunction(torch.autograd.Function):

@@ -64,6 +64,26 @@ def test_bn_act_training(device, n, c, act):
         assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("momentum", [0.1, None])
+def test_bn_running_stat_bookkeeping(device, momentum):
+    """num_batches_tracked is bumped on the device by the fold kernel (momentum given) or on the host (cumulative
+    average, momentum None); running statistics follow nn.BatchNorm1d over several steps either way."""
+    from dpcr_agb_amd.norm_ops import batch_norm_act
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm1d(16, momentum=momentum).to(device)
+    ref = torch.nn.BatchNorm1d(16, momentum=momentum).double()
+    for i in range(3):
+        x = torch.randn(500 + 7 * i, 16, device=device) * (1 + i) + i
+        batch_norm_act(x, bn, None)
+        ref(x.double().cpu())
+        assert int(bn.num_batches_tracked) == i + 1
+    assert rel(bn.running_mean, ref.running_mean) < 1e-5
+    assert rel(bn.running_var, ref.running_var) < 1e-4
+    bn.eval()
+    batch_norm_act(x, bn, None)
+    assert int(bn.num_batches_tracked) == 3
+
+
 @pytest.mark.parametrize("act", ["relu", "gelu"])
 def test_add_act(device, act):
     from dpcr_agb_amd.norm_ops import ACT_IDS, AddActFunction

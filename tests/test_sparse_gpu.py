@@ -129,6 +129,16 @@ def test_conv_forward_backward(device, cin, cout, K, stride, ts_in):
     _conv_case(device, cin, cout, K, stride, ts_in)
 
 
+@pytest.mark.parametrize("K3,R,C", [(27, 64, 64), (27, 68, 132), (8, 4, 64), (1, 256, 8), (343, 4, 12)])
+def test_weight_transpose_exact(device, K3, R, C):
+    """The per-offset weight transpose feeding the data gradient is a pure permutation: bit-exact."""
+    from dpcr_agb_amd import _lib
+    w = torch.randn(K3, R, C, device=device)
+    wt = torch.full((K3, C, R), float("nan"), device=device)
+    _lib.call("agb_spconv_weight_transpose", w.data_ptr(), wt.data_ptr(), K3, R, C, _lib.stream())
+    assert torch.equal(wt, w.transpose(1, 2))
+
+
 @pytest.mark.parametrize("rows_per_wave", [64, 128])
 @pytest.mark.parametrize("cin,cout,K,stride,ts_in", [(64, 64, 3, 1, 2), (64, 128, 3, 2, 2), (64, 128, 1, 2, 2),
                                                       (128, 128, 3, 1, 4), (64, 80, 3, 1, 1), (256, 64, 3, 1, 2),
@@ -142,6 +152,44 @@ def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride,
         _conv_case(device, cin, cout, K, stride, ts_in)
     finally:
         _lib.call("agb_spconv_set_cmp_mode", 1)
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("K,stride,ts_in", [(7, 1, 1), (3, 1, 1), (5, 2, 1), (2, 2, 2), (1, 1, 1)])
+def test_stem_conv_sparse_and_dense_kernels(device, sparse, K, stride, ts_in):
+    """3 -> 64 channels: the pair-sparse vector kernels (csrc/stem.hip, default) and the dense MFMA kernels they replace
+    both match the oracle, forward and weight gradient."""
+    from dpcr_agb_amd import sparse_ops
+    sparse_ops.set_stem_sparse(sparse)
+    try:
+        _conv_case(device, 3, 64, K, stride, ts_in)
+    finally:
+        sparse_ops.set_stem_sparse(False)
+
+
+def test_stem_conv_sparse_is_deterministic(device):
+    """Fixed summation order (offsets, rows, row groups): two runs give bit-identical outputs and weight gradients."""
+    import dpcr_agb_amd.me_compat as ME
+    rng = np.random.default_rng(11)
+    torch.manual_seed(11)
+    coords = random_coords(rng, 3, 4000, 24)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    conv = ME.MinkowskiConvolution(3, 64, kernel_size=7, stride=1, bias=True, dimension=3).to(device)
+    x = torch.randn(cm.level(1).n, 3, device=device)
+    g = torch.randn(cm.level(1).n, 64, device=device)
+    from dpcr_agb_amd import sparse_ops
+    res = []
+    sparse_ops.set_stem_sparse(True)
+    try:
+        for _ in range(2):
+            conv.zero_grad(set_to_none=True)
+            out = conv(ME.SparseTensor(x, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm))
+            out.F.backward(g)
+            res.append((out.F.detach().clone(), conv.kernel.grad.clone()))
+    finally:
+        sparse_ops.set_stem_sparse(False)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
 @pytest.mark.parametrize("split", [2, 4])
