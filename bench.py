@@ -55,13 +55,10 @@ def conv_cost(rec, pairs):
 def kernel_of(rec):
     """Name of the HIP kernel a recorded launch ran (mirrors the dispatch rule of csrc/spconv.hip:launch_conv)."""
     small = rec["cin"] in (4, 8)
-    stem_sparse = os.environ.get("AGB_STEM_SPARSE", "0") != "0"
     if rec["kind"] == "wgrad":
-        if rec["cin"] == 3 and stem_sparse:
-            return "k_stem_wgrad_sparse<32>"
         return f"k_spconv_dw_small_cmp<{rec['cin']}>" if small else "k_spconv_dw_cmp"
     if rec["cin"] == 3:
-        return "k_stem_fwd_sparse" if (stem_sparse and rec["cout"] == 64) else "k_spconv_fwd3"
+        return "k_spconv_fwd3"
     if small:
         return f"k_spconv_fwd<{rec['cin']}>"
     if rec.get("perm"):

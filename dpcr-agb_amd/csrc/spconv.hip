@@ -1327,11 +1327,6 @@ static void cmp_geometry(const ConvArgs& a, int* R_out, int* rpt_out, int* ntile
     *R_out = R; *rpt_out = rpt; *ntiles_out = agb_cdiv(a.n_out, rpt); *nct_out = nct;
 }
 
-// stem.hip (internal: not part of include/agb_hip.h)
-extern "C" int agb_stem_sparse_enabled();
-extern "C" int agb_stem_fwd_sparse_launch(const float* X, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
-                               const float* bias, float* Y, int ldy, int n_out, int K3, hipStream_t s);
-
 static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
     const bool small = (a.Cin == 4 || a.Cin == 8);
     dim3 block(256);
@@ -1340,8 +1335,6 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             agb_set_error("agb_spconv_fwd_ex: the packed 3-channel path takes neither a class partition nor a split");
             return AGB_EUNSUPPORTED;
         }
-        if (a.Cout == 64 && a.ldx == 4 && agb_stem_sparse_enabled())   // pair-sparse vector kernel (stem.hip)
-            return agb_stem_fwd_sparse_launch(a.X, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias, a.Y, a.ldy, a.n_out, a.K3, s);
         hipLaunchKernelGGL(k_spconv_fwd3, dim3(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN)), block, 0, s, a.X, a.ldx, a.W,
                            a.nbr, a.nbr_stride, a.kflip, a.bias, a.Y, a.ldy, a.n_out, a.K3, a.Cout);
         return AGB_OK;

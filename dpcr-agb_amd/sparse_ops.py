@@ -17,15 +17,6 @@ _P = _lib.ptr
 import os as _os
 CONV_PRECISION = _os.environ.get("AGB_CONV_PRECISION", "fp32")
 _PREC_ID = {"bf16": 1, "bf16x3": 2}
-# 3 -> 64 channel stem through the pair-sparse vector kernels of csrc/stem.hip (False: the dense MFMA kernels)
-STEM_SPARSE = _os.environ.get("AGB_STEM_SPARSE", "0") != "0"
-
-
-def set_stem_sparse(on: bool):
-    """Switch the stem kernels of both directions (tests and tools compare the two paths)."""
-    global STEM_SPARSE
-    STEM_SPARSE = bool(on)
-    _lib.call("agb_spconv_set_stem_mode", int(bool(on)))
 _lib.declare("agb_spconv_fwd_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
                                    _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                    _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
@@ -159,16 +150,7 @@ class SparseConvFunction(torch.autograd.Function):
                 dxp = spconv_forward_raw(dy, wt2d, nbr, 1, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, None,
                                          wkm)
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
-        if ctx.needs_input_grad[1] and cin == 3 and cout == 64 and STEM_SPARSE:
-            # 3 -> 64 stem: pair-sparse vector kernel, writes [K3, 3, 64] directly (csrc/stem.hip)
-            lib = _lib.load()
-            scratch = torch.empty(lib.agb_spconv_bwd_weight3_scratch(n_out, K3), dtype=torch.float32, device=dy.device)
-            dk = torch.empty(K3, 3, 64, dtype=torch.float32, device=dy.device)
-            ev = _prof_begin()
-            _lib.call("agb_spconv_bwd_weight3", _P(x), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0), _P(dk),
-                      _P(scratch), n_out, K3, 64, _lib.stream())
-            _prof_end(ev, "wgrad", K3, 3, 64, n_out, ctx.pairs)
-        elif ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1]:
             dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
             ev = _prof_begin()
             _lib.call("agb_spconv_bwd_weight", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),

@@ -108,16 +108,6 @@ int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper
  * register-accumulator kernels otherwise), 0 = never the pair-compacted kernel, 64 / 128 = always, with that many rows
  * per wave.  All choices compute the same sums; only the fp32 summation order differs. */
 int agb_spconv_set_cmp_mode(int mode);
-/* 3 -> 64 channel stem (7^3 offsets, ~17 % of them present per row): pair-sparse vector kernels, csrc/stem.hip.
- * agb_spconv_fwd_ex routes Cin == 3, Cout == 64, ldx == 4 there when the mode is 1 (default; env AGB_STEM_SPARSE);
- * mode 0 keeps the dense MFMA kernels.  Replaces the same ME convolution as agb_spconv_fwd (resnet.py conv1). */
-int agb_spconv_set_stem_mode(int mode);
-/* weight gradient of that layer: X [n_in, 4] (3 used), dY [n_out, ldy], nbr [K3][n_out]; dW [K3, 3, 64] is WRITTEN
- * (not accumulated; deterministic: row groups are folded in order).  scratch: agb_spconv_bwd_weight3_scratch(n_out,
- * K3) floats. */
-int agb_spconv_bwd_weight3_scratch(int n_out, int K3);
-int agb_spconv_bwd_weight3(const float* X, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
-                           float* dW, float* scratch, int n_out, int K3, int Cout, void* stream);
 /* WT [K3][C][R] = per-offset transpose of W [K3][R][C] (R, C multiples of 4): the operand of the data gradient
  * dX = sum_k dY[nbrT[k]] @ W[k]^T, rebuilt once per layer per step (ME does the same inside its backward GEMMs with
  * a transposed-operand flag: MinkowskiEngine/src/convolution_kernel.cu ConvolutionBackwardKernelGPU). */

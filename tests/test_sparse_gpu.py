@@ -154,44 +154,6 @@ def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride,
         _lib.call("agb_spconv_set_cmp_mode", 1)
 
 
-@pytest.mark.parametrize("sparse", [True, False])
-@pytest.mark.parametrize("K,stride,ts_in", [(7, 1, 1), (3, 1, 1), (5, 2, 1), (2, 2, 2), (1, 1, 1)])
-def test_stem_conv_sparse_and_dense_kernels(device, sparse, K, stride, ts_in):
-    """3 -> 64 channels: the pair-sparse vector kernels (csrc/stem.hip, default) and the dense MFMA kernels they replace
-    both match the oracle, forward and weight gradient."""
-    from dpcr_agb_amd import sparse_ops
-    sparse_ops.set_stem_sparse(sparse)
-    try:
-        _conv_case(device, 3, 64, K, stride, ts_in)
-    finally:
-        sparse_ops.set_stem_sparse(False)
-
-
-def test_stem_conv_sparse_is_deterministic(device):
-    """Fixed summation order (offsets, rows, row groups): two runs give bit-identical outputs and weight gradients."""
-    import dpcr_agb_amd.me_compat as ME
-    rng = np.random.default_rng(11)
-    torch.manual_seed(11)
-    coords = random_coords(rng, 3, 4000, 24)
-    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
-    cm = st.coordinate_manager
-    conv = ME.MinkowskiConvolution(3, 64, kernel_size=7, stride=1, bias=True, dimension=3).to(device)
-    x = torch.randn(cm.level(1).n, 3, device=device)
-    g = torch.randn(cm.level(1).n, 64, device=device)
-    from dpcr_agb_amd import sparse_ops
-    res = []
-    sparse_ops.set_stem_sparse(True)
-    try:
-        for _ in range(2):
-            conv.zero_grad(set_to_none=True)
-            out = conv(ME.SparseTensor(x, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm))
-            out.F.backward(g)
-            res.append((out.F.detach().clone(), conv.kernel.grad.clone()))
-    finally:
-        sparse_ops.set_stem_sparse(False)
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-
-
 @pytest.mark.parametrize("split", [2, 4])
 def test_conv_pair_compacted_channel_split(device, split):
     """Input-channel split of the pair-compacted kernel (few-row wide layers): partial tiles + ordered fold must give
