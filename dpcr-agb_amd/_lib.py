@@ -51,6 +51,8 @@ _SIGNATURES = {
                            c_void_p, c_void_p, c_void_p],
     "agb_segment_broadcast": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                               c_void_p],
+    "agb_segment_scale_add": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                              c_void_p],
     "agb_segment_max_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "agb_adabelief_chunk": [],
     "agb_adabelief_step": [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_float,

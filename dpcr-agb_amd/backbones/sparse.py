@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import me_compat as ME
-from ..se_ops import MAX_HIDDEN as MAX_SE_HIDDEN, se_excite
+from ..se_ops import MAX_HIDDEN as MAX_SE_HIDDEN, se_layer
 
 ACTIVATIONS = {
     "relu": ME.MinkowskiReLU,
@@ -165,16 +165,17 @@ class SELayer(nn.Module):
         self.broadcast_mul = ME.MinkowskiBroadcastMultiplication()
 
     def forward(self, x):
-        pooled = self.pooling(x)
         lin1, act, lin2, gate = self.fc[0], self.fc[1], self.fc[2], self.fc[3]
         name = getattr(act, "act_name", None)
-        if (name in ("relu", "gelu") and isinstance(gate, ME.MinkowskiSigmoid) and pooled.F.is_cuda
-                and lin1.linear.out_features <= MAX_SE_HIDDEN):
-            # the excitation MLP on [B, C] as one fused launch (two in the backward pass): csrc/se.hip
-            s = pooled._like(se_excite(pooled.F, lin1.linear, name, lin2.linear))
-        else:
-            s = self.fc(pooled)
-        return self.broadcast_mul(x, s)
+        if (name in ("relu", "gelu") and isinstance(gate, ME.MinkowskiSigmoid) and x.F.is_cuda
+                and lin1.linear.out_features <= MAX_SE_HIDDEN and x._ts != 0 and x.F.shape[1] % 4 == 0):
+            # pooling + excitation MLP + broadcast multiplication as one autograd node (csrc/se.hip, pool.hip):
+            # 3 launches forward, 4 backward, and no gradient addition where x feeds both branches
+            cm, ts = x.coordinate_manager, x._ts
+            return x._like(se_layer(x.F, cm.level(ts).coords, cm.batch_ptr(ts), cm.batch_size, lin1.linear, name,
+                                    lin2.linear))
+        pooled = self.pooling(x)
+        return self.broadcast_mul(x, self.fc(pooled))
 
 
 class SEBasicBlock(BasicBlock):

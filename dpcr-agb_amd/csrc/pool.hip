@@ -227,6 +227,29 @@ __global__ void k_segment_broadcast(const float* __restrict__ S, const int32_t* 
     *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = s;
 }
 
+// out[r,c] = M[r,c] * S[batch(r),c] + T[batch(r),c] / rows(batch(r)): the input gradient of the squeeze-excite layer
+// (product-rule term of the broadcast multiplication + the gradient that reaches the rows through the average pooling)
+// in one pass, instead of two broadcast kernels and an addition
+__global__ void k_segment_scale_add(const float* __restrict__ S, const float* __restrict__ T,
+                                    const int32_t* __restrict__ coords, const int32_t* __restrict__ ptr,
+                                    const float* __restrict__ M, int ldm, float* __restrict__ out, int ldo, int n,
+                                    int C4) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4);
+    int c = (int)(t % C4) * 4;
+    if (r >= n) return;
+    int b = coords[4 * (long long)r];
+    const float4 s = *reinterpret_cast<const float4*>(S + (long long)b * (C4 * 4) + c);
+    const float4 g = *reinterpret_cast<const float4*>(T + (long long)b * (C4 * 4) + c);
+    const float inv = 1.f / (float)(ptr[b + 1] - ptr[b]);
+    const float4 m = *reinterpret_cast<const float4*>(M + (long long)r * ldm + c);
+    float4 o;
+    // same operation order as the unfused path: (m * s) + (g * inv)
+    o.x = m.x * s.x + g.x * inv; o.y = m.y * s.y + g.y * inv;
+    o.z = m.z * s.z + g.z * inv; o.w = m.w * s.w + g.w * inv;
+    *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = o;
+}
+
 // gradient of global max pooling: dX = 0 except dX[arg[b,c], c] = dY[b,c]
 __global__ void k_segment_max_bwd(const float* __restrict__ dY, const int32_t* __restrict__ arg, float* dX, int ldx,
                                   int B, int C) {
@@ -303,6 +326,19 @@ int agb_segment_broadcast(const float* S, const int32_t* coords, const int32_t* 
     hipLaunchKernelGGL(k_segment_broadcast, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, S, coords,
                        ptr, M, ldm, out, ldo, n, C / 4, average);
     AGB_CHECK_LAUNCH("agb_segment_broadcast");
+    return AGB_OK;
+}
+
+// out[r,:] = M[r,:] * S[batch(r),:] + T[batch(r),:] / rows(batch(r));  S, T [B, C]; M, out [n, C]
+int agb_segment_scale_add(const float* S, const float* T, const int32_t* coords, const int32_t* ptr, const float* M,
+                          int ldm, float* out, int ldo, int n, int C, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldo % 4 == 0 && ldm % 4 == 0, "agb_segment_scale_add: C/ld must be multiples of 4");
+    AGB_CHECK_ARG(S && T && M, "agb_segment_scale_add: S, T and M are required");
+    if (n == 0) return AGB_OK;
+    long long total = (long long)n * (C / 4);
+    hipLaunchKernelGGL(k_segment_scale_add, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, S, T, coords,
+                       ptr, M, ldm, out, ldo, n, C / 4);
+    AGB_CHECK_LAUNCH("agb_segment_scale_add");
     return AGB_OK;
 }
 

@@ -146,6 +146,10 @@ int agb_segment_reduce(const float* A, int lda, const float* Bm, int ldb, const 
 /* out[r,:] = S[batch(r),:] (/ rows of the batch if average) (* M[r,:] if M) */
 int agb_segment_broadcast(const float* S, const int32_t* coords, const int32_t* ptr, const float* M, int ldm,
                           float* out, int ldo, int n, int C, int average, void* stream);
+/* out[r,:] = M[r,:] * S[batch(r),:] + T[batch(r),:] / rows(batch(r)): input gradient of the squeeze-excite layer
+ * (SELayer, senet_block.py:33-50: global average pooling -> fc -> broadcast multiplication) in one pass. */
+int agb_segment_scale_add(const float* S, const float* T, const int32_t* coords, const int32_t* ptr, const float* M,
+                          int ldm, float* out, int ldo, int n, int C, void* stream);
 /* dX[argmax[b,c], c] = dY[b,c]; dX zero-filled by the caller */
 int agb_segment_max_bwd(const float* dY, const int32_t* argmax, float* dX, int ldx, int B, int C, void* stream);
 

@@ -158,3 +158,37 @@ def test_se_excitation_mlp(device, act, B, C):
     assert rel(pg.grad, pr.grad) < 1e-4
     for a, b in ((l1.weight, r1.weight), (l1.bias, r1.bias), (l2.weight, r2.weight), (l2.bias, r2.bias)):
         assert rel(a.grad, b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("act,C", [("relu", 64), ("gelu", 128)])
+def test_se_layer_one_node(device, act, C):
+    """The whole SELayer (average pooling -> fc -> broadcast multiplication, senet_block.py:33-50) as one autograd node
+    vs the same composition in fp64: output, input gradient (both branches summed in the fused kernel) and the four
+    parameter gradients.  Ragged batch: plots of different sizes, one of them a single row."""
+    from dpcr_agb_amd.se_ops import se_layer
+    torch.manual_seed(C)
+    sizes = [700, 1, 1300, 257]
+    B, n = len(sizes), sum(sizes)
+    batch = torch.cat([torch.full((s,), i, dtype=torch.int32) for i, s in enumerate(sizes)])
+    coords = torch.zeros(n, 4, dtype=torch.int32)
+    coords[:, 0] = batch
+    ptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32)
+    H = C // 16
+    l1, l2 = torch.nn.Linear(C, H), torch.nn.Linear(H, C)
+    r1, r2 = torch.nn.Linear(C, H).double(), torch.nn.Linear(H, C).double()
+    r1.load_state_dict({k: v.double() for k, v in l1.state_dict().items()})
+    r2.load_state_dict({k: v.double() for k, v in l2.state_dict().items()})
+    l1, l2 = l1.to(device), l2.to(device)
+    x, g = torch.randn(n, C), torch.randn(n, C)
+    xg = x.to(device).requires_grad_(True)
+    out = se_layer(xg, coords.to(device), ptr.to(device), B, l1, act, l2)
+    out.backward(g.to(device))
+    xr = x.double().requires_grad_(True)
+    pooled = torch.stack([xr[ptr[i]:ptr[i + 1]].mean(0) for i in range(B)])
+    sr = torch.sigmoid(r2(ACTS[act](r1(pooled))))
+    outr = xr * sr[batch.long()]
+    outr.backward(g.double())
+    assert rel(out, outr) < 1e-5
+    assert rel(xg.grad, xr.grad) < 1e-4
+    for a, b in ((l1.weight, r1.weight), (l1.bias, r1.bias), (l2.weight, r2.weight), (l2.bias, r2.bias)):
+        assert rel(a.grad, b.grad) < 1e-4
