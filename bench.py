@@ -85,8 +85,8 @@ def pmc_traffic(kernel):
     return None
 
 
-def roofline_from_profile(prof):
-    """Group launches by kernel flavour; the dominant one (largest total time) is reported."""
+def group_profile(prof, table=False):
+    """Group the recorded launches by kernel flavour: name -> dict(ms, n, bytes, flops)."""
     groups = {}
     pair_cache = {}
     for rec in prof:
@@ -105,26 +105,31 @@ def roofline_from_profile(prof):
         g["n"] += 1
         g["bytes"] += byts
         g["flops"] += flops
-    # per-layer table (stderr): where the conv time goes
-    layers = {}
-    for rec in prof:
-        if rec["pairs"] is None:
-            continue
-        key = (rec["kind"], rec["K3"], rec["cin"], rec["cout"], rec["rows"] // 1000)
-        pairs = pair_cache[id(rec["pairs"])]
-        e = layers.setdefault(key, [0, 0.0, 0.0, 0])
-        e[0] += 1
-        e[1] += rec["start"].elapsed_time(rec["end"])
-        e[2] += 2.0 * pairs * rec["cin"] * rec["cout"]
-        e[3] += pairs
-    for key, (cnt, ms, fl, pr) in sorted(layers.items(), key=lambda kv: -kv[1][1])[:40]:
-        kind, K3, cin, cout, krows = key
-        log(f"  {kind:5s} K3={K3:3d} {cin:4d}->{cout:4d} rows~{krows:4d}k  n={cnt:3d}  {ms / cnt * 1e3:8.1f} us/launch  "
-            f"{fl / (ms / 1e3) / 1e12:6.1f} TF  density={pr / cnt / (K3 * max(krows, 1) * 1000.0):.2f}")
-    if not groups:
-        return None, {}
-    dom = max(groups, key=lambda k: groups[k]["ms"])
-    g = groups[dom]
+    if table:   # per-layer table (stderr): where the conv time goes
+        layers = {}
+        for rec in prof:
+            if rec["pairs"] is None:
+                continue
+            key = (rec["kind"], rec["K3"], rec["cin"], rec["cout"], rec["rows"] // 1000)
+            pairs = pair_cache[id(rec["pairs"])]
+            e = layers.setdefault(key, [0, 0.0, 0.0, 0])
+            e[0] += 1
+            e[1] += rec["start"].elapsed_time(rec["end"])
+            e[2] += 2.0 * pairs * rec["cin"] * rec["cout"]
+            e[3] += pairs
+        for key, (cnt, ms, fl, pr) in sorted(layers.items(), key=lambda kv: -kv[1][1])[:40]:
+            kind, K3, cin, cout, krows = key
+            log(f"  {kind:5s} K3={K3:3d} {cin:4d}->{cout:4d} rows~{krows:4d}k  n={cnt:3d}  {ms / cnt * 1e3:8.1f} us/launch  "
+                f"{fl / (ms / 1e3) / 1e12:6.1f} TF  density={pr / cnt / (K3 * max(krows, 1) * 1000.0):.2f}")
+    return groups
+
+
+def dominant_kernel(groups):
+    return max(groups, key=lambda k: groups[k]["ms"]) if groups else None
+
+
+def roofline_of(dom, g):
+    """Roofline entry of one kernel group (algorithmic bytes / flops of SURVEY.md §8(d) over its measured time)."""
     secs = g["ms"] / 1e3
     intensity = g["flops"] / g["bytes"]
     ridge = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
@@ -138,10 +143,13 @@ def roofline_from_profile(prof):
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom))
     roof.update(kernel=dom, launches=g["n"], avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2),
                 alg_bytes_per_launch=round(g["bytes"] / g["n"]), alg_flops_per_launch=round(g["flops"] / g["n"]))
-    summary = {k: dict(total_ms=round(v["ms"], 3), launches=v["n"],
-                       gbs=round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1),
-                       tflops=round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)) for k, v in groups.items()}
-    return roof, summary
+    return roof
+
+
+def kernel_summary(groups):
+    return {k: dict(total_ms=round(v["ms"], 3), launches=v["n"],
+                    gbs=round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1),
+                    tflops=round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)) for k, v in groups.items()}
 
 
 def usable_cores():
@@ -268,21 +276,35 @@ def main():
     gc.freeze()
     gc.disable()
     log(f"model + {len(pool)} batches resident ({voxels:.0f} voxels/plot); warmup")
+    # HIP events around a launch cost ~6 us of queue bubbles each side.  Every sparse-conv launch is bracketed only in
+    # up to three (untimed) warmup steps: that gives the per-kernel table and tells which kernel dominates.  Inside the
+    # timed region only that kernel is bracketed, in every EV_EVERY-th step.
+    EV_EVERY = 5   # coprime with the pool of 4 batches: the bracketed steps cycle through all of them
+    n_instr = min(3, args.warmup)
+    prof_all = []
     for i in range(args.warmup):
+        if rank == 0 and i >= args.warmup - n_instr:
+            sparse_ops.PROFILE, sparse_ops.PROFILE_FILTER = prof_all, None
         step(i)
+        sparse_ops.PROFILE = None
         if i == 0:
             torch.cuda.synchronize()
             log("first step done")
     torch.cuda.synchronize()
+    groups_all = group_profile(prof_all, table=True) if rank == 0 else {}
+    dom = dominant_kernel(groups_all)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if rank == 0:
-        sparse_ops.PROFILE = []
+    prof = []
     t0 = time.perf_counter()
     step_events = []
     for i in range(args.steps):
+        if rank == 0 and i % EV_EVERY == 0:   # (no warmup step to pick the kernel from: bracket them all)
+            sparse_ops.PROFILE = prof
+            sparse_ops.PROFILE_FILTER = (lambda rec: kernel_of(rec) == dom) if dom is not None else None
         step(args.warmup + i)
+        sparse_ops.PROFILE = None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         step_events.append(ev)
@@ -291,7 +313,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof, sparse_ops.PROFILE = sparse_ops.PROFILE, None
+    sparse_ops.PROFILE_FILTER = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -308,7 +330,14 @@ def main():
         f"{hm[len(hm) // 2]:.2f} ms, min {hm[0]:.2f} ms (GPU-bound when well below ms_per_step)")
 
     if rank == 0:
-        roof, summary = roofline_from_profile(prof or [])
+        groups_timed = group_profile(prof, table=not groups_all)
+        if dom is None:
+            dom, groups_all = dominant_kernel(groups_timed), groups_timed
+        roof = None
+        if dom in groups_timed:
+            roof = roofline_of(dom, groups_timed[dom])
+            roof["timed_steps_bracketed"] = len(range(0, args.steps, EV_EVERY))
+        summary = kernel_summary(groups_all)
         line = {
             "metric": "training plots/sec (16k-pt NFI plots) MSENet14",
             "value": round(world * args.batch * args.steps / elapsed, 2),
@@ -322,7 +351,7 @@ def main():
                                    f"~{voxels:.0f} voxels/plot, fwd+bwd+AdaBelief incl. coordinate hash/kernel maps",
                        "global_batch": gb, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
             "roofline": roof,
-            "kernels": summary,
+            "kernels": summary, "kernels_from": f"{n_instr} fully bracketed warmup step(s), outside the timed region",
         }
         if world == 1 and not args.no_cpu_baseline:
             stats = (model.reg_center_targets.cpu(), model.reg_scale_targets.cpu(), model.reg_weights.cpu())

@@ -24,12 +24,18 @@ _lib.declare("agb_spconv_fwd_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _li
 
 # When set to a list, every sparse-conv launch appends
 #   dict(kind, K3, cin, cout, rows, pairs (device int64 tensor or None), start, end (torch.cuda.Event))
-# bench.py uses this to time the dominant kernel with HIP events on the launch stream.
+# bench.py uses this to time the dominant kernel with HIP events on the launch stream.  PROFILE_FILTER (a predicate over
+# the same fields, events excluded) restricts the instrumentation: an event pair costs ~6 us of queue bubbles around
+# the launch it brackets, so the timed region of the benchmark only brackets the kernel the roofline is quoted on.
 PROFILE = None
+PROFILE_FILTER = None
 
 
-def _prof_begin():
+def _prof_begin(kind=None, K3=0, cin=0, cout=0, rows=0, perm=False, split=1):
     if PROFILE is None:
+        return None
+    if PROFILE_FILTER is not None and not PROFILE_FILTER(dict(kind=kind, K3=K3, cin=cin, cout=cout, rows=rows, perm=perm,
+                                                              split=split)):
         return None
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
@@ -74,7 +80,7 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     n_tiles = 0
     if plan is not None:
         perm, tile_cls, cls_tab, n_tiles = plan
-    ev = _prof_begin()
+    ev = _prof_begin(kind, K3, cin, cout, n_out, plan is not None, split)
     prec = _PREC_ID.get(CONV_PRECISION, 0) if (w_kmajor is not None and cin >= 12) else 0
     if prec:
         _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), nbr.stride(0), int(kflip),
@@ -152,7 +158,7 @@ class SparseConvFunction(torch.autograd.Function):
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
-            ev = _prof_begin()
+            ev = _prof_begin("wgrad", K3, cin_p, cout_p, n_out)
             _lib.call("agb_spconv_bwd_weight", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
                       _P(dwp), n_out, K3, cin_p, cout_p, _lib.stream())
             _prof_end(ev, "wgrad", K3, cin_p, cout_p, n_out, ctx.pairs)
