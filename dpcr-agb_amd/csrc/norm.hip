@@ -90,57 +90,66 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
     }
 }
 
-// block = 4 channels x 64 chunk lanes: every lane folds chunks j, j+64, ... in order, the 64 lane results are combined
-// in lane order (fixed order -> bitwise reproducible); writes mean / rstd, updates the running stats.  (64 lanes per
-// channel: with up to 2048 chunk partials the serial chain per lane stays at 32 combines.)
-#define FOLD_LANES 64
+// Chan's parallel combine of (count, mean, M2) partials; b may be empty (count 0)
+__device__ __forceinline__ void chan_combine(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    const float nt = na + nb, d = mb - ma;
+    const float r = nt > 0.f ? nb / nt : 0.f;
+    ma += d * r;
+    qa += qb + d * d * (na * r);
+    na = nt;
+}
+
+// block = 4 channels x 256 chunk lanes (1024 threads).  Lane l owns chunks l, l+256, ... (FOLD_PER = 8 of them with the
+// 2048-chunk cap of agb_bn_chunks): all of its partials are loaded up front (one memory round trip; the previous version
+// took four, plus a 64-long serial combine by one thread), folded as a binary tree in registers, across the 16 lanes of
+// a wave that share the channel with shuffles, and across the 16 waves through LDS.  The tree is fixed: results are
+// bitwise reproducible.  Writes mean / rstd, updates the running stats (and the layer's batch counter).  This tiny
+// kernel sits on the critical path of every BatchNorm (12 per step) and is latency-bound.
+#define FOLD_LANES 256
 #define FOLD_CH 4
-__global__ __launch_bounds__(256) void k_bn_stats_fold(const float* __restrict__ part, int chunks, int C, float eps,
-                                                       float momentum, float* __restrict__ mean,
-                                                       float* __restrict__ rstd, float* running_mean,
-                                                       float* running_var, long long* num_batches_tracked) {
+#define FOLD_PER 8
+__global__ __launch_bounds__(1024) void k_bn_stats_fold(const float* __restrict__ part, int chunks, int C, float eps,
+                                                        float momentum, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, float* running_mean,
+                                                        float* running_var, long long* num_batches_tracked) {
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-    __shared__ float s_n[FOLD_LANES][FOLD_CH], s_m[FOLD_LANES][FOLD_CH], s_q[FOLD_LANES][FOLD_CH];
+    __shared__ float s_n[16][FOLD_CH], s_m[16][FOLD_CH], s_q[16][FOLD_CH];
     const int cl = threadIdx.x & (FOLD_CH - 1), lane = threadIdx.x / FOLD_CH;
-    const int c = blockIdx.x * FOLD_CH + cl;
-    float na = 0.f, ma = 0.f, qa = 0.f;
-    if (c < C) {
-        // batches of 8 chunk partials: 24 independent loads in flight, then the (serial) Chan combines — a dependent
-        // load per combine made this tiny kernel take 17 us
-        for (int j0 = lane; j0 < chunks; j0 += 8 * FOLD_LANES) {
-            float nb[8], mb[8], qb[8];
+    const int c = min(blockIdx.x * FOLD_CH + cl, C - 1);   // clamped: every thread takes part in the shuffles
+    float nb[FOLD_PER], mb[FOLD_PER], qb[FOLD_PER];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * FOLD_LANES;
-                nb[u] = 0.f; mb[u] = 0.f; qb[u] = 0.f;
-                if (j < chunks) {
-                    const float* p = part + (long long)j * 3 * C;
-                    nb[u] = p[c]; mb[u] = p[C + c]; qb[u] = p[2 * C + c];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (nb[u] == 0.f) continue;
-                float nt = na + nb[u], d = mb[u] - ma;
-                ma += d * (nb[u] / nt);
-                qa += qb[u] + d * d * (na * nb[u] / nt);
-                na = nt;
-            }
+    for (int u = 0; u < FOLD_PER; ++u) {
+        const int j = lane + u * FOLD_LANES;
+        nb[u] = 0.f; mb[u] = 0.f; qb[u] = 0.f;
+        if (j < chunks) {
+            const float* p = part + (long long)j * 3 * C;
+            nb[u] = p[c]; mb[u] = p[C + c]; qb[u] = p[2 * C + c];
         }
     }
-    s_n[lane][cl] = na; s_m[lane][cl] = ma; s_q[lane][cl] = qa;
+    chan_combine(nb[0], mb[0], qb[0], nb[1], mb[1], qb[1]);
+    chan_combine(nb[2], mb[2], qb[2], nb[3], mb[3], qb[3]);
+    chan_combine(nb[4], mb[4], qb[4], nb[5], mb[5], qb[5]);
+    chan_combine(nb[6], mb[6], qb[6], nb[7], mb[7], qb[7]);
+    chan_combine(nb[0], mb[0], qb[0], nb[2], mb[2], qb[2]);
+    chan_combine(nb[4], mb[4], qb[4], nb[6], mb[6], qb[6]);
+    chan_combine(nb[0], mb[0], qb[0], nb[4], mb[4], qb[4]);
+    float na = nb[0], ma = mb[0], qa = qb[0];
+    // chunks beyond FOLD_PER * FOLD_LANES (not produced by agb_bn_chunks; kept for generality)
+    for (int j = lane + FOLD_PER * FOLD_LANES; j < chunks; j += FOLD_LANES) {
+        const float* p = part + (long long)j * 3 * C;
+        chan_combine(na, ma, qa, p[c], p[C + c], p[2 * C + c]);
+    }
+    // the 16 chunk lanes of this wave that share the channel sit FOLD_CH threads apart
+    for (int o = FOLD_CH; o < 64; o *= 2) {
+        const float n2 = __shfl_down(na, o), m2 = __shfl_down(ma, o), q2 = __shfl_down(qa, o);
+        chan_combine(na, ma, qa, n2, m2, q2);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < FOLD_CH) { s_n[wave][cl] = na; s_m[wave][cl] = ma; s_q[wave][cl] = qa; }
     __syncthreads();
-    if (lane == 0 && c < C) {
-        na = 0.f; ma = 0.f; qa = 0.f;
-        for (int j = 0; j < FOLD_LANES; ++j) {
-            float nb = s_n[j][cl];
-            if (nb == 0.f) continue;
-            float mb = s_m[j][cl], qb = s_q[j][cl];
-            float nt = na + nb, d = mb - ma;
-            ma += d * (nb / nt);
-            qa += qb + d * d * (na * nb / nt);
-            na = nt;
-        }
+    if (threadIdx.x < FOLD_CH && blockIdx.x * FOLD_CH + cl < C) {
+        na = s_n[0][cl]; ma = s_m[0][cl]; qa = s_q[0][cl];
+        for (int w = 1; w < 16; ++w) chan_combine(na, ma, qa, s_n[w][cl], s_m[w][cl], s_q[w][cl]);
         float var_b = na > 0.f ? qa / na : 0.f;
         mean[c] = ma;
         rstd[c] = rsqrtf(var_b + eps);
@@ -256,14 +265,15 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
     }
 }
 
+#define BFOLD_LANES 64   // 4 channels x 64 chunk lanes per 256-thread block
 __global__ __launch_bounds__(256) void k_bn_bwd_fold(const float* __restrict__ part, int chunks, int C,
                                                      float* dbeta, float* dgamma, float* colsum) {
-    __shared__ float s_a[FOLD_LANES][FOLD_CH], s_b[FOLD_LANES][FOLD_CH];
+    __shared__ float s_a[BFOLD_LANES][FOLD_CH], s_b[BFOLD_LANES][FOLD_CH];
     const int cl = threadIdx.x & (FOLD_CH - 1), lane = threadIdx.x / FOLD_CH;
     const int c = blockIdx.x * FOLD_CH + cl;
     float a = 0.f, b = 0.f;
     if (c < C) {
-        for (int j = lane; j < chunks; j += FOLD_LANES) {
+        for (int j = lane; j < chunks; j += BFOLD_LANES) {
             const float* p = part + (long long)j * 2 * C;
             a += p[c];
             b += p[C + c];
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_fold(const float* __restrict__ p
     __syncthreads();
     if (lane == 0 && c < C) {
         a = 0.f; b = 0.f;
-        for (int j = 0; j < FOLD_LANES; ++j) { a += s_a[j][cl]; b += s_b[j][cl]; }
+        for (int j = 0; j < BFOLD_LANES; ++j) { a += s_a[j][cl]; b += s_b[j][cl]; }
         dbeta[c] = a;
         dgamma[c] = b;
         if (colsum) colsum[c] = 0.f;   // accumulated by the apply pass that follows
@@ -454,7 +464,7 @@ int agb_bn_stats_tracked(const float* X, int ldx, int n, int C, float eps, float
         int chunks = agb_bn_chunks(n);
         hipLaunchKernelGGL(k_bn_stats_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, n, C,
                            rows_per_chunk(n, chunks), part);
-        hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(256), 0, s, part, chunks, C, eps, momentum,
+        hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, eps, momentum,
                            mean, rstd, running_mean, running_var, num_batches_tracked);
     }
     AGB_CHECK_LAUNCH("agb_bn_stats");

@@ -792,11 +792,13 @@ __global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_o
 
 // WT[k][c][r] = W[k][r][c]: the data gradient multiplies by W[k]^T, and the weights change every step, so this runs
 // once per layer per step.  64x64 tiles through LDS, float4 on both sides (R, C multiples of 4).
+// zero (optional, same element count): the layer's weight-gradient buffer, cleared here instead of by a separate fill.
 __global__ __launch_bounds__(256) void k_weight_transpose(const float* __restrict__ W, float* __restrict__ WT, int R,
-                                                          int C) {
+                                                          int C, float* __restrict__ zero) {
     __shared__ float tile[64][65];
     const float* w = W + (long long)blockIdx.z * R * C;
     float* wt = WT + (long long)blockIdx.z * R * C;
+    float* zp = zero ? zero + (long long)blockIdx.z * R * C : nullptr;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int g = threadIdx.x & 15, h = threadIdx.x >> 4;
 #pragma unroll
@@ -814,6 +816,7 @@ __global__ __launch_bounds__(256) void k_weight_transpose(const float* __restric
         if (c0 + c < C && r0 + 4 * g < R) {
             float4 v = make_float4(tile[4 * g + 0][c], tile[4 * g + 1][c], tile[4 * g + 2][c], tile[4 * g + 3][c]);
             *reinterpret_cast<float4*>(wt + (long long)(c0 + c) * R + r0 + 4 * g) = v;
+            if (zp) *reinterpret_cast<float4*>(zp + (long long)(c0 + c) * R + r0 + 4 * g) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }
@@ -1386,13 +1389,17 @@ int agb_spconv_cmp_occupancy(int R) {
 }
 
 // WT [K3][C][R] = transpose of W [K3][R][C] per offset (the weights the data gradient multiplies by); R, C % 4 == 0.
-int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C, void* stream) {
+int agb_spconv_weight_transpose_z(const float* W, float* WT, float* zero, int K3, int R, int C, void* stream) {
     AGB_CHECK_ARG(K3 >= 1 && R >= 4 && C >= 4 && R % 4 == 0 && C % 4 == 0 && K3 <= 65535,
                   "agb_spconv_weight_transpose: K3 %d, R %d, C %d (multiples of 4)", K3, R, C);
     hipLaunchKernelGGL(k_weight_transpose, dim3(agb_cdiv(C, 64), agb_cdiv(R, 64), K3), dim3(256), 0,
-                       (hipStream_t)stream, W, WT, R, C);
+                       (hipStream_t)stream, W, WT, R, C, zero);
     AGB_CHECK_LAUNCH("agb_spconv_weight_transpose");
     return AGB_OK;
+}
+
+int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C, void* stream) {
+    return agb_spconv_weight_transpose_z(W, WT, nullptr, K3, R, C, stream);
 }
 
 int agb_spconv_set_cmp_mode(int mode) {

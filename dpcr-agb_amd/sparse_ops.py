@@ -137,7 +137,7 @@ class SparseConvFunction(torch.autograd.Function):
         dy = dy.contiguous()
         if cout_p != cout:
             dy = F.pad(dy, (0, cout_p - cout)).contiguous()
-        dx = dk = db = None
+        dx = dk = db = dwp = None
         if ctx.needs_input_grad[0]:
             # dX[q] = sum_k dY[nbrT[k][q]] @ W[k]^T : same implicit GEMM with the transposed weights
             lp = CONV_PRECISION in _PREC_ID and cout_p >= 12
@@ -147,7 +147,9 @@ class SparseConvFunction(torch.autograd.Function):
             if not lp:
                 w = w.contiguous()
                 wt2d = torch.empty(K3 * cout_p, cin_p, dtype=torch.float32, device=w.device)
-                _lib.call("agb_spconv_weight_transpose", _P(w), _P(wt2d), K3, cin_p, cout_p, _lib.stream())
+                if ctx.needs_input_grad[1]:   # the weight-gradient buffer is cleared by the same launch
+                    dwp = torch.empty(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
+                _lib.call("agb_spconv_weight_transpose_z", _P(w), _P(wt2d), _P(dwp), K3, cin_p, cout_p, _lib.stream())
             if has_T:
                 plan = ctx.plan if cout_p >= 12 else None
                 dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, plan,
@@ -157,7 +159,8 @@ class SparseConvFunction(torch.autograd.Function):
                                          wkm)
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
+            if dwp is None:
+                dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
             ev = _prof_begin("wgrad", K3, cin_p, cout_p, n_out)
             _lib.call("agb_spconv_bwd_weight", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
                       _P(dwp), n_out, K3, cin_p, cout_p, _lib.stream())

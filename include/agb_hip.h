@@ -112,6 +112,9 @@ int agb_spconv_set_cmp_mode(int mode);
  * dX = sum_k dY[nbrT[k]] @ W[k]^T, rebuilt once per layer per step (ME does the same inside its backward GEMMs with
  * a transposed-operand flag: MinkowskiEngine/src/convolution_kernel.cu ConvolutionBackwardKernelGPU). */
 int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C, void* stream);
+/* the same, and `zero` (K3*R*C floats, or NULL) is cleared in the same pass: the weight-gradient buffer
+ * agb_spconv_bwd_weight accumulates into, saving one fill launch per layer */
+int agb_spconv_weight_transpose_z(const float* W, float* WT, float* zero, int K3, int R, int C, void* stream);
 int agb_spconv_cmp_occupancy(int rows_per_wave);  /* resident workgroups per CU of that kernel (tuning aid) */
 /* Low-precision MFMA operands, fp32 accumulate and I/O: precision 1 = bf16 (BASELINE config 5), 2 = split-bf16 x3
  * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi: fp32-level accuracy at 3/16 of the fp32 MFMA cost).  Same contract as

@@ -137,6 +137,11 @@ def test_weight_transpose_exact(device, K3, R, C):
     wt = torch.full((K3, C, R), float("nan"), device=device)
     _lib.call("agb_spconv_weight_transpose", w.data_ptr(), wt.data_ptr(), K3, R, C, _lib.stream())
     assert torch.equal(wt, w.transpose(1, 2))
+    # the variant that also clears the weight-gradient buffer of the layer in the same pass
+    wt2 = torch.full((K3, C, R), float("nan"), device=device)
+    z = torch.full((K3, R, C), float("nan"), device=device)
+    _lib.call("agb_spconv_weight_transpose_z", w.data_ptr(), wt2.data_ptr(), z.data_ptr(), K3, R, C, _lib.stream())
+    assert torch.equal(wt2, wt) and float(z.abs().sum()) == 0.0
 
 
 @pytest.mark.parametrize("rows_per_wave", [64, 128])
