@@ -36,20 +36,37 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 #define SE_MAX_H 256
 
-// grid B, block 256.  h_pre [B,H] and s [B,C] are written (saved for the backward pass).
+// grid (B, column slabs), block 256.  h_pre [B,H] and s [B,C] are written (saved for the backward pass).
+// Hidden layer: thread (j-group, slice) — 8 slices of 4 consecutive channels each read one contiguous 128-B piece of
+// row j of W1 per step, all loads of a thread independent; the 8 slice partials meet by shuffles.  (One wave per hidden
+// unit with a shuffle reduction per unit serialised 8 memory round trips: 30 us on the 512-channel level.)
 __global__ __launch_bounds__(256) void k_se_fwd(const float* __restrict__ P, const float* __restrict__ W1,
                                                 const float* __restrict__ b1, const float* __restrict__ W2,
                                                 const float* __restrict__ b2, int C, int H, int act,
                                                 float* __restrict__ h_pre, float* __restrict__ S) {
     __shared__ float s_a[SE_MAX_H];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, sl = threadIdx.x & 7, jg = threadIdx.x >> 3;
     const float* p = P + (long long)b * C;
-    for (int j = wave; j < H; j += 4) {
-        const float* w = W1 + (long long)j * C;
+    for (int j0 = 0; j0 < H; j0 += 32) {
+        const int j = j0 + jg;
         float acc = 0.f;
-        for (int c = lane; c < C; c += 64) acc += w[c] * p[c];
-        acc = wave_sum(acc);
-        if (lane == 0) {
+        if (j < H) {
+            const float* w = W1 + (long long)j * C;
+            if ((C & 3) == 0) {
+#pragma unroll 4
+                for (int c = 4 * sl; c < C; c += 32) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w + c);
+                    const float4 pv = *reinterpret_cast<const float4*>(p + c);
+                    acc += wv.x * pv.x + wv.y * pv.y + wv.z * pv.z + wv.w * pv.w;
+                }
+            } else {
+                for (int c = sl; c < C; c += 8) acc += w[c] * p[c];
+            }
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        if (sl == 0 && j < H) {
             float h = acc + (b1 ? b1[j] : 0.f);
             if (blockIdx.y == 0) h_pre[(long long)b * H + j] = h;
             s_a[j] = se_act(h, act);
@@ -61,19 +78,28 @@ __global__ __launch_bounds__(256) void k_se_fwd(const float* __restrict__ P, con
     for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {
         const float* w = W2 + (long long)c * H;
         float acc = b2 ? b2[c] : 0.f;
-        for (int j = 0; j < H; ++j) acc += w[j] * s_a[j];
+        if ((H & 3) == 0) {
+#pragma unroll 4
+            for (int j = 0; j < H; j += 4) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + j);
+                acc += wv.x * s_a[j] + wv.y * s_a[j + 1] + wv.z * s_a[j + 2] + wv.w * s_a[j + 3];
+            }
+        } else {
+            for (int j = 0; j < H; ++j) acc += w[j] * s_a[j];
+        }
         S[(long long)b * C + c] = 1.f / (1.f + expf(-acc));
     }
 }
 
-// grid B, block 256: per-plot vectors dz2 [B,C], dh [B,H] (scratch for pass B) and dP [B,C]
+// grid (B, column slabs), block 256: per-plot vectors dz2 [B,C], dh [B,H] (scratch for pass B) and dP [B,C]
 __global__ __launch_bounds__(256) void k_se_bwd_a(const float* __restrict__ W1, const float* __restrict__ W2, int C,
                                                   int H, int act, const float* __restrict__ h_pre,
                                                   const float* __restrict__ S, const float* __restrict__ dS,
                                                   float* __restrict__ dz2, float* __restrict__ dh,
                                                   float* __restrict__ dP) {
     __shared__ float s_dh[SE_MAX_H];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_red[8][32];
+    const int b = blockIdx.x;
     // every workgroup of the plot needs the whole dz2 vector for the hidden-layer gradient: each keeps a private copy in
     // the scratch slice dz2[blockIdx.y][b] (slice 0 is the one pass B reads)
     float* zw = dz2 + ((long long)blockIdx.y * gridDim.x + b) * C;
@@ -83,52 +109,76 @@ __global__ __launch_bounds__(256) void k_se_bwd_a(const float* __restrict__ W1, 
     }
     __syncthreads();   // read back below by other threads of the workgroup
     const float* z = zw;
-    for (int j = wave; j < H; j += 4) {
+    // dh[j] = act'(h[j]) * sum_c z[c] W2[c][j]: thread (slice, j) with j fastest — the 32 lanes of a slice read one
+    // contiguous piece of row c of W2; 8 slices take rows c = slice, slice + 8, ...; partials meet in LDS
+    const int jl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (int j0 = 0; j0 < H; j0 += 32) {
+        const int j = j0 + jl;
         float acc = 0.f;
-        for (int c = lane; c < C; c += 64) acc += z[c] * W2[(long long)c * H + j];
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            float g = acc * se_act_grad(h_pre[(long long)b * H + j], act);
+        if (j < H) {
+#pragma unroll 4
+            for (int c = sl; c < C; c += 8) acc += z[c] * W2[(long long)c * H + j];
+        }
+        s_red[sl][jl] = acc;
+        __syncthreads();
+        if (threadIdx.x < 32 && j < H) {
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += s_red[u][jl];
+            float g = t * se_act_grad(h_pre[(long long)b * H + j], act);
             if (blockIdx.y == 0) dh[(long long)b * H + j] = g;
             s_dh[j] = g;
         }
+        __syncthreads();
     }
-    __syncthreads();
     for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {
         float acc = 0.f;
+#pragma unroll 4
         for (int j = 0; j < H; ++j) acc += s_dh[j] * W1[(long long)j * C + c];
         dP[(long long)b * C + c] = acc;
     }
 }
 
-// one thread per weight element (2*C*H) plus the biases (C + H); sums over the plots in plot order
-__global__ void k_se_bwd_b(const float* __restrict__ P, int C, int H, int B, int act,
-                           const float* __restrict__ h_pre, const float* __restrict__ dz2,
-                           const float* __restrict__ dh, float* __restrict__ dW1, float* __restrict__ db1,
-                           float* __restrict__ dW2, float* __restrict__ db2) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// eight lanes per weight element (2*C*H of them) or bias (C + H): lane q sums plots q, q+8, ... (independent loads, one
+// memory round trip for B <= 32), the eight partial sums meet by shuffles in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void k_se_bwd_b(const float* __restrict__ P, int C, int H, int B, int act,
+                                                  const float* __restrict__ h_pre, const float* __restrict__ dz2,
+                                                  const float* __restrict__ dh, float* __restrict__ dW1,
+                                                  float* __restrict__ db1, float* __restrict__ dW2,
+                                                  float* __restrict__ db2, int shift) {
+    // shift 3: eight lanes per element (small layers: latency-bound); shift 0: one thread per element (C*H >= 64 k:
+    // enough threads already, eight times more only add overhead — 33 vs 15 us at C = 2048)
+    const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)(gt >> shift), q = (int)(gt & ((1 << shift) - 1)), st = 1 << shift;
     const int nw = C * H;
-    if (t < nw) {                       // dW1[j][c] = sum_b dh[b][j] * p[b][c]        (c fastest: coalesced p reads)
+    float acc = 0.f;
+    if (t < nw) {                       // dW1[j][c] = sum_b dh[b][j] * p[b][c]        (c fastest)
         const int j = t / C, c = t % C;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dh[(long long)b * H + j] * P[(long long)b * C + c];
-        dW1[t] = acc;
+#pragma unroll 4
+        for (int b = q; b < B; b += st) acc += dh[(long long)b * H + j] * P[(long long)b * C + c];
     } else if (t < 2 * nw) {            // dW2[c][j] = sum_b dz2[b][c] * act(h[b][j])
         const int u = t - nw, c = u / H, j = u % H;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dz2[(long long)b * C + c] * se_act(h_pre[(long long)b * H + j], act);
-        dW2[u] = acc;
+#pragma unroll 4
+        for (int b = q; b < B; b += st) acc += dz2[(long long)b * C + c] * se_act(h_pre[(long long)b * H + j], act);
     } else if (t < 2 * nw + C) {
         const int c = t - 2 * nw;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dz2[(long long)b * C + c];
-        if (db2) db2[c] = acc;
+#pragma unroll 4
+        for (int b = q; b < B; b += st) acc += dz2[(long long)b * C + c];
     } else if (t < 2 * nw + C + H) {
         const int j = t - 2 * nw - C;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dh[(long long)b * H + j];
-        if (db1) db1[j] = acc;
+#pragma unroll 4
+        for (int b = q; b < B; b += st) acc += dh[(long long)b * H + j];
     }
+    if (shift == 3) {
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+    }
+    if (q != 0) return;
+    if (t < nw) dW1[t] = acc;
+    else if (t < 2 * nw) dW2[t - nw] = acc;
+    else if (t < 2 * nw + C) { if (db2) db2[t - 2 * nw] = acc; }
+    else if (t < 2 * nw + C + H) { if (db1) db1[t - 2 * nw - C] = acc; }
 }
 
 extern "C" {
@@ -157,9 +207,10 @@ int agb_se_mlp_bwd(const float* P, const float* W1, const float* W2, int B, int 
     if (B > 0)
         hipLaunchKernelGGL(k_se_bwd_a, dim3(B, agb_cdiv(C, 512)), dim3(256), 0, s, W1, W2, C, H, act, h_pre, S, dS, dz2, dh,
                            dP);
-    const long long total = 2LL * C * H + C + H;
+    const int shift = (long long)C * H >= 65536 ? 0 : 3;
+    const long long total = (2LL * C * H + C + H) << shift;
     hipLaunchKernelGGL(k_se_bwd_b, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, P, C, H, B, act, h_pre, dz2, dh, dW1,
-                       db1, dW2, db2);
+                       db1, dW2, db2, shift);
     AGB_CHECK_LAUNCH("agb_se_mlp_bwd");
     return AGB_OK;
 }
