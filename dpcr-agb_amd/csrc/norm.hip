@@ -265,25 +265,41 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
     }
 }
 
-#define BFOLD_LANES 64   // 4 channels x 64 chunk lanes per 256-thread block
-__global__ __launch_bounds__(256) void k_bn_bwd_fold(const float* __restrict__ part, int chunks, int C,
-                                                     float* dbeta, float* dgamma, float* colsum) {
-    __shared__ float s_a[BFOLD_LANES][FOLD_CH], s_b[BFOLD_LANES][FOLD_CH];
+// block = 4 channels x 256 chunk lanes (1024 threads), like k_bn_stats_fold: every lane loads its (up to 8) chunk
+// partials up front, adds them pairwise, the 16 lanes of a wave that share a channel meet by shuffles, the 16 waves in
+// LDS.  Fixed tree: deterministic.  (64 lanes walking 32 chunks each + one thread adding 64 partials: 19 us at 2048
+// chunks, on the critical path of every BatchNorm backward.)
+__global__ __launch_bounds__(1024) void k_bn_bwd_fold(const float* __restrict__ part, int chunks, int C,
+                                                      float* dbeta, float* dgamma, float* colsum) {
+    __shared__ float s_a[16][FOLD_CH], s_b[16][FOLD_CH];
     const int cl = threadIdx.x & (FOLD_CH - 1), lane = threadIdx.x / FOLD_CH;
-    const int c = blockIdx.x * FOLD_CH + cl;
-    float a = 0.f, b = 0.f;
-    if (c < C) {
-        for (int j = lane; j < chunks; j += BFOLD_LANES) {
+    const int c = min(blockIdx.x * FOLD_CH + cl, C - 1);
+    float av[FOLD_PER], bv[FOLD_PER];
+#pragma unroll
+    for (int u = 0; u < FOLD_PER; ++u) {
+        const int j = lane + u * FOLD_LANES;
+        av[u] = 0.f; bv[u] = 0.f;
+        if (j < chunks) {
             const float* p = part + (long long)j * 2 * C;
-            a += p[c];
-            b += p[C + c];
+            av[u] = p[c]; bv[u] = p[C + c];
         }
     }
-    s_a[lane][cl] = a; s_b[lane][cl] = b;
+    float a = ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+    float b = ((bv[0] + bv[1]) + (bv[2] + bv[3])) + ((bv[4] + bv[5]) + (bv[6] + bv[7]));
+    for (int j = lane + FOLD_PER * FOLD_LANES; j < chunks; j += FOLD_LANES) {
+        const float* p = part + (long long)j * 2 * C;
+        a += p[c]; b += p[C + c];
+    }
+    for (int o = FOLD_CH; o < 64; o *= 2) {
+        a += __shfl_down(a, o);
+        b += __shfl_down(b, o);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < FOLD_CH) { s_a[wave][cl] = a; s_b[wave][cl] = b; }
     __syncthreads();
-    if (lane == 0 && c < C) {
-        a = 0.f; b = 0.f;
-        for (int j = 0; j < BFOLD_LANES; ++j) { a += s_a[j][cl]; b += s_b[j][cl]; }
+    if (threadIdx.x < FOLD_CH && blockIdx.x * FOLD_CH + cl < C) {
+        a = s_a[0][cl]; b = s_b[0][cl];
+        for (int w = 1; w < 16; ++w) { a += s_a[w][cl]; b += s_b[w][cl]; }
         dbeta[c] = a;
         dgamma[c] = b;
         if (colsum) colsum[c] = 0.f;   // accumulated by the apply pass that follows
@@ -501,7 +517,7 @@ int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int
     int chunks = agb_bn_chunks(n);
     hipLaunchKernelGGL(k_bn_act_bwd_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY, ldy, n, C,
                        rows_per_chunk(n, chunks), mean, rstd, gamma, beta, act, part);
-    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(256), 0, s, part, chunks, C, dbeta, dgamma, colsum);
+    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, dbeta, dgamma, colsum);
     if (n > 0 && dX) {
         hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY,
                            ldy, n, C, mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx, colsum);
