@@ -15,7 +15,7 @@ def rel(a, b):
 ACTS = {"none": lambda z: z, "relu": F.relu, "gelu": F.gelu}
 
 
-@pytest.mark.parametrize("n,c", [(1, 64), (37, 4), (5000, 64), (70001, 128), (333, 1024)])
+@pytest.mark.parametrize("n,c", [(1, 64), (37, 4), (5000, 64), (70001, 128), (333, 1024), (300017, 64)])
 @pytest.mark.parametrize("act", ["none", "relu", "gelu"])
 def test_bn_act_training(device, n, c, act):
     from dpcr_agb_amd.norm_ops import batch_norm_act
@@ -134,7 +134,7 @@ def test_prefetched_input_gives_identical_step(device):
 
 
 @pytest.mark.parametrize("act", ["relu", "gelu"])
-@pytest.mark.parametrize("B,C", [(32, 64), (5, 512), (1, 2048), (32, 100)])
+@pytest.mark.parametrize("B,C", [(32, 64), (5, 512), (1, 2048), (32, 2048), (32, 100)])
 def test_se_excitation_mlp(device, act, B, C):
     """Fused squeeze-excite MLP (csrc/se.hip) vs nn.Linear -> act -> nn.Linear -> Sigmoid in fp64
     (senet_block.py:35-42), forward and every gradient."""
