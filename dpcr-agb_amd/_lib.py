@@ -41,6 +41,7 @@ _SIGNATURES = {
     "agb_spconv_split_hint": [c_int, c_int, c_int, c_int],
     "agb_spconv_set_cmp_mode": [c_int],
     "agb_spconv_cmp_occupancy": [c_int],
+    "agb_spconv_set_cmp_interleave": [c_int],
     "agb_spconv_weight_transpose": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "agb_spconv_weight_transpose_z": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "agb_parity_partition": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p],

@@ -586,8 +586,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CMP_YS 68   // LDS row stride of the running sums (floats): 16-B aligned rows, 4-bank skew per row
 #define CMP_CB 4    // 16-channel blocks per step (64 input channels)
 
+// il_shift > 0: INTERLEAVED tiles — a tile is rows_per_tile / 2^il_shift blocks of 2^il_shift consecutive rows, block j of
+// tile t being global block j * ntiles + t.  Pair density varies by region (tile work: std 19 % of the mean on the NFI
+// plots, and with ~2 tiles per resident wave slot the slowest slots set the kernel time: 796 of 1024 slots busy on
+// average); a tile that samples several regions has a third of that spread.  Row blocks keep the 32/64-byte coalescing
+// of the map reads and the x+-1 neighbour reuse; consecutive tiles still walk every region consecutively (L2).
 template <int R>
-__global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int nct, int rows_per_tile, int csplit) {
+__global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int nct, int rows_per_tile, int csplit,
+                                                   int il_shift) {
     constexpr int NJ = R / 64;
     constexpr int CB = CMP_CB;
     // row R of Ys is a sink: list padding (up to 15 entries per offset) multiplies input row 0 into it
@@ -607,6 +613,13 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     if (tile >= ntiles || jx / (nct * csplit) >= per_xcd) return;
     const int row0 = tile * rows_per_tile;
     const int row_end = min(a.n_out, row0 + rows_per_tile);
+    // local row of the tile -> row of the level (-1: past the end)
+    auto grow = [&](int rl) -> int {
+        if (il_shift == 0) return row0 + rl < row_end ? row0 + rl : -1;
+        if (rl >= rows_per_tile) return -1;
+        const int r = ((((rl >> il_shift) * ntiles + tile) << il_shift) | (rl & ((1 << il_shift) - 1)));
+        return r < a.n_out ? r : -1;
+    };
     const int n0 = ct0 * 64;
     const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
     const int NSB = Cin / (CB * 16) / csplit;            // 64-channel steps per offset handled here
@@ -625,8 +638,8 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
         const int kn = a.kflip ? (K3 - 1 - k) : k;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            int r = row0 + 64 * j + lane;
-            nv[j] = r < row_end ? a.nbr[(long long)kn * a.nbr_stride + r] : -1;
+            const int r = grow(64 * j + lane);
+            nv[j] = r >= 0 ? a.nbr[(long long)kn * a.nbr_stride + r] : -1;
         }
     };
     // pairs of offset k (whose neighbour indices are in nv) -> list k&1, padded to a multiple of 16; returns groups
@@ -767,8 +780,8 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     float* out = csplit > 1 ? a.partial + (long long)sp * a.n_out * Cout : a.Y;
     const int ldo = csplit > 1 ? Cout : a.ldy;
     for (int r = lane >> 4; r < rows_per_tile; r += 4) {
-        const int row = row0 + r;
-        if (row < row_end && n0 + c4 < Cout) {
+        const int row = grow(r);
+        if (row >= 0 && n0 + c4 < Cout) {
             float4 y = *reinterpret_cast<const float4*>(&Ys[r * CMP_YS + c4]);
             y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
             *reinterpret_cast<float4*>(out + (long long)row * ldo + n0 + c4) = y;
@@ -1029,7 +1042,10 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
                                                        const float* __restrict__ dY, int ldy,
                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
                                                        float* __restrict__ dW, int n_out, int K3, int Cin, int Cout,
-                                                       int rows_per_wg, int cin_tiles, int chunks, int m_tiles) {
+                                                       int rows_per_wg, int cin_tiles, int chunks, int m_tiles,
+                                                       int il_shift) {
+    // il_shift > 0: a row chunk is made of 2^il_shift-row blocks taken `chunks` blocks apart (see k_spconv_cmp: evens
+    // out the pair count per workgroup where the density varies by region)
     __shared__ __attribute__((aligned(16))) float As[DW_KS * 64];  // [pair][m]
     __shared__ __attribute__((aligned(16))) float Bs[DW_KS * 64];  // [pair][n]
     __shared__ int p_in[DW_MAXROWS], p_out[DW_MAXROWS];
@@ -1051,11 +1067,17 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     }
     const int n0 = blockIdx.y * 64;
     const int r_begin = chunk * rows_per_wg;
-    const int r_end = min(n_out, r_begin + rows_per_wg);
+    const int r_end = il_shift ? r_begin + rows_per_wg : min(n_out, r_begin + rows_per_wg);
     const int k = mt / cin_tiles;
     const int c0 = (mt % cin_tiles) * 64;
     const int t_r = tid >> 4, t_c = (tid & 15) * 4;
     const int32_t* nrow = nbr + (long long)k * nbr_stride;
+    // local row of the chunk -> row of the level (-1: past the end)
+    auto grow = [&](int i) -> int {
+        if (il_shift == 0) return r_begin + i;
+        const int r = ((((i >> il_shift) * chunks + chunk) << il_shift) | (i & ((1 << il_shift) - 1)));
+        return r < n_out ? r : -1;
+    };
 
     // ---- phase 1: ordered compaction of the present pairs.  All index loads are issued up front (one exposed memory
     // latency per workgroup instead of one per 256 rows: the prologue was ~30 % of a workgroup's time)
@@ -1066,7 +1088,8 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = it * 256 + tid;
-        idxs[it] = i < nrows ? nrow[r_begin + i] : -1;
+        const int gr = i < nrows ? grow(i) : -1;
+        idxs[it] = gr >= 0 ? nrow[gr] : -1;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1087,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
         if (idx >= 0) {
             int p = off + __popcll(bal & ((1ull << lane) - 1ull));
             p_in[p] = idx;
-            p_out[p] = r_begin + i;
+            p_out[p] = grow(i);
         }
         total += round;
     }
@@ -1317,17 +1340,44 @@ static int cmp_rows(const ConvArgs& a) {
 
 // Tile geometry of the pair-compacted kernel: equal-cost tiles, workgroup count a multiple of the resident-wave
 // capacity (LDS: 4 / 8 waves per CU) so that the last round of workgroups is not half empty.
-static void cmp_geometry(const ConvArgs& a, int* R_out, int* rpt_out, int* ntiles_out, int* nct_out) {
+static int g_cmp_il = -2;   // log2 of the interleave block (rows); 0 = contiguous tiles; -1 = by level size
+// Interleave block of a level with n rows.  Measured (tools/bench_conv.py --il 0,2,3,4, us per launch, contiguous /
+// 4-row / 8-row / 16-row blocks): 64->64 at 211 k rows 377 / 326 / 308 / 320; 128->128 at 61 k rows 432 / 387 / 396 / 424;
+// 256->256 at 14 k rows 416 / 390 / 401 / 452; 512->512 at 2.9 k rows 289 / - / 311 / 302 (few-row levels: contiguous).
+static int cmp_interleave(int n) {
+    if (g_cmp_il == -2) {
+        const char* e = getenv("AGB_CONV_IL");
+        g_cmp_il = e ? atoi(e) : -1;
+        if (g_cmp_il < -1 || g_cmp_il > 5) g_cmp_il = -1;
+    }
+    if (n < 8192) return 0;
+    if (g_cmp_il >= 0) return g_cmp_il;
+    return n >= 100000 ? 3 : 2;
+}
+
+static void cmp_geometry(const ConvArgs& a, int* R_out, int* rpt_out, int* ntiles_out, int* nct_out, int* il_out) {
     const int R = cmp_rows(a), nct = agb_cdiv(a.Cout, 64) * 1;
     const long long per_tile = (long long)nct * a.ksplit;
     const long long slots = (R == 128 ? 4 : 8) * 256;
     const long long rounds = ((long long)agb_cdiv(a.n_out, R) * per_tile + slots - 1) / slots;
     long long want_tiles = rounds * slots / per_tile;
     if (want_tiles < 1) want_tiles = 1;
+    const int il = cmp_interleave(a.n_out);
+    *R_out = R; *nct_out = nct; *il_out = 0;
+    if (il > 0) {
+        // tiles of `bpt` row blocks taken ntiles blocks apart
+        const int bs = 1 << il, nblk = agb_cdiv(a.n_out, bs);
+        int bpt = agb_cdiv(nblk, want_tiles);
+        if (bpt > R / bs) bpt = R / bs;
+        if (bpt >= 2) {
+            *rpt_out = bpt * bs; *ntiles_out = agb_cdiv(nblk, bpt); *il_out = il;
+            return;
+        }
+    }
     int rpt = agb_cdiv(a.n_out, want_tiles);
     if (rpt > R) rpt = R;
     if (rpt < 16) rpt = 16;
-    *R_out = R; *rpt_out = rpt; *ntiles_out = agb_cdiv(a.n_out, rpt); *nct_out = nct;
+    *rpt_out = rpt; *ntiles_out = agb_cdiv(a.n_out, rpt);
 }
 
 static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
@@ -1358,11 +1408,11 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
                                a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
     } else if (cmp_rows(a) > 0) {
-        int R, rpt, ntiles, nct;
-        cmp_geometry(a, &R, &rpt, &ntiles, &nct);
+        int R, rpt, ntiles, nct, il;
+        cmp_geometry(a, &R, &rpt, &ntiles, &nct, &il);
         dim3 grid(8 * agb_cdiv(ntiles, 8) * nct * a.ksplit), blk(64);
-        if (R == 128) hipLaunchKernelGGL((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit);
-        else hipLaunchKernelGGL((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit);
+        if (R == 128) hipLaunchKernelGGL((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
+        else hipLaunchKernelGGL((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
     } else if (conv_tile_rows(a.n_out, a.Cin, a.Cout) == 128) {
         // 128-row tiles: the W tile is reused by twice as many rows (layers with many rows, or W-heavy layers)
         hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
@@ -1400,6 +1450,13 @@ int agb_spconv_weight_transpose_z(const float* W, float* WT, float* zero, int K3
 
 int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C, void* stream) {
     return agb_spconv_weight_transpose_z(W, WT, nullptr, K3, R, C, stream);
+}
+
+// log2 of the row-block size of the interleaved tiles of the pair-compacted kernel (0: contiguous tiles; 3 / 4: 8 / 16 rows)
+int agb_spconv_set_cmp_interleave(int shift) {
+    AGB_CHECK_ARG(shift >= -1 && shift <= 5, "agb_spconv_set_cmp_interleave: shift %d (-1: by level size)", shift);
+    g_cmp_il = shift;
+    return AGB_OK;
 }
 
 int agb_spconv_set_cmp_mode(int mode) {
@@ -1554,9 +1611,14 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
         // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
         if (rows > DW_MAXROWS) rows = DW_MAXROWS;
         chunks = agb_cdiv(n_out, rows);
+        int il = chunks >= 16 ? cmp_interleave(n_out) : 0;
+        if (il > 0) {
+            const int nblk = agb_cdiv(n_out, 1 << il), bpc = (int)rows >> il;
+            chunks = agb_cdiv(nblk, bpc);
+        }
         dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
         hipLaunchKernelGGL(k_spconv_dw_cmp, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
-                           Cout, (int)rows, cin_tiles, chunks, m_tiles);
+                           Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
     }
     AGB_CHECK_LAUNCH("agb_spconv_bwd_weight");
     return AGB_OK;

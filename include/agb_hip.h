@@ -115,7 +115,12 @@ int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C,
 /* the same, and `zero` (K3*R*C floats, or NULL) is cleared in the same pass: the weight-gradient buffer
  * agb_spconv_bwd_weight accumulates into, saving one fill launch per layer */
 int agb_spconv_weight_transpose_z(const float* W, float* WT, float* zero, int K3, int R, int C, void* stream);
-int agb_spconv_cmp_occupancy(int rows_per_wave);  /* resident workgroups per CU of that kernel (tuning aid) */
+int agb_spconv_cmp_occupancy(int rows_per_wave);
+/* tiles of the pair-compacted kernel made of 2^shift-row blocks taken from regions ntiles blocks apart (0: contiguous
+ * row tiles; -1, the default: chosen by the number of rows): evens out the per-tile work where the pair density varies
+ * by region.  Tuning switch; forward / data-gradient results are bit-identical (a row's sum does not depend on the
+ * tile that holds it). */
+int agb_spconv_set_cmp_interleave(int shift);  /* resident workgroups per CU of that kernel (tuning aid) */
 /* Low-precision MFMA operands, fp32 accumulate and I/O: precision 1 = bf16 (BASELINE config 5), 2 = split-bf16 x3
  * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi: fp32-level accuracy at 3/16 of the fp32 MFMA cost).  Same contract as
  * agb_spconv_fwd_ex but the weights are K-major: Wt float[K3][Cout][Cin] (forward: the transposed kernel; data

@@ -159,6 +159,41 @@ def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride,
         _lib.call("agb_spconv_set_cmp_mode", 1)
 
 
+@pytest.mark.parametrize("shift", [3, 4])
+def test_conv_pair_compacted_interleaved_tiles(device, shift):
+    """Interleaved tiles (row blocks taken from regions ntiles blocks apart) only change which wave sums a row: the
+    output is bit-identical to the contiguous tiling, for both tile heights and with a channel split."""
+    from dpcr_agb_amd import _lib
+    import dpcr_agb_amd.me_compat as ME
+    rng = np.random.default_rng(7)
+    torch.manual_seed(7)
+    coords = random_coords(rng, 4, 3500, 26)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    n = cm.level(1).n
+    assert n >= 8192   # smaller levels always take contiguous tiles
+    nbr = cm.kernel_map(1, 3, 1)
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    try:
+        for mode, cin, cout, sp in ((128, 64, 64, 1), (64, 128, 96, 1), (128, 256, 64, 2)):
+            x = torch.randn(n, cin, device=device)
+            w = torch.randn(27 * cin, cout, device=device) * 0.05
+            b = torch.randn(cout, device=device)
+            outs = []
+            _lib.call("agb_spconv_set_cmp_mode", mode)
+            for il in (0, shift):
+                _lib.call("agb_spconv_set_cmp_interleave", il)
+                y = torch.full((n, cout), float("nan"), device=device)
+                part = torch.empty(sp, n, cout, device=device) if sp > 1 else None
+                _lib.call("agb_spconv_fwd_ex", P(x), cin, P(w), P(nbr), nbr.stride(0), 0, P(b), P(y), cout, n, 27, cin,
+                          cout, None, None, None, 0, sp, P(part), _lib.stream())
+                outs.append(y)
+            assert torch.equal(outs[0], outs[1])
+    finally:
+        _lib.call("agb_spconv_set_cmp_mode", 1)
+        _lib.call("agb_spconv_set_cmp_interleave", -1)
+
+
 @pytest.mark.parametrize("split", [2, 4])
 def test_conv_pair_compacted_channel_split(device, split):
     """Input-channel split of the pair-compacted kernel (few-row wide layers): partial tiles + ordered fold must give

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--wgrad", action="store_true")
+    ap.add_argument("--il", default="0", help="interleave block shifts to sweep for the pair-compacted kernel, e.g. 0,3,4")
     args = ap.parse_args()
     from dpcr_agb_amd import _lib, synthetic
     from dpcr_agb_amd.coords import CoordinateManager
@@ -40,8 +41,9 @@ def main():
         x = torch.randn(n, cin, device=dev)
         w = torch.randn(27 * cin, cout, device=dev) * 0.05
         ref = None
-        for mode in [int(m) for m in args.modes.split(",")]:
+        for mode, il in [(int(m), int(i)) for m in args.modes.split(",") for i in args.il.split(",")]:
             _lib.call("agb_spconv_set_cmp_mode", mode)
+            _lib.call("agb_spconv_set_cmp_interleave", il)
             y = spconv_forward_raw(x, w, nbr, 0, None, n, 27, cin, cout)
             torch.cuda.synchronize()
             if ref is None:
@@ -54,22 +56,33 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / args.reps * 1e3
-            print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} rows {n:7d} density {pairs / (27 * n):.2f} mode {mode:3d}: "
+            print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} rows {n:7d} density {pairs / (27 * n):.2f} mode {mode:3d} il {il}: "
                   f"{us:8.1f} us  {2.0 * pairs * cin * cout / us / 1e6:6.1f} TF  (max rel diff vs first mode {err:.1e})",
                   flush=True)
         if args.wgrad:
             dy = torch.randn(n, cout, device=dev)
-            dw = torch.zeros(27, cin, cout, device=dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.reps):
+            ref_dw = None
+            for il in [int(i) for i in args.il.split(",")]:
+                _lib.call("agb_spconv_set_cmp_interleave", il)
+                dw = torch.zeros(27, cin, cout, device=dev)
                 _lib.call("agb_spconv_bwd_weight", x.data_ptr(), cin, dy.data_ptr(), cout, nbr.data_ptr(),
                           nbr.stride(0), dw.data_ptr(), n, 27, cin, cout, _lib.stream())
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / args.reps * 1e3
-            print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} wgrad: {us:8.1f} us  {2.0 * pairs * cin * cout / us / 1e6:6.1f} TF")
+                torch.cuda.synchronize()
+                if ref_dw is None:
+                    ref_dw = dw.clone()
+                err = float((dw - ref_dw).abs().max() / ref_dw.abs().max())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    _lib.call("agb_spconv_bwd_weight", x.data_ptr(), cin, dy.data_ptr(), cout, nbr.data_ptr(),
+                              nbr.stride(0), dw.data_ptr(), n, 27, cin, cout, _lib.stream())
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / args.reps * 1e3
+                print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} wgrad il {il}: {us:8.1f} us  "
+                      f"{2.0 * pairs * cin * cout / us / 1e6:6.1f} TF  (max rel diff vs first {err:.1e})")
     _lib.call("agb_spconv_set_cmp_mode", 1)
+    _lib.call("agb_spconv_set_cmp_interleave", -1)
 
 
 if __name__ == "__main__":
