@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--wgrad", action="store_true")
-    ap.add_argument("--il", default="0", help="interleave block shifts to sweep for the pair-compacted kernel, e.g. 0,3,4")
+    ap.add_argument("--il", default="-1", help="interleave block shifts to sweep for the pair-compacted kernel, e.g. 0,2,3 (-1: by level size, the library default)")
     args = ap.parse_args()
     from dpcr_agb_amd import _lib, synthetic
     from dpcr_agb_amd.coords import CoordinateManager
