@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define BM 64
 #define BN 64
@@ -180,6 +181,44 @@ __global__ __launch_bounds__(256) void k_spconv_fwd3(const float* __restrict__ X
     if (tid < BM) { As[tid * LDA + 30] = 0.f; As[tid * LDA + 31] = 0.f; }
 
     const int nchunks = (K3 + OPC - 1) / OPC;
+    // Software pipeline (registers): while chunk ch multiplies, the input rows and weights of chunk ch+1 are in flight
+    // and the neighbour indices of chunk ch+2 are being fetched — the dependent index -> gather chain (two memory
+    // latencies per 0.43 us of MFMA work per chunk) was hidden by occupancy alone and left the MFMA pipe 54 % busy.
+    // All loads are unconditional (clamped addresses) and validity is applied when a value is stored to LDS: a load
+    // under a branch makes the compiler wait for it at the join.
+    int idxn[3];         // neighbour index of this thread's (row, offset) pairs of the chunk to gather next
+    int idxc[3];         // ... of the chunk whose rows are in xv
+    f32x4 xv[3];         // gathered rows of the chunk to multiply next (kept as whole 4-register tuples, see below)
+    float4 wv[2];        // weight rows of the chunk to multiply next
+    const int rowc[3] = {min(row0 + ((tid + 0) & (BM - 1)), n_out - 1), min(row0 + ((tid + 256) & (BM - 1)), n_out - 1),
+                         min(row0 + ((tid + 512) & (BM - 1)), n_out - 1)};
+    const int wcol = min(n0 + (tid & 15) * 4, Cout - 4);
+    auto load_idx = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = min(ch * OPC + ((tid + 256 * j) >> 6), K3 - 1);
+            const int kn = kflip ? (K3 - 1 - k) : k;
+            idxn[j] = nbr[(long long)kn * nbr_stride + rowc[j]];
+        }
+    };
+    auto gather = [&]() {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            idxc[j] = idxn[j];
+            xv[j] = *reinterpret_cast<const f32x4*>(X + (long long)max(idxc[j], 0) * ldx);
+        }
+    };
+    auto load_w = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long wrow = min((long long)ch * OPC * 3 + (tid >> 4) + 16 * j, (long long)K3 * 3 - 1);
+            wv[j] = *reinterpret_cast<const float4*>(W + wrow * Cout + wcol);
+        }
+    };
+    load_idx(0);
+    gather();
+    load_w(0);
+    load_idx(nchunks > 1 ? 1 : 0);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int k0 = ch * OPC;
 #pragma unroll
@@ -187,27 +226,26 @@ __global__ __launch_bounds__(256) void k_spconv_fwd3(const float* __restrict__ X
             const int e = tid + 256 * j;          // 64 rows x 10 offsets = 640 (row, offset) pairs per chunk
             if (e < BM * OPC) {
                 const int r = e & (BM - 1), off = e >> 6;
-                const int k = k0 + off;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K3 && row0 + r < n_out) {
-                    const int kn = kflip ? (K3 - 1 - k) : k;
-                    const int idx = nbr[(long long)kn * nbr_stride + row0 + r];
-                    if (idx >= 0) v = *reinterpret_cast<const float4*>(X + (long long)idx * ldx);
-                }
+                const bool ok = idxc[j] >= 0 && k0 + off < K3 && row0 + r < n_out;
                 float* dst = &As[r * LDA + off * 3];
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+                // the row stays one 128-bit register tuple until here: with a 3-dword load the compiler moved the
+                // components out of the tuple right behind the load (and waited for it there)
+                asm volatile("" : "+v"(xv[j]));
+                dst[0] = ok ? xv[j][0] : 0.f; dst[1] = ok ? xv[j][1] : 0.f; dst[2] = ok ? xv[j][2] : 0.f;
             }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int kr = (tid >> 4) + 16 * j;
-            const int n = n0 + (tid & 15) * 4;
-            const long long wrow = (long long)k0 * 3 + kr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kr < 3 * OPC && wrow < (long long)K3 * 3 && n < Cout) v = *reinterpret_cast<const float4*>(W + wrow * Cout + n);
-            *reinterpret_cast<float4*>(&Bs[kr * LDB + (tid & 15) * 4]) = v;
+            const bool ok = kr < 3 * OPC && (long long)k0 * 3 + kr < (long long)K3 * 3 && n0 + (tid & 15) * 4 < Cout;
+            *reinterpret_cast<float4*>(&Bs[kr * LDB + (tid & 15) * 4]) = ok ? wv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        // rows / weights of chunk ch+1 (its indices arrived during the previous chunk), indices of chunk ch+2; past
+        // the last chunk the (clamped) loads are harmless repeats
+        gather();
+        load_w(min(ch + 1, nchunks - 1));
+        load_idx(min(ch + 2, nchunks - 1));
         const float* arow = &As[(wr * 32 + li) * LDA + 4 * lh];
         const float* bcol = &Bs[wc * 32 + li];
 #pragma unroll
@@ -585,7 +623,6 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
 // 1-D grid, XCD-aware: every XCD (workgroup id % 8) walks one contiguous range of row tiles, so the gathers of
 // neighbouring tiles share that XCD's L2.  rows_per_tile <= R is chosen by the host so that the number of workgroups is
 // a multiple of the resident-wave capacity (tiles of equal cost: no half-empty last round).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CMP_YS 68   // LDS row stride of the running sums (floats): 16-B aligned rows, 4-bank skew per row
 #define CMP_CB 4    // 16-channel blocks per step (64 input channels)
 
