@@ -1242,14 +1242,26 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
     const int k0 = mt * OPT;
     const int nk = min(OPT, K3 - k0);
 
-    // ---- phase 1: rows with at least one present neighbour among the tile's offsets (order kept)
+    // ---- phase 1: rows with at least one present neighbour among the tile's offsets (order kept).  The neighbour
+    // indices of the whole chunk are loaded up front (unconditional, clamped: one exposed latency per workgroup instead
+    // of one per 256 rows, as in k_spconv_dw_cmp)
     int total = 0;
     const int nrows = r_end - r_begin;
-    for (int base = 0, it = 0; base < nrows; base += 256, ++it) {
-        const int i = base + tid;
-        bool any = false;
-        if (i < nrows)
-            for (int o = 0; o < nk; ++o) any |= nbr[(long long)(k0 + o) * nbr_stride + r_begin + i] >= 0;
+    constexpr int NIT = 4;                 // rows_per_wg <= 1024 on this path
+    bool anyv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rc = min(r_begin + it * 256 + tid, n_out - 1);
+        int mx = -1;                        // >= 0 iff a neighbour exists at one of the offsets (absent = -1)
+#pragma unroll
+        for (int o = 0; o < OPT; ++o) mx = max(mx, nbr[(long long)min(k0 + o, K3 - 1) * nbr_stride + rc]);
+        anyv[it] = mx >= 0 && it * 256 + tid < nrows;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (it * 256 >= nrows) break;
+        const int i = it * 256 + tid;
+        const bool any = anyv[it];
         const unsigned long long bal = __ballot(any);
         if (lane == 0) s_wcnt[it & 1][wave] = __popcll(bal);
         __syncthreads();
