@@ -120,7 +120,10 @@ class AddActFunction(torch.autograd.Function):
         dy = dy.contiguous()
         n, c = a.shape
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        dr = torch.empty_like(r) if ctx.needs_input_grad[1] else None
+        # without a drop-path scale both gradients are the same values: one buffer, handed to both inputs (nothing in
+        # this package writes gradients in place, and autograd only accumulates in place into buffers it owns alone)
+        shared = not has_s and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        dr = torch.empty_like(r) if (ctx.needs_input_grad[1] and not shared) else None
         _lib.call("agb_add_act_bwd", _P(a), a.stride(0), _P(r), r.stride(0), _P(scale) if has_s else None,
                   _P(coords) if has_s else None, _P(dy), dy.stride(0), n, c, act_id, _P(da), _P(dr), _lib.stream())
-        return da, dr, None, None, None
+        return da, (da if shared else dr), None, None, None
