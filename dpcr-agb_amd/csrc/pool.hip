@@ -82,6 +82,77 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ d
     *reinterpret_cast<float4*>(dX + (long long)q * ldx + c) = g;
 }
 
+// The same pair with the winner kept as its OFFSET index (one byte per output element instead of the 4-byte input row):
+// nbrT[k][q] = o  <=>  nbr[k][o] = q, so input row q won channel c of output o iff arg8[o][c] == k.  The gradient pass
+// gathers 4 + 16 bytes per (pair, 4 channels) instead of 16 + 16 (it is bound by those gathers: every output row is read
+// by ~7 input rows), and the forward pass writes a quarter of the argmax bytes.  K3 <= 255.
+__global__ __launch_bounds__(256) void k_maxpool_fwd8(const float* __restrict__ X, int ldx, const int32_t* __restrict__ nbr,
+                                                      long long nbr_stride, float* __restrict__ Y, int ldy,
+                                                      uint8_t* __restrict__ arg, int n_out, int K3, int C4) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int r = (int)(t / C4);
+    int c = (int)(t % C4) * 4;
+    if (r >= n_out) return;
+    float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    int bx = 255, by = 255, bz = 255, bw = 255;   // 255 = no neighbour at all
+    for (int k0 = 0; k0 < K3; k0 += PB) {
+        int idx[PB];
+        float4 v[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) idx[u] = (k0 + u < K3) ? nbr[(long long)(k0 + u) * nbr_stride + r] : -1;
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+            if (idx[u] >= 0) v[u] = *reinterpret_cast<const float4*>(X + (long long)idx[u] * ldx + c);
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            if (idx[u] < 0) continue;
+            if (v[u].x > best.x) { best.x = v[u].x; bx = k0 + u; }
+            if (v[u].y > best.y) { best.y = v[u].y; by = k0 + u; }
+            if (v[u].z > best.z) { best.z = v[u].z; bz = k0 + u; }
+            if (v[u].w > best.w) { best.w = v[u].w; bw = k0 + u; }
+        }
+    }
+    if (bx == 255) best.x = 0.f;
+    if (by == 255) best.y = 0.f;
+    if (bz == 255) best.z = 0.f;
+    if (bw == 255) best.w = 0.f;
+    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = best;
+    *reinterpret_cast<uchar4*>(arg + (long long)r * (C4 * 4) + c) = make_uchar4(bx, by, bz, bw);
+}
+
+__global__ __launch_bounds__(256) void k_maxpool_bwd8(const float* __restrict__ dY, int ldy, const uint8_t* __restrict__ arg,
+                                                      const int32_t* __restrict__ nbrT, long long nbrT_stride,
+                                                      float* __restrict__ dX, int ldx, int n_in, int K3, int C4) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int q = (int)(t / C4);
+    int c = (int)(t % C4) * 4;
+    if (q >= n_in) return;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < K3; k0 += PB) {
+        int o[PB];
+        uchar4 a[PB];
+        float4 d[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) o[u] = (k0 + u < K3) ? nbrT[(long long)(k0 + u) * nbrT_stride + q] : -1;
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+            if (o[u] >= 0) {
+                a[u] = *reinterpret_cast<const uchar4*>(arg + (long long)o[u] * (C4 * 4) + c);
+                d[u] = *reinterpret_cast<const float4*>(dY + (long long)o[u] * ldy + c);
+            }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            if (o[u] < 0) continue;
+            const int k = k0 + u;
+            if (a[u].x == k) g.x += d[u].x;
+            if (a[u].y == k) g.y += d[u].y;
+            if (a[u].z == k) g.z += d[u].z;
+            if (a[u].w == k) g.w += d[u].w;
+        }
+    }
+    *reinterpret_cast<float4*>(dX + (long long)q * ldx + c) = g;
+}
+
 // ------------------------------------------------------------ segment reduce
 // grid (B, ceil(C/64), S), block 256 = 4 row lanes x 64 channels. Segment b is cut into S contiguous row
 // chunks so that long segments (6.8k rows/plot at 64 channels) still fill the chip; chunk partials go to
@@ -304,6 +375,32 @@ int agb_maxpool_bwd(const float* dY, int ldy, const int32_t* argmax, const int32
     hipLaunchKernelGGL(k_maxpool_bwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dY, ldy, argmax,
                        nbrT, nbrT_stride, dX, ldx, n_in, K3, C / 4);
     AGB_CHECK_LAUNCH("agb_maxpool_bwd");
+    return AGB_OK;
+}
+
+// Variant whose argmax is the winning OFFSET index (uint8, 255 = none): argk [n_out, C] bytes.  K3 <= 255.
+int agb_maxpool_fwd_k(const float* X, int ldx, const int32_t* nbr, long long nbr_stride, float* Y, int ldy,
+                      uint8_t* argk, int n_out, int K3, int C, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_maxpool_fwd_k: C/ld must be multiples of 4");
+    AGB_CHECK_ARG(K3 >= 1 && K3 <= 255, "agb_maxpool_fwd_k: K3 %d (1..255)", K3);
+    if (n_out == 0) return AGB_OK;
+    long long total = (long long)n_out * (C / 4);
+    hipLaunchKernelGGL(k_maxpool_fwd8, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, nbr,
+                       nbr_stride, Y, ldy, argk, n_out, K3, C / 4);
+    AGB_CHECK_LAUNCH("agb_maxpool_fwd_k");
+    return AGB_OK;
+}
+
+// nbrT must be the transpose of the map the forward pass used (same offset numbering).
+int agb_maxpool_bwd_k(const float* dY, int ldy, const uint8_t* argk, const int32_t* nbrT, long long nbrT_stride,
+                      float* dX, int ldx, int n_in, int K3, int C, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_maxpool_bwd_k: C/ld must be multiples of 4");
+    AGB_CHECK_ARG(K3 >= 1 && K3 <= 255, "agb_maxpool_bwd_k: K3 %d (1..255)", K3);
+    if (n_in == 0) return AGB_OK;
+    long long total = (long long)n_in * (C / 4);
+    hipLaunchKernelGGL(k_maxpool_bwd8, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dY, ldy, argk,
+                       nbrT, nbrT_stride, dX, ldx, n_in, K3, C / 4);
+    AGB_CHECK_LAUNCH("agb_maxpool_bwd_k");
     return AGB_OK;
 }
 

@@ -175,6 +175,10 @@ class SparseConvFunction(torch.autograd.Function):
 
 
 class MaxPoolFunction(torch.autograd.Function):
+    """Strided max pooling over a kernel map.  The winner of every output element is kept as its kernel-offset index
+    (one byte; K3 <= 255) — the transposed map nbrT uses the same offset numbering, so the gradient pass only has to
+    compare bytes — or as the input row (int32) for larger kernels."""
+
     @staticmethod
     def forward(ctx, feats, nbr, nbrT, n_in, n_out):
         c = feats.shape[1]
@@ -182,21 +186,22 @@ class MaxPoolFunction(torch.autograd.Function):
         cp = x.shape[1]
         K3 = nbr.shape[0]
         y = torch.empty(n_out, cp, dtype=torch.float32, device=x.device)
-        arg = torch.empty(n_out, cp, dtype=torch.int32, device=x.device)
-        _lib.call("agb_maxpool_fwd", _P(x), x.stride(0), _P(nbr), nbr.stride(0), _P(y), y.stride(0), _P(arg), n_out,
-                  K3, cp, _lib.stream())
+        small = K3 <= 255
+        arg = torch.empty(n_out, cp, dtype=torch.uint8 if small else torch.int32, device=x.device)
+        _lib.call("agb_maxpool_fwd_k" if small else "agb_maxpool_fwd", _P(x), x.stride(0), _P(nbr), nbr.stride(0), _P(y),
+                  y.stride(0), _P(arg), n_out, K3, cp, _lib.stream())
         ctx.save_for_backward(arg, nbrT)
-        ctx.dims = (c, cp, n_in, K3)
+        ctx.dims = (c, cp, n_in, K3, small)
         return y if cp == c else y[:, :c].contiguous()
 
     @staticmethod
     def backward(ctx, dy):
         arg, nbrT = ctx.saved_tensors
-        c, cp, n_in, K3 = ctx.dims
+        c, cp, n_in, K3, small = ctx.dims
         dy = _pad_cols(dy, 4)
         dx = torch.empty(n_in, cp, dtype=torch.float32, device=dy.device)
-        _lib.call("agb_maxpool_bwd", _P(dy), dy.stride(0), _P(arg), _P(nbrT), nbrT.stride(0), _P(dx), dx.stride(0),
-                  n_in, K3, cp, _lib.stream())
+        _lib.call("agb_maxpool_bwd_k" if small else "agb_maxpool_bwd", _P(dy), dy.stride(0), _P(arg), _P(nbrT),
+                  nbrT.stride(0), _P(dx), dx.stride(0), n_in, K3, cp, _lib.stream())
         return (dx if cp == c else dx[:, :c].contiguous()), None, None, None, None
 
 

@@ -146,6 +146,13 @@ int agb_maxpool_fwd(const float* X, int ldx, const int32_t* nbr, long long nbr_s
                     int32_t* argmax /* [n_out, C] */, int n_out, int K3, int C, void* stream);
 int agb_maxpool_bwd(const float* dY, int ldy, const int32_t* argmax, const int32_t* nbrT, long long nbrT_stride,
                     float* dX, int ldx, int n_in, int K3, int C, void* stream);
+/* the same pair with the winner stored as its offset index (uint8 argk [n_out, C], 255 = no neighbour; K3 <= 255): the
+ * gradient pass is bound by its gathers of (argmax, dY) rows and reads a quarter of the argmax bytes.  nbrT must be the
+ * transpose of the forward map (same offset numbering: nbrT[k][q] = o <=> nbr[k][o] = q). */
+int agb_maxpool_fwd_k(const float* X, int ldx, const int32_t* nbr, long long nbr_stride, float* Y, int ldy,
+                      uint8_t* argk, int n_out, int K3, int C, void* stream);
+int agb_maxpool_bwd_k(const float* dY, int ldy, const uint8_t* argk, const int32_t* nbrT, long long nbrT_stride,
+                      float* dX, int ldx, int n_in, int K3, int C, void* stream);
 /* Y[b,:] = reduce over rows ptr[b]..ptr[b+1] of A (optionally A*Bm); mode 0 sum, 1 average, 2 max (+argmax rows).
  * splits > 1 cuts every segment into that many row chunks (scratch: part float[B*splits*C], part_arg
  * int32[B*splits*C] for max) folded in a fixed order: deterministic, no float atomics. */

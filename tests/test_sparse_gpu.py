@@ -283,6 +283,19 @@ def test_maxpool_and_global_pools(device):
     pr.backward(g.double())
     assert rel_err(pooled.F, pr) < 1e-6
     assert rel_err(xg.grad, xr.grad) < 1e-6
+    # other window shapes: 2^3 / stride 2 (disjoint windows), 3^3 / stride 1 (every input in 27 windows), and 7^3 (343
+    # offsets: the winner no longer fits the one-byte offset index, the int32 input-row variant takes over)
+    for K, stride in ((2, 2), (3, 1), (7, 2)):
+        xg2 = x.to(device).requires_grad_(True)
+        inp2 = ME.SparseTensor(xg2, coordinate_map_key=inp.coordinate_map_key, coordinate_manager=inp.coordinate_manager)
+        p2 = ME.MinkowskiMaxPooling(K, stride, dimension=3)(inp2)
+        g2 = torch.randn(*p2.F.shape)
+        p2.F.backward(g2.to(device))
+        xr2 = x.double().requires_grad_(True)
+        pr2 = R.max_pool(xr2, ref.map(1, K, stride))
+        pr2.backward(g2.double())
+        assert rel_err(p2.F, pr2) < 1e-6, (K, stride)
+        assert rel_err(xg2.grad, xr2.grad) < 1e-6, (K, stride)
 
     bidx = ref.batch_index(2)
     for name, mod in [("sum", ME.MinkowskiGlobalSumPooling()), ("avg", ME.MinkowskiGlobalPooling()),

@@ -42,6 +42,7 @@ def main():
     x = torch.randn(n_in, C, device=dev)
     y = torch.empty(n_out, C, device=dev)
     arg = torch.empty(n_out, C, dtype=torch.int32, device=dev)
+    arg8 = torch.empty(n_out, C, dtype=torch.uint8, device=dev)
     dy = torch.randn(n_out, C, device=dev)
     dx = torch.empty(n_in, C, device=dev)
     P = lambda t: t.data_ptr()   # noqa: E731
@@ -53,6 +54,12 @@ def main():
                                  _lib.stream()), args.reps)
     byts = (n_in * C + 2 * n_out * C) * 4 + 27 * n_in * 4
     print(f"bwd {us:7.1f} us  {byts / us / 1e3:6.0f} GB/s on {byts / 1e6:.0f} MB")
+    us = timed(lambda: _lib.call("agb_maxpool_fwd_k", P(x), C, P(nbr), nbr.stride(0), P(y), C, P(arg8), n_out, 27, C,
+                                 _lib.stream()), args.reps)
+    print(f"byte-argmax variant: fwd {us:7.1f} us", end="")
+    us = timed(lambda: _lib.call("agb_maxpool_bwd_k", P(dy), C, P(arg8), P(nbrT), nbrT.stride(0), P(dx), C, n_in, 27, C,
+                                 _lib.stream()), args.reps)
+    print(f"  bwd {us:7.1f} us")
 
 
 if __name__ == "__main__":
