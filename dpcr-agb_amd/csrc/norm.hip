@@ -269,8 +269,16 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
 // partials up front, adds them pairwise, the 16 lanes of a wave that share a channel meet by shuffles, the 16 waves in
 // LDS.  Fixed tree: deterministic.  (64 lanes walking 32 chunks each + one thread adding 64 partials: 19 us at 2048
 // chunks, on the critical path of every BatchNorm backward.)
+// colsum (optional): the column sums of dX = the bias gradient of the convolution that feeds this BatchNorm, in closed
+// form.  dX = gamma rstd (dz - [training](dbeta + xhat dgamma) / n), dbeta = sum dz, so in training mode
+// sum_rows dX = -gamma rstd dgamma sum(xhat) / n = 0 (batch statistics: sum(xhat) = 0; BatchNorm is blind to a constant
+// added to its input), and with running statistics it is gamma rstd dbeta.  (Summing dX in the apply pass instead — one
+// float atomic per column and workgroup, 3290 atomics per address on the stem level — cost 41 us of a 158 us backward
+// there, and produced rounding noise around that zero.)
 __global__ __launch_bounds__(1024) void k_bn_bwd_fold(const float* __restrict__ part, int chunks, int C,
-                                                      float* dbeta, float* dgamma, float* colsum) {
+                                                      float* dbeta, float* dgamma, float* colsum,
+                                                      const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                      int training) {
     __shared__ float s_a[16][FOLD_CH], s_b[16][FOLD_CH];
     const int cl = threadIdx.x & (FOLD_CH - 1), lane = threadIdx.x / FOLD_CH;
     const int c = min(blockIdx.x * FOLD_CH + cl, C - 1);
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_fold(const float* __restrict__ 
         for (int w = 1; w < 16; ++w) { a += s_a[w][cl]; b += s_b[w][cl]; }
         dbeta[c] = a;
         dgamma[c] = b;
-        if (colsum) colsum[c] = 0.f;   // accumulated by the apply pass that follows
+        if (colsum) colsum[c] = training ? 0.f : (gamma ? gamma[c] : 1.f) * rstd[c] * a;
     }
 }
 
@@ -313,9 +321,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int act, const float* __restrict__ dbeta,
                                                           const float* __restrict__ dgamma, int training,
-                                                          float* __restrict__ dX, int lddx,
-                                                          float* __restrict__ colsum) {
-    __shared__ float s_cs[16][64];
+                                                          float* __restrict__ dX, int lddx) {
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = min(blockIdx.y * 64 + cg * 4, C - 4);   // a partial last slab recomputes its last group (C % 4 == 0)
     float m[4], s[4], g[4], b[4], db[4], dg[4];
@@ -331,7 +337,6 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restric
     const float inv_n = training ? 1.f / (float)n : 0.f;
     const int r0 = blockIdx.x * EW_ROWS + rl;
     constexpr int NR = EW_ROWS / 16, HALF = NR / 2;
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float4 xv[HALF], dv[HALF];
@@ -354,23 +359,8 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restric
                 float xh = (x[q] - m[q]) * s[q];
                 float dz = d[q] * act_grad(xh * g[q] + b[q], act);
                 o[q] = g[q] * s[q] * (dz - (db[q] + xh * dg[q]) * inv_n);
-                cs[q] += o[q];
             }
             *reinterpret_cast<float4*>(dX + (long long)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    // column sums of dX = the bias gradient of the convolution that feeds this BatchNorm (mathematically zero in
-    // training mode: what is left is rounding noise, which the reference also feeds to its optimiser); one float
-    // atomic per column and workgroup
-    if (colsum) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s_cs[rl][cg * 4 + q] = cs[q];
-        __syncthreads();
-        if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < C) {
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) a += s_cs[j][threadIdx.x];
-            atomicAdd(&colsum[blockIdx.y * 64 + threadIdx.x], a);
         }
     }
 }
@@ -517,10 +507,11 @@ int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int
     int chunks = agb_bn_chunks(n);
     hipLaunchKernelGGL(k_bn_act_bwd_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY, ldy, n, C,
                        rows_per_chunk(n, chunks), mean, rstd, gamma, beta, act, part);
-    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, dbeta, dgamma, colsum);
+    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, dbeta, dgamma, colsum,
+                       gamma, rstd, training);
     if (n > 0 && dX) {
         hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY,
-                           ldy, n, C, mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx, colsum);
+                           ldy, n, C, mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx);
     }
     AGB_CHECK_LAUNCH("agb_bn_act_bwd");
     return AGB_OK;

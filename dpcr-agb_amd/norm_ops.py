@@ -72,8 +72,9 @@ class BatchNormActFunction(torch.autograd.Function):
                   0 if dx is None else dx.stride(0), _P(dgb[0]), _P(dgb[1]), _P(dgb[2]) if dx is not None else None,
                   _lib.stream())
         if dx is not None:
-            # column sums of dx, a by-product of the apply pass: the convolution that produced x (its backward node
-            # receives this very tensor) takes them as its bias gradient instead of reducing dx again
+            # column sums of dx in closed form (0 with batch statistics, gamma * rstd * dbeta with running ones): the
+            # convolution that produced x (its backward node receives this very tensor) takes them as its bias gradient
+            # instead of reducing dx again
             dx.agb_colsum = dgb[2]
         return dx, (dgb[0] if has_g else None), (dgb[1] if has_b else None), None, None, None, None, None, None, None
 

@@ -190,7 +190,9 @@ int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int
                    const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
                    float* dX, int lddx, float* dgamma, float* dbeta, void* stream);
 /* Same, plus colsum float[C] (optional): the column sums of dX — the bias gradient of the convolution feeding the
- * BatchNorm (common.py:215-226 ConvNormActivation, resnet_block.py:62-69) — accumulated while dX is written. */
+ * BatchNorm (common.py:215-226 ConvNormActivation, resnet_block.py:62-69) — in closed form from the folded sums:
+ * exactly 0 with batch statistics (BatchNorm is blind to a constant added to its input; the reference's optimiser sees
+ * fp32 rounding noise around that zero), gamma * rstd * dbeta with running statistics. */
 int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
                           const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
                           float* dX, int lddx, float* dgamma, float* dbeta, float* colsum, void* stream);

@@ -64,6 +64,36 @@ def test_bn_act_training(device, n, c, act):
         assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_backward_column_sums(device, training):
+    """The column sums of dx handed to the preceding convolution as its bias gradient (closed form in the fold kernel)
+    equal the actual sums of dx: gamma * rstd * dbeta with running statistics, zero (up to the rounding of the dx
+    values themselves) with batch statistics."""
+    from dpcr_agb_amd.norm_ops import batch_norm_act
+    torch.manual_seed(11)
+    n, c = 20011, 64
+    bn = torch.nn.BatchNorm1d(c).to(device)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2.0)
+    bn.train(training)
+    x = (torch.randn(n, c, device=device) * 2 + 1).requires_grad_(True)
+    captured = {}
+    def keep(g):
+        captured["colsum"] = getattr(g, "agb_colsum", None)
+
+    x.register_hook(keep)
+    y = batch_norm_act(x, bn, "gelu")
+    y.backward(torch.randn(n, c, device=device))
+    cs = captured["colsum"]
+    assert cs is not None and cs.shape == (c,)
+    true = x.grad.double().sum(0)
+    scale = float(x.grad.double().abs().sum(0).max())
+    assert float((cs.double() - true).abs().max()) < 1e-5 * scale
+    if training:
+        assert float(cs.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("momentum", [0.1, None])
 def test_bn_running_stat_bookkeeping(device, momentum):
     """num_batches_tracked is bumped on the device by the fold kernel (momentum given) or on the host (cumulative
