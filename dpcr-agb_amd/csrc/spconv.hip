@@ -1163,25 +1163,29 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
 
     constexpr int LJ = DW_KS / 16;
     float4 a_reg[LJ], b_reg[LJ];
+    // loads are unconditional (clamped pair / column) and masked when stored to LDS: under branches every pair's
+    // "LDS list read -> global load" chain sat in its own block, four of them back to back before the first MFMA
+    const int a_col = min(c0 + t_c, Cin - 4), b_col = min(n0 + t_c, Cout - 4);
+    const bool a_ok = c0 + t_c < Cin, b_ok = n0 + t_c < Cout;
     auto load_data = [&](int pb) {
 #pragma unroll
         for (int j = 0; j < LJ; ++j) {
-            int p = pb + t_r + 16 * j;
-            a_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < total) {
-                int in = p_in[p], out = p_out[p];
-                if (c0 + t_c < Cin) a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)in * ldx + c0 + t_c);
-                if (n0 + t_c < Cout) b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)out * ldy + n0 + t_c);
-            }
+            const int p = min(pb + t_r + 16 * j, total - 1);
+            const int in = p_in[p], out = p_out[p];
+            a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)in * ldx + a_col);
+            b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)out * ldy + b_col);
         }
     };
     load_data(0);
     for (int pb = 0; pb < total; pb += DW_KS) {
 #pragma unroll
         for (int j = 0; j < LJ; ++j) {
-            *reinterpret_cast<float4*>(&As[(t_r + 16 * j) * 64 + t_c]) = a_reg[j];
-            *reinterpret_cast<float4*>(&Bs[(t_r + 16 * j) * 64 + t_c]) = b_reg[j];
+            const bool live = pb + t_r + 16 * j < total;
+            float4 av = a_reg[j], bv = b_reg[j];
+            if (!(live && a_ok)) av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(live && b_ok)) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&As[(t_r + 16 * j) * 64 + t_c]) = av;
+            *reinterpret_cast<float4*>(&Bs[(t_r + 16 * j) * 64 + t_c]) = bv;
         }
         __syncthreads();
         if (pb + DW_KS < total) load_data(pb + DW_KS);   // in flight during the MFMAs below
