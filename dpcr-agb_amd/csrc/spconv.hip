@@ -424,18 +424,28 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* out = a.ksplit > 1 ? a.partial + (long long)blockIdx.z * a.n_out * Cout : a.Y;
     const int ldo = a.ksplit > 1 ? Cout : a.ldy;
+    // the 16 permutation entries of this lane are loaded together (a load + branch per register serialised 16 memory
+    // latencies at the end of every workgroup)
+    int rows[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        int rt = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        int row = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
+        const int rt = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        rows[reg] = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
+    }
+    float bvs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + (wn * NT + nt) * 32 + li;
+        bvs[nt] = (a.bias && a.ksplit == 1 && col < Cout) ? a.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = rows[reg];
         if (row < 0) continue;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + (wn * NT + nt) * 32 + li;
-            if (col < Cout) {
-                float bv = (a.bias && a.ksplit == 1) ? a.bias[col] : 0.f;
-                out[(long long)row * ldo + col] = acc[nt][reg] + bv;
-            }
+            if (col < Cout) out[(long long)row * ldo + col] = acc[nt][reg] + bvs[nt];
         }
     }
 }
@@ -590,18 +600,28 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
     }
     float* out = a.ksplit > 1 ? a.partial + (long long)blockIdx.z * a.n_out * Cout : a.Y;
     const int ldo = a.ksplit > 1 ? Cout : a.ldy;
+    // the 16 permutation entries of this lane are loaded together (a load + branch per register serialised 16 memory
+    // latencies at the end of every workgroup)
+    int rows[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        int rt = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        int row = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
+        const int rt = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        rows[reg] = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
+    }
+    float bvs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + (wn * NT + nt) * 32 + li;
+        bvs[nt] = (a.bias && a.ksplit == 1 && col < Cout) ? a.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = rows[reg];
         if (row < 0) continue;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + (wn * NT + nt) * 32 + li;
-            if (col < Cout) {
-                float bv = (a.bias && a.ksplit == 1) ? a.bias[col] : 0.f;
-                out[(long long)row * ldo + col] = acc[nt][reg] + bv;
-            }
+            if (col < Cout) out[(long long)row * ldo + col] = acc[nt][reg] + bvs[nt];
         }
     }
 }
