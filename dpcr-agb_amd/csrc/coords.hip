@@ -351,16 +351,23 @@ __global__ void k_grid_kernel_map(const int4* __restrict__ q_coords, int n, cons
         int4 c = q_coords[r];
         int y = c.z + sign * (iy - half) * step;
         int z = c.w + sign * (iz - half) * step;
-        for (int ix = 0; ix < K; ++ix) {
-            int x = c.y + sign * (ix - half) * step;
-            long long cell = grid_cell(g, c.x, x, y, z);
-            int res = -1;
-            if (cell >= 0) {
-                int v = grid[cell];
-                if (v != INT_MAX) res = v;
-            }
+        // the K probes of a thread are independent: all cells first, all loads in flight together (unconditional,
+        // clamped), then the stores — a load under a branch inside a rolled loop serialised K memory latencies
+        long long cell[9];
+        int v[9];
+#pragma unroll
+        for (int ix = 0; ix < 9; ++ix) {
+            const int x = c.y + sign * (ix - half) * step;
+            cell[ix] = ix < K ? grid_cell(g, c.x, x, y, z) : -1;
+        }
+#pragma unroll
+        for (int ix = 0; ix < 9; ++ix) v[ix] = grid[cell[ix] >= 0 ? cell[ix] : 0];
+#pragma unroll
+        for (int ix = 0; ix < 9; ++ix) {
+            if (ix >= K) break;
+            const int res = (cell[ix] >= 0 && v[ix] != INT_MAX) ? v[ix] : -1;
             cnt += res >= 0;
-            int k = ix + K * (iy + K * iz);
+            const int k = ix + K * (iy + K * iz);
             nbr[(long long)k * nbr_stride + r] = res;
         }
     }
