@@ -285,8 +285,8 @@ def main():
     log(f"model + {len(pool)} batches resident ({voxels:.0f} voxels/plot); warmup")
     # HIP events around a launch cost ~6 us of queue bubbles each side.  Every sparse-conv launch is bracketed only in
     # up to three (untimed) warmup steps: that gives the per-kernel table and tells which kernel dominates.  Inside the
-    # timed region only that kernel is bracketed, in every EV_EVERY-th step.
-    EV_EVERY = 5   # coprime with the pool of 4 batches: the bracketed steps cycle through all of them
+    # timed region only that kernel is bracketed, in every EV_EVERY-th step (a bracketed step measures ~0.6 ms longer).
+    EV_EVERY = 9   # coprime with the pool of 4 batches: the bracketed steps cycle through all of them
     n_instr = min(3, args.warmup)
     prof_all = []
     for i in range(args.warmup):
