@@ -47,6 +47,8 @@ _SIGNATURES = {
     "agb_parity_partition": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "agb_spconv_bwd_weight": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int,
                               c_void_p],
+    "agb_spconv_fwd3_grid": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                             c_int, c_int, c_void_p, c_ll, c_void_p],
     "agb_maxpool_fwd": [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "agb_maxpool_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "agb_maxpool_fwd_k": [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],

@@ -285,7 +285,8 @@ class ResNetBase(nn.Module):
             if getattr(conv, "use_mm", False):
                 return ts
             k, s, d = conv.kernel_size, conv.stride, conv.dilation
-            specs.append((ts, k, s, d, needs_dx and not (s == 1 and k % 2 == 1)))
+            # a 3-channel layer whose input needs no gradient probes the dense grid itself when it can
+            specs.append((ts, k, s, d, needs_dx and not (s == 1 and k % 2 == 1), conv.in_channels == 3 and not needs_dx))
             return ts * s
 
         stem, pool = self.blocks[0][0], self.blocks[0][1]

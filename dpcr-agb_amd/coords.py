@@ -24,6 +24,7 @@ import torch
 from . import _lib
 
 GRID_MAX_CELLS = 1 << 28  # 1 GiB of int32 per level at most; beyond that the hash mode is used
+GRID_HALO = 3             # empty cells around every level's grid: stride-1 kernels up to 7^3 probe it without bounds checks
 
 
 class CoordinateMapKey:
@@ -153,8 +154,8 @@ class CoordinateManager:
 
     # ------------------------------------------------------------------ dense-grid geometry
     def _grid_geometry(self, ts):
-        lo = [_floor_to(v, ts) for v in self.bounds[:3]]
-        hi = [_floor_to(v, ts) for v in self.bounds[3:]]
+        lo = [_floor_to(v, ts) - GRID_HALO * ts for v in self.bounds[:3]]
+        hi = [_floor_to(v, ts) + GRID_HALO * ts for v in self.bounds[3:]]
         dims = [(h - l) // ts + 1 for l, h in zip(lo, hi)]
         return lo, dims
 
@@ -165,7 +166,7 @@ class CoordinateManager:
     def _alloc_grid(self, lvl: _Level):
         lo, dims = self._grid_geometry(lvl.ts)
         lvl.desc_host = (ctypes.c_int32 * 8)(lo[0], lo[1], lo[2], dims[0], dims[1], dims[2], lvl.ts,
-                                             self.batch_size)
+                                             self.batch_size | (GRID_HALO << 16))
         lvl.grid = torch.empty(self.batch_size * dims[0] * dims[1] * dims[2], dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------ helpers
@@ -304,9 +305,23 @@ class CoordinateManager:
         ev.synchronize()
         self._apply_counts(pending, host.tolist())
 
+    def grid_probe(self, ts, K, stride=1, dilation=1):
+        """(coords, grid, desc) of level ts if a K^3 stride-1 convolution can probe the level's dense grid directly
+        (grid mode, odd K within the halo, no dilation), else None."""
+        if self.mode != "grid" or stride != 1 or dilation != 1 or K % 2 == 0 or K // 2 > GRID_HALO:
+            return None
+        lvl = self.level(ts)
+        if lvl.grid is None or self.batch_size > 0xffff:
+            return None
+        return lvl.coords, lvl.grid, lvl.desc_host
+
     def prebuild(self, specs):
-        """Build kernel maps ahead of the forward pass. specs: iterable of (ts_in, K, stride, dilation, need_T)."""
-        for ts_in, K, s, d, need_t in specs:
+        """Build kernel maps ahead of the forward pass. specs: iterable of (ts_in, K, stride, dilation, need_T[, probe]):
+        probe = True marks a layer that reads the dense grid itself when it can (it writes its own map then)."""
+        for spec in specs:
+            ts_in, K, s, d, need_t = spec[:5]
+            if len(spec) > 5 and spec[5] and not need_t and self.grid_probe(ts_in, K, s, d) is not None:
+                continue
             self.kernel_map(ts_in, K, s, d)
             if need_t:
                 self.transposed_map(ts_in, K, s, d)

@@ -224,9 +224,13 @@ struct GridDesc {
     int X, Y, Z;     // cells per axis
     int ts;          // tensor stride of the level
     int B;
+    int halo;        // margin of cells on every side that rows may not occupy (kept empty: kernels that probe
+                     // grid[cell + delta] directly never leave the grid or the plot's own block of it)
 };
 
-__device__ __forceinline__ long long grid_cell(const GridDesc& g, int b, int x, int y, int z) {
+// strict: also -1 inside the halo margin (where rows are inserted: a coordinate outside the declared bounds must be
+// reported, not parked in the halo)
+__device__ __forceinline__ long long grid_cell(const GridDesc& g, int b, int x, int y, int z, bool strict = false) {
     // returns -1 when (b,x,y,z) is outside the grid or off the level's lattice
     int dx = x - g.ox, dy = y - g.oy, dz = z - g.oz;
     if (b < 0 || b >= g.B || dx < 0 || dy < 0 || dz < 0) return -1;
@@ -235,6 +239,9 @@ __device__ __forceinline__ long long grid_cell(const GridDesc& g, int b, int x, 
         dx /= g.ts; dy /= g.ts; dz /= g.ts;
     }
     if (dx >= g.X || dy >= g.Y || dz >= g.Z) return -1;
+    if (strict && (dx < g.halo || dy < g.halo || dz < g.halo || dx >= g.X - g.halo || dy >= g.Y - g.halo ||
+                   dz >= g.Z - g.halo))
+        return -1;
     return (((long long)b * g.Z + dz) * g.Y + dy) * g.X + dx;
 }
 
@@ -278,7 +285,7 @@ __global__ void k_grid_insert(const int4* __restrict__ coords, int n, const int3
     if (i >= n) return;
     int4 c = coords[i];
     if (i > 0 && coords[i - 1].x > c.x) atomicAdd(&status[2], 1);
-    long long cell = grid_cell(g, c.x, c.y, c.z, c.w);
+    long long cell = grid_cell(g, c.x, c.y, c.z, c.w, true);
     cell_of_row[i] = cell;
     if (cell < 0) {
         atomicAdd(&status[1], 1);
@@ -303,7 +310,7 @@ __global__ void k_grid_stride_insert(const int4* __restrict__ coords, int n, con
     if (i >= n) return;
     int4 c = coords[i];
     int x = agb_floordiv(c.y, g.ts) * g.ts, y = agb_floordiv(c.z, g.ts) * g.ts, z = agb_floordiv(c.w, g.ts) * g.ts;
-    long long cell = grid_cell(g, c.x, x, y, z);
+    long long cell = grid_cell(g, c.x, x, y, z, true);
     cell_of_row[i] = cell;
     if (cell < 0) {
         atomicAdd(&status[1], 1);
@@ -478,13 +485,14 @@ int agb_batch_ptr(const int32_t* coords, int n, const int32_t* n_dev, int B, int
 }
 
 // ---- dense-grid mode --------------------------------------------------------------------------------
-// desc = {ox, oy, oz, X, Y, Z, ts, B} (host ints). grid: int32[B*Z*Y*X], filled with INT_MAX by these calls.
+// desc = {ox, oy, oz, X, Y, Z, ts, B | halo << 16} (host ints). grid: int32[B*Z*Y*X], filled with INT_MAX by these calls.
 static inline GridDesc mk_desc(const int32_t* d) {
     GridDesc g;
-    g.ox = d[0]; g.oy = d[1]; g.oz = d[2]; g.X = d[3]; g.Y = d[4]; g.Z = d[5]; g.ts = d[6]; g.B = d[7];
+    g.ox = d[0]; g.oy = d[1]; g.oz = d[2]; g.X = d[3]; g.Y = d[4]; g.Z = d[5]; g.ts = d[6]; g.B = d[7] & 0xffff;
+    g.halo = (d[7] >> 16) & 0xff;
     return g;
 }
-static inline long long desc_cells(const int32_t* d) { return (long long)d[7] * d[5] * d[4] * d[3]; }
+static inline long long desc_cells(const int32_t* d) { return (long long)(d[7] & 0xffff) * d[5] * d[4] * d[3]; }
 
 int agb_coords_bbox(const int32_t* coords, int n, const int32_t* n_dev, int32_t* bbox, void* stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -154,15 +154,40 @@ __global__ __launch_bounds__(256) void k_spconv_fwd(const float* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Direct probes of the level's dense lookup grid instead of a pre-built kernel map (stride-1 odd kernels on a grid-mode
+// level whose grid carries a halo of >= K/2 empty cells on every side, so a neighbour cell is always inside the grid and
+// inside the plot's own block of it): neighbour of row r at offset (dx, dy, dz) = grid[cell(r) + (dz * Y + dy) * X + dx],
+// INT_MAX = none.  The stem forward kernel probes while it convolves and writes the [K^3][N] map out as a by-product for
+// the weight gradient: the map kernel (0.5 ms on the side stream, the same probes plus 578 MB of stores, contending
+// with the compute stream) disappears.
+struct GridProbe {
+    const int4* coords;      // [n] (batch, x, y, z) of the level's rows
+    const int32_t* grid;     // int32[B][Z][Y][X], INT_MAX = empty
+    int ox, oy, oz, X, Y, Z, ts, K;
+    int32_t* nbr_out;        // optional: the kernel map [K^3][nbr_out_stride] to write (rows or -1)
+    long long nbr_out_stride;
+};
+__device__ __forceinline__ int probe_base(const GridProbe& g, int row) {
+    const int4 c = g.coords[row];
+    return ((c.x * g.Z + (c.w - g.oz) / g.ts) * g.Y + (c.z - g.oy) / g.ts) * g.X + (c.y - g.ox) / g.ts;
+}
+__device__ __forceinline__ int probe_delta(const GridProbe& g, int k) {
+    const int h = g.K >> 1;
+    const int ix = k % g.K, iy = (k / g.K) % g.K, iz = k / (g.K * g.K);
+    return ((iz - h) * g.Y + (iy - h)) * g.X + (ix - h);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Three input channels (the 7^3 x 3 -> 64 stem of the NFI models), PACKED: a K-chunk of 32 holds 10 offsets x 3 channels
 // (+ 2 zero rows) instead of 8 offsets x 4 padded channels: 35 chunks instead of 43 for the 343 offsets, a fifth less
 // MFMA work in an MFMA-bound kernel.  X rows are still 4 floats wide (one aligned 16-B gather per pair), W is the layer's
 // own [K3*3, Cout] matrix.
+template <bool GRID>
 __global__ __launch_bounds__(256) void k_spconv_fwd3(const float* __restrict__ X, int ldx,
                                                      const float* __restrict__ W,  // [K3*3, Cout]
                                                      const int32_t* __restrict__ nbr, long long nbr_stride, int kflip,
                                                      const float* __restrict__ bias, float* __restrict__ Y, int ldy,
-                                                     int n_out, int K3, int Cout) {
+                                                     int n_out, int K3, int Cout, GridProbe gp) {
     constexpr int OPC = 10;
     __shared__ __attribute__((aligned(16))) float As[BM * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
@@ -193,19 +218,39 @@ __global__ __launch_bounds__(256) void k_spconv_fwd3(const float* __restrict__ X
     const int rowc[3] = {min(row0 + ((tid + 0) & (BM - 1)), n_out - 1), min(row0 + ((tid + 256) & (BM - 1)), n_out - 1),
                          min(row0 + ((tid + 512) & (BM - 1)), n_out - 1)};
     const int wcol = min(n0 + (tid & 15) * 4, Cout - 4);
+    // GRID: the three (row, offset) slots of a thread share the row (256 % 64 == 0): one cell index per thread; the cell
+    // offsets of the K^3 kernel offsets are tabulated once per workgroup (three runtime divisions per probe otherwise)
+    const int base = GRID ? probe_base(gp, rowc[0]) : 0;
+    const bool row_ok = row0 + (tid & (BM - 1)) < n_out;
+    __shared__ int s_delta[GRID ? 736 : 1];   // K <= 9: 729 offsets
+    if (GRID) {
+        for (int k = tid; k < K3; k += 256) s_delta[k] = probe_delta(gp, k);
+        __syncthreads();
+    }
     auto load_idx = [&](int ch) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int k = min(ch * OPC + ((tid + 256 * j) >> 6), K3 - 1);
-            const int kn = kflip ? (K3 - 1 - k) : k;
-            idxn[j] = nbr[(long long)kn * nbr_stride + rowc[j]];
+            if (GRID) {
+                idxn[j] = gp.grid[base + s_delta[k]];   // raw cell value (INT_MAX = none): decoded at use
+            } else {
+                const int kn = kflip ? (K3 - 1 - k) : k;
+                idxn[j] = nbr[(long long)kn * nbr_stride + rowc[j]];
+            }
         }
     };
-    auto gather = [&]() {
+    // rows of chunk ch (whose indices are in idxn)
+    auto gather = [&](int ch) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            idxc[j] = idxn[j];
+            idxc[j] = (GRID && idxn[j] == INT_MAX) ? -1 : idxn[j];
             xv[j] = *reinterpret_cast<const f32x4*>(X + (long long)max(idxc[j], 0) * ldx);
+            if (GRID && gp.nbr_out && blockIdx.y == 0) {
+                // the kernel map as a by-product (64 consecutive rows per offset: coalesced 256-B stores)
+                const int e = tid + 256 * j, k = ch * OPC + (e >> 6);
+                if (e < BM * OPC && k < K3 && row_ok)
+                    gp.nbr_out[(long long)k * gp.nbr_out_stride + row0 + (tid & (BM - 1))] = idxc[j];
+            }
         }
     };
     auto load_w = [&](int ch) {
@@ -216,7 +261,7 @@ __global__ __launch_bounds__(256) void k_spconv_fwd3(const float* __restrict__ X
         }
     };
     load_idx(0);
-    gather();
+    gather(0);
     load_w(0);
     load_idx(nchunks > 1 ? 1 : 0);
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -243,7 +288,7 @@ __global__ __launch_bounds__(256) void k_spconv_fwd3(const float* __restrict__ X
         __syncthreads();
         // rows / weights of chunk ch+1 (its indices arrived during the previous chunk), indices of chunk ch+2; past
         // the last chunk the (clamped) loads are harmless repeats
-        gather();
+        gather(min(ch + 1, nchunks - 1));
         load_w(min(ch + 1, nchunks - 1));
         load_idx(min(ch + 2, nchunks - 1));
         const float* arow = &As[(wr * 32 + li) * LDA + 4 * lh];
@@ -1464,8 +1509,8 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             agb_set_error("agb_spconv_fwd_ex: the packed 3-channel path takes neither a class partition nor a split");
             return AGB_EUNSUPPORTED;
         }
-        hipLaunchKernelGGL(k_spconv_fwd3, dim3(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN)), block, 0, s, a.X, a.ldx, a.W,
-                           a.nbr, a.nbr_stride, a.kflip, a.bias, a.Y, a.ldy, a.n_out, a.K3, a.Cout);
+        hipLaunchKernelGGL(k_spconv_fwd3<false>, dim3(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN)), block, 0, s, a.X, a.ldx,
+                           a.W, a.nbr, a.nbr_stride, a.kflip, a.bias, a.Y, a.ldy, a.n_out, a.K3, a.Cout, GridProbe{});
         return AGB_OK;
     }
     if (a.perm) {
@@ -1697,6 +1742,32 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
                            Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
     }
     AGB_CHECK_LAUNCH("agb_spconv_bwd_weight");
+    return AGB_OK;
+}
+
+// Stride-1 K^3 convolution of a 3-channel input (X rows 4 floats wide) whose neighbours are probed in the level's dense
+// grid instead of a pre-built kernel map.  coords int32[n_out][4]; grid / desc = the level's lookup grid ({ox, oy, oz, X,
+// Y, Z, ts, B | halo << 16}), halo >= K/2.  W [K^3 * 3, Cout].  nbr_out (optional): int32 [K^3][nbr_out_stride >= n_out],
+// receives the kernel map (the same values agb_grid_kernel_map writes) for the weight-gradient pass.
+int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                         const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                         int32_t* nbr_out, long long nbr_out_stride, void* stream) {
+    AGB_CHECK_ARG(n_out >= 0 && Cout >= 4 && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout, "agb_spconv_fwd3_grid: bad sizes");
+    AGB_CHECK_ARG(coords && grid && desc, "agb_spconv_fwd3_grid: coords, grid and desc are required");
+    AGB_CHECK_ARG(K >= 1 && K <= 9 && (K & 1), "agb_spconv_fwd3_grid: kernel size %d (odd, <= 9)", K);
+    AGB_CHECK_ARG((long long)(desc[7] & 0xffff) * desc[5] * desc[4] * desc[3] < (1LL << 31),
+                  "agb_spconv_fwd3_grid: grid too large for 32-bit cells");
+    AGB_CHECK_ARG(((desc[7] >> 16) & 0xff) >= K / 2, "agb_spconv_fwd3_grid: the grid's halo (%d cells) is narrower than "
+                  "K/2 = %d", (desc[7] >> 16) & 0xff, K / 2);
+    AGB_CHECK_ARG(nbr_out == nullptr || nbr_out_stride >= n_out, "agb_spconv_fwd3_grid: nbr_out_stride < n_out");
+    if (n_out == 0) return AGB_OK;
+    GridProbe gp;
+    gp.coords = (const int4*)coords; gp.grid = grid;
+    gp.ox = desc[0]; gp.oy = desc[1]; gp.oz = desc[2]; gp.X = desc[3]; gp.Y = desc[4]; gp.Z = desc[5];
+    gp.ts = desc[6]; gp.K = K; gp.nbr_out = nbr_out; gp.nbr_out_stride = nbr_out_stride;
+    hipLaunchKernelGGL(k_spconv_fwd3<true>, dim3(agb_cdiv(n_out, BM), agb_cdiv(Cout, BN)), dim3(256), 0,
+                       (hipStream_t)stream, X, ldx, W, nullptr, 0LL, 0, bias, Y, ldy, n_out, K * K * K, Cout, gp);
+    AGB_CHECK_LAUNCH("agb_spconv_fwd3_grid");
     return AGB_OK;
 }
 

@@ -171,10 +171,20 @@ class MinkowskiConvolution(nn.Module):
             if self.bias is not None:
                 out = out + self.bias
             return input._like(out)
-        nbr = cm.kernel_map(ts, self.kernel_size, self.stride, self.dilation)
         ts_out = ts * self.stride
-        nbrT = plan = None
         needs_dx = input.F.requires_grad and torch.is_grad_enabled()
+        if self.in_channels == 3 and not needs_dx and ("fwd", ts, self.kernel_size, self.stride, self.dilation) \
+                not in cm.kernel_maps:
+            # three-channel stem: the forward kernel probes the level's dense grid itself and writes the kernel map out
+            # for its weight gradient (no separate 7^3 map pass)
+            probe = cm.grid_probe(ts, self.kernel_size, self.stride, self.dilation)
+            if probe is not None:
+                n = cm.level(ts).n
+                out = SparseConvFunction.apply(input.F, self.kernel, self.bias, None, None, n, n, None,
+                                               (probe, self.kernel_size))
+                return SparseTensor(out, coordinate_map_key=CoordinateMapKey(ts_out), coordinate_manager=cm)
+        nbr = cm.kernel_map(ts, self.kernel_size, self.stride, self.dilation)
+        nbrT = plan = None
         if needs_dx and not (self.stride == 1 and self.kernel_size % 2 == 1):
             nbrT = cm.transposed_map(ts, self.kernel_size, self.stride, self.dilation)
             if self.stride > 1:

@@ -99,8 +99,10 @@ class SparseConvFunction(torch.autograd.Function):
     nbrT: transposed map [K3, N_in] or None when the k-flipped forward map serves (stride 1, odd kernel)."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, bias, nbr, nbrT, n_in, n_out, plan=None):
+    def forward(ctx, feats, kernel, bias, nbr, nbrT, n_in, n_out, plan=None, probe=None):
         K3, cin, cout = kernel.shape
+        if probe is not None:
+            return SparseConvFunction._forward_probe(ctx, feats, kernel, bias, n_out, probe)
         cin_p = _small_cin_pad(cin)
         cout_p = (cout + 3) // 4 * 4
         x = (feats if cin_p == cin else F.pad(feats, (0, cin_p - cin))).contiguous()
@@ -130,7 +132,51 @@ class SparseConvFunction(torch.autograd.Function):
         return y if cout_p == cout else y[:, :cout].contiguous()
 
     @staticmethod
+    def _forward_probe(ctx, feats, kernel, bias, n_out, probe):
+        """3-channel stride-1 layer: the forward kernel probes the level's dense grid for its neighbours and writes the
+        kernel map out for the weight gradient (csrc/spconv.hip GridProbe)."""
+        (coords, grid, desc), K = probe
+        K3, cin, cout = kernel.shape
+        if cin != 3 or cout % 4 != 0:
+            raise _lib.AgbError("the grid-probing path takes 3 input channels and a multiple of 4 output channels")
+        x = F.pad(feats, (0, 1)).contiguous()
+        b = None if bias is None else bias.reshape(-1).contiguous()
+        y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+        need_w = ctx.needs_input_grad[1]   # (grad mode is off inside Function.forward)
+        nbr = torch.empty(K3, max(n_out, 1), dtype=torch.int32, device=x.device) if need_w else None
+        ev = _prof_begin("fwd", K3, 3, cout, n_out)
+        _lib.call("agb_spconv_fwd3_grid", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
+                  _P(b), _P(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0), _lib.stream())
+        _prof_end(ev, "fwd", K3, 3, cout, n_out, None)
+        ctx.probe = True
+        ctx.save_for_backward(x, nbr if nbr is not None else torch.empty(0))
+        ctx.dims = (K3, cout, n_out, bias is not None, None if bias is None else bias.shape)
+        return y
+
+    @staticmethod
+    def _backward_probe(ctx, dy):
+        x, nbr = ctx.saved_tensors
+        K3, cout, n_out, has_bias, bias_shape = ctx.dims
+        colsum = getattr(dy, "agb_colsum", None)
+        dy = dy.contiguous()
+        dk = db = None
+        if ctx.needs_input_grad[1]:
+            if nbr.numel() == 0:
+                raise _lib.AgbError("the forward pass ran without gradients enabled: no kernel map was written")
+            dwp = torch.zeros(K3, 4, cout, dtype=torch.float32, device=dy.device)
+            ev = _prof_begin("wgrad", K3, 4, cout, n_out)
+            _lib.call("agb_spconv_bwd_weight", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
+                      _P(dwp), n_out, K3, 4, cout, _lib.stream())
+            _prof_end(ev, "wgrad", K3, 4, cout, n_out, None)
+            dk = dwp[:, :3, :].contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(bias_shape)
+        return None, dk, db, None, None, None, None, None, None
+
+    @staticmethod
     def backward(ctx, dy):
+        if getattr(ctx, "probe", False):
+            return SparseConvFunction._backward_probe(ctx, dy)
         x, w, nbr, nbrT = ctx.saved_tensors
         K3, cin, cout, cin_p, cout_p, n_in, n_out, has_T, has_bias, bias_shape = ctx.dims
         colsum = getattr(dy, "agb_colsum", None)   # left by the BatchNorm backward that produced dy (norm_ops.py)
@@ -171,7 +217,7 @@ class SparseConvFunction(torch.autograd.Function):
                 db = colsum.reshape(bias_shape)
             else:
                 db = dy[:, :cout].sum(0).reshape(bias_shape)
-        return dx, dk, db, None, None, None, None, None
+        return dx, dk, db, None, None, None, None, None, None
 
 
 class MaxPoolFunction(torch.autograd.Function):

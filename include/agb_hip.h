@@ -65,8 +65,10 @@ int agb_kernel_map(const int32_t* q_coords, int n, const int32_t* n_dev, int K, 
                    long long nbr_stride, unsigned long long* pair_count, void* stream);
 
 /* Dense-grid mode (small bounding volumes, e.g. LiDAR plots): every level keeps int32 grid[B][Z][Y][X]
- * (x fastest, INT_MAX = empty) described by desc = {ox, oy, oz, X, Y, Z, ts, B} (HOST int32[8]; origin a multiple
- * of ts).  Same results as the hash entry points above, one load per probe. */
+ * (x fastest, INT_MAX = empty) described by desc = {ox, oy, oz, X, Y, Z, ts, B | halo << 16} (HOST int32[8]; origin a
+ * multiple of ts; halo = margin of cells on every side that stays empty — rows falling there are reported as out of
+ * range like rows outside the grid — so that kernels probing grid[cell + delta] directly never leave the plot's block).
+ * Same results as the hash entry points above, one load per probe. */
 int agb_coords_bbox(const int32_t* coords, int n, const int32_t* n_dev, int32_t* bbox /* dev int32[8]:
                     min x,y,z, max x,y,z, max batch */, void* stream);
 int agb_grid_insert(const int32_t* coords, int n, const int32_t* n_dev, const int32_t* desc, int32_t* grid,
@@ -108,6 +110,13 @@ int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper
  * register-accumulator kernels otherwise), 0 = never the pair-compacted kernel, 64 / 128 = always, with that many rows
  * per wave.  All choices compute the same sums; only the fp32 summation order differs. */
 int agb_spconv_set_cmp_mode(int mode);
+/* Stride-1 odd-kernel convolution of a 3-channel input (the 7^3 stem; X rows 4 floats wide, W [K^3*3, Cout]) whose
+ * neighbours are probed in the level's dense lookup grid (agb_grid_insert; halo >= K/2) instead of a pre-built [K^3][n]
+ * kernel map.  nbr_out (optional) receives that map as a by-product — the values agb_grid_kernel_map would write — for
+ * agb_spconv_bwd_weight.  Same ME convolution as agb_spconv_fwd (resnet.py conv1). */
+int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                         const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                         int32_t* nbr_out, long long nbr_out_stride, void* stream);
 /* WT [K3][C][R] = per-offset transpose of W [K3][R][C] (R, C multiples of 4): the operand of the data gradient
  * dX = sum_k dY[nbrT[k]] @ W[k]^T, rebuilt once per layer per step (ME does the same inside its backward GEMMs with
  * a transposed-operand flag: MinkowskiEngine/src/convolution_kernel.cu ConvolutionBackwardKernelGPU). */

@@ -159,6 +159,46 @@ def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride,
         _lib.call("agb_spconv_set_cmp_mode", 1)
 
 
+@pytest.mark.parametrize("K,negative", [(7, False), (7, True), (3, True), (5, False)])
+def test_stem_conv_probes_dense_grid(device, K, negative):
+    """A 3-channel stride-1 layer whose input needs no gradient reads its neighbours from the level's dense grid and
+    writes the kernel map out itself (no separate map pass).  The map equals the one the map kernel builds, the forward
+    output is bit-identical to the map-driven kernel's, the weight gradient equal up to the order of its float atomics;
+    both match the oracle."""
+    import dpcr_agb_amd.me_compat as ME
+    rng = np.random.default_rng(40 + K)
+    torch.manual_seed(40 + K)
+    coords = random_coords(rng, 3, 2500, 18, negative=negative)
+    ref = R.Coords(coords, 3)
+    x = torch.randn(len(coords), 3)
+    conv = ME.MinkowskiConvolution(3, 64, kernel_size=K, stride=1, bias=True, dimension=3).to(device)
+    res = {}
+    for mode in ("probe", "map"):
+        st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+        cm = st.coordinate_manager
+        assert cm.mode == "grid"
+        xin = x.to(device).requires_grad_(mode == "map")   # an input gradient needs the (flipped) map: map path
+        conv.zero_grad(set_to_none=True)
+        out = conv(ME.SparseTensor(xin, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm))
+        written = out.F.grad_fn.saved_tensors[1] if mode == "probe" else None
+        g = torch.randn(out.F.shape[0], 64, generator=torch.Generator().manual_seed(1)).to(device)
+        out.F.backward(g)
+        res[mode] = (out.F.detach().clone(), conv.kernel.grad.clone(), conv.bias.grad.clone(), g)
+        assert (("fwd", 1, K, 1, 1) in cm.kernel_maps) == (mode == "map")   # the probing path runs no map pass
+        if mode == "probe":
+            assert torch.equal(written, cm.kernel_map(1, K, 1))              # ... and wrote the same map itself
+    assert torch.equal(res["probe"][0], res["map"][0])
+    assert rel_err(res["probe"][1], res["map"][1]) < 1e-5
+    assert rel_err(res["probe"][2], res["map"][2]) < 1e-5
+    xr = x.double()
+    wr = conv.kernel.detach().cpu().double().requires_grad_(True)
+    br = conv.bias.detach().cpu().double().requires_grad_(True)
+    outr = R.conv(xr, ref.map(1, K, 1), wr, br)
+    outr.backward(res["probe"][3].cpu().double())
+    assert rel_err(res["probe"][0], outr) < RTOL
+    assert rel_err(res["probe"][1], wr.grad) < RTOL
+
+
 @pytest.mark.parametrize("shift", [3, 4])
 def test_conv_pair_compacted_interleaved_tiles(device, shift):
     """Interleaved tiles (row blocks taken from regions ntiles blocks apart) only change which wave sums a row: the
