@@ -58,7 +58,7 @@ def kernel_of(rec):
     if rec["kind"] == "wgrad":
         return f"k_spconv_dw_small_cmp<{rec['cin']}>" if small else "k_spconv_dw_cmp"
     if rec["cin"] == 3:
-        return "k_spconv_fwd3"
+        return "k_spconv_fwd3"   # (<true>: the grid-probing instantiation, when the level is in grid mode)
     if small:
         return f"k_spconv_fwd<{rec['cin']}>"
     if rec.get("perm"):

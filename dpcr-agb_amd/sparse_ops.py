@@ -148,6 +148,9 @@ class SparseConvFunction(torch.autograd.Function):
         _lib.call("agb_spconv_fwd3_grid", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
                   _P(b), _P(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0), _lib.stream())
         _prof_end(ev, "fwd", K3, 3, cout, n_out, None)
+        if ev is not None and nbr is not None:   # profiling only: the kernel-map size, after the closing event
+            PROFILE[-1]["pairs"] = (nbr >= 0).sum()
+        ctx.pairs = None
         ctx.probe = True
         ctx.save_for_backward(x, nbr if nbr is not None else torch.empty(0))
         ctx.dims = (K3, cout, n_out, bias is not None, None if bias is None else bias.shape)
@@ -168,6 +171,8 @@ class SparseConvFunction(torch.autograd.Function):
             _lib.call("agb_spconv_bwd_weight", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
                       _P(dwp), n_out, K3, 4, cout, _lib.stream())
             _prof_end(ev, "wgrad", K3, 4, cout, n_out, None)
+            if ev is not None:
+                PROFILE[-1]["pairs"] = (nbr >= 0).sum()
             dk = dwp[:, :3, :].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(bias_shape)
