@@ -226,6 +226,8 @@ struct GridDesc {
     int B;
     int halo;        // margin of cells on every side that rows may not occupy (kept empty: kernels that probe
                      // grid[cell + delta] directly never leave the grid or the plot's own block of it)
+    int lg;          // log2(ts) when ts is a power of two (the usual case: shifts instead of runtime divisions in every
+                     // probe), else -1
 };
 
 // strict: also -1 inside the halo margin (where rows are inserted: a coordinate outside the declared bounds must be
@@ -234,7 +236,10 @@ __device__ __forceinline__ long long grid_cell(const GridDesc& g, int b, int x, 
     // returns -1 when (b,x,y,z) is outside the grid or off the level's lattice
     int dx = x - g.ox, dy = y - g.oy, dz = z - g.oz;
     if (b < 0 || b >= g.B || dx < 0 || dy < 0 || dz < 0) return -1;
-    if (g.ts > 1) {
+    if (g.lg > 0) {
+        if ((dx | dy | dz) & (g.ts - 1)) return -1;
+        dx >>= g.lg; dy >>= g.lg; dz >>= g.lg;
+    } else if (g.ts > 1 && g.lg < 0) {
         if ((dx % g.ts) | (dy % g.ts) | (dz % g.ts)) return -1;
         dx /= g.ts; dy /= g.ts; dz /= g.ts;
     }
@@ -490,6 +495,9 @@ static inline GridDesc mk_desc(const int32_t* d) {
     GridDesc g;
     g.ox = d[0]; g.oy = d[1]; g.oz = d[2]; g.X = d[3]; g.Y = d[4]; g.Z = d[5]; g.ts = d[6]; g.B = d[7] & 0xffff;
     g.halo = (d[7] >> 16) & 0xff;
+    g.lg = -1;
+    for (int l = 0; l < 31; ++l)
+        if (g.ts == (1 << l)) g.lg = l;
     return g;
 }
 static inline long long desc_cells(const int32_t* d) { return (long long)(d[7] & 0xffff) * d[5] * d[4] * d[3]; }
