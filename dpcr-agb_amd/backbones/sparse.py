@@ -43,7 +43,9 @@ class MinkowskiDropPath(nn.Module):
         self.drop_prob = drop_prob
         self.scale_by_keep = scale_by_keep
 
-    _RING, _ring, _slot = 64, None, 0  # pinned staging rows: the per-step H2D copies stay asynchronous
+    # pinned staging rows: the per-step H2D copies stay asynchronous; a row is rewritten only after the device has
+    # executed the copy that read it (one event per row)
+    _RING, _ring, _slot, _done = 64, None, 0, None
 
     def scale_vector(self, x):
         """float[B] on the device: keep/(1-p) per batch element, or None when nothing is to be applied."""
@@ -56,11 +58,24 @@ class MinkowskiDropPath(nn.Module):
             keep = [k / keep_prob for k in keep]
         cls = MinkowskiDropPath
         if cls._ring is None or cls._ring.shape[1] < B:
+            if cls._done is not None:
+                for ev in cls._done:
+                    if ev is not None:
+                        ev.synchronize()
             cls._ring = torch.empty(cls._RING, max(B, 256), dtype=torch.float32).pin_memory()
-        row = cls._ring[cls._slot % cls._RING, :B]
+            cls._done = [None] * cls._RING
+        slot = cls._slot % cls._RING
         cls._slot += 1
+        if cls._done[slot] is not None:
+            cls._done[slot].synchronize()
+        row = cls._ring[slot, :B]
         row.copy_(torch.tensor(keep, dtype=torch.float32))
-        return row.to(x.device, non_blocking=True)
+        out = row.to(x.device, non_blocking=True)
+        if out.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            cls._done[slot] = ev
+        return out
 
     def forward(self, x):
         scale = self.scale_vector(x)

@@ -191,9 +191,13 @@ class CoordinateManager:
     def _resolve(self, lvl: _Level):
         """Make the host row count of a level available (one read-back if it is still device-only)."""
         if lvl.n is None:
-            lvl.n = int(lvl.n_dev.item())
+            # the one unavoidable read-back of a lazily created level also carries the insert status (duplicates /
+            # range / batch order): strided levels add to the range counter, so it is re-checked with every level
+            vals = torch.cat([lvl.n_dev, self.levels[self.origin_ts].status]).tolist()
+            lvl.n = int(vals[0])
             lvl.n_dev = None
             lvl.bound = lvl.n
+            self._check_status(vals[1:])
         return lvl
 
     def level(self, ts: int) -> _Level:
@@ -354,6 +358,11 @@ class CoordinateManager:
     # -------------------------------------------------------------- kernel maps
     def _lookup(self, q: _Level, table: _Level, K, step, sign, require_multiple_of, count_pairs):
         self._resolve(q)
+        if not self._validated:
+            # first kernel map of a manager that was not built through prefetch_strides (e.g. a plain
+            # ME.SparseTensor(features, coordinates) in user code): duplicates / out-of-range rows / unordered batches
+            # must not pass silently — one read-back, like ME's own host synchronisation at this point
+            self.validate()
         nbr = torch.empty(K ** 3, max(q.n, 1), dtype=torch.int32, device=self.device)
         # sharded counter (64 slots on separate lines); the kernel-map size is the sum — read only by profiling code
         pairs = torch.zeros(64 * 16, dtype=torch.int64, device=self.device) if count_pairs else None

@@ -123,7 +123,7 @@ __global__ void k_stride_flag(int n, const int32_t* n_dev, const int32_t* vals, 
     flags[i] = (i < nn && vals[slot_of_row[i]] == i) ? 1 : 0;
 }
 
-#include "scan.cuh"
+#include "scan.h"
 
 // pass 3: representatives write the output coordinate and publish their row id in the table
 __global__ void k_stride_emit(const int4* __restrict__ coords, int n, const int32_t* n_dev, int ts_out,

@@ -15,7 +15,7 @@
 //     and are scaled by (float)(1.0/count); emission order is canonical (cell key ascending per cloud) — the
 //     reference emits in libstdc++ unordered_map iteration order, an artefact no consumer depends on.
 #include "agb_common.h"
-#include "scan.cuh"
+#include "scan.h"
 #include <float.h>
 #include <limits.h>
 

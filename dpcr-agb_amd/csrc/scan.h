@@ -1,4 +1,4 @@
-// scan.cuh — deterministic exclusive scan over int32 (three small kernels), shared by coords.hip and kpindex.hip.
+// scan.h — deterministic exclusive scan over int32 (three small kernels), shared by coords.hip and kpindex.hip.
 #pragma once
 #include "agb_common.h"
 

@@ -404,9 +404,10 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
     auto load_idx = [&](int ch, int* dst) {
         int k = ch < ch_end ? offset_of(ch) : 0;
         int kn = a.kflip ? (K3 - 1 - k) : k;
+        // nbr == nullptr: the identity map (K3 == 1): a dense [n, Cin] x [Cin, Cout] product (1x1 stride-1 convolution)
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
-            dst[j] = (ch < ch_end && grow[j] >= 0) ? a.nbr[(long long)kn * a.nbr_stride + grow[j]] : -1;
+            dst[j] = (ch < ch_end && grow[j] >= 0) ? (a.nbr ? a.nbr[(long long)kn * a.nbr_stride + grow[j]] : grow[j]) : -1;
     };
     auto load_data = [&](int ch, const int* idx) {
         int k = offset_of(ch);
@@ -583,9 +584,10 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
     auto load_idx = [&](int ch, int* dst) {
         int k = ch < ch_end ? offset_of(ch) : 0;
         int kn = a.kflip ? (K3 - 1 - k) : k;
+        // nbr == nullptr: the identity map (K3 == 1): a dense [n, Cin] x [Cin, Cout] product (1x1 stride-1 convolution)
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
-            dst[j] = (ch < ch_end && grow[j] >= 0) ? a.nbr[(long long)kn * a.nbr_stride + grow[j]] : -1;
+            dst[j] = (ch < ch_end && grow[j] >= 0) ? (a.nbr ? a.nbr[(long long)kn * a.nbr_stride + grow[j]] : grow[j]) : -1;
     };
     auto load_data = [&](int ch, const int* idx) {
         int k = offset_of(ch);
@@ -1143,6 +1145,20 @@ __global__ __launch_bounds__(256) void k_spconv_dw(const float* __restrict__ X, 
 // chunk, so the chunk's dY / X rows are re-read from that XCD's L2 instead of crossing to HBM/MALL 27 times.
 #define DW_KS 64
 #define DW_MAXROWS 2048
+// PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// PREC = 1 / 2: bf16 / split-bf16x3 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The reduction index of
+//   this product is the PAIR, which is the slow index of both operands in memory, while the bf16 MFMA wants 8 consecutive
+//   reduction elements per lane: the gathered rows are transposed while they are staged — a thread loads the same four
+//   channels of two consecutive pairs, packs them pairwise into bf16x2 dwords and writes T[channel][pair / 2].  Rows of
+//   48 dwords with the 4-dword chunk index XORed with (channel >> 2) & 7 keep the ds_write_b32 2-way (free) and the
+//   fragment ds_read_b128 conflict-free (searched by brute force over the bank rules of MI355X_MICROARCH.md §LDS).
+// nbr == nullptr: identity map (dense X^T dY of a 1x1 stride-1 convolution).
+#define DWT_LD 48     // dwords per transposed row (32 used: 64 pairs)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned pack_bf16_lo(float a, float b) {
+    return (unsigned)f2bf(a - bf2f(f2bf(a))) | ((unsigned)f2bf(b - bf2f(f2bf(b))) << 16);
+}
+template <int PREC>
 __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ dY, int ldy,
                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
@@ -1151,8 +1167,10 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
                                                        int il_shift) {
     // il_shift > 0: a row chunk is made of 2^il_shift-row blocks taken `chunks` blocks apart (see k_spconv_cmp: evens
     // out the pair count per workgroup where the density varies by region)
-    __shared__ __attribute__((aligned(16))) float As[DW_KS * 64];  // [pair][m]
-    __shared__ __attribute__((aligned(16))) float Bs[DW_KS * 64];  // [pair][n]
+    constexpr int NP = PREC == 2 ? 2 : 1;
+    // fp32: As [pair][m], Bs [pair][n];  bf16: At [m][pair/2] / Bt [n][pair/2] (transposed, swizzled), hi (and lo) planes
+    __shared__ __attribute__((aligned(16))) float As[PREC == 0 ? DW_KS * 64 : NP * 64 * DWT_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[PREC == 0 ? DW_KS * 64 : NP * 64 * DWT_LD];
     __shared__ int p_in[DW_MAXROWS], p_out[DW_MAXROWS];
     __shared__ int s_wcnt[2][4];
     const int tid = threadIdx.x;
@@ -1176,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     const int k = mt / cin_tiles;
     const int c0 = (mt % cin_tiles) * 64;
     const int t_r = tid >> 4, t_c = (tid & 15) * 4;
-    const int32_t* nrow = nbr + (long long)k * nbr_stride;
+    const int32_t* nrow = nbr ? nbr + (long long)k * nbr_stride : nullptr;
     // local row of the chunk -> row of the level (-1: past the end)
     auto grow = [&](int i) -> int {
         if (il_shift == 0) return r_begin + i;
@@ -1194,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     for (int it = 0; it < NIT; ++it) {
         const int i = it * 256 + tid;
         const int gr = i < nrows ? grow(i) : -1;
-        idxs[it] = gr >= 0 ? nrow[gr] : -1;
+        idxs[it] = gr >= 0 ? (nrow ? nrow[gr] : gr) : -1;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1232,10 +1250,12 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     // "LDS list read -> global load" chain sat in its own block, four of them back to back before the first MFMA
     const int a_col = min(c0 + t_c, Cin - 4), b_col = min(n0 + t_c, Cout - 4);
     const bool a_ok = c0 + t_c < Cin, b_ok = n0 + t_c < Cout;
+    // pair (inside the 64-pair step) of register j: fp32 rows t_r + 16 j; bf16: the two pairs of pair-pair t_r + 16 (j >> 1)
+    auto pair_of = [&](int j) { return PREC == 0 ? t_r + 16 * j : 2 * (t_r + 16 * (j >> 1)) + (j & 1); };
     auto load_data = [&](int pb) {
 #pragma unroll
         for (int j = 0; j < LJ; ++j) {
-            const int p = min(pb + t_r + 16 * j, total - 1);
+            const int p = min(pb + pair_of(j), total - 1);
             const int in = p_in[p], out = p_out[p];
             a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)in * ldx + a_col);
             b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)out * ldy + b_col);
@@ -1243,24 +1263,74 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     };
     load_data(0);
     for (int pb = 0; pb < total; pb += DW_KS) {
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int j = 0; j < LJ; ++j) {
-            const bool live = pb + t_r + 16 * j < total;
-            float4 av = a_reg[j], bv = b_reg[j];
-            if (!(live && a_ok)) av = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(live && b_ok)) bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&As[(t_r + 16 * j) * 64 + t_c]) = av;
-            *reinterpret_cast<float4*>(&Bs[(t_r + 16 * j) * 64 + t_c]) = bv;
+            for (int j = 0; j < LJ; ++j) {
+                const bool live = pb + t_r + 16 * j < total;
+                float4 av = a_reg[j], bv = b_reg[j];
+                if (!(live && a_ok)) av = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(live && b_ok)) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&As[(t_r + 16 * j) * 64 + t_c]) = av;
+                *reinterpret_cast<float4*>(&Bs[(t_r + 16 * j) * 64 + t_c]) = bv;
+            }
+        } else {
+            unsigned* At = reinterpret_cast<unsigned*>(As);
+            unsigned* Bt = reinterpret_cast<unsigned*>(Bs);
+#pragma unroll
+            for (int jj = 0; jj < LJ / 2; ++jj) {
+                float av[2][4], bv[2][4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool live = pb + pair_of(2 * jj + e) < total;
+                    const float4 a4 = a_reg[2 * jj + e], b4 = b_reg[2 * jj + e];
+                    const bool la = live && a_ok, lb = live && b_ok;
+                    av[e][0] = la ? a4.x : 0.f; av[e][1] = la ? a4.y : 0.f; av[e][2] = la ? a4.z : 0.f; av[e][3] = la ? a4.w : 0.f;
+                    bv[e][0] = lb ? b4.x : 0.f; bv[e][1] = lb ? b4.y : 0.f; bv[e][2] = lb ? b4.z : 0.f; bv[e][3] = lb ? b4.w : 0.f;
+                }
+                const int pp = t_r + 16 * jj;                          // pair-pair (dword column) 0..31
+                const int col = (((pp >> 2) ^ ((t_c >> 2) & 7)) << 2) | (pp & 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    At[(t_c + i) * DWT_LD + col] = pack_bf16(av[0][i], av[1][i]);
+                    Bt[(t_c + i) * DWT_LD + col] = pack_bf16(bv[0][i], bv[1][i]);
+                    if constexpr (PREC == 2) {
+                        At[(64 + t_c + i) * DWT_LD + col] = pack_bf16_lo(av[0][i], av[1][i]);
+                        Bt[(64 + t_c + i) * DWT_LD + col] = pack_bf16_lo(bv[0][i], bv[1][i]);
+                    }
+                }
+            }
         }
         __syncthreads();
         if (pb + DW_KS < total) load_data(pb + DW_KS);   // in flight during the MFMAs below
-        const float* ap = &As[wr * 32 + li];
-        const float* bp = &Bs[wc * 32 + li];
+        if constexpr (PREC == 0) {
+            const float* ap = &As[wr * 32 + li];
+            const float* bp = &Bs[wc * 32 + li];
 #pragma unroll
-        for (int s2 = 0; s2 < DW_KS / 2; ++s2) {
-            float av = ap[(2 * s2 + lh) * 64];
-            float bv = bp[(2 * s2 + lh) * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            for (int s2 = 0; s2 < DW_KS / 2; ++s2) {
+                float av = ap[(2 * s2 + lh) * 64];
+                float bv = bp[(2 * s2 + lh) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+        } else {
+            // lane (r = lane & 31, h = lane >> 5) holds A[m = r][pair 16 s + 8 h + j] and B[same pairs][n = r], j = 0..7:
+            // chunk 2 s + h of row r of the transposed tiles
+            const unsigned* At = reinterpret_cast<const unsigned*>(As);
+            const unsigned* Bt = reinterpret_cast<const unsigned*>(Bs);
+            const int ar = wr * 32 + li, br = wc * 32 + li;
+            const int ag = (ar >> 2) & 7, bg = (br >> 2) & 7;
+#pragma unroll
+            for (int s2 = 0; s2 < DW_KS / 16; ++s2) {
+                const int q = 2 * s2 + lh;
+                bf16x8 ah = *reinterpret_cast<const bf16x8*>(&At[ar * DWT_LD + ((q ^ ag) << 2)]);
+                bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bt[br * DWT_LD + ((q ^ bg) << 2)]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                if constexpr (PREC == 2) {
+                    bf16x8 al = *reinterpret_cast<const bf16x8*>(&At[(64 + ar) * DWT_LD + ((q ^ ag) << 2)]);
+                    bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bt[(64 + br) * DWT_LD + ((q ^ bg) << 2)]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                }
+            }
         }
         __syncthreads();
     }
@@ -1528,7 +1598,7 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
         else
             hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
                                a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
-    } else if (cmp_rows(a) > 0) {
+    } else if (a.nbr != nullptr && cmp_rows(a) > 0) {   // (a dense product has no absent pairs to skip)
         int R, rpt, ntiles, nct, il;
         cmp_geometry(a, &R, &rpt, &ntiles, &nct, &il);
         dim3 grid(8 * agb_cdiv(ntiles, 8) * nct * a.ksplit), blk(64);
@@ -1613,7 +1683,9 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
     AGB_CHECK_ARG((Cin % 4 == 0 || Cin == 3) && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout,
                   "agb_spconv_fwd: Cin (%d: a multiple of 4, or 3 with 4-float rows), Cout (%d), ldx (%d) must be "
                   "multiples of 4 (pad small inputs)", Cin, Cout, ldx);
-    AGB_CHECK_ARG(nbr_stride >= n_out, "agb_spconv_fwd: nbr_stride < n_out");
+    AGB_CHECK_ARG(nbr == nullptr || nbr_stride >= n_out, "agb_spconv_fwd: nbr_stride < n_out");
+    AGB_CHECK_ARG(nbr != nullptr || (K3 == 1 && perm == nullptr && Cin >= 12),
+                  "agb_spconv_fwd: the identity map (nbr == NULL: dense 1x1 stride-1 product) needs K3 == 1, Cin >= 12");
     AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_ex: ksplit needs `partial`");
     AGB_CHECK_ARG(perm == nullptr || (tile_cls != nullptr && cls_tab != nullptr && n_tiles > 0),
                   "agb_spconv_fwd_ex: perm needs tile_cls, cls_tab and n_tiles");
@@ -1636,6 +1708,7 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 4 && Cout >= 4 && Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0,
                   "agb_spconv_fwd_lp: Cin (%d), Cout (%d), ldx must be multiples of 4", Cin, Cout);
     AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_lp: ksplit needs `partial`");
+    AGB_CHECK_ARG(nbr != nullptr || (K3 == 1 && perm == nullptr), "agb_spconv_fwd_lp: the identity map needs K3 == 1");
     if (n_out == 0) return AGB_OK;
     hipStream_t s = (hipStream_t)stream;
     ConvArgs a{X, ldx, Wt, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit,
@@ -1693,9 +1766,15 @@ int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, in
 }
 
 // dW must be zero-filled by the caller (it is accumulated into).
-int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
-                          float* dW, int n_out, int K3, int Cin, int Cout, void* stream) {
+// precision: 0 = fp32 MFMA, 1 = bf16 operands, 2 = split-bf16 x3 (the small-Cin stem path is always fp32).
+// nbr == nullptr (K3 == 1): identity map, dW = X^T dY of a 1x1 stride-1 convolution.
+int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
+                             float* dW, int n_out, int K3, int Cin, int Cout, int precision, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_bwd_weight: bad sizes");
+    AGB_CHECK_ARG(precision >= 0 && precision <= 2, "agb_spconv_bwd_weight_lp: precision %d (0 fp32, 1 bf16, 2 bf16x3)",
+                  precision);
+    AGB_CHECK_ARG(nbr != nullptr || K3 == 1, "agb_spconv_bwd_weight: the identity map (nbr == NULL) needs K3 == 1");
+    AGB_CHECK_ARG(nbr != nullptr || (Cin != 4 && Cin != 8), "agb_spconv_bwd_weight: the identity map needs Cin >= 12");
     AGB_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
                   "agb_spconv_bwd_weight: Cin (%d), Cout (%d), ldx, ldy must be multiples of 4", Cin, Cout);
     if (n_out == 0) return AGB_OK;
@@ -1738,11 +1817,23 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
             chunks = agb_cdiv(nblk, bpc);
         }
         dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
-        hipLaunchKernelGGL(k_spconv_dw_cmp, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin,
-                           Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+        if (precision == 1)
+            hipLaunchKernelGGL(k_spconv_dw_cmp<1>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+        else if (precision == 2)
+            hipLaunchKernelGGL(k_spconv_dw_cmp<2>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+        else
+            hipLaunchKernelGGL(k_spconv_dw_cmp<0>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
     }
     AGB_CHECK_LAUNCH("agb_spconv_bwd_weight");
     return AGB_OK;
+}
+
+int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
+                          float* dW, int n_out, int K3, int Cin, int Cout, void* stream) {
+    return agb_spconv_bwd_weight_lp(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, 0, stream);
 }
 
 // Stride-1 K^3 convolution of a 3-channel input (X rows 4 floats wide) whose neighbours are probed in the level's dense

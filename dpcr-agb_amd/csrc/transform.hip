@@ -18,7 +18,7 @@
 // fp32 coordinates like matplotlib does: results are bit-identical to the CPU chain except for points lying exactly on
 // a polygon edge.  HBM-bound, a few bytes per point: N*(12 read + 12+12+8+4 written).
 #include "agb_common.h"
-#include "scan.cuh"
+#include "scan.h"
 
 struct PlotXform {
     float sx, sy, sz;     // ScalePos

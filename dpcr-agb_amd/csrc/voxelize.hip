@@ -10,7 +10,7 @@
 // Method: per-cloud dense key grid with atomicMax of the shuffled position, flag + exclusive scan (cell order is
 // key order), emit.  Integer/byte work, HBM-bound.
 #include "agb_common.h"
-#include "scan.cuh"
+#include "scan.h"
 #include <limits.h>
 
 __device__ __forceinline__ int vf2ord(float f) {

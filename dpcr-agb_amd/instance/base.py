@@ -51,6 +51,9 @@ class InstanceBase(torch.nn.Module):
             self.loss_fns["reg"] = [REG_LOSSES[n] for n in names.split(",")] if names else []
         self.num_reg_classes = dataset.num_reg_classes
         self.double_batch = option.get("double_batch", dataset.double_batch)
+        if self.double_batch:
+            raise NotImplementedError("double_batch (paired-sample batches) is not used by the NFI recipes and is not "
+                                      "implemented")
 
     # ----------------------------------------------------------- target statistics (base.py:86-134)
     def _register_target_stats(self, dataset):
@@ -187,16 +190,23 @@ class InstanceBase(torch.nn.Module):
         from ..metrics import RegressionMeter
         was_training = self.training
         self.eval()
-        outs, ys = [], []
+        outs, ys, masks = [], [], []
         for data in batches:
             self.set_input(data, device)
             self.forward()
             outs.append(self.get_reg_output().detach().cpu())
             ys.append(self.get_reg_input().detach().cpu())
+            masks.append(self.reg_y_mask.detach().cpu())
         self.train(was_training)
-        outs, ys = torch.cat(outs), torch.cat(ys)
-        meter = RegressionMeter(ys.double().mean(0) if target_mean is None else target_mean)
-        meter.add(outs, ys)
+        outs, ys, masks = torch.cat(outs), torch.cat(ys), torch.cat(masks)
+        # missing targets (masked out or NaN) are ignored per target, as the tracker does
+        # (metrics/instance_tracker.py:116-134)
+        valid = masks & ~torch.isnan(ys)
+        if target_mean is None:
+            yd = torch.where(valid, ys.double(), torch.zeros_like(ys, dtype=torch.float64))
+            target_mean = yd.sum(0) / valid.sum(0).clamp(min=1)
+        meter = RegressionMeter(target_mean)
+        meter.add(outs, ys, valid)
         return meter.value()
 
     def optimize_parameters(self, epoch, batch_size, num_batches):

@@ -20,7 +20,8 @@ import torch.nn as nn
 from . import _lib
 from .coords import CoordinateManager, CoordinateMapKey, _as_int
 from .norm_ops import ACT_IDS, AddActFunction, batch_norm_act
-from .sparse_ops import (BroadcastMulFunction, GlobalPoolFunction, MaxPoolFunction, SparseConvFunction)
+from .sparse_ops import (BroadcastMulFunction, DenseConvFunction, GlobalPoolFunction, MaxPoolFunction,
+                         SparseConvFunction)
 
 
 class SparseTensor:
@@ -167,7 +168,10 @@ class MinkowskiConvolution(nn.Module):
             raise NotImplementedError("explicit output coordinates are not supported")
         cm, ts = input.coordinate_manager, input._ts
         if self.use_mm:
-            out = input.F @ self.kernel
+            if input.F.is_cuda and DenseConvFunction.supported(self.in_channels, self.out_channels):
+                # 1x1 stride-1: this library's own MFMA kernels on the identity map (csrc/spconv.hip), not a BLAS call
+                return input._like(DenseConvFunction.apply(input.F, self.kernel, self.bias))
+            out = input.F @ self.kernel     # odd channel counts (not used by the NFI models)
             if self.bias is not None:
                 out = out + self.bias
             return input._like(out)

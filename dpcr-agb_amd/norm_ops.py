@@ -75,7 +75,9 @@ class BatchNormActFunction(torch.autograd.Function):
             # column sums of dx in closed form (0 with batch statistics, gamma * rstd * dbeta with running ones): the
             # convolution that produced x (its backward node receives this very tensor) takes them as its bias gradient
             # instead of reducing dx again
-            dx.agb_colsum = dgb[2]
+            # The hint is tied to the tensor's version: if autograd accumulates another consumer's gradient into this
+            # buffer in place, the version moves and the convolution's backward recomputes the sum itself.
+            dx.agb_colsum = (dgb[2], dx._version)
         return dx, (dgb[0] if has_g else None), (dgb[1] if has_b else None), None, None, None, None, None, None, None
 
 

@@ -81,6 +81,10 @@ class AdaBelief(Optimizer):
             if self.fused and params[0].is_cuda and group["decoupled_decay"]:
                 self._fused_step(group, params, grads, m, v, step)
                 continue
+            if self.fused and self.clip_value:
+                # a group that cannot take the fused launch is clipped here (the caller skips clip_grad_value_ for
+                # fused optimisers); out of place, like the fused kernel leaves the gradients untouched
+                grads = [g.clamp(-float(self.clip_value), float(self.clip_value)) for g in grads]
 
             if group["decoupled_decay"]:
                 torch._foreach_mul_(params, 1.0 - (wd if group["fixed_decay"] else lr * wd))
@@ -132,19 +136,29 @@ class AdaBelief(Optimizer):
             cache = dict(ct=torch.tensor(ct, dtype=torch.int32, device=dev),
                          ci=torch.tensor(ci, dtype=torch.int32, device=dev), n=len(ct),
                          # ring of pinned staging tables: the host may run a step ahead of the device
+                         # ring of pinned staging tables: the host may run ahead of the device; a slot is rewritten
+                         # only after the device has executed the copy that read it (event per slot)
                          host=[torch.empty(len(params), 5, dtype=torch.int64).pin_memory() for _ in range(4)],
-                         dev=[torch.empty(len(params), 5, dtype=torch.int64, device=dev) for _ in range(4)], it=0)
+                         dev=[torch.empty(len(params), 5, dtype=torch.int64, device=dev) for _ in range(4)],
+                         done=[None] * 4, it=0)
             self._fused_cache[key] = cache
         slot = cache["it"] % 4
         cache["it"] += 1
         table = []
         for p, g, mm, vv in zip(params, grads, m, v):
-            if not (p.is_contiguous() and g.is_contiguous()):
-                raise RuntimeError("fused AdaBelief needs contiguous parameters and gradients")
+            if not (p.is_contiguous() and g.is_contiguous() and mm.is_contiguous() and vv.is_contiguous()):
+                raise RuntimeError("fused AdaBelief needs contiguous parameters, gradients and state")
+            if not (p.dtype == g.dtype == mm.dtype == vv.dtype == torch.float32):
+                raise RuntimeError("fused AdaBelief needs fp32 parameters, gradients and state")
             table.append((p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel()))
+        if cache["done"][slot] is not None:
+            cache["done"][slot].synchronize()   # the copy that last read this pinned slot has run
         cache["host"][slot].numpy()[:] = table
         descs = cache["dev"][slot]
         descs.copy_(cache["host"][slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        cache["done"][slot] = ev
         beta1, beta2 = group["betas"]
         lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
         decay = 1.0 - (wd if group["fixed_decay"] else lr * wd)

@@ -17,6 +17,22 @@ _P = _lib.ptr
 import os as _os
 CONV_PRECISION = _os.environ.get("AGB_CONV_PRECISION", "fp32")
 _PREC_ID = {"bf16": 1, "bf16x3": 2}
+
+
+def set_conv_precision(name):
+    """Operand precision of the sparse / 1x1 convolution MFMAs from now on: "fp32", "bf16" or "bf16x3" (forward, data
+    gradient and weight gradient; accumulation, I/O, the 3-channel stem, BatchNorm, SE and the index kernels stay fp32).
+    Returns the previous setting."""
+    global CONV_PRECISION
+    if name not in ("fp32", "bf16", "bf16x3"):
+        raise ValueError(f"conv precision '{name}': choose fp32, bf16 or bf16x3")
+    old, CONV_PRECISION = CONV_PRECISION, name
+    return old
+
+
+_lib.declare("agb_spconv_bwd_weight_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
+                                          _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
+                                          _lib.c_void_p])
 _lib.declare("agb_spconv_fwd_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
                                    _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                    _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
@@ -51,6 +67,17 @@ def _prof_end(ev0, kind, K3, cin, cout, rows, pairs, perm=False, split=1):
                         split=split))
 
 
+def _colsum_hint(dy):
+    """Column sums of dy left by the BatchNorm backward that produced it (norm_ops.py), or None.  Valid only for the
+    very tensor the BatchNorm node returned: an in-place accumulation of another consumer's gradient bumps the
+    version counter (and an out-of-place one creates a new tensor without the attribute)."""
+    hint = getattr(dy, "agb_colsum", None)
+    if hint is None:
+        return None
+    colsum, version = hint
+    return colsum if dy._version == version else None
+
+
 def _pad_cols(x, mult):
     c = x.shape[-1]
     pad = (-c) % mult
@@ -74,7 +101,7 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
     w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes."""
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
-    split = _lib.load().agb_spconv_split_hint(n_out, K3, cin, cout) if plan is None else 1
+    split = _lib.load().agb_spconv_split_hint(n_out, K3, cin, cout) if (plan is None and nbr is not None) else 1
     partial = torch.empty(split, n_out, cout, dtype=torch.float32, device=x.device) if split > 1 else None
     perm = tile_cls = cls_tab = None
     n_tiles = 0
@@ -83,11 +110,11 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     ev = _prof_begin(kind, K3, cin, cout, n_out, plan is not None, split)
     prec = _PREC_ID.get(CONV_PRECISION, 0) if (w_kmajor is not None and cin >= 12) else 0
     if prec:
-        _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), nbr.stride(0), int(kflip),
+        _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip),
                   _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
                   split, _P(partial), prec, _lib.stream())
     else:
-        _lib.call("agb_spconv_fwd_ex", _P(x), x.stride(0), _P(w2d), _P(nbr), nbr.stride(0), int(kflip), _P(bias),
+        _lib.call("agb_spconv_fwd_ex", _P(x), x.stride(0), _P(w2d), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip), _P(bias),
                   _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles, split,
                   _P(partial), _lib.stream())
     _prof_end(ev, kind, K3, cin, cout, n_out, pairs, plan is not None, split)
@@ -160,7 +187,7 @@ class SparseConvFunction(torch.autograd.Function):
     def _backward_probe(ctx, dy):
         x, nbr = ctx.saved_tensors
         K3, cout, n_out, has_bias, bias_shape = ctx.dims
-        colsum = getattr(dy, "agb_colsum", None)
+        colsum = _colsum_hint(dy)
         dy = dy.contiguous()
         dk = db = None
         if ctx.needs_input_grad[1]:
@@ -184,7 +211,7 @@ class SparseConvFunction(torch.autograd.Function):
             return SparseConvFunction._backward_probe(ctx, dy)
         x, w, nbr, nbrT = ctx.saved_tensors
         K3, cin, cout, cin_p, cout_p, n_in, n_out, has_T, has_bias, bias_shape = ctx.dims
-        colsum = getattr(dy, "agb_colsum", None)   # left by the BatchNorm backward that produced dy (norm_ops.py)
+        colsum = _colsum_hint(dy)
         dy = dy.contiguous()
         if cout_p != cout:
             dy = F.pad(dy, (0, cout_p - cout)).contiguous()
@@ -213,8 +240,9 @@ class SparseConvFunction(torch.autograd.Function):
             if dwp is None:
                 dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
             ev = _prof_begin("wgrad", K3, cin_p, cout_p, n_out)
-            _lib.call("agb_spconv_bwd_weight", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
-                      _P(dwp), n_out, K3, cin_p, cout_p, _lib.stream())
+            _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
+                      _P(dwp), n_out, K3, cin_p, cout_p, _PREC_ID.get(CONV_PRECISION, 0) if cin_p >= 12 else 0,
+                      _lib.stream())
             _prof_end(ev, "wgrad", K3, cin_p, cout_p, n_out, ctx.pairs)
             dk = dwp if (cin_p == cin and cout_p == cout) else dwp[:, :cin, :cout].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
@@ -223,6 +251,61 @@ class SparseConvFunction(torch.autograd.Function):
             else:
                 db = dy[:, :cout].sum(0).reshape(bias_shape)
         return dx, dk, db, None, None, None, None, None, None
+
+
+class DenseConvFunction(torch.autograd.Function):
+    """1x1 stride-1 convolution (ME's ``use_mm`` case: kernel [Cin, Cout], the coordinate map is the identity):
+    Y = X @ W + b on this library's own MFMA kernels — the register-accumulator implicit-GEMM kernels and the weight-gradient
+    kernel run with the identity map (nbr == NULL), in the operand precision of ``CONV_PRECISION``.
+    Needs Cin >= 12 and Cin, Cout multiples of 4 (the caller falls back to a library matmul otherwise)."""
+
+    @staticmethod
+    def supported(cin, cout):
+        return cin >= 12 and cin % 4 == 0 and cout % 4 == 0
+
+    @staticmethod
+    def forward(ctx, feats, kernel, bias):
+        cin, cout = kernel.shape
+        x = feats.contiguous()
+        n = x.shape[0]
+        w = kernel.contiguous()
+        b = None if bias is None else bias.reshape(-1).contiguous()
+        lp = CONV_PRECISION in _PREC_ID
+        wkm = w.t().contiguous() if lp else None          # K-major [Cout][Cin]
+        y = spconv_forward_raw(x, w, None, 0, b, n, 1, cin, cout, "fwd1x1", None, None, wkm)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.bias_shape = None if bias is None else bias.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        cin, cout = w.shape
+        n = x.shape[0]
+        colsum = _colsum_hint(dy)
+        dy = dy.contiguous()
+        dx = dk = db = None
+        lp = CONV_PRECISION in _PREC_ID
+        if ctx.needs_input_grad[0]:
+            if lp:     # the data gradient multiplies by W^T: its K-major form [Cin][Cout] is the kernel itself
+                dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None, w)
+            else:
+                wt = torch.empty(cout, cin, dtype=torch.float32, device=w.device)
+                if ctx.needs_input_grad[1]:   # the weight-gradient buffer is cleared by the same launch
+                    dk = torch.empty(cin, cout, dtype=torch.float32, device=w.device)
+                _lib.call("agb_spconv_weight_transpose_z", _P(w), _P(wt), _P(dk), 1, cin, cout, _lib.stream())
+                dx = spconv_forward_raw(dy, wt, None, 0, None, n, 1, cout, cin, "dgrad1x1")
+        if ctx.needs_input_grad[1]:
+            if dk is None:
+                dk = torch.zeros(cin, cout, dtype=torch.float32, device=w.device)
+            ev = _prof_begin("wgrad1x1", 1, cin, cout, n)
+            _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), None, 0, _P(dk), n, 1, cin,
+                      cout, _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
+            _prof_end(ev, "wgrad1x1", 1, cin, cout, n, None)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(ctx.bias_shape)
+        return dx, dk, db
 
 
 class MaxPoolFunction(torch.autograd.Function):

@@ -155,6 +155,8 @@ class SyntheticDataset:
         self.has_reg_targets = True
         self.reg_targets_idx = np.array([True, True])
         self.targets = NFI_TARGETS
+        self.reg_targets = list(NFI_TARGETS.keys())
+        self.areas = {"synthetic": None}
         self.double_batch = False
         self.dataset_opt = Opt(fixed=Opt(num_points=num_points))
         ys = np.stack([self._labels(s) for s in stat_seeds])
@@ -171,7 +173,10 @@ class SyntheticDataset:
                          VOLUME_RATIO * BIOMASS_A * float(np.sum(heights ** BIOMASS_B))], dtype=np.float64)
 
     def _get(self, stat):
-        return {"synthetic": {"train": self._stats[stat]}}
+        # one area, the same statistics for every stage (the tracker reads [area][stage], instance_tracker.py:69-87)
+        v = self._stats[stat]
+        per_stage = {"train": v, "val": v, "test": v}
+        return {"synthetic": dict(per_stage), "total": dict(per_stage)}
 
     def get_mean_targets(self):
         return self._get("mean")

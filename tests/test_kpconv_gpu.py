@@ -88,15 +88,19 @@ def test_kpcnn_end_to_end_matches_reference(device, g):
     y.backward(D(g["N_g"], device))
     assert rel(y, g["N_y"]) < RTOL
     gmax = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("N_grad/"))
-    worst = 0.0
+    worst, worst_name = 0.0, None
     for k in g.files:
         if k.startswith("N_grad/"):
             p = dict(net.named_parameters())[k[7:]]
             e = float(np.abs(p.grad.cpu().double().numpy() - g[k]).max()) / max(float(np.abs(g[k]).max()), 1e-3 * gmax)
-            worst = max(worst, e)
+            if e > worst:
+                worst, worst_name = e, k
         if k.startswith("N_after/"):
             assert rel(net.state_dict()[k[8:]], g[k]) < 1e-4, k
-    assert worst < 20 * RTOL, worst
+    # measured floor: the reference's fp32 gradients (the golden vectors) sit 1.3e-6 from an fp64 evaluation of the same
+    # network (oracle/kpconv_ref.py in double), the fp32 oracle 2.4e-6 — the 1e-4 bar applies to every tensor
+    print(f"KPCNN: worst gradient rel err {worst:.2e} ({worst_name})")
+    assert worst < RTOL, (worst, worst_name)
 
 
 def test_input_pyramid_and_network_vs_oracle(device):

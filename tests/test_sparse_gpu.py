@@ -413,8 +413,44 @@ def test_network_forward_backward_matches_oracle(device, name, layers):
         e = float((p.grad.detach().cpu().double() - ref_g).abs().max()) / denom
         if e > worst:
             worst, worst_name = e, k
-    # gradients pass through training-mode BN of ~10 layers: allow 10x the forward tolerance
-    assert worst < 10 * RTOL, (worst, worst_name)
+    # Measured floor of plain fp32 (oracle/sparse_ref.py run in fp32 on the CPU vs the same oracle in fp64, this batch):
+    # 1.4e-5 on every weight / BN / SE / head tensor and 5e-4 on the zero-gradient conv biases in front of a training-mode
+    # BatchNorm (pure rounding noise there; the HIP path returns their closed form, exactly 0).  So the north-star bar
+    # of 1e-4 applies to every tensor.
+    print(f"{name}: output rel err {rel_err(model.output, out):.2e}, worst gradient rel err {worst:.2e} ({worst_name})")
+    assert worst < RTOL, (worst, worst_name)
+
+
+@pytest.mark.parametrize("n_points", [16000])
+def test_senet14_full_size_plots_match_oracle(device, n_points):
+    """B = 2 plots of 16 000 points (BASELINE config 4's plot size): the pair-compacted, interleaved-tile and
+    channel-split kernels are dispatched exactly as in the benchmark (27 k voxels at stride 1: >= 8192 rows take
+    interleaved tiles; 13 k rows x 64 channels at stride 2 take the pair-compacted kernel) and meet the fp64 oracle."""
+    model, batch = _model_and_batch("SENet14", device, n_points, [11, 12])
+    sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    model.to(device).train()
+    model.set_input(batch, device)
+    model.forward()
+    model.loss.backward()
+    sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v)
+          for k, v in sd32.items()}
+    coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
+    out = R.resnet_forward(sd, coords, batch.x.double(), (1, 1, 1, 1), batch_size=len(batch))
+    loss = R.reg_loss(out, batch.y_reg.double(), model.reg_center_targets.cpu().double(),
+                      model.reg_scale_targets.cpu().double(), model.reg_weights.cpu().double())
+    loss.backward()
+    assert rel_err(model.output, out) < RTOL
+    gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.model.named_parameters())
+    worst, worst_name = 0.0, None
+    for k, p in model.model.named_parameters():
+        ref_g = sd[k].grad
+        denom = max(float(ref_g.abs().max()), 1e-3 * gmax)
+        e = float((p.grad.detach().cpu().double() - ref_g).abs().max()) / denom
+        if e > worst:
+            worst, worst_name = e, k
+    print(f"SENet14 2 x {n_points}: output rel err {rel_err(model.output, out):.2e}, worst gradient {worst:.2e} "
+          f"({worst_name})")
+    assert worst < RTOL, (worst, worst_name)
 
 
 def test_drop_path_consumes_rng_like_oracle(device):
@@ -456,7 +492,8 @@ def test_train_steps_track_oracle(device):
         for k, v in upd.items():
             sd[k] = v
         lg, lr_ = float(model.loss.detach()), float(loss.detach())
-        assert abs(lg - lr_) < 1e-3 * max(1.0, abs(lr_)), (step, lg, lr_)
+        print(f"step {step}: loss hip {lg:.7f} oracle {lr_:.7f}")
+        assert abs(lg - lr_) < RTOL * max(1.0, abs(lr_)), (step, lg, lr_)
 
 
 @pytest.mark.parametrize("pool", ["sum", "max"])
@@ -487,7 +524,7 @@ def test_mpointnet_matches_oracle(device, pool):
     gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.model.named_parameters())
     for k, p in model.model.named_parameters():
         denom = max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
-        assert float((p.grad.detach().cpu().double() - sd[k].grad).abs().max()) / denom < 10 * RTOL, k
+        assert float((p.grad.detach().cpu().double() - sd[k].grad).abs().max()) / denom < RTOL, k
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16", 2e-2), ("bf16x3", 1e-4)])
@@ -528,4 +565,75 @@ def test_conv_low_precision_operands(device, precision, tol, cin, cout, K, strid
     outr.backward(g.double())
     assert rel_err(out.F, outr) < tol
     assert rel_err(xg.grad, xr.grad) < tol
-    assert rel_err(conv.kernel.grad, wr.grad) < RTOL      # the weight gradient stays fp32
+    # the weight gradient runs in the same operand precision (k_spconv_dw_cmp<1/2>); layers with Cin < 12 stay fp32
+    assert rel_err(conv.kernel.grad, wr.grad) < (tol if cin >= 12 else RTOL)
+    assert rel_err(conv.bias.grad, br.grad) < RTOL
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 2e-2), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("cin,cout,n", [(64, 256, 5000), (256, 64, 3001), (128, 512, 700), (512, 2048, 90), (16, 12, 333),
+                                        (96, 80, 1)])
+def test_dense_1x1_conv(device, precision, tol, cin, cout, n):
+    """1x1 stride-1 convolutions (ME's use_mm case; two thirds of SENet50's layers) run on this library's own kernels
+    with the identity map: forward, data gradient, weight gradient and bias gradient vs fp64, in all operand modes."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import sparse_ops
+    from dpcr_agb_amd.sparse_ops import DenseConvFunction
+    torch.manual_seed(cin + cout + n)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=1, stride=1, bias=True, dimension=3).to(device)
+    assert conv.use_mm and conv.kernel.shape == (cin, cout) and DenseConvFunction.supported(cin, cout)
+    x = torch.randn(n, cin)
+    g = torch.randn(n, cout)
+    old = sparse_ops.set_conv_precision(precision)
+    try:
+        xg = x.to(device).requires_grad_(True)
+        out = DenseConvFunction.apply(xg, conv.kernel, conv.bias)
+        out.backward(g.to(device))
+    finally:
+        sparse_ops.set_conv_precision(old)
+    xr = x.double().requires_grad_(True)
+    wr = conv.kernel.detach().cpu().double().requires_grad_(True)
+    br = conv.bias.detach().cpu().double().requires_grad_(True)
+    outr = xr @ wr + br
+    outr.backward(g.double())
+    assert rel_err(out, outr) < tol
+    assert rel_err(xg.grad, xr.grad) < tol
+    assert rel_err(conv.kernel.grad, wr.grad) < tol
+    assert rel_err(conv.bias.grad, br.grad) < RTOL
+
+
+@pytest.mark.parametrize("precision,out_tol,grad_tol", [("bf16", 3e-2, 1.5e-1), ("bf16x3", 1e-4, 1e-3)])
+def test_senet50_low_precision_matches_oracle(device, precision, out_tol, grad_tol):
+    """BASELINE config 5's single-GPU leg: MSENet50 (SEBottleneck x (3,4,6,3), two targets) with bf16 operands / fp32
+    accumulate / fp32 index, BatchNorm and SE kernels, forward + backward vs the fp64 oracle.  bf16 tolerances are the
+    stated bf16 bar (8 mantissa bits through 53 convolutions); split-bf16x3 must meet the fp32 bars."""
+    from dpcr_agb_amd import sparse_ops
+    model, batch = _model_and_batch("SENet50", device, 1500, [0, 1, 2])
+    sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    model.to(device).train()
+    old = sparse_ops.set_conv_precision(precision)
+    try:
+        model.set_input(batch, device)
+        model.forward()
+        model.loss.backward()
+    finally:
+        sparse_ops.set_conv_precision(old)
+    sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v)
+          for k, v in sd32.items()}
+    coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
+    out = R.resnet_forward(sd, coords, batch.x.double(), (3, 4, 6, 3), batch_size=len(batch))
+    loss = R.reg_loss(out, batch.y_reg.double(), model.reg_center_targets.cpu().double(),
+                      model.reg_scale_targets.cpu().double(), model.reg_weights.cpu().double())
+    loss.backward()
+    e_out = rel_err(model.output, out)
+    gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.model.named_parameters())
+    worst, worst_name = 0.0, None
+    for k, p in model.model.named_parameters():
+        ref_g = sd[k].grad
+        denom = max(float(ref_g.abs().max()), 1e-3 * gmax)
+        e = float((p.grad.detach().cpu().double() - ref_g).abs().max()) / denom
+        if e > worst:
+            worst, worst_name = e, k
+    print(f"SENet50 {precision}: output rel err {e_out:.3e}, worst gradient rel err {worst:.3e} ({worst_name})")
+    assert e_out < out_tol, e_out
+    assert worst < grad_tol, (worst, worst_name)
