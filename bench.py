@@ -23,6 +23,12 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0  # bf16 MFMA dense peak (split-bf16x3 issues 3 bf16 MFMAs per product: priced at 2500 / 3)
+PRECISION = "fp32"         # operand precision of the convolution MFMAs (--precision)
+
+
+def mfma_peak_tf():
+    return {"fp32": MFMA_F32_PEAK_TF, "bf16": MFMA_BF16_PEAK_TF, "bf16x3": MFMA_BF16_PEAK_TF / 3.0}[PRECISION]
 
 
 def parse():
@@ -33,6 +39,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="plots per GPU")
     ap.add_argument("--points", type=int, default=16000)
     ap.add_argument("--model", default="SENet14")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+                    help="operand precision of the convolution MFMAs (fp32 accumulate; BN / SE / index kernels fp32). The "
+                         "headline (BASELINE config 4) is fp32; bf16 is BASELINE config 5's mode")
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated batches cycled per rank")
     ap.add_argument("--features", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -42,34 +51,46 @@ def parse():
 
 
 def conv_cost(rec, pairs):
-    """SURVEY.md §8(d) algorithmic bytes / FLOPs of one sparse-conv launch (fp32, e = 4)."""
+    """Algorithmic bytes / FLOPs of one convolution launch (activations and weights are fp32 in HBM in every operand
+    mode: e = 4).  bytes: SURVEY.md §8(d)'s per-pair formula P*(Cin+Cout)*e + 8P + K^3*Cin*Cout*e; compulsory: its
+    output-stationary lower bound N_in*Cin*e + N_out*Cout*e + K^3*Cin*Cout*e + 8P (every row read / written once) — the
+    figure an HBM-bound kernel is priced against (the per-pair figure counts each gathered row once per pair although
+    the gathers are served by L2 / MALL: it can exceed the HBM peak and is not a bound)."""
     cin, cout, K3 = rec["cin"], rec["cout"], rec["K3"]
     flops = 2.0 * pairs * cin * cout
-    if rec["kind"] == "wgrad":
-        byts = pairs * (cin + cout) * 4 + pairs * 8 + K3 * cin * cout * 4
-    else:
-        byts = pairs * (cin + cout) * 4 + pairs * 8 + K3 * cin * cout * 4
-    return byts, flops
+    byts = pairs * (cin + cout) * 4 + pairs * 8 + K3 * cin * cout * 4
+    n_in = rec.get("rows_in") or rec["rows"]
+    comp = (n_in * cin + rec["rows"] * cout) * 4 + K3 * cin * cout * 4 + pairs * 8
+    return byts, flops, comp
 
 
 def kernel_of(rec):
-    """Name of the HIP kernel a recorded launch ran (mirrors the dispatch rule of csrc/spconv.hip:launch_conv)."""
+    """Name of the HIP kernel a recorded launch ran (mirrors the dispatch rules of csrc/spconv.hip)."""
     small = rec["cin"] in (4, 8)
-    if rec["kind"] == "wgrad":
-        return f"k_spconv_dw_small_cmp<{rec['cin']}>" if small else "k_spconv_dw_cmp"
+    lp = PRECISION != "fp32" and rec["cin"] >= 12
+    dense = rec["kind"].endswith("1x1")
+    if rec["kind"].startswith("wgrad"):
+        if small:
+            return f"k_spconv_dw_small_cmp<{rec['cin']}>"
+        return f"k_spconv_dw_cmp<{ {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[PRECISION] }>" + (" (dense)" if dense else "")
     if rec["cin"] == 3:
         return "k_spconv_fwd3"   # (<true>: the grid-probing instantiation, when the level is in grid mode)
     if small:
         return f"k_spconv_fwd<{rec['cin']}>"
+    col_tiles = -(-rec["cout"] // 64)
+    tall = -(-rec["rows"] // 128) * col_tiles >= 1024 or (rec["cin"] >= 256 and rec["rows"] >= 1024)
+    if lp:
+        x3 = "true" if PRECISION == "bf16x3" else "false"
+        if rec.get("perm"):
+            return f"k_spconv_pipe_bf16<64, true, {x3}>"
+        return f"k_spconv_pipe_bf16<{128 if tall else 64}, false, {x3}>" + (" (dense)" if dense else "")
     if rec.get("perm"):
         return "k_spconv_pipe<64, true>"
-    col_tiles = -(-rec["cout"] // 64)
     split = rec.get("split", 1)
-    if rec["cin"] % 64 == 0 and (rec["cin"] // 64) % split == 0 and -(-rec["rows"] // 128) * col_tiles * split >= 384:
+    if not dense and rec["cin"] % 64 == 0 and (rec["cin"] // 64) % split == 0 and \
+            -(-rec["rows"] // 128) * col_tiles * split >= 384:
         return "k_spconv_cmp<128>"
-    if -(-rec["rows"] // 128) * col_tiles >= 1024 or (rec["cin"] >= 256 and rec["rows"] >= 1024):
-        return "k_spconv_pipe<128, false>"
-    return "k_spconv_pipe<64, false>"
+    return f"k_spconv_pipe<{128 if tall else 64}, false>" + (" (dense)" if dense else "")
 
 
 def pmc_traffic(kernel):
@@ -86,32 +107,40 @@ def pmc_traffic(kernel):
 
 
 def group_profile(prof, table=False):
-    """Group the recorded launches by kernel flavour: name -> dict(ms, n, bytes, flops)."""
+    """Group the recorded launches by kernel flavour: name -> dict(ms, n, bytes, flops, comp)."""
     groups = {}
     pair_cache = {}
-    for rec in prof:
-        ms = rec["start"].elapsed_time(rec["end"])
+
+    def pairs_of(rec):
         p = rec["pairs"]
         if p is None:
+            return None
+        if isinstance(p, int):      # dense 1x1 products: one pair per row
+            return p
+        if id(p) not in pair_cache:
+            pair_cache[id(p)] = int(p.sum().item())
+        return pair_cache[id(p)]
+
+    for rec in prof:
+        pairs = pairs_of(rec)
+        if pairs is None:
             continue
-        key = id(p)
-        if key not in pair_cache:
-            pair_cache[key] = int(p.sum().item())
-        pairs = pair_cache[key]
-        byts, flops = conv_cost(rec, pairs)
+        ms = rec["start"].elapsed_time(rec["end"])
+        byts, flops, comp = conv_cost(rec, pairs)
         name = kernel_of(rec)
-        g = groups.setdefault(name, dict(ms=0.0, n=0, bytes=0.0, flops=0.0))
+        g = groups.setdefault(name, dict(ms=0.0, n=0, bytes=0.0, flops=0.0, comp=0.0))
         g["ms"] += ms
         g["n"] += 1
         g["bytes"] += byts
         g["flops"] += flops
+        g["comp"] += comp
     if table:   # per-layer table (stderr): where the conv time goes
         layers = {}
         for rec in prof:
-            if rec["pairs"] is None:
+            pairs = pairs_of(rec)
+            if pairs is None:
                 continue
             key = (rec["kind"], rec["K3"], rec["cin"], rec["cout"], rec["rows"] // 1000)
-            pairs = pair_cache[id(rec["pairs"])]
             e = layers.setdefault(key, [0, 0.0, 0.0, 0])
             e[0] += 1
             e[1] += rec["start"].elapsed_time(rec["end"])
@@ -119,7 +148,7 @@ def group_profile(prof, table=False):
             e[3] += pairs
         for key, (cnt, ms, fl, pr) in sorted(layers.items(), key=lambda kv: -kv[1][1])[:40]:
             kind, K3, cin, cout, krows = key
-            log(f"  {kind:5s} K3={K3:3d} {cin:4d}->{cout:4d} rows~{krows:4d}k  n={cnt:3d}  {ms / cnt * 1e3:8.1f} us/launch  "
+            log(f"  {kind:8s} K3={K3:3d} {cin:4d}->{cout:4d} rows~{krows:4d}k  n={cnt:3d}  {ms / cnt * 1e3:8.1f} us/launch  "
                 f"{fl / (ms / 1e3) / 1e12:6.1f} TF  density={pr / cnt / (K3 * max(krows, 1) * 1000.0):.2f}")
     return groups
 
@@ -129,26 +158,31 @@ def dominant_kernel(groups):
 
 
 def roofline_of(dom, g):
-    """Roofline entry of one kernel group (algorithmic bytes / flops of SURVEY.md §8(d) over its measured time)."""
+    """Roofline entry of one kernel group over its measured time.  MFMA-bound (FLOPs / compulsory bytes above the
+    ridge of the operand mode): achieved = algorithmic FLOP/s against the dense MFMA peak of that mode.  HBM-bound:
+    achieved = compulsory bytes/s against the HBM peak (see conv_cost)."""
     secs = g["ms"] / 1e3
-    intensity = g["flops"] / g["bytes"]
-    ridge = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+    peak = mfma_peak_tf()
+    intensity = g["flops"] / g["comp"]
+    ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
     if intensity >= ridge:
         ach = g["flops"] / secs / 1e12
-        roof = dict(bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                    frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=pmc_traffic(dom))
+        roof = dict(bound="mfma", achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s",
+                    frac=round(ach / peak, 4), traffic=pmc_traffic(dom))
     else:
-        ach = g["bytes"] / secs / 1e9
+        ach = g["comp"] / secs / 1e9
         roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom))
     roof.update(kernel=dom, launches=g["n"], avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2),
-                alg_bytes_per_launch=round(g["bytes"] / g["n"]), alg_flops_per_launch=round(g["flops"] / g["n"]))
+                alg_bytes_per_launch=round(g["bytes"] / g["n"]), compulsory_bytes_per_launch=round(g["comp"] / g["n"]),
+                alg_flops_per_launch=round(g["flops"] / g["n"]), flop_per_compulsory_byte=round(intensity, 1),
+                ridge=round(ridge, 1))
     return roof
 
 
 def kernel_summary(groups):
     return {k: dict(total_ms=round(v["ms"], 3), launches=v["n"],
-                    gbs=round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1),
+                    compulsory_gbs=round(v["comp"] / (v["ms"] / 1e3) / 1e9, 1),
                     tflops=round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)) for k, v in groups.items()}
 
 
@@ -230,6 +264,9 @@ def main():
             dist.init_process_group(backend)
 
     from dpcr_agb_amd import sparse_ops, synthetic
+    global PRECISION
+    PRECISION = args.precision
+    sparse_ops.set_conv_precision(args.precision)
     from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
     from dpcr_agb_amd.dist import GradAllReduce, broadcast_parameters, shard_seeds
     from dpcr_agb_amd.instance import MinkowskiBaselineModel
@@ -332,6 +369,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(model.loss.detach())
+    gaps = []
     if len(step_events) > 1:
         gaps = [step_events[j].elapsed_time(step_events[j + 1]) for j in range(len(step_events) - 1)]
         log("device time between step ends (ms): " + " ".join(f"{g:.2f}" for g in gaps))
@@ -358,18 +396,25 @@ def main():
             roof["timed_steps_bracketed"] = len(range(0, args.steps, EV_EVERY))
         summary = kernel_summary(groups_all)
         line = {
-            "metric": "training plots/sec (16k-pt NFI plots) MSENet14",
+            "metric": f"training plots/sec (16k-pt NFI plots) M{args.model}",
             "value": round(world * args.batch * args.steps / elapsed, 2),
             "unit": "plots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.model} sparse-voxel training step, {args.points}-pt synthetic plots, "
                                    f"voxel 0.0125 (0.375x0.375x0.5 m), batch {args.batch}/GPU, F={args.features}, "
                                    f"~{voxels:.0f} voxels/plot, fwd+bwd+AdaBelief incl. coordinate hash/kernel maps",
-                       "global_batch": gb, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
+                       "global_batch": gb, "parallelism": f"dp{world}", "final_loss": round(loss, 5),
+                       "operands": {"fp32": "fp32 MFMA (exact)", "bf16": "bf16 operands, fp32 accumulate; stem, BN, SE, "
+                                    "index kernels fp32", "bf16x3": "split-bf16 (3 MFMAs per product), fp32 accumulate"}[
+                                        args.precision]},
             "roofline": roof,
+            "step_ms_p50": round(sorted(gaps)[len(gaps) // 2], 3) if gaps else None,
+            "step_ms_p90": round(sorted(gaps)[int(len(gaps) * 0.9)], 3) if gaps else None,
+            "step_ms_min": round(min(gaps), 3) if gaps else None,
+            "device_allocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
             "kernels": summary, "kernels_from": f"{n_instr} fully bracketed warmup step(s), outside the timed region",
         }
         if world == 1 and not args.no_cpu_baseline:

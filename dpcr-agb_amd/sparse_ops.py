@@ -47,24 +47,24 @@ PROFILE = None
 PROFILE_FILTER = None
 
 
-def _prof_begin(kind=None, K3=0, cin=0, cout=0, rows=0, perm=False, split=1):
+def _prof_begin(kind=None, K3=0, cin=0, cout=0, rows=0, perm=False, split=1, rows_in=None):
     if PROFILE is None:
         return None
     if PROFILE_FILTER is not None and not PROFILE_FILTER(dict(kind=kind, K3=K3, cin=cin, cout=cout, rows=rows, perm=perm,
-                                                              split=split)):
+                                                              split=split, rows_in=rows_in)):
         return None
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
     return ev
 
 
-def _prof_end(ev0, kind, K3, cin, cout, rows, pairs, perm=False, split=1):
+def _prof_end(ev0, kind, K3, cin, cout, rows, pairs, perm=False, split=1, rows_in=None):
     if ev0 is None:
         return
     ev1 = torch.cuda.Event(enable_timing=True)
     ev1.record()
     PROFILE.append(dict(kind=kind, K3=K3, cin=cin, cout=cout, rows=rows, pairs=pairs, start=ev0, end=ev1, perm=perm,
-                        split=split))
+                        split=split, rows_in=rows_in))
 
 
 def _colsum_hint(dy):
@@ -107,7 +107,9 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     n_tiles = 0
     if plan is not None:
         perm, tile_cls, cls_tab, n_tiles = plan
-    ev = _prof_begin(kind, K3, cin, cout, n_out, plan is not None, split)
+    if nbr is None and pairs is None:
+        pairs = int(n_out)        # dense product: one (in, out) pair per row
+    ev = _prof_begin(kind, K3, cin, cout, n_out, plan is not None, split, x.shape[0])
     prec = _PREC_ID.get(CONV_PRECISION, 0) if (w_kmajor is not None and cin >= 12) else 0
     if prec:
         _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip),
@@ -117,7 +119,7 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
         _lib.call("agb_spconv_fwd_ex", _P(x), x.stride(0), _P(w2d), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip), _P(bias),
                   _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles, split,
                   _P(partial), _lib.stream())
-    _prof_end(ev, kind, K3, cin, cout, n_out, pairs, plan is not None, split)
+    _prof_end(ev, kind, K3, cin, cout, n_out, pairs, plan is not None, split, x.shape[0])
     return y
 
 
@@ -302,7 +304,7 @@ class DenseConvFunction(torch.autograd.Function):
             ev = _prof_begin("wgrad1x1", 1, cin, cout, n)
             _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), None, 0, _P(dk), n, 1, cin,
                       cout, _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
-            _prof_end(ev, "wgrad1x1", 1, cin, cout, n, None)
+            _prof_end(ev, "wgrad1x1", 1, cin, cout, n, int(n))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(ctx.bias_shape)
         return dx, dk, db

@@ -96,18 +96,24 @@ def main():
                                          update=upd)
                         for k, v in upd.items():
                             sd[k] = v
-        meter = RegressionMeter(val_mean)
-        preds = []
-        with torch.no_grad():
-            for b in val:
-                coords = torch.cat([b.batch[:, None], b.coords.long()], 1).numpy()
-                out = R.resnet_forward(sd, coords, b.x, (1, 1, 1, 1), batch_size=len(b), training=False)
-                pred = out * scale + center
-                meter.add(pred, b.y_reg)
-                preds.append(pred)
-        m = meter.value()
-        hist.append(dict(epoch=epoch, train_loss=float(loss.detach()), **m))
+        rec = dict(epoch=epoch, train_loss=float(loss.detach()))
+        # "bs": BatchNorm on the statistics of the evaluated batch (train-mode forward, no gradients, drop-path off);
+        # "rs": running statistics (the reference's eval.py)
+        for tag in ("bs", "rs"):
+            meter, preds = RegressionMeter(val_mean), []
+            with torch.no_grad():
+                for b in val:
+                    coords = torch.cat([b.batch[:, None], b.coords.long()], 1).numpy()
+                    out = R.resnet_forward(sd, coords, b.x, (1, 1, 1, 1), batch_size=len(b), training=tag == "bs")
+                    pred = out * scale + center
+                    meter.add(pred, b.y_reg)
+                    preds.append(pred)
+            rec.update({f"{k}_{tag}": v for k, v in meter.value().items()})
+            if tag == "bs":
+                preds_bs = preds
+        hist.append(rec)
         print(json.dumps(hist[-1]), f"[{time.time() - t0:.0f}s]", flush=True)
+    preds = preds_bs
     out = dict(config=cfg, history=hist, final=hist[-1], val_predictions=torch.cat(preds).tolist(),
                threads=torch.get_num_threads(), seconds=round(time.time() - t0, 1))
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "r2_cpu_leg.json"), "w") as f:

@@ -80,13 +80,15 @@ def test_bn_backward_column_sums(device, training):
     x = (torch.randn(n, c, device=device) * 2 + 1).requires_grad_(True)
     captured = {}
     def keep(g):
-        captured["colsum"] = getattr(g, "agb_colsum", None)
+        hint = getattr(g, "agb_colsum", None)     # (column sums, tensor version the hint is valid for)
+        captured["colsum"] = None if hint is None else hint[0]
+        captured["version_ok"] = hint is not None and hint[1] == g._version
 
     x.register_hook(keep)
     y = batch_norm_act(x, bn, "gelu")
     y.backward(torch.randn(n, c, device=device))
     cs = captured["colsum"]
-    assert cs is not None and cs.shape == (c,)
+    assert cs is not None and cs.shape == (c,) and captured["version_ok"]
     true = x.grad.double().sum(0)
     scale = float(x.grad.double().abs().sum(0).max())
     assert float((cs.double() - true).abs().max()) < 1e-5 * scale
