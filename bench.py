@@ -206,7 +206,7 @@ def log(msg):
 T_START = time.perf_counter()
 
 
-def cpu_baseline(args, model_sd, stats):
+def cpu_baseline(args, model_sd, stats, layers=(1, 1, 1, 1)):
     """The oracle (torch-CPU restatement, fp32, all host cores) on a bounded sample of the same workload:
     full training steps (fwd + bwd + AdaBelief) on `--cpu-plots` synthetic 16k-point plots."""
     from oracle import sparse_ref as R
@@ -225,7 +225,7 @@ def cpu_baseline(args, model_sd, stats):
     t0 = time.time()
     steps = 0
     while steps < 2 or (time.time() - t0 < 12 and steps < 40):   # a bounded sample: about 10-15 s of CPU work
-        out = R.resnet_forward(sd, coords, batch.x, (1, 1, 1, 1), batch_size=args.cpu_plots)
+        out = R.resnet_forward(sd, coords, batch.x, layers, batch_size=args.cpu_plots)
         loss = R.reg_loss(out, batch.y_reg, center, scale, w)
         opt.zero_grad()
         loss.backward()
@@ -236,7 +236,7 @@ def cpu_baseline(args, model_sd, stats):
             log(f"cpu baseline: step {steps} done after {time.time() - t0:.1f}s")
     dt = time.time() - t0
     return dict(value=round(args.cpu_plots * steps / dt, 4), unit="plots/s", cores=cores, kind="port",
-                sample=f"{steps} training step(s) of MSENet14 on {args.cpu_plots} synthetic {args.points}-pt plots "
+                sample=f"{steps} training step(s) of M{args.model} on {args.cpu_plots} synthetic {args.points}-pt plots "
                        f"(oracle/sparse_ref.py, torch-CPU fp32, {cores} threads), {dt:.1f} s")
 
 
@@ -419,7 +419,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             stats = (model.reg_center_targets.cpu(), model.reg_scale_targets.cpu(), model.reg_weights.cpu())
-            line["cpu_baseline"] = cpu_baseline(args, model_sd_cpu, stats)
+            line["cpu_baseline"] = cpu_baseline(args, model_sd_cpu, stats, tuple(model.model.LAYERS))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
