@@ -39,9 +39,7 @@ _SIGNATURES = {
     "agb_spconv_fwd_ex": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "agb_spconv_split_hint": [c_int, c_int, c_int, c_int],
-    "agb_spconv_set_cmp_mode": [c_int],
     "agb_spconv_cmp_occupancy": [c_int],
-    "agb_spconv_set_cmp_interleave": [c_int],
     "agb_spconv_weight_transpose": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "agb_spconv_weight_transpose_z": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "agb_parity_partition": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
@@ -124,6 +122,13 @@ def call(name, *args):
     if rc != 0:
         raise AgbError(f"{name} failed ({rc}): {lib.agb_last_error().decode()}")
     return rc
+
+
+def size_call(name, *args):
+    """Host helper that returns a byte count (size_t), e.g. the *_workspace_bytes functions."""
+    fn = getattr(load(), name)
+    fn.restype = ctypes.c_size_t
+    return int(fn(*args))
 
 
 def hash_capacity(n):

@@ -20,7 +20,7 @@ from .. import _lib
 from ..kp_dispositions import kernel_disposition
 from ..kpconv_ops import KPGatherFunction, KPMaxPoolFunction, as_index
 from ..norm_ops import ACT_IDS, AddActFunction, batch_norm_act
-from ..sparse_ops import segment_reduce
+from ..sparse_ops import DenseConvFunction, dense_linear, segment_reduce
 
 ACTIVATION_NAMES = {"relu": "relu", "gelu": "gelu"}
 
@@ -49,8 +49,11 @@ class KPConv(nn.Module):
     def forward(self, q_pts, s_pts, neighb_inds, x):
         idx = as_index(neighb_inds)
         wf = KPGatherFunction.apply(x, q_pts, s_pts, idx, self.kernel_points, self.KP_extent)
-        # dense feature x kernel-weight contraction: [N, K*Cin] @ [K*Cin, Cout]
-        return wf.view(wf.shape[0], -1) @ self.weights.view(-1, self.out_channels)
+        # dense feature x kernel-weight contraction [N, K*Cin] @ [K*Cin, Cout] on the library's own MFMA kernels
+        w2d = self.weights.view(-1, self.out_channels)
+        if wf.is_cuda and DenseConvFunction.supported(w2d.shape[0], w2d.shape[1]):
+            return DenseConvFunction.apply(wf.view(wf.shape[0], -1), w2d, None)
+        return wf.view(wf.shape[0], -1) @ w2d
 
     def __repr__(self):
         return f"KPConv(radius: {self.radius:.2f}, in_feat: {self.in_channels:d}, out_feat: {self.out_channels:d})"
@@ -90,7 +93,7 @@ class UnaryBlock(nn.Module):
         self.act = None if (no_relu or act_name in ACTIVATION_NAMES) else _act_module(act_name)
 
     def forward(self, x, batch=None):
-        x = self.mlp(x)
+        x = dense_linear(x, self.mlp.weight, self.mlp.bias)
         if self.no_relu:
             return self.batch_norm(x)
         if self.act is None:

@@ -67,3 +67,23 @@ __host__ __device__ static inline int agb_floordiv(int a, int d) {
     int r = a % d;
     return (r != 0 && ((r < 0) != (d < 0))) ? q - 1 : q;
 }
+
+// ---- activations fused into the BatchNorm / pooling kernels ---------------------
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_GELU 2
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+    return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == ACT_GELU) {
+        float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+        float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+        return cdf + z * pdf;
+    }
+    return 1.f;
+}

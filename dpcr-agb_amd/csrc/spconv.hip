@@ -340,6 +340,8 @@ struct ConvArgs {
     int n_out, K3, Cin, Cout;
     const int32_t* perm; const int32_t* tile_cls; const int32_t* cls_tab;
     int ksplit; float* partial;
+    int cmp_mode;   // pair-compacted kernel: 1 = automatic, 0 = never, 64 / 128 = always with that tile height
+    int cmp_il;     // log2 of the interleave block of its tiles (0 = contiguous, -1 = by level size)
 };
 
 template <int TM, bool PERM>
@@ -1498,10 +1500,6 @@ static int conv_tile_rows(int n_out, int Cin, int Cout) {
     return 64;
 }
 
-// Rows per wave of the pair-compacted kernel, or 0 when the layer should take the register-accumulator kernels.
-// Mode (agb_spconv_set_cmp_mode, or the AGB_CONV_CMP environment variable at first use): 1 = automatic (default),
-// 0 = never, 64 / 128 = always with that tile height (tests, tuning).
-static int g_cmp_mode = -1;
 // Input-channel split the pair-compacted kernel wants for this shape (1, 2, 4, ... dividing Cin/64), 0 when the layer
 // should take the register-accumulator kernels: enough waves to fill the 1024 resident-wave slots.
 static int cmp_want_split(int n_out, int Cin, int Cout) {
@@ -1513,12 +1511,11 @@ static int cmp_want_split(int n_out, int Cin, int Cout) {
     return waves128 * sp >= 384 ? sp : 0;
 }
 
+// Rows per wave of the pair-compacted kernel, or 0 when the layer should take the register-accumulator kernels
+// (a.cmp_mode: 1 = automatic, 0 = never, 64 / 128 = always with that tile height — tests, tuning; a per-call argument,
+// the library keeps no state).
 static int cmp_rows(const ConvArgs& a) {
-    if (g_cmp_mode < 0) {
-        const char* e = getenv("AGB_CONV_CMP");
-        g_cmp_mode = e ? atoi(e) : 1;
-    }
-    const int mode = g_cmp_mode;
+    const int mode = a.cmp_mode;
     if (mode == 0 || a.perm || a.Cin % 64 != 0 || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Cout % 4 != 0) return 0;
     if (a.ksplit < 1 || (a.Cin / 64) % a.ksplit != 0 || (a.ksplit > 1 && a.partial == nullptr)) return 0;
     if (mode == 64 || mode == 128) return mode;
@@ -1531,18 +1528,13 @@ static int cmp_rows(const ConvArgs& a) {
 
 // Tile geometry of the pair-compacted kernel: equal-cost tiles, workgroup count a multiple of the resident-wave
 // capacity (LDS: 4 / 8 waves per CU) so that the last round of workgroups is not half empty.
-static int g_cmp_il = -2;   // log2 of the interleave block (rows); 0 = contiguous tiles; -1 = by level size
-// Interleave block of a level with n rows.  Measured (tools/bench_conv.py --il 0,2,3,4, us per launch, contiguous /
-// 4-row / 8-row / 16-row blocks): 64->64 at 211 k rows 377 / 326 / 308 / 320; 128->128 at 61 k rows 432 / 387 / 396 / 424;
-// 256->256 at 14 k rows 416 / 390 / 401 / 452; 512->512 at 2.9 k rows 289 / - / 311 / 302 (few-row levels: contiguous).
-static int cmp_interleave(int n) {
-    if (g_cmp_il == -2) {
-        const char* e = getenv("AGB_CONV_IL");
-        g_cmp_il = e ? atoi(e) : -1;
-        if (g_cmp_il < -1 || g_cmp_il > 5) g_cmp_il = -1;
-    }
+// Interleave block (log2 rows) of a level with n rows; request: -1 = by level size, else the requested shift.
+// Measured (tools/bench_conv.py --il 0,2,3,4, us per launch, contiguous / 4-row / 8-row / 16-row blocks): 64->64 at 211 k
+// rows 377 / 326 / 308 / 320; 128->128 at 61 k rows 432 / 387 / 396 / 424; 256->256 at 14 k rows 416 / 390 / 401 / 452;
+// 512->512 at 2.9 k rows 289 / - / 311 / 302 (few-row levels: contiguous).
+static int cmp_interleave(int n, int request) {
     if (n < 8192) return 0;
-    if (g_cmp_il >= 0) return g_cmp_il;
+    if (request >= 0 && request <= 5) return request;
     return n >= 100000 ? 3 : 2;
 }
 
@@ -1553,7 +1545,7 @@ static void cmp_geometry(const ConvArgs& a, int* R_out, int* rpt_out, int* ntile
     const long long rounds = ((long long)agb_cdiv(a.n_out, R) * per_tile + slots - 1) / slots;
     long long want_tiles = rounds * slots / per_tile;
     if (want_tiles < 1) want_tiles = 1;
-    const int il = cmp_interleave(a.n_out);
+    const int il = cmp_interleave(a.n_out, a.cmp_il);
     *R_out = R; *nct_out = nct; *il_out = 0;
     if (il > 0) {
         // tiles of `bpt` row blocks taken ntiles blocks apart
@@ -1643,31 +1635,12 @@ int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C,
     return agb_spconv_weight_transpose_z(W, WT, nullptr, K3, R, C, stream);
 }
 
-// log2 of the row-block size of the interleaved tiles of the pair-compacted kernel (0: contiguous tiles; 3 / 4: 8 / 16 rows)
-int agb_spconv_set_cmp_interleave(int shift) {
-    AGB_CHECK_ARG(shift >= -1 && shift <= 5, "agb_spconv_set_cmp_interleave: shift %d (-1: by level size)", shift);
-    g_cmp_il = shift;
-    return AGB_OK;
-}
-
-int agb_spconv_set_cmp_mode(int mode) {
-    AGB_CHECK_ARG(mode == 0 || mode == 1 || mode == 64 || mode == 128, "agb_spconv_set_cmp_mode: mode %d", mode);
-    g_cmp_mode = mode;
-    return AGB_OK;
-}
-
 // How many offset splits a layer of n_out rows wants (1 = none): host helper for sizing `partial`.
-int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
+int agb_spconv_split_hint_opt(int n_out, int K3, int Cin, int Cout, int cmp_mode) {
     if (Cin == 3 || Cin == 4 || Cin == 8 || K3 < 8) return 1;
-    {
-        if (g_cmp_mode < 0) {
-            const char* e = getenv("AGB_CONV_CMP");
-            g_cmp_mode = e ? atoi(e) : 1;
-        }
-        const int sp = g_cmp_mode == 0 ? 0 : cmp_want_split(n_out, Cin, Cout);
-        if (sp > 0) return sp;   // the pair-compacted kernel takes the layer, input channels split sp ways
-        if (g_cmp_mode == 64 || g_cmp_mode == 128) return 1;
-    }
+    const int sp = cmp_mode == 0 ? 0 : cmp_want_split(n_out, Cin, Cout);
+    if (sp > 0) return sp;   // the pair-compacted kernel takes the layer, input channels split sp ways
+    if (cmp_mode == 64 || cmp_mode == 128) return 1;
     long long tiles = (long long)agb_cdiv(n_out, conv_tile_rows(n_out, Cin, Cout)) * agb_cdiv(Cout, BN);
     if (tiles >= 768) return 1;
     long long s = (1024 + tiles - 1) / tiles;
@@ -1675,10 +1648,18 @@ int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
     return (int)(s < 1 ? 1 : s);
 }
 
-int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
-                      const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
-                      const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
-                      float* partial, void* stream) {
+int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
+    return agb_spconv_split_hint_opt(n_out, K3, Cin, Cout, 1);
+}
+
+int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                       const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                       float* partial, int cmp_mode, int cmp_interleave_shift, void* stream) {
+    AGB_CHECK_ARG(cmp_mode == 0 || cmp_mode == 1 || cmp_mode == 64 || cmp_mode == 128, "agb_spconv_fwd_opt: cmp_mode %d "
+                  "(1 automatic, 0 never, 64 / 128 forced)", cmp_mode);
+    AGB_CHECK_ARG(cmp_interleave_shift >= -1 && cmp_interleave_shift <= 5, "agb_spconv_fwd_opt: interleave shift %d "
+                  "(-1: by level size)", cmp_interleave_shift);
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_fwd: bad sizes");
     AGB_CHECK_ARG((Cin % 4 == 0 || Cin == 3) && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout,
                   "agb_spconv_fwd: Cin (%d: a multiple of 4, or 3 with 4-float rows), Cout (%d), ldx (%d) must be "
@@ -1691,11 +1672,19 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
                   "agb_spconv_fwd_ex: perm needs tile_cls, cls_tab and n_tiles");
     if (n_out == 0) return AGB_OK;
     ConvArgs a{X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit,
-               partial};
+               partial, cmp_mode, cmp_interleave_shift};
     int rc = launch_conv(a, n_tiles, (hipStream_t)stream);
     if (rc) return rc;
     AGB_CHECK_LAUNCH("agb_spconv_fwd");
     return AGB_OK;
+}
+
+int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                      const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                      const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                      float* partial, void* stream) {
+    return agb_spconv_fwd_opt(X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls,
+                              cls_tab, n_tiles, ksplit, partial, 1, -1, stream);
 }
 
 // Low-precision operands (precision 1 = bf16, 2 = split-bf16 x3), fp32 accumulate and fp32 I/O.  Same contract as
@@ -1712,7 +1701,7 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
     if (n_out == 0) return AGB_OK;
     hipStream_t s = (hipStream_t)stream;
     ConvArgs a{X, ldx, Wt, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit,
-               partial};
+               partial, 0, -1};
     dim3 block(256);
     const bool x3 = precision == 2;
     if (perm) {
@@ -1811,7 +1800,7 @@ int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, 
         // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
         if (rows > DW_MAXROWS) rows = DW_MAXROWS;
         chunks = agb_cdiv(n_out, rows);
-        int il = chunks >= 16 ? cmp_interleave(n_out) : 0;
+        int il = chunks >= 16 ? cmp_interleave(n_out, -1) : 0;
         if (il > 0) {
             const int nblk = agb_cdiv(n_out, 1 << il), bpc = (int)rows >> il;
             chunks = agb_cdiv(nblk, bpc);

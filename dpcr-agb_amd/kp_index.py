@@ -29,8 +29,8 @@ _lib.declare("agb_rotate_points", [_V, _V, _V, _I, _I, _V, _V])
 _lib.declare("agb_ball_grid_build", [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V])
 _lib.declare("agb_ball_query_count", [_V, _I, _V, _V, _V, _V, _V, _F, _V, _V, _V])
 _lib.declare("agb_ball_query_fill", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V])
-_lib.declare("agb_grid_subsample", [_V, _V, _I, _I, _V, _V, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V,
-                                    _V, _V, _V, _V, _V])
+_lib.declare("agb_grid_subsample_workspace_bytes", [_I, _I, _I])
+_lib.declare("agb_grid_subsample_ws", [_V, _V, _I, _I, _V, _V, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V])
 
 MAX_CELLS = 1 << 27
 
@@ -191,20 +191,14 @@ def _subsample_core(p, f, lens, dl, bounds_hint=None):
         cap *= int(np.floor(e / dl)) + 3
     if B * cap > MAX_CELLS:
         raise _lib.AgbError(f"grid subsampling would need {B * cap} cells: sampleDl too small for these clouds")
-    nc = B * cap + 1
     i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
-    bbox_ord, dims = i32(6 * B), i32(3 * B)
-    origin = torch.empty(3 * B, dtype=torch.float32, device=dev)
-    cell_cnt, cell_start, slot, flag = i32(nc), i32(nc), i32(nc), i32(nc)
-    cell_of, members = i32(max(n, 1)), i32(max(n, 1))
-    scratch = i32(_lib.scan_scratch_elems(nc))
+    ws = torch.empty(_lib.size_call("agb_grid_subsample_workspace_bytes", n, B, cap), dtype=torch.uint8, device=dev)
     out_p = torch.empty(max(n, 1), 3, dtype=torch.float32, device=dev)
     fdim = 0 if f is None else f.shape[1]
     out_f = torch.empty(max(n, 1), fdim, dtype=torch.float32, device=dev) if f is not None else None
     out_ptr, n_out, status = i32(B + 1), i32(1), i32(4)
-    _lib.call("agb_grid_subsample", _P(p), _P(f), fdim, n, _P(ptr), _P(elem), B, float(np.float32(dl)), cap,
-              _P(bbox_ord), _P(origin), _P(dims), _P(cell_cnt), _P(cell_start), _P(slot), _P(flag), _P(cell_of),
-              _P(members), _P(scratch), _P(out_p), _P(out_f), _P(out_ptr), _P(n_out), _P(status), _lib.stream())
+    _lib.call("agb_grid_subsample_ws", _P(p), _P(f), fdim, n, _P(ptr), _P(elem), B, float(np.float32(dl)), cap, _P(ws),
+              _P(out_p), _P(out_f), _P(out_ptr), _P(n_out), _P(status), _lib.stream())
     host = torch.cat([out_ptr, status[:1]]).tolist()   # one host read: sizes of the subsampled clouds
     if host[-1]:
         raise _lib.AgbError("grid subsampling: a cloud exceeds the reserved cell capacity")

@@ -21,7 +21,7 @@ from . import _lib
 from .coords import CoordinateManager, CoordinateMapKey, _as_int
 from .norm_ops import ACT_IDS, AddActFunction, batch_norm_act
 from .sparse_ops import (BroadcastMulFunction, DenseConvFunction, GlobalPoolFunction, MaxPoolFunction,
-                         SparseConvFunction)
+                         SparseConvFunction, dense_linear)
 
 
 class SparseTensor:
@@ -276,7 +276,8 @@ class MinkowskiLinear(nn.Module):
         self.linear = nn.Linear(in_features, out_features, bias=bias)
 
     def forward(self, input: SparseTensor) -> SparseTensor:
-        return input._like(self.linear(input.F))
+        # per-row dense layer on the library's own MFMA kernels (no BLAS call on the shared-MLP path)
+        return input._like(dense_linear(input.F, self.linear.weight, self.linear.bias))
 
 
 class MinkowskiBatchNorm(nn.Module):

@@ -130,3 +130,110 @@ class AddActFunction(torch.autograd.Function):
         _lib.call("agb_add_act_bwd", _P(a), a.stride(0), _P(r), r.stride(0), _P(scale) if has_s else None,
                   _P(coords) if has_s else None, _P(dy), dy.stride(0), n, c, act_id, _P(da), _P(dr), _lib.stream())
         return da, (da if shared else dr), None, None, None
+
+
+_V, _I = _lib.c_void_p, _lib.c_int
+_lib.declare("agb_pointnet_pool_splits", [_I, _I])
+_lib.declare("agb_pointnet_pool_fwd", [_V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _I, _I, _I, _V, _V, _V, _V, _V])
+_lib.declare("agb_pointnet_pool_bwd", [_V, _I, _I, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V, _I, _I, _V, _V, _I, _V, _V,
+                                       _V])
+POOL_MODES = {"sum": 0, "avg": 1, "mean": 1, "max": 2}
+
+
+class BatchNormActPoolFunction(torch.autograd.Function):
+    """pooled[b] = reduce_{rows of plot b} act(batchnorm(z))  without materialising the [N, C] activation, and its
+    backward without materialising the broadcast pooled gradient (csrc/pointnet.hip): the tail of MinkowskiPointNet's
+    shared MLP (PointNet.py:24-29)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, act_id, training, counter, coords, ptr,
+                B, mode):
+        z = z.contiguous()
+        n, c = z.shape
+        if c % 4 != 0:
+            raise _lib.AgbError("fused batch norm + pooling needs a channel count that is a multiple of 4")
+        dev = z.device
+        stats = torch.empty(2, c, dtype=torch.float32, device=dev)
+        part = torch.empty(bn_chunks(n) * 3 * c, dtype=torch.float32, device=dev) if training else None
+        _lib.call("agb_bn_stats_tracked", _P(z), z.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
+                  _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter), _lib.stream())
+        sp = _lib.load().agb_pointnet_pool_splits(n, B)
+        pooled = torch.empty(B, c, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, c, dtype=torch.int32, device=dev) if mode == 2 else None
+        ppart = torch.empty(B * sp, c, dtype=torch.float32, device=dev) if sp > 1 else None
+        parg = torch.empty(B * sp, c, dtype=torch.int32, device=dev) if (sp > 1 and mode == 2) else None
+        _lib.call("agb_pointnet_pool_fwd", _P(z), z.stride(0), n, c, _P(stats[0]), _P(stats[1]), _P(gamma), _P(beta),
+                  act_id, _P(ptr), B, mode, sp, _P(ppart), _P(parg), _P(pooled), _P(arg), _lib.stream())
+        ctx.save_for_backward(z, stats, gamma if gamma is not None else torch.empty(0),
+                              beta if beta is not None else torch.empty(0), coords, ptr,
+                              arg if arg is not None else torch.empty(0))
+        ctx.cfg = (act_id, bool(training), gamma is not None, beta is not None, B, mode)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        z, stats, gamma, beta, coords, ptr, arg = ctx.saved_tensors
+        act_id, training, has_g, has_b, B, mode = ctx.cfg
+        dpooled = dpooled.contiguous()
+        n, c = z.shape
+        dev = z.device
+        part = torch.empty(bn_chunks(n) * 2 * c, dtype=torch.float32, device=dev)
+        dgb = torch.empty(2, c, dtype=torch.float32, device=dev)
+        dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        _lib.call("agb_pointnet_pool_bwd", _P(z), z.stride(0), n, c, _P(coords), _P(ptr), B, _P(dpooled),
+                  _P(arg) if mode == 2 else None, mode, _P(stats[0]), _P(stats[1]), _P(gamma) if has_g else None,
+                  _P(beta) if has_b else None, act_id, int(training), _P(part), _P(dz),
+                  0 if dz is None else dz.stride(0), _P(dgb[0]), _P(dgb[1]), _lib.stream())
+        return (dz, dgb[0] if has_g else None, dgb[1] if has_b else None) + (None,) * 11
+
+
+def batch_norm_act_pool(z, bn: torch.nn.BatchNorm1d, act, coords, ptr, B, mode):
+    """nn.BatchNorm1d semantics (as batch_norm_act) + activation + per-plot pooling ("sum" / "avg" / "max")."""
+    rm, rv = bn.running_mean, bn.running_var
+    use_batch_stats = bn.training or rm is None
+    momentum, counter = 0.0, None
+    if bn.training and rm is not None:
+        if bn.momentum is not None:
+            momentum, counter = bn.momentum, bn.num_batches_tracked
+        else:
+            bn.num_batches_tracked.add_(1)
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    return BatchNormActPoolFunction.apply(z, bn.weight, bn.bias, rm, rv, momentum, bn.eps, ACT_IDS[act], use_batch_stats,
+                                          counter, coords, ptr, B, POOL_MODES[mode])
+
+
+_lib.declare("agb_pointnet_mlp_workspace_bytes", [_I] * 5)
+_lib.declare("agb_pointnet_mlp_fwd", [_V, _I, _I, _I, _V, _V, _I, _V, _V, _I, _V, _V, _I, _I, _lib.c_float, _lib.c_float, _I, _V,
+                                      _I, _I, _V, _V, _V, _V])
+
+
+def pointnet_mlp_forward(x, layers, act, ptr, B, mode, training=False, momentum=0.0):
+    """The whole shared MLP in ONE library call (agb_pointnet_mlp_fwd; inference path of MinkowskiPointNet):
+    x [n, cin]; layers: three (nn.Linear without bias, nn.BatchNorm1d); returns pooled [B, c3] (and argmax for "max")."""
+    import ctypes
+    import torch.nn.functional as F
+    n, cin = x.shape
+    cin_p = max(12, (cin + 3) // 4 * 4)
+    xp = (x if cin_p == cin else F.pad(x, (0, cin_p - cin))).contiguous()
+    ws_, bns, keep = [], [], []
+    prev = cin_p
+    for lin, bn in layers:
+        w = lin.weight.detach().t()                                   # [in, out]
+        if w.shape[0] != prev:
+            w = F.pad(w, (0, 0, 0, prev - w.shape[0]))
+        w = w.contiguous()
+        keep.append(w)
+        ws_.append(w)
+        tab = (ctypes.c_void_p * 4)(_P(bn.weight), _P(bn.bias), _P(bn.running_mean), _P(bn.running_var))
+        bns.append(tab)
+        prev = w.shape[1]
+    c1, c2, c3 = (w.shape[1] for w in ws_)
+    dev = x.device
+    work = torch.empty(_lib.size_call("agb_pointnet_mlp_workspace_bytes", n, B, c1, c2, c3), dtype=torch.uint8, device=dev)
+    pooled = torch.empty(B, c3, dtype=torch.float32, device=dev)
+    m = POOL_MODES[mode]
+    arg = torch.empty(B, c3, dtype=torch.int32, device=dev) if m == 2 else None
+    _lib.call("agb_pointnet_mlp_fwd", _P(xp), xp.stride(0), n, cin_p, _P(ws_[0]), bns[0], c1, _P(ws_[1]), bns[1], c2,
+              _P(ws_[2]), bns[2], c3, ACT_IDS[act], float(layers[0][1].eps), float(momentum), int(bool(training)), _P(ptr),
+              B, m, _P(work), _P(pooled), _P(arg), _lib.stream())
+    return pooled, arg

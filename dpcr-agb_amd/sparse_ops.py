@@ -30,6 +30,17 @@ def set_conv_precision(name):
     return old
 
 
+# Kernel choice of the fp32 forward / data-gradient product, handed to the library with every call (the library itself
+# keeps no state): CMP_MODE 1 = automatic (the pair-compacted kernel for many-row layers), 0 = never, 64 / 128 = always
+# with that tile height (tests, tuning); CMP_INTERLEAVE = log2 of the row-block size of its interleaved tiles
+# (-1: chosen by the level's size, 0: contiguous tiles).
+CMP_MODE = 1
+CMP_INTERLEAVE = -1
+_lib.declare("agb_spconv_fwd_opt", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
+                                    _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
+                                    _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
+                                    _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p])
+_lib.declare("agb_spconv_split_hint_opt", [_lib.c_int] * 5)
 _lib.declare("agb_spconv_bwd_weight_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
                                           _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                           _lib.c_void_p])
@@ -101,7 +112,8 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
     w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes."""
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
-    split = _lib.load().agb_spconv_split_hint(n_out, K3, cin, cout) if (plan is None and nbr is not None) else 1
+    split = _lib.load().agb_spconv_split_hint_opt(n_out, K3, cin, cout, CMP_MODE) if (plan is None and nbr is not None) \
+        else 1
     partial = torch.empty(split, n_out, cout, dtype=torch.float32, device=x.device) if split > 1 else None
     perm = tile_cls = cls_tab = None
     n_tiles = 0
@@ -116,9 +128,9 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
                   _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
                   split, _P(partial), prec, _lib.stream())
     else:
-        _lib.call("agb_spconv_fwd_ex", _P(x), x.stride(0), _P(w2d), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip), _P(bias),
-                  _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles, split,
-                  _P(partial), _lib.stream())
+        _lib.call("agb_spconv_fwd_opt", _P(x), x.stride(0), _P(w2d), _P(nbr), 0 if nbr is None else nbr.stride(0),
+                  int(kflip), _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab),
+                  n_tiles, split, _P(partial), CMP_MODE, CMP_INTERLEAVE, _lib.stream())
     _prof_end(ev, kind, K3, cin, cout, n_out, pairs, plan is not None, split, x.shape[0])
     return y
 
@@ -308,6 +320,71 @@ class DenseConvFunction(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(ctx.bias_shape)
         return dx, dk, db
+
+
+class DenseLinearFunction(torch.autograd.Function):
+    """y = x @ weight.T + bias with nn.Linear's parameter layout (weight [out, in]) on this library's own MFMA kernels
+    (the identity-map convolution kernels of csrc/spconv.hip), in the operand precision of ``CONV_PRECISION``: the shared
+    per-point MLP of MinkowskiPointNet (PointNet.py:16-28), KPConv's unary blocks (blocks.py:499-535) and its
+    feature x kernel-weight contraction (blocks.py:396-400).  Feature widths are zero-padded to a multiple of 4 (>= 12)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        n, cin = x.shape
+        cout = weight.shape[0]
+        cin_p, cout_p = max(12, (cin + 3) // 4 * 4), (cout + 3) // 4 * 4
+        xp = (x if cin_p == cin else F.pad(x, (0, cin_p - cin))).contiguous()
+        wp = weight if (cin_p == cin and cout_p == cout) else F.pad(weight, (0, cin_p - cin, 0, cout_p - cout))
+        wp = wp.contiguous()                                   # [out, in]: K-major for the forward product
+        b = None
+        if bias is not None:
+            b = (bias if cout_p == cout else F.pad(bias, (0, cout_p - cout))).contiguous()
+        if CONV_PRECISION in _PREC_ID:
+            y = spconv_forward_raw(xp, None, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1", None, None, wp)
+        else:
+            wt = torch.empty(cin_p, cout_p, dtype=torch.float32, device=x.device)
+            _lib.call("agb_spconv_weight_transpose", _P(wp), _P(wt), 1, cout_p, cin_p, _lib.stream())
+            y = spconv_forward_raw(xp, wt, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1")
+        ctx.save_for_backward(xp, wp)
+        ctx.dims = (cin, cout, cin_p, cout_p, bias is not None)
+        return y if cout_p == cout else y[:, :cout].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp = ctx.saved_tensors
+        cin, cout, cin_p, cout_p, has_bias = ctx.dims
+        n = xp.shape[0]
+        colsum = _colsum_hint(dy)
+        dy = dy.contiguous()
+        dyp = dy if cout_p == cout else F.pad(dy, (0, cout_p - cout)).contiguous()
+        dx = dw = db = None
+        lp = CONV_PRECISION in _PREC_ID
+        if ctx.needs_input_grad[0]:
+            # dX = dY @ weight: weight [out, in] is the [K, N] operand as stored; its K-major form is the transpose
+            if lp:
+                wkm = wp.t().contiguous()
+                dxp = spconv_forward_raw(dyp, None, None, 0, None, n, 1, cout_p, cin_p, "dgrad1x1", None, None, wkm)
+            else:
+                dxp = spconv_forward_raw(dyp, wp, None, 0, None, n, 1, cout_p, cin_p, "dgrad1x1")
+            dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros(cout_p, cin_p, dtype=torch.float32, device=dy.device)
+            ev = _prof_begin("wgrad1x1", 1, cout_p, cin_p, n)
+            # dWeight [out, in] = dY^T X: the weight-gradient kernel with the roles of the operands swapped
+            _lib.call("agb_spconv_bwd_weight_lp", _P(dyp), dyp.stride(0), _P(xp), xp.stride(0), None, 0, _P(dwp), n, 1,
+                      cout_p, cin_p, _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
+            _prof_end(ev, "wgrad1x1", 1, cout_p, cin_p, n, int(n))
+            dw = dwp if (cin_p == cin and cout_p == cout) else dwp[:cout, :cin].contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)
+        return dx, dw, db
+
+
+def dense_linear(x, weight, bias=None):
+    """nn.Linear semantics on the library's own kernels for device tensors with >= 1 row; plain F.linear otherwise."""
+    if x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.dtype == torch.float32:
+        return DenseLinearFunction.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
 
 
 class MaxPoolFunction(torch.autograd.Function):

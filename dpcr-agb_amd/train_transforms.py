@@ -30,7 +30,7 @@ _P = _lib.ptr
 _V, _I, _F = _lib.c_void_p, _lib.c_int, _lib.c_float
 _lib.declare("agb_plot_augment", [_V, _V, _V, _V, _I, _I, _V, _V, _V, _V, _V])
 _lib.declare("agb_plot_extend", [_V, _V, _V, _V, _V, _I, _I, _V, _V, _V, _V, _V, _V])
-_lib.declare("agb_plot_crop", [_V, _V, _V, _I, _I, _V, _I, _F, _F] + [_V] * 10)
+_lib.declare("agb_plot_crop_ws", [_V, _V, _V, _I, _I, _V, _I, _F, _F, _V, _V, _V, _V, _V, _V, _V])
 
 
 @dataclass
@@ -197,13 +197,12 @@ class SparseTrainPipeline:
             raise NotImplementedError("polygons of one batch must have the same number of vertices")
         polys = torch.from_numpy(np.stack([d["polygon"] for d in draws]).reshape(B, -1)).to(dev)
         nn_ = max(n2, 1)
-        flag, slot, cnt, scratch = i32(nn_), i32(nn_), i32(B), i32(_lib.scan_scratch_elems(nn_))
+        ws = torch.empty(_lib.size_call("agb_plot_workspace_bytes", n2, B), dtype=torch.uint8, device=dev)
         pos_o, x_o = f32(nn_, 3), f32(nn_, 3)
         src = torch.empty(nn_, dtype=torch.int64, device=dev)
         out_ptr, n_out = i32(B + 1), i32(1)
-        _lib.call("agb_plot_crop", _P(pos2), _P(ptr2), _P(elem2), B, n2, _P(polys), nv, float(c.center[0]),
-                  float(c.center[1]), _P(flag), _P(slot), _P(cnt), _P(scratch), _P(pos_o), _P(x_o), _P(src), _P(out_ptr),
-                  _P(n_out), _lib.stream())
+        _lib.call("agb_plot_crop_ws", _P(pos2), _P(ptr2), _P(elem2), B, n2, _P(polys), nv, float(c.center[0]),
+                  float(c.center[1]), _P(ws), _P(pos_o), _P(x_o), _P(src), _P(out_ptr), _P(n_out), _lib.stream())
         return pos_o, x_o, src, out_ptr
 
     def __call__(self, plots: List, device, y_reg=None, draws: Optional[List[dict]] = None, perms=None):

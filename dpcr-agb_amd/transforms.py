@@ -26,7 +26,8 @@ from .voxelize import draw_permutations, voxelize_last
 
 _P = _lib.ptr
 _V, _I = _lib.c_void_p, _lib.c_int
-_lib.declare("agb_plot_prepare", [_V, _V, _V, _I, _I, _V, _I, _I, _V, _I] + [_V] * 10 + [_V])
+_lib.declare("agb_plot_workspace_bytes", [_I, _I])
+_lib.declare("agb_plot_prepare_ws", [_V, _V, _V, _I, _I, _V, _I, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V])
 _lib.declare("agb_coords_augment", [_V, _V, _I, _I, _V, _V, _V, _V])
 
 HEXAGON = [[0.0, 0.5], [0.25, 0.9330127], [0.75, 0.9330127], [1.0, 0.5], [0.75, 0.0669873], [0.25, 0.0669873]]
@@ -173,8 +174,8 @@ class SparsePlotPipeline:
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
         i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)      # noqa: E731
         nn_ = max(n, 1)
-        zmin, pos_t, pos_o, x_o = f32(B), f32(nn_, 3), f32(nn_, 3), f32(nn_, 3)
-        flag, slot, scratch = i32(nn_), i32(nn_), i32(_lib.scan_scratch_elems(nn_))
+        pos_o, x_o = f32(nn_, 3), f32(nn_, 3)
+        ws = torch.empty(_lib.size_call("agb_plot_workspace_bytes", n, B), dtype=torch.uint8, device=dev)
         src = torch.empty(nn_, dtype=torch.int64, device=dev)
         out_ptr, n_out = i32(B + 1), i32(1)
         xform = (_lib.c_float * 8)(*self.scale, *self.center, *self.feat_center)
@@ -183,9 +184,8 @@ class SparsePlotPipeline:
         if self.polygon is not None:
             poly = torch.tensor(self.polygon, dtype=torch.float64).reshape(-1).to(dev)
             nv = len(self.polygon)
-        _lib.call("agb_plot_prepare", _P(stacked), _P(ptr), _P(elem), B, n, xform, self.div, int(self.z0), _P(poly), nv,
-                  _P(zmin), _P(pos_t), _P(flag), _P(slot), _P(scratch), _P(pos_o), _P(x_o), _P(src), _P(out_ptr),
-                  _P(n_out), _lib.stream())
+        _lib.call("agb_plot_prepare_ws", _P(stacked), _P(ptr), _P(elem), B, n, xform, self.div, int(self.z0), _P(poly), nv,
+                  _P(ws), _P(pos_o), _P(x_o), _P(src), _P(out_ptr), _P(n_out), _lib.stream())
         return self.fix_counts(pos_o, x_o, src, out_ptr)
 
     def fix_counts(self, pos_o, x_o, src, out_ptr):

@@ -16,7 +16,8 @@ from .kp_index import _elem_of_row, _lengths, _ptr_tensor
 
 _P = _lib.ptr
 _V, _I, _F = _lib.c_void_p, _lib.c_int, _lib.c_float
-_lib.declare("agb_voxelize_last", [_V, _V, _V, _V, _I, _I, _F, _I] + [_V] * 14 + [_V])
+_lib.declare("agb_voxelize_last_workspace_bytes", [_I, _I, _I])
+_lib.declare("agb_voxelize_last_ws", [_V, _V, _V, _V, _I, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V, _V])
 
 
 def draw_permutations(lengths):
@@ -52,17 +53,13 @@ def voxelize_last(pos, lengths, size, perm=None, extent_hint=None):
         cap *= int(np.floor(e)) + 3
     if B * cap >= (1 << 30):
         raise _lib.AgbError(f"voxel grid of {B * cap} cells is too large: voxel size too small for these clouds")
-    nc = B * cap + 1
     i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
-    bbox_ord, span, cells, slot, flag = i32(6 * B), i32(3 * B), i32(nc), i32(nc), i32(nc)
-    cell_of, scratch = i32(max(n, 1)), i32(_lib.scan_scratch_elems(nc))
-    lo = torch.empty(3 * B, dtype=torch.float32, device=dev)
+    ws = torch.empty(_lib.size_call("agb_voxelize_last_workspace_bytes", n, B, cap), dtype=torch.uint8, device=dev)
     coords = torch.empty(max(n, 1), 3, dtype=torch.int32, device=dev)
     keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     out_ptr, n_out, bounds, status = i32(B + 1), i32(1), i32(6), i32(4)
-    _lib.call("agb_voxelize_last", _P(p), _P(perm), _P(ptr), _P(elem), B, n, size32, cap, _P(bbox_ord), _P(lo),
-              _P(span), _P(cells), _P(slot), _P(flag), _P(cell_of), _P(scratch), _P(coords), _P(keep), _P(out_ptr),
-              _P(n_out), _P(bounds), _P(status), _lib.stream())
+    _lib.call("agb_voxelize_last_ws", _P(p), _P(perm), _P(ptr), _P(elem), B, n, size32, cap, _P(ws), _P(coords), _P(keep),
+              _P(out_ptr), _P(n_out), _P(bounds), _P(status), _lib.stream())
     host = torch.cat([out_ptr, bounds, status[:1]]).tolist()   # one host read: new lengths + coordinate bounds
     if host[-1]:
         raise _lib.AgbError("voxelize_last: a cloud exceeds the reserved cell capacity (extent_hint too small)")

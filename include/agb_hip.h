@@ -16,6 +16,7 @@
  */
 #ifndef AGB_HIP_H
 #define AGB_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -104,12 +105,21 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
                       const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                       float* partial, void* stream);
-int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper */
-/* Kernel selection of agb_spconv_fwd(_ex) for layers with Cin % 64 == 0 (host state, tests and tuning):
- * 1 = automatic (default: the pair-compacted LDS-accumulating kernel for many-row layers with Cin <= 128, the
- * register-accumulator kernels otherwise), 0 = never the pair-compacted kernel, 64 / 128 = always, with that many rows
- * per wave.  All choices compute the same sums; only the fp32 summation order differs. */
-int agb_spconv_set_cmp_mode(int mode);
+int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper (automatic kernel choice) */
+/* The same product with the kernel choice as per-call arguments (the library keeps no tuning state):
+ * cmp_mode: 1 = automatic (the pair-compacted LDS-accumulating kernel for many-row layers with Cin % 64 == 0, the
+ * register-accumulator kernels otherwise; what agb_spconv_fwd / _ex use), 0 = never the pair-compacted kernel,
+ * 64 / 128 = always, with that many rows per wave.  cmp_interleave_shift: tiles of the pair-compacted kernel made of
+ * 2^shift-row blocks taken from regions ntiles blocks apart (0: contiguous row tiles; -1: chosen by the number of rows):
+ * evens out the per-tile work where the pair density varies by region.  All choices compute the same sums; tile
+ * interleaving is bit-identical, kernel choice changes only the fp32 summation order.
+ * nbr == NULL (K3 == 1, Cin >= 12): the identity map — a dense [n, Cin] x [Cin, Cout] product, i.e. ME's 1x1 stride-1
+ * convolution (kernel [Cin, Cout]; resnet_block.py:95-107 Bottleneck conv1 / conv3) and every nn.Linear of the path. */
+int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                       const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                       float* partial, int cmp_mode, int cmp_interleave_shift, void* stream);
+int agb_spconv_split_hint_opt(int n_out, int K3, int Cin, int Cout, int cmp_mode);  /* host helper */
 /* Stride-1 odd-kernel convolution of a 3-channel input (the 7^3 stem; X rows 4 floats wide, W [K^3*3, Cout]) whose
  * neighbours are probed in the level's dense lookup grid (agb_grid_insert; halo >= K/2) instead of a pre-built [K^3][n]
  * kernel map.  nbr_out (optional) receives that map as a by-product — the values agb_grid_kernel_map would write — for
@@ -124,12 +134,7 @@ int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C,
 /* the same, and `zero` (K3*R*C floats, or NULL) is cleared in the same pass: the weight-gradient buffer
  * agb_spconv_bwd_weight accumulates into, saving one fill launch per layer */
 int agb_spconv_weight_transpose_z(const float* W, float* WT, float* zero, int K3, int R, int C, void* stream);
-int agb_spconv_cmp_occupancy(int rows_per_wave);
-/* tiles of the pair-compacted kernel made of 2^shift-row blocks taken from regions ntiles blocks apart (0: contiguous
- * row tiles; -1, the default: chosen by the number of rows): evens out the per-tile work where the pair density varies
- * by region.  Tuning switch; forward / data-gradient results are bit-identical (a row's sum does not depend on the
- * tile that holds it). */
-int agb_spconv_set_cmp_interleave(int shift);  /* resident workgroups per CU of that kernel (tuning aid) */
+int agb_spconv_cmp_occupancy(int rows_per_wave);  /* resident workgroups per CU of the pair-compacted kernel (tuning aid) */
 /* Low-precision MFMA operands, fp32 accumulate and I/O: precision 1 = bf16 (BASELINE config 5), 2 = split-bf16 x3
  * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi: fp32-level accuracy at 3/16 of the fp32 MFMA cost).  Same contract as
  * agb_spconv_fwd_ex but the weights are K-major: Wt float[K3][Cout][Cin] (forward: the transposed kernel; data
@@ -146,6 +151,12 @@ int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, in
 /* dW[k] += sum_r X[nbr[k][r],:]^T @ dY[r,:]; dW ([K3*Cin, Cout]) must be zero-filled by the caller. */
 int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                           long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, void* stream);
+/* The same with the operand precision as an argument: 0 = fp32 MFMA, 1 = bf16 operands, 2 = split-bf16 x3 (fp32
+ * accumulate; gathered rows are transposed and packed to bf16 pairs while they are staged; Cin = 4 / 8 stays fp32).
+ * nbr == NULL (K3 == 1): identity map, dW = X^T dY (1x1 stride-1 convolutions and nn.Linear weight gradients). */
+int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
+                             long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, int precision,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Pooling / broadcast (replaces ME.MinkowskiMaxPooling SENet.py:53; ME.MinkowskiGlobal{Sum,Avg,Max}Pooling
@@ -237,14 +248,13 @@ int agb_ball_query_fill(const float* queries, int nq, const int32_t* q_elem, con
                         const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
                         int width, int32_t* out, int32_t* status, void* stream);
 /* Grid subsampling (barycentres, optional feature means), canonical order = cell key ascending per cloud.
- * cap = cells reserved per cloud. Scratch int32: bbox_ord[6B], dims[3B], cell_cnt/cell_start/slot/flag[B*cap+1],
- * cell_of[n], members[n], scan_scratch[agb_scan_scratch_elems(B*cap+1)]; origin float[3B].
+ * cap = cells reserved per cloud (>= the cloud's NX*NY*NZ; status[0] counts violations).  workspace: one device buffer of
+ * agb_grid_subsample_workspace_bytes(n, B, cap) bytes (all internal scratch is carved from it).
  * Out: out_pts float[n*3] (upper bound), out_feats float[n*fdim] or NULL, out_ptr int32[B+1], n_out_dev, status[4]. */
-int agb_grid_subsample(const float* pts, const float* feats, int fdim, int n, const int32_t* ptr,
-                       const int32_t* elem, int B, float dl, int cap, int32_t* bbox_ord, float* origin,
-                       int32_t* dims, int32_t* cell_cnt, int32_t* cell_start, int32_t* slot, int32_t* flag,
-                       int32_t* cell_of, int32_t* members, int32_t* scan_scratch, float* out_pts, float* out_feats,
-                       int32_t* out_ptr, int32_t* n_out_dev, int32_t* status, void* stream);
+size_t agb_grid_subsample_workspace_bytes(int n, int B, int cap);
+int agb_grid_subsample_ws(const float* pts, const float* feats, int fdim, int n, const int32_t* ptr, const int32_t* elem,
+                          int B, float dl, int cap, void* workspace, float* out_pts, float* out_feats, int32_t* out_ptr,
+                          int32_t* n_out_dev, int32_t* status, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * KPConv layer (replaces KPConv.forward modules/KPConv/blocks.py:264-400 and max_pool :98-114).
@@ -264,13 +274,13 @@ int agb_kp_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int ld
  * GridSampling3D(size, quantize_coords=True, mode="last") for a batch of clouds
  * (replaces core/data_transform/grid_transform.py:112-128).  perm int64[n]: within-cloud shuffle.
  * Out: coords int32[n,3] (upper bound), keep int64[n] (rows of the ORIGINAL stacked order), out_ptr int32[B+1],
- * n_out_dev, bounds int32[6] (min/max of coords), status[4].  Scratch as documented in csrc/voxelize.hip.
+ * n_out_dev, bounds int32[6] (min/max of coords), status[4].  cap = cells reserved per cloud; workspace: one device
+ * buffer of agb_voxelize_last_workspace_bytes(n, B, cap) bytes.
  * --------------------------------------------------------------------------------------------------------- */
-int agb_voxelize_last(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
-                      float size, int cap, int32_t* bbox_ord, float* lo, int32_t* span, int32_t* cells,
-                      int32_t* slot, int32_t* flag, int32_t* cell_of, int32_t* scan_scratch, int32_t* coords,
-                      long long* keep, int32_t* out_ptr, int32_t* n_out_dev, int32_t* bounds, int32_t* status,
-                      void* stream);
+size_t agb_voxelize_last_workspace_bytes(int n, int B, int cap);
+int agb_voxelize_last_ws(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
+                         float size, int cap, void* workspace, int32_t* coords, long long* keep, int32_t* out_ptr,
+                         int32_t* n_out_dev, int32_t* bounds, int32_t* status, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Fused multi-tensor AdaBelief step with clip_grad_value_ (replaces core/optimizer/adabelief.py:89-201 +
@@ -288,13 +298,13 @@ int agb_adabelief_step(const void* descs, const int32_t* chunk_tensor, const int
  * ScalePos, MoveCenterPosPerSample, StartZFromZero (core/data_transform/transforms.py:590-598,722-739,766-769),
  * Polygon2dExtend (:1461-1496, matplotlib Path.contains_points restated in double) and the feature build
  * x = [1, pos.z, ||pos.xy - c + 1e-6||] (features.py:307-334,353-383).  xform: HOST float[8] = (sx, sy, sz, cx, cy, cz,
- * fcx, fcy); poly: device double[2*nv] (nv = 0: no crop).  Scratch: zmin float[B], pos_t float[n,3], flag / slot
- * int32[n], scan_scratch int32[agb_scan_scratch_elems(n)].  Out (n rows reserved): pos_out, x_out float[n,3], src
- * int64[n] (input row of every kept point, order preserved), out_ptr int32[B+1], n_out_dev int32[1]. */
-int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
-                     int scale_div, int z_from_zero, const double* poly, int nv, float* zmin, float* pos_t,
-                     int32_t* flag, int32_t* slot, int32_t* scan_scratch, float* pos_out, float* x_out, long long* src,
-                     int32_t* out_ptr, int32_t* n_out_dev, void* stream);
+ * fcx, fcy); poly: device double[2*nv] (nv = 0: no crop).  workspace: one device buffer of agb_plot_workspace_bytes(n, B)
+ * bytes.  Out (n rows reserved): pos_out, x_out float[n,3], src int64[n] (input row of every kept point, order
+ * preserved), out_ptr int32[B+1], n_out_dev int32[1]. */
+size_t agb_plot_workspace_bytes(int n, int B);
+int agb_plot_prepare_ws(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
+                        int scale_div, int z_from_zero, const double* poly, int nv, void* workspace, float* pos_out,
+                        float* x_out, long long* src, int32_t* out_ptr, int32_t* n_out_dev, void* stream);
 /* RandomCoordsFlip (core/data_transform/sparse_transforms.py:49-55) + ShiftVoxels (transforms.py:1046-1054) on voxel
  * coordinates int32[n,3], in place: flip int32[B,3] (0/1), shift int32[B,3], both drawn by the host; cmax int32[B,3]
  * scratch. */
@@ -311,16 +321,16 @@ int agb_coords_augment(int32_t* coords, const int32_t* elem, int B, int n, const
  * agb_plot_extend: StartZFromZero (:766-769) + AddRandomPoints (:775-815, as upstream every added point equals the
  *   per-axis minimum) + CopyJitterRandomPoints (:818-873): pos2 = per plot [pos1 with z - zmin] ++ [n_add x minimum] ++
  *   [pos_prev[cj_idx] + cj_noise]; ptr2 / elem2 = output layout (host-known counts).
- * agb_plot_crop: RandomPolygon2dExtend (:1502-1552) with one transformed polygon per plot (polys double[B][2*nv]); a plot
+ * agb_plot_crop_ws: RandomPolygon2dExtend (:1502-1552) with one transformed polygon per plot (polys double[B][2*nv]); a plot
  *   with no point inside is left whole; emits positions, features [1, z, xy distance], source rows like agb_plot_prepare. */
 int agb_plot_augment(const float* raw, const long long* sel, const int32_t* elem, const int32_t* ptr, int B, int n,
                      const float* aug, const float* noise, float* pos1, float* mins, void* stream);
 int agb_plot_extend(const float* pos1, const int32_t* ptr1, const float* mins, const int32_t* ptr2,
                     const int32_t* elem2, int B, int n2, const int32_t* n_add, const int32_t* cj_ptr,
                     const long long* cj_idx, const float* cj_noise, float* pos2, void* stream);
-int agb_plot_crop(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const double* polys, int nv,
-                  float fcx, float fcy, int32_t* flag, int32_t* slot, int32_t* cnt, int32_t* scan_scratch,
-                  float* pos_out, float* x_out, long long* src, int32_t* out_ptr, int32_t* n_out_dev, void* stream);
+int agb_plot_crop_ws(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const double* polys, int nv,
+                     float fcx, float fcy, void* workspace /* agb_plot_workspace_bytes(n, B) */, float* pos_out,
+                     float* x_out, long long* src, int32_t* out_ptr, int32_t* n_out_dev, void* stream);
 
 /* ---- squeeze-excite excitation MLP (dpcr-agb_amd/csrc/se.hip) -------------------------------------------------------
  * SELayer.fc of modules/MinkowskiEngine/senet_block.py:35-42 on the pooled features P [B,C]:
@@ -332,6 +342,36 @@ int agb_se_mlp_fwd(const float* P, const float* W1, const float* b1, const float
 int agb_se_mlp_bwd(const float* P, const float* W1, const float* W2, int B, int C, int H, int act, const float* h_pre,
                    const float* S, const float* dS, float* dz2, float* dh, float* dP, float* dW1, float* db1,
                    float* dW2, float* db2, void* stream);
+
+/* ---- MinkowskiPointNet shared MLP (dpcr-agb_amd/csrc/pointnet.hip) --------------------------------------------------
+ * modules/MinkowskiEngine/PointNet.py:16-29: three (Linear without bias -> BatchNorm -> activation) layers over the points
+ * of a batch and a per-plot pooling of the last one.  The last layer's BatchNorm + activation is fused INTO the pooling
+ * (the [n, C] activation is never written) and, in the backward pass, into the BatchNorm gradient (the broadcast pooled
+ * gradient is never written).
+ * agb_pointnet_pool_fwd: pooled[b,:] = reduce over rows ptr[b]..ptr[b+1] of act(gamma (Z - mean) rstd + beta); mode 0 sum,
+ *   1 average, 2 max (+ argmax int32[B, C]: the winning row).  mean / rstd from agb_bn_stats on Z.  splits =
+ *   agb_pointnet_pool_splits(n, B) row splits per plot, folded in order (part float[B*splits*C], part_arg int32[B*splits*C]
+ *   for max; unused when splits == 1).
+ * agb_pointnet_pool_bwd: dZ [n, C] (the operand of the following weight / data gradient products), dgamma, dbeta from
+ *   dpooled [B, C]; coords int32[n][4] (plot index in column 0); part: float[agb_bn_chunks(n) * 2 * C].
+ * agb_pointnet_mlp_fwd: the whole chain for C callers / inference: x [n, cin_pad] -> pooled [B, c3]; W_l [c_{l-1}, c_l]
+ *   row-major (nn.Linear.weight transposed), widths multiples of 4 (cin_pad >= 12: zero-pad the 6 input columns);
+ *   bn_l = HOST array of 4 device pointers {gamma, beta, running_mean, running_var}; workspace:
+ *   agb_pointnet_mlp_workspace_bytes(n, B, c1, c2, c3) bytes.  The products run on the identity-map convolution
+ *   kernels (agb_spconv_fwd_ex with nbr == NULL), no BLAS. */
+int agb_pointnet_pool_splits(int n, int B);  /* host helper */
+int agb_pointnet_pool_fwd(const float* Z, int ldz, int n, int C, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int act, const int32_t* ptr, int B, int mode, int splits, float* part,
+                          int32_t* part_arg, float* pooled, int32_t* argmax, void* stream);
+int agb_pointnet_pool_bwd(const float* Z, int ldz, int n, int C, const int32_t* coords, const int32_t* ptr, int B,
+                          const float* dpooled, const int32_t* argmax, int mode, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int act, int training, float* part, float* dZ, int lddz,
+                          float* dgamma, float* dbeta, void* stream);
+size_t agb_pointnet_mlp_workspace_bytes(int n, int B, int c1, int c2, int c3);
+int agb_pointnet_mlp_fwd(const float* x, int ldx, int n, int cin_pad, const float* W1, const float* const* bn1, int c1,
+                         const float* W2, const float* const* bn2, int c2, const float* W3, const float* const* bn3,
+                         int c3, int act, float eps, float momentum, int training, const int32_t* ptr, int B, int mode,
+                         void* workspace, float* pooled, int32_t* argmax, void* stream);
 
 #ifdef __cplusplus
 }

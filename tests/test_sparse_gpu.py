@@ -151,12 +151,12 @@ def test_weight_transpose_exact(device, K3, R, C):
 def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride, ts_in):
     """The pair-compacted LDS-accumulating kernel (k_spconv_cmp; picked automatically only for many-row layers) forced
     on the small parity cases: forward and stride-1 data gradient run through it."""
-    from dpcr_agb_amd import _lib
-    _lib.call("agb_spconv_set_cmp_mode", rows_per_wave)
+    from dpcr_agb_amd import sparse_ops
+    sparse_ops.CMP_MODE = rows_per_wave
     try:
         _conv_case(device, cin, cout, K, stride, ts_in)
     finally:
-        _lib.call("agb_spconv_set_cmp_mode", 1)
+        sparse_ops.CMP_MODE = 1
 
 
 @pytest.mark.parametrize("K,negative", [(7, False), (7, True), (3, True), (5, False)])
@@ -214,24 +214,18 @@ def test_conv_pair_compacted_interleaved_tiles(device, shift):
     assert n >= 8192   # smaller levels always take contiguous tiles
     nbr = cm.kernel_map(1, 3, 1)
     P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
-    try:
-        for mode, cin, cout, sp in ((128, 64, 64, 1), (64, 128, 96, 1), (128, 256, 64, 2)):
-            x = torch.randn(n, cin, device=device)
-            w = torch.randn(27 * cin, cout, device=device) * 0.05
-            b = torch.randn(cout, device=device)
-            outs = []
-            _lib.call("agb_spconv_set_cmp_mode", mode)
-            for il in (0, shift):
-                _lib.call("agb_spconv_set_cmp_interleave", il)
-                y = torch.full((n, cout), float("nan"), device=device)
-                part = torch.empty(sp, n, cout, device=device) if sp > 1 else None
-                _lib.call("agb_spconv_fwd_ex", P(x), cin, P(w), P(nbr), nbr.stride(0), 0, P(b), P(y), cout, n, 27, cin,
-                          cout, None, None, None, 0, sp, P(part), _lib.stream())
-                outs.append(y)
-            assert torch.equal(outs[0], outs[1])
-    finally:
-        _lib.call("agb_spconv_set_cmp_mode", 1)
-        _lib.call("agb_spconv_set_cmp_interleave", -1)
+    for mode, cin, cout, sp in ((128, 64, 64, 1), (64, 128, 96, 1), (128, 256, 64, 2)):
+        x = torch.randn(n, cin, device=device)
+        w = torch.randn(27 * cin, cout, device=device) * 0.05
+        b = torch.randn(cout, device=device)
+        outs = []
+        for il in (0, shift):     # kernel choice and tile interleave are per-call arguments of the C ABI
+            y = torch.full((n, cout), float("nan"), device=device)
+            part = torch.empty(sp, n, cout, device=device) if sp > 1 else None
+            _lib.call("agb_spconv_fwd_opt", P(x), cin, P(w), P(nbr), nbr.stride(0), 0, P(b), P(y), cout, n, 27, cin,
+                      cout, None, None, None, 0, sp, P(part), mode, il, _lib.stream())
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("split", [2, 4])
@@ -253,16 +247,12 @@ def test_conv_pair_compacted_channel_split(device, split):
     b = torch.randn(cout, device=device)
     P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
     outs = []
-    _lib.call("agb_spconv_set_cmp_mode", 128)
-    try:
-        for sp in (1, split):
-            y = torch.empty(n, cout, device=device)
-            part = torch.empty(sp, n, cout, device=device) if sp > 1 else None
-            _lib.call("agb_spconv_fwd_ex", P(x), cin, P(w), P(nbr), nbr.stride(0), 0, P(b), P(y), cout, n, 27, cin, cout,
-                      None, None, None, 0, sp, P(part), _lib.stream())
-            outs.append(y)
-    finally:
-        _lib.call("agb_spconv_set_cmp_mode", 1)
+    for sp in (1, split):
+        y = torch.empty(n, cout, device=device)
+        part = torch.empty(sp, n, cout, device=device) if sp > 1 else None
+        _lib.call("agb_spconv_fwd_opt", P(x), cin, P(w), P(nbr), nbr.stride(0), 0, P(b), P(y), cout, n, 27, cin, cout,
+                  None, None, None, 0, sp, P(part), 128, -1, _lib.stream())
+        outs.append(y)
     assert rel_err(outs[1], outs[0]) < 1e-5
 
 
@@ -653,3 +643,73 @@ def test_senet50_low_precision_matches_oracle(device, precision, out_tol, grad_t
     assert e_out < out_tol, e_out
     assert worst < grad_tol, (worst, worst_name)
     assert one_minus_cos < cos_tol, one_minus_cos
+
+
+@pytest.mark.parametrize("pool", ["sum", "max", "mean"])
+def test_pointnet_fused_tail_and_c_chain(device, pool):
+    """The fused BatchNorm + activation + pooling tail (csrc/pointnet.hip) against the unfused kernels of the same library
+    (same arithmetic, different reduction order: 1e-6), its gradients against the fp64 oracle, and the one-call C chain
+    agb_pointnet_mlp_fwd (eval mode, running statistics) against the module path and the oracle."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import norm_ops
+    from dpcr_agb_amd.backbones.pointnet import MinkowskiPointNet
+    from dpcr_agb_amd import synthetic
+    torch.manual_seed(3)
+    net = MinkowskiPointNet(3, 2, activation="gelu", global_pool=pool).to(device)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+                m.running_mean.normal_(0, 0.05); m.running_var.uniform_(0.5, 1.5)
+    batch = synthetic.make_sparse_batch([0, 1, 2, 3, 4], n_points=3000)
+    feats = torch.cat([batch.pos, batch.x], 1)
+    coords = torch.cat([batch.batch[:, None].int(), batch.coords.int()], 1)
+
+    def run(fused, train):
+        net.train(train)
+        st = ME.SparseTensor(feats.clone(), coordinates=coords, device=device)
+        if fused:
+            return net._embed(st).F
+        mods = list(net.blocks)
+        return net.global_pool(net._run(mods, st)).F
+
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    a = run(True, True)
+    net.load_state_dict(sd0)
+    b = run(False, True)
+    assert rel_err(a, b) < 2e-6
+    # eval mode without gradients: the one-call C chain; against the module path (eval, grad enabled -> fused tail)
+    net.load_state_dict(sd0)
+    with torch.no_grad():
+        c_chain = run(True, False)
+    c_mod = run(True, False)
+    assert rel_err(c_chain, c_mod) < 2e-6
+    sd = {k: v.detach().cpu().double() for k, v in sd0.items()}
+    x = feats.double()
+    for lin, bn in ((0, 1), (3, 4), (6, 7)):
+        x = torch.nn.functional.linear(x, sd[f"blocks.{lin}.linear.weight"])
+        x = torch.nn.functional.gelu(R.batch_norm(x, sd, f"blocks.{bn}", False, 0.1))
+    ref = R.global_pool(x, batch.batch, 5, "avg" if pool == "mean" else pool)
+    assert rel_err(c_chain, ref) < RTOL
+    # gradients of the fused tail (training mode) against the oracle
+    net.load_state_dict(sd0)
+    net.train(True)
+    net.zero_grad()
+    out = run(True, True)
+    g = torch.randn(*out.shape, generator=torch.Generator().manual_seed(1))
+    out.backward(g.to(device))
+    P = {k: (v.clone().requires_grad_("running" not in k and "num_batches" not in k)) for k, v in sd.items()}
+    x = feats.double()
+    for lin, bn in ((0, 1), (3, 4), (6, 7)):
+        x = torch.nn.functional.linear(x, P[f"blocks.{lin}.linear.weight"])
+        x = torch.nn.functional.gelu(R.batch_norm(x, P, f"blocks.{bn}", True, 0.1))
+    refp = R.global_pool(x, batch.batch, 5, "avg" if pool == "mean" else pool)
+    assert rel_err(out, refp) < RTOL
+    refp.backward(g.double())
+    named = dict(net.named_parameters())
+    gmax = max(float(P[k].grad.abs().max()) for k in P if k.startswith("blocks") and P[k].grad is not None)
+    for k, v in P.items():
+        if v.grad is None or not k.startswith("blocks"):
+            continue
+        e = float((named[k].grad.detach().cpu().double() - v.grad).abs().max()) / max(float(v.grad.abs().max()), 1e-3 * gmax)
+        assert e < RTOL, (k, e)

@@ -2,7 +2,7 @@
 
   python tools/bench_conv.py [--modes 0,64,128] [--reps 20]
 For every (level, Cin, Cout) of the stride-1 3^3 layers it times agb_spconv_fwd_ex per kernel-selection mode
-(agb_spconv_set_cmp_mode) and the weight gradient, and prints us/launch and algorithmic TFLOP/s (2*pairs*Cin*Cout)."""
+(sparse_ops.CMP_MODE) and the weight gradient, and prints us/launch and algorithmic TFLOP/s (2*pairs*Cin*Cout)."""
 import argparse
 import os
 import sys
@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--il", default="-1", help="interleave block shifts to sweep for the pair-compacted kernel, e.g. 0,2,3 (-1: by level size, the library default)")
     args = ap.parse_args()
-    from dpcr_agb_amd import _lib, synthetic
+    from dpcr_agb_amd import _lib, sparse_ops, synthetic
     from dpcr_agb_amd.coords import CoordinateManager
     from dpcr_agb_amd.sparse_ops import spconv_forward_raw
     dev = torch.device("cuda", 0)
@@ -42,8 +42,7 @@ def main():
         w = torch.randn(27 * cin, cout, device=dev) * 0.05
         ref = None
         for mode, il in [(int(m), int(i)) for m in args.modes.split(",") for i in args.il.split(",")]:
-            _lib.call("agb_spconv_set_cmp_mode", mode)
-            _lib.call("agb_spconv_set_cmp_interleave", il)
+            sparse_ops.CMP_MODE, sparse_ops.CMP_INTERLEAVE = mode, il
             y = spconv_forward_raw(x, w, nbr, 0, None, n, 27, cin, cout)
             torch.cuda.synchronize()
             if ref is None:
@@ -63,7 +62,6 @@ def main():
             dy = torch.randn(n, cout, device=dev)
             ref_dw = None
             for il in [int(i) for i in args.il.split(",")]:
-                _lib.call("agb_spconv_set_cmp_interleave", il)
                 dw = torch.zeros(27, cin, cout, device=dev)
                 _lib.call("agb_spconv_bwd_weight", x.data_ptr(), cin, dy.data_ptr(), cout, nbr.data_ptr(),
                           nbr.stride(0), dw.data_ptr(), n, 27, cin, cout, _lib.stream())
@@ -81,8 +79,7 @@ def main():
                 us = e0.elapsed_time(e1) / args.reps * 1e3
                 print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} wgrad il {il}: {us:8.1f} us  "
                       f"{2.0 * pairs * cin * cout / us / 1e6:6.1f} TF  (max rel diff vs first {err:.1e})")
-    _lib.call("agb_spconv_set_cmp_mode", 1)
-    _lib.call("agb_spconv_set_cmp_interleave", -1)
+    sparse_ops.CMP_MODE, sparse_ops.CMP_INTERLEAVE = 1, -1
 
 
 if __name__ == "__main__":
