@@ -1,0 +1,92 @@
+/* A plain-C caller of libagbhip.so (include/agb_hip.h): coordinate hash insert -> kernel map -> sparse convolution on a
+ * 3-voxel input, checked against a brute-force evaluation on the host.  Built by tests/c_abi/Makefile (gcc + the HIP
+ * runtime API for device memory only), run by tests/test_c_caller.py on a GPU box.  Exit code 0 = all values match. */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "agb_hip.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); return 2; } } while (0)
+#define CHECK_AGB(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, r_, agb_last_error()); return 3; } } while (0)
+
+int main(void) {
+    enum { N = 3, K = 3, K3 = 27, CIN = 4, COUT = 4 };
+    const int32_t coords[N][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};   /* (batch, x, y, z) */
+    float X[N][CIN], W[K3][CIN][COUT], bias[COUT], Y[N][COUT], ref[N][COUT];
+    for (int r = 0; r < N; ++r) for (int c = 0; c < CIN; ++c) X[r][c] = (float)(1 + r * CIN + c) * 0.25f;
+    for (int k = 0; k < K3; ++k) for (int c = 0; c < CIN; ++c) for (int o = 0; o < COUT; ++o)
+        W[k][c][o] = (float)(((k * 7 + c * 3 + o * 5) % 11) - 5) * 0.125f;
+    for (int o = 0; o < COUT; ++o) bias[o] = 0.5f * (float)o;
+
+    /* host reference: Y[r] = bias + sum_k X[row of coords[r] + offset_k] W[k], offset_k = (ix-1, iy-1, iz-1), x fastest */
+    int expected_pairs = 0;
+    for (int r = 0; r < N; ++r) {
+        for (int o = 0; o < COUT; ++o) ref[r][o] = bias[o];
+        for (int k = 0; k < K3; ++k) {
+            const int dx = k % K - 1, dy = (k / K) % K - 1, dz = k / (K * K) - 1;
+            for (int q = 0; q < N; ++q) {
+                if (coords[q][0] == coords[r][0] && coords[q][1] == coords[r][1] + dx && coords[q][2] == coords[r][2] + dy &&
+                    coords[q][3] == coords[r][3] + dz) {
+                    ++expected_pairs;
+                    for (int c = 0; c < CIN; ++c) for (int o = 0; o < COUT; ++o) ref[r][o] += X[q][c] * W[k][c][o];
+                }
+            }
+        }
+    }
+
+    const int cap = agb_hash_capacity(N);
+    int32_t *d_coords, *d_vals, *d_slot, *d_status, *d_nbr;
+    uint64_t* d_keys;
+    unsigned long long* d_pairs;
+    float *d_X, *d_W, *d_b, *d_Y;
+    CHECK_HIP(hipMalloc((void**)&d_coords, sizeof(coords)));
+    CHECK_HIP(hipMalloc((void**)&d_keys, sizeof(uint64_t) * cap));
+    CHECK_HIP(hipMalloc((void**)&d_vals, sizeof(int32_t) * cap));
+    CHECK_HIP(hipMalloc((void**)&d_slot, sizeof(int32_t) * N));
+    CHECK_HIP(hipMalloc((void**)&d_status, sizeof(int32_t) * 4));
+    CHECK_HIP(hipMalloc((void**)&d_nbr, sizeof(int32_t) * K3 * N));
+    CHECK_HIP(hipMalloc((void**)&d_pairs, sizeof(unsigned long long) * 64 * 16));
+    CHECK_HIP(hipMalloc((void**)&d_X, sizeof(X)));
+    CHECK_HIP(hipMalloc((void**)&d_W, sizeof(W)));
+    CHECK_HIP(hipMalloc((void**)&d_b, sizeof(bias)));
+    CHECK_HIP(hipMalloc((void**)&d_Y, sizeof(Y)));
+    CHECK_HIP(hipMemcpy(d_coords, coords, sizeof(coords), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_X, X, sizeof(X), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_W, W, sizeof(W), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_b, bias, sizeof(bias), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemset(d_pairs, 0, sizeof(unsigned long long) * 64 * 16));
+
+    CHECK_AGB(agb_hash_clear(d_keys, d_vals, cap, NULL));
+    CHECK_AGB(agb_coords_insert(d_coords, N, NULL, d_keys, d_vals, cap, d_slot, d_status, NULL));
+    CHECK_AGB(agb_kernel_map(d_coords, N, NULL, K, 1, 1, 0, d_keys, d_vals, cap, d_nbr, N, d_pairs, NULL));
+    CHECK_AGB(agb_spconv_fwd(d_X, CIN, d_W, d_nbr, N, 0, d_b, d_Y, COUT, N, K3, CIN, COUT, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+
+    int32_t status[4], nbr[K3][N];
+    unsigned long long pairs[64 * 16], total = 0;
+    CHECK_HIP(hipMemcpy(status, d_status, sizeof(status), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(nbr, d_nbr, sizeof(nbr), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(pairs, d_pairs, sizeof(pairs), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(Y, d_Y, sizeof(Y), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 64 * 16; ++i) total += pairs[i];
+    if (status[0] || status[1] || status[2]) { fprintf(stderr, "insert status %d %d %d\n", status[0], status[1], status[2]); return 4; }
+    if ((int)total != expected_pairs) { fprintf(stderr, "kernel map holds %llu pairs, expected %d\n", total, expected_pairs); return 5; }
+    if (nbr[13][0] != 0 || nbr[14][0] != 1 || nbr[16][0] != 2 || nbr[12][1] != 0 || nbr[10][2] != 0 || nbr[0][0] != -1) {
+        fprintf(stderr, "kernel map entries differ\n");
+        return 6;
+    }
+    double worst = 0.0;
+    for (int r = 0; r < N; ++r) for (int o = 0; o < COUT; ++o) {
+        const double e = fabs((double)Y[r][o] - (double)ref[r][o]);
+        if (e > worst) worst = e;
+    }
+    printf("c caller: %d pairs, max |Y - ref| = %.3g\n", expected_pairs, worst);
+    /* the error path is part of the contract: a bad argument returns AGB_EINVAL and leaves a message */
+    if (agb_spconv_fwd(d_X, 3, d_W, d_nbr, N, 0, d_b, d_Y, COUT, N, K3, CIN, COUT, NULL) != AGB_EINVAL ||
+        strlen(agb_last_error()) == 0) { fprintf(stderr, "error path\n"); return 7; }
+    return worst < 1e-5 ? 0 : 1;
+}
