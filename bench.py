@@ -83,7 +83,10 @@ def kernel_of(rec):
         x3 = "true" if PRECISION == "bf16x3" else "false"
         if rec.get("perm"):
             return f"k_spconv_pipe_bf16<64, true, {x3}>"
-        return f"k_spconv_pipe_bf16<{128 if tall else 64}, false, {x3}>" + (" (dense)" if dense else "")
+        split = rec.get("split", 1)
+        wide = tall and rec["cout"] >= 128 and -(-rec["rows"] // 128) * -(-rec["cout"] // 128) * split >= 512
+        return f"k_spconv_pipe_bf16<{128 if tall else 64}, false, {x3}{', 128' if wide else ''}>" + \
+            (" (dense)" if dense else "")
     if rec.get("perm"):
         return "k_spconv_pipe<64, true>"
     split = rec.get("split", 1)

@@ -510,34 +510,43 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define LBK 64        // K elements per chunk
 #define LLD 72        // LDS row stride in bf16 (144 B = 36 dwords: conflict-free ds_read_b128, as LDA)
 
+// fp32 -> bf16, round to nearest even: a plain cast compiles to v_cvt_pk_bf16_f32 on gfx950 (one instruction per PAIR of
+// values instead of ~5 integer operations per value: the staging of the bf16 kernels is VALU-heavy)
 __device__ __forceinline__ unsigned short f2bf(float x) {
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);   // round to nearest even (NaN payloads are not preserved: features are finite)
-    return (unsigned short)(u >> 16);
+    const __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned, h);
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 template <bool X3>
 __device__ __forceinline__ void stage_bf16(unsigned short* hi, unsigned short* lo, int off, float4 v) {
-    unsigned short h0 = f2bf(v.x), h1 = f2bf(v.y), h2 = f2bf(v.z), h3 = f2bf(v.w);
-    *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+    const unsigned p0 = pack2_bf16(v.x, v.y), p1 = pack2_bf16(v.z, v.w);
+    *reinterpret_cast<uint2*>(hi + off) = make_uint2(p0, p1);
     if (X3) {
-        unsigned short l0 = f2bf(v.x - bf2f(h0)), l1 = f2bf(v.y - bf2f(h1)), l2 = f2bf(v.z - bf2f(h2)),
-                       l3 = f2bf(v.w - bf2f(h3));
-        *reinterpret_cast<uint2*>(lo + off) =
-            make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+        const float r0 = v.x - __uint_as_float(p0 << 16), r1 = v.y - __uint_as_float(p0 & 0xFFFF0000u);
+        const float r2 = v.z - __uint_as_float(p1 << 16), r3 = v.w - __uint_as_float(p1 & 0xFFFF0000u);
+        *reinterpret_cast<uint2*>(lo + off) = make_uint2(pack2_bf16(r0, r1), pack2_bf16(r2, r3));
     }
 }
 
-template <int TM, bool PERM, bool X3>
+// CW: output columns per workgroup (64 or 128): a gathered / converted A tile serves CW columns
+template <int TM, bool PERM, bool X3, int CW = 64>
 __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
     constexpr int WAVES_M = TM / 32;
     constexpr int WAVES_N = 4 / WAVES_M;
-    constexpr int NT = 2 / WAVES_N;
+    constexpr int NT = (CW / 32) / WAVES_N;
+    constexpr int BJ = CW / 16;            // float4 weight loads per thread per chunk
     constexpr int AJ = TM / 16;            // float4 A gathers per thread per chunk (16 rows per pass)
     constexpr int NP = X3 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) unsigned short As[NP][TM * LLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][64 * LLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][CW * LLD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tile = blockIdx.x;
     const int row0 = tile * TM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * CW;
     const int li = lane & 31, lh = lane >> 5;
     const int t_r = tid >> 4, t_c = (tid & 15) * 4;   // staging: row (+16j), k offset inside the chunk
     const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
         else grow[j] = r < a.n_out ? r : -1;
     }
     int idx_cur[AJ], idx_nxt[AJ];
-    float4 a_reg[AJ], b_reg[4];
+    float4 a_reg[AJ], b_reg[BJ];
 
     auto offset_of = [&](int ch) {
         int ko = ch / cpk;
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
                 a_reg[j] = *reinterpret_cast<const float4*>(a.X + (long long)idx[j] * a.ldx + c0 + t_c);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < BJ; ++j) {
             int n = n0 + t_r + 16 * j;
             b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (n < Cout && c0 + t_c < Cin)
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) stage_bf16<X3>(As[0], As[NP - 1], (t_r + 16 * j) * LLD + t_c, a_reg[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) stage_bf16<X3>(Bs[0], Bs[NP - 1], (t_r + 16 * j) * LLD + t_c, b_reg[j]);
+        for (int j = 0; j < BJ; ++j) stage_bf16<X3>(Bs[0], Bs[NP - 1], (t_r + 16 * j) * LLD + t_c, b_reg[j]);
         __syncthreads();
         if (ch + 1 < ch_end) {
 #pragma unroll
@@ -1156,9 +1165,10 @@ __global__ __launch_bounds__(256) void k_spconv_dw(const float* __restrict__ X, 
 //   fragment ds_read_b128 conflict-free (searched by brute force over the bank rules of MI355X_MICROARCH.md §LDS).
 // nbr == nullptr: identity map (dense X^T dY of a 1x1 stride-1 convolution).
 #define DWT_LD 48     // dwords per transposed row (32 used: 64 pairs)
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return pack2_bf16(a, b); }
 __device__ __forceinline__ unsigned pack_bf16_lo(float a, float b) {
-    return (unsigned)f2bf(a - bf2f(f2bf(a))) | ((unsigned)f2bf(b - bf2f(f2bf(b))) << 16);
+    const unsigned h = pack2_bf16(a, b);
+    return pack2_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xFFFF0000u));
 }
 template <int PREC>
 __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__ X, int ldx,
@@ -1709,8 +1719,14 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
         if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<64, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_spconv_pipe_bf16<64, true, false>), grid, block, 0, s, a);
     } else if (conv_tile_rows(n_out, Cin, Cout) == 128) {
-        dim3 grid(agb_cdiv(n_out, 128), agb_cdiv(Cout, BN), ksplit);
-        if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, true>), grid, block, 0, s, a);
+        // 128-column tiles when the layer is wide enough and still fills the chip: the gathered and converted A tile
+        // (the VALU / L2 cost of this kernel) serves twice the columns
+        const bool wide = Cout >= 128 && (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, 128) * ksplit >= 512;
+        dim3 grid(agb_cdiv(n_out, 128), agb_cdiv(Cout, wide ? 128 : 64), ksplit);
+        if (wide) {
+            if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, true, 128>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, false, 128>), grid, block, 0, s, a);
+        } else if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, false>), grid, block, 0, s, a);
     } else {
         dim3 grid(agb_cdiv(n_out, 64), agb_cdiv(Cout, BN), ksplit);

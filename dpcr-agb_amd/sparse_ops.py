@@ -275,7 +275,8 @@ class DenseConvFunction(torch.autograd.Function):
 
     @staticmethod
     def supported(cin, cout):
-        return cin >= 12 and cin % 4 == 0 and cout % 4 == 0
+        # (both widths are reduction dimensions of one of the three products)
+        return cin >= 12 and cout >= 12 and cin % 4 == 0 and cout % 4 == 0
 
     @staticmethod
     def forward(ctx, feats, kernel, bias):
@@ -332,7 +333,8 @@ class DenseLinearFunction(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         n, cin = x.shape
         cout = weight.shape[0]
-        cin_p, cout_p = max(12, (cin + 3) // 4 * 4), (cout + 3) // 4 * 4
+        # both widths are the reduction dimension of one of the three products: at least 12, multiples of 4
+        cin_p, cout_p = max(12, (cin + 3) // 4 * 4), max(12, (cout + 3) // 4 * 4)
         xp = (x if cin_p == cin else F.pad(x, (0, cin_p - cin))).contiguous()
         wp = weight if (cin_p == cin and cout_p == cout) else F.pad(weight, (0, cin_p - cin, 0, cout_p - cout))
         wp = wp.contiguous()                                   # [out, in]: K-major for the forward product

@@ -236,14 +236,22 @@ def resnet_forward(sd, coords, feats, layers, strides=(1, 2, 2, 2), activation="
 
 
 def pointnet_forward(sd, batch_index, feats, B, activation="gelu", global_pool_mode="sum", training=True,
-                     momentum=0.1, update=None):
-    """PointNet.py:43-49: blocks (3x Linear no-bias + BN + act) -> global pool -> mlp -> final."""
+                     momentum=0.1, update=None, pool_rows=None, keep=None):
+    """PointNet.py:43-49: blocks (3x Linear no-bias + BN + act) -> global pool -> mlp -> final.
+    pool_rows (optional, long [B, C], max pooling only): take these rows as the winners instead of the arg-max (a test
+    can pin the selection where two candidates tie within rounding).  keep (optional dict): receives the pre-pool
+    activation under "embedding"."""
     act = ACT[activation]
     x = feats
     for lin, bn in ((0, 1), (3, 4), (6, 7)):
         x = F.linear(x, sd[f"blocks.{lin}.linear.weight"])
         x = act(batch_norm(x, sd, f"blocks.{bn}", training, momentum, update=update))
-    x = global_pool(x, batch_index, B, global_pool_mode)
+    if keep is not None:
+        keep["embedding"] = x
+    if pool_rows is not None:
+        x = x[pool_rows, torch.arange(x.shape[1]).unsqueeze(0).expand_as(pool_rows)]
+    else:
+        x = global_pool(x, batch_index, B, global_pool_mode)
     for lin, bn in ((0, 1), (3, 4)):
         x = F.linear(x, sd[f"mlp.{lin}.linear.weight"])
         x = act(batch_norm(x, sd, f"mlp.{bn}", training, momentum, update=update))

@@ -507,12 +507,29 @@ def test_mpointnet_matches_oracle(device, pool):
     batch = synthetic.make_sparse_batch([0, 1, 2, 3], n_points=1500)
     sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
     model.to(device).train()
+    captured = {}
+    hook = model.model.mlp[0].register_forward_hook(lambda m, inp, out: captured.setdefault("pooled", inp[0].F))
     model.set_input(batch, device)
     model.forward()
+    hook.remove()
     model.loss.backward()
     sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in sd32.items()}
     feats = torch.cat([batch.pos, batch.x], 1).double()
-    out = R.pointnet_forward(sd, batch.batch, feats, 4, global_pool_mode=pool)
+    rows = None
+    if pool == "max":
+        # Max pooling routes a channel's whole gradient to ONE row: where the two best rows of a plot tie within fp32
+        # rounding, fp32 and fp64 may crown different rows (same forward value, different gradient path).  The oracle is
+        # evaluated with the rows the HIP path crowned, after checking that every one of them IS a maximum up to rounding.
+        rows = captured["pooled"].grad_fn.saved_tensors[6].cpu().long()
+        keep = {}
+        with torch.no_grad():
+            R.pointnet_forward({k: v.detach() for k, v in sd.items()}, batch.batch, feats, 4, global_pool_mode=pool, keep=keep)
+        emb = keep["embedding"]
+        true_max = R.global_pool(emb, batch.batch, 4, "max")
+        picked = emb[rows, torch.arange(emb.shape[1]).unsqueeze(0).expand_as(rows)]
+        assert float(((true_max - picked) / true_max.abs().clamp(min=1e-3)).max()) < 1e-5
+        assert (batch.batch[rows] == torch.arange(4).unsqueeze(1)).all()
+    out = R.pointnet_forward(sd, batch.batch, feats, 4, global_pool_mode=pool, pool_rows=rows)
     loss = R.reg_loss(out, batch.y_reg.double(), model.reg_center_targets.cpu().double(),
                       model.reg_scale_targets.cpu().double(), model.reg_weights.cpu().double())
     loss.backward()

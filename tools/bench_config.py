@@ -1,0 +1,319 @@
+"""Bench lines for BASELINE.json configs 2 and 3 (bench.py stays on the headline, config 4):
+
+  python tools/bench_config.py pointnet [--steps 20] [--warmup 5]     config 2: MPointNet fp32, B = 64 x 16k-pt plots
+  python tools/bench_config.py kpconv [--points 16000|6144]           config 3: KPConv rigid, B = 32 plots
+
+One JSON line per run in bench.py's format: training plots/s (whole step: input pyramid / coordinate maps on the device +
+forward + backward + AdaBelief), `roofline` of the library entry point that takes the most device time (HIP events around
+every library call during three instrumented steps OUTSIDE the timed region; algorithmic bytes / FLOPs per SURVEY.md
+§8d) and `cpu_baseline`:
+  * pointnet: oracle/sparse_ref.py:pointnet_forward (torch-CPU fp32, all usable cores), full training steps on a sample;
+  * kpconv: the KPConv index path (5 x radius neighbours, 4 x grid subsampling, 4 x pooling neighbours) of the same
+    batch on the C++ restatement oracle/kpconv_index_ref.cpp — single thread (how the reference runs it, GIL held) and all
+    usable cores (one plot per task) — the part of a KPConv step the reference spends on the CPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS, MFMA_F32_PEAK_TF = 8000.0, 157.3
+
+
+def log(msg):
+    print(f"[bench_config] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+class CallTimer:
+    """Brackets every library call (dpcr_agb_amd._lib.call) with HIP events on torch's current stream while active."""
+
+    def __init__(self):
+        from dpcr_agb_amd import _lib
+        self._lib, self._orig, self.records = _lib, _lib.call, []
+
+    def __enter__(self):
+        def timed(name, *args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = self._orig(name, *args)
+            e1.record()
+            self.records.append((name, args, e0, e1))
+            return rc
+        self._lib.call = timed
+        import dpcr_agb_amd.sparse_ops as so, dpcr_agb_amd.norm_ops as no, dpcr_agb_amd.kpconv_ops as ko  # noqa: E401
+        import dpcr_agb_amd.kp_index as ki
+        self._mods = [m for m in (so, no, ko, ki) if hasattr(m, "_lib")]
+        return self
+
+    def __exit__(self, *exc):
+        self._lib.call = self._orig
+
+    def by_name(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, args, e0, e1 in self.records:
+            g = out.setdefault(name, dict(ms=0.0, n=0, calls=[]))
+            ms = e0.elapsed_time(e1)
+            g["ms"] += ms
+            g["n"] += 1
+            g["calls"].append((args, ms))
+        return out
+
+
+def conv_call_cost(args):
+    """agb_spconv_fwd_opt / _lp(X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, ...) with the
+    identity map: a dense [n, Cin] x [Cin, Cout] product."""
+    n, K3, cin, cout = args[9], args[10], args[11], args[12]
+    return 2.0 * n * cin * cout, (n * (cin + cout) + K3 * cin * cout) * 4.0
+
+
+def wgrad_call_cost(args):
+    """agb_spconv_bwd_weight_lp(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, precision)"""
+    n, K3, cin, cout = args[7], args[8], args[9], args[10]
+    return 2.0 * n * cin * cout, (n * (cin + cout) + K3 * cin * cout) * 4.0
+
+
+def roofline_entry(name, g, cost):
+    flops = sum(cost(a)[0] for a, _ in g["calls"])
+    byts = sum(cost(a)[1] for a, _ in g["calls"])
+    secs = g["ms"] / 1e3
+    ridge = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if flops / max(byts, 1.0) >= ridge:
+        ach = flops / secs / 1e12
+        r = dict(bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4))
+    else:
+        ach = byts / secs / 1e9
+        r = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+    r.update(traffic=None, kernel=name, launches=g["n"], avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2),
+             alg_bytes_per_launch=round(byts / g["n"]), alg_flops_per_launch=round(flops / g["n"]))
+    return r
+
+
+def timed_loop(step, steps, warmup):
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs = []
+    for i in range(steps):
+        step(warmup + i)
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        evs.append(e)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    gaps = sorted(evs[j].elapsed_time(evs[j + 1]) for j in range(len(evs) - 1))
+    return dt, gaps
+
+
+def top_table(groups, k=8):
+    for name, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:k]:
+        log(f"  {g['ms']:9.3f} ms  {g['n']:5d} calls  {name}")
+
+
+# ------------------------------------------------------------------------------------------------ config 2
+def run_pointnet(a):
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B = a.batch or 64
+    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_064))
+    model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS["MPointNet"]), "minkowski", ds)
+    sd_cpu = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    pool = [synthetic.make_sparse_batch(list(range(i * B, (i + 1) * B)), n_points=a.points).to(dev) for i in range(3)]
+    model.to(dev).train()
+    model.init_train_objects(TRAINING_NFI)
+    voxels = sum(int(b.coords.shape[0]) for b in pool) / len(pool) / B
+
+    def step(i):
+        model.set_input(pool[i % 3], dev)
+        model.optimize_parameters(epoch=0, batch_size=B, num_batches=133)
+        model.prefetch_input(pool[(i + 1) % 3], dev)
+
+    dt, gaps = timed_loop(step, a.steps, a.warmup)
+    with CallTimer() as ct:
+        for i in range(3):
+            step(i)
+    groups = ct.by_name()
+    top_table(groups)
+    costs = {"agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_fwd_lp": conv_call_cost,
+             "agb_spconv_bwd_weight_lp": wgrad_call_cost}
+    dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
+    roof = roofline_entry(dom, groups[dom], costs[dom])
+    line = dict(metric="training plots/sec (16k-pt NFI plots) MPointNet", value=round(B * a.steps / dt, 2), unit="plots/s",
+                n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
+                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload=f"BASELINE config 2: MinkowskiPointNet (shared MLP 6-64-128-1024 + BN + GELU, per-plot sum "
+                                     f"pooling, head) training step, {a.points}-pt synthetic plots, batch {B}, ~{voxels:.0f} "
+                                     "voxels/plot", global_batch=B, parallelism="dp1",
+                            final_loss=round(float(model.loss.detach()), 5)),
+                roofline=roof, step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
+                entry_points_ms_per_step={n: round(g["ms"] / 3, 3) for n, g in
+                                          sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:8]})
+    if not a.no_cpu_baseline:
+        from oracle import sparse_ref as R
+        from dpcr_agb_amd.optim import AdaBelief
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        nb = 4
+        cb = synthetic.make_sparse_batch(list(range(900_000, 900_000 + nb)), n_points=a.points)
+        sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd_cpu.items()}
+        params = [v for v in sd.values() if v.requires_grad]
+        opt = AdaBelief(params, lr=0.005, weight_decay=1e-2)
+        feats = torch.cat([cb.pos, cb.x], 1)
+        center, scale, w = model.reg_center_targets.cpu(), model.reg_scale_targets.cpu(), model.reg_weights.cpu()
+        t0, n = time.time(), 0
+        while n < 2 or (time.time() - t0 < 12 and n < 40):
+            out = R.pointnet_forward(sd, cb.batch, feats, nb)
+            loss = R.reg_loss(out, cb.y_reg, center, scale, w)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_value_(params, 100)
+            opt.step()
+            n += 1
+        d = time.time() - t0
+        line["cpu_baseline"] = dict(value=round(nb * n / d, 3), unit="plots/s", cores=cores, kind="port",
+                                    sample=f"{n} training steps of MPointNet on {nb} synthetic {a.points}-pt plots "
+                                           f"(oracle/sparse_ref.py, torch-CPU fp32, {cores} threads), {d:.1f} s")
+    print(json.dumps(line), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ config 3
+def ballquery_cost(args):
+    """agb_ball_query_fill(queries, nq, q_elem, origin_cs, dims, cell_start, sorted, radius, ns, width, out, status):
+    SURVEY.md §8d: Ns*12 (supports) + Nq*12 (queries) + Nq*width*4 (the padded matrix the API returns)."""
+    nq, ns, width = args[1], args[8], args[9]
+    return 0.0, ns * 16.0 + nq * 12.0 + nq * width * 4.0
+
+
+def run_kpconv(a):
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
+    from dpcr_agb_amd.instance import KPConvModel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    B = a.batch or 32
+    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_032))
+    model = KPConvModel(Opt(MODEL_OPTIONS["KPConv"]), "kpconv", ds)
+    pool = [synthetic.make_point_batch(list(range(i * B, (i + 1) * B)), n_points=a.points) for i in range(2)]
+    for b in pool:
+        b.pos, b.x = b.pos.to(dev), b.x.to(dev)
+    model.to(dev).train()
+    model.init_train_objects(TRAINING_NFI)
+
+    def step(i):
+        model.set_input(pool[i % 2], dev)
+        model.optimize_parameters(epoch=0, batch_size=B, num_batches=133)
+        model.prefetch_input(pool[(i + 1) % 2], dev)
+
+    dt, gaps = timed_loop(step, a.steps, a.warmup)
+    # the instrumented steps run the input pyramid on the compute stream (the events are recorded there)
+    with CallTimer() as ct:
+        for i in range(3):
+            model.set_input(pool[i % 2], dev)
+            model.optimize_parameters(epoch=0, batch_size=B, num_batches=133)
+    groups = ct.by_name()
+    top_table(groups, 12)
+    costs = {"agb_ball_query_fill": ballquery_cost, "agb_spconv_fwd_opt": conv_call_cost,
+             "agb_spconv_bwd_weight_lp": wgrad_call_cost}
+    dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
+    roof = roofline_entry(dom, groups[dom], costs[dom])
+    index_names = ("agb_ball_query_fill", "agb_ball_query_count", "agb_ball_grid_build", "agb_grid_subsample_ws",
+                   "agb_elem_bbox", "agb_elem_of_row", "agb_rotate_points")
+    index_ms = sum(groups[n]["ms"] for n in index_names if n in groups) / 3
+    bq = roofline_entry("agb_ball_query_fill", groups["agb_ball_query_fill"], ballquery_cost)
+    line = dict(metric="training plots/sec KPConv rigid", value=round(B * a.steps / dt, 2), unit="plots/s", n_gpus=1,
+                steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
+                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload=f"BASELINE config 3: KPConv rigid (KPCNN, 15 blocks, K = 15) training step incl. the "
+                                     f"5-level input pyramid (radius neighbours, grid subsampling) on the device, "
+                                     f"{a.points}-pt synthetic plots, batch {B}", global_batch=B, parallelism="dp1",
+                            final_loss=round(float(model.loss.detach()), 5)),
+                roofline=roof, ball_query_roofline=bq, index_path_ms_per_step=round(index_ms, 3),
+                step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
+                entry_points_ms_per_step={n: round(g["ms"] / 3, 3) for n, g in
+                                          sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:10]})
+    if not a.no_cpu_baseline:
+        line["cpu_baseline"] = kpconv_cpu_index(pool[0], B, a.points)
+    print(json.dumps(line), flush=True)
+
+
+def kpconv_cpu_index(batch, B, points):
+    """The index path of one batch on the C++ restatement: single thread, then one plot per task on all cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import kpconv_index as O
+    from dpcr_agb_amd.config import kpconv_config
+    cfg = kpconv_config()
+    pos = batch.pos.cpu().numpy().astype(np.float32)
+    nplots = min(B, 8)                       # a bounded sample: 8 plots (the reference does the whole batch per step)
+    per = [pos[i * points:(i + 1) * points] for i in range(nplots)]
+
+    def pyramid(pts_list):
+        pts = np.concatenate(pts_list)
+        lens = np.array([len(p) for p in pts_list], dtype=np.int32)
+        r = cfg.first_subsampling_dl * cfg.conv_radius
+        for level in range(5):
+            O.batch_neighbors(pts, pts, lens, lens, r)
+            if level == 4:
+                break
+            sub, sub_l = O.batch_grid_subsampling(pts, lens, sampleDl=2 * r / cfg.conv_radius)[:2]
+            O.batch_neighbors(sub, pts, sub_l, lens, r)
+            pts, lens, r = sub, sub_l, r * 2
+
+    t0 = time.time()
+    pyramid(per)
+    single = time.time() - t0
+    cores = usable_cores()
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda p: pyramid([p]), per))
+    multi = time.time() - t0
+    return dict(value=round(nplots / single, 3), unit="plots/s (index path only)", cores=1, kind="port",
+                all_cores=dict(value=round(nplots / multi, 3), cores=cores),
+                sample=f"the KPConv index path (5 x radius neighbours + 4 x grid subsampling + 4 x pooling neighbours) of "
+                       f"{nplots} synthetic {points}-pt plots on oracle/kpconv_index_ref.cpp: {single:.1f} s single thread "
+                       f"(how the reference runs it), {multi:.1f} s with one plot per task on {cores} threads; the GPU "
+                       f"number next to it is the WHOLE training step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", choices=["pointnet", "kpconv"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--points", type=int, default=16000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a HIP device")
+    (run_pointnet if a.which == "pointnet" else run_kpconv)(a)
+
+
+if __name__ == "__main__":
+    main()
