@@ -52,9 +52,10 @@ class KPConvModel(InstanceBase):
             return mat[:, :self.neighborhood_limits[layer]].contiguous()
         return mat
 
-    def prepare_inputs(self, stacked_points, stacked_features, stack_lengths, device, rotations=None):
+    def prepare_inputs(self, stacked_points, stacked_features, stack_lengths, device, rotations=None, bounds=None):
         """stacked_points [N,3] / stacked_features [N,F] (numpy or tensors), stack_lengths int[B].
-        rotations: optional list (one float32 [B,3,3] per strided level) replacing the np.random grid orientations."""
+        rotations: optional list (one float32 [B,3,3] per strided level) replacing the np.random grid orientations.
+        bounds: optional (min xyz, max xyz) of all points (saves the one bounding-box read-back)."""
         cfg = self.config
         pts = torch.as_tensor(stacked_points, dtype=torch.float32).to(device).contiguous()
         feats = torch.as_tensor(stacked_features, dtype=torch.float32).to(device).contiguous()
@@ -62,25 +63,51 @@ class KPConvModel(InstanceBase):
         r_normal = cfg.first_subsampling_dl * cfg.conv_radius
         layer_blocks, points, neighbors, pools, lengths = [], [], [], [], []
         empty_i = torch.zeros(0, 1, dtype=torch.int32, device=device)
+        # Bounding box of the whole batch: ONE host read for the pyramid (barycentres never leave their parent's box, and
+        # a cloud rotated about the origin keeps an extent below the box's diagonal), or none when the caller knows it.
+        if bounds is None:
+            bounds = kp_index.support_bounds(pts, lens)
+        diag = float(np.linalg.norm(np.asarray(bounds[3:]) - np.asarray(bounds[:3]))) * 1.0001 + 1e-6
         level = 0
+        pool_job = None          # pooled radius search of the previous level: its width is read with this level's counts
         for block in cfg.architecture:
             if not ("pool" in block or "strided" in block or "global" in block or "upsample" in block):
                 layer_blocks.append(block)
                 continue
-            conv_i = kp_index.batch_neighbors(pts, pts, lens, lens, r_normal) if layer_blocks else empty_i
-            if "pool" in block or "strided" in block:
+            strided = "pool" in block or "strided" in block
+            # enqueue everything of this level that needs no host value, then read all counts back at once: one
+            # synchronisation per level instead of seven (each one waits for the side stream behind a running step)
+            conv_job = kp_index.neighbors_begin(pts, pts, lens, lens, r_normal, bounds) if layer_blocks else None
+            sub_job = rot = None
+            if strided:
                 dl = 2 * r_normal / cfg.conv_radius
-                rot = None if rotations is None else rotations[level]
-                pool_p, pool_b = kp_index.batch_grid_subsampling(pts, lens, sampleDl=dl,
-                                                                 random_grid_orient=self.random_grid_orient,
-                                                                 rotations=rot)
-                pool_b = pool_b.numpy().astype(np.int64)
-                pool_i = kp_index.batch_neighbors(pool_p, pts, pool_b, lens, r_normal)
+                src = pts
+                if self.random_grid_orient:
+                    rot = kp_index.random_grid_rotations(len(lens)) if rotations is None else \
+                        np.asarray(rotations[level], dtype=np.float32)
+                    src = kp_index.rotate_points(pts, lens, rot, False)
+                ext = (diag,) * 3 if self.random_grid_orient else tuple(np.asarray(bounds[3:]) - np.asarray(bounds[:3]))
+                sub_job = kp_index.subsample_begin(src, None, lens, dl, ext)
+            want = ([conv_job.max_count] if conv_job else []) + ([pool_job.max_count] if pool_job else []) + \
+                ([sub_job.out_ptr, sub_job.status[:1]] if sub_job else [])
+            got = kp_index.read_back(*want) if want else []
+            conv_i = kp_index.neighbors_finish(conv_job, got.pop(0)[0]) if conv_job else empty_i
+            if pool_job is not None:
+                pools[-1] = self._crop(kp_index.neighbors_finish(pool_job, got.pop(0)[0]), len(points) - 1)
+                pool_job = None
+            if strided:
+                optr, st = got
+                pool_p, _, pool_b, _ = kp_index.subsample_finish(sub_job, optr, st[0])
+                pool_b = pool_b.astype(np.int64)
+                if rot is not None:
+                    pool_p = kp_index.rotate_points(pool_p, pool_b, rot, True)
+                pool_job = kp_index.neighbors_begin(pool_p, pts, pool_b, lens, r_normal, bounds)
+                pool_i = None        # filled in when the next level's counts are read
             else:
                 pool_i, pool_p, pool_b = empty_i, torch.zeros(0, 3, device=device), np.zeros(0, dtype=np.int64)
             points.append(pts)
             neighbors.append(self._crop(conv_i, len(points) - 1))
-            pools.append(self._crop(pool_i, len(points) - 1))
+            pools.append(pool_i if pool_i is None else self._crop(pool_i, len(points) - 1))
             lengths.append(torch.from_numpy(lens.copy()))
             pts, lens = pool_p, pool_b
             r_normal *= 2
@@ -88,6 +115,8 @@ class KPConvModel(InstanceBase):
             level += 1
             if "global" in block or "upsample" in block:
                 break
+        if pool_job is not None:     # (an architecture that ends on a strided block)
+            pools[-1] = self._crop(kp_index.neighbors_finish(pool_job, int(pool_job.max_count.item())), len(points) - 1)
         ptr = np.zeros(len(lengths[-1]) + 1, dtype=np.int32)
         np.cumsum(lengths[-1].numpy(), out=ptr[1:])
         return dict(points=points, neighbors=neighbors, pools=pools, lengths=lengths, features=feats,
@@ -96,7 +125,8 @@ class KPConvModel(InstanceBase):
     def _pyramid(self, data, device):
         ptr = data.ptr
         lens = (ptr[1:] - ptr[:-1]).cpu().numpy().astype(np.int64)
-        return self.prepare_inputs(data.pos.view(-1, 3), data.x.view(-1, data.x.shape[-1]), lens, device)
+        return self.prepare_inputs(data.pos.view(-1, 3), data.x.view(-1, data.x.shape[-1]), lens, device,
+                                   bounds=getattr(data, "pos_bounds", None))
 
     def prefetch_input(self, data, device):
         """Build the NEXT batch's input pyramid on a side stream.  ``prepare_inputs`` reads counts back to the host after

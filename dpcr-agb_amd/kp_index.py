@@ -86,6 +86,83 @@ def _check_shapes(queries, supports, q_batches, s_batches):
         raise RuntimeError("Wrong dimensions : batch lengths do not sum to the number of points")
 
 
+def read_back(*tensors):
+    """ONE host synchronisation for several small device tensors: returns their values as lists, in order."""
+    flat = torch.cat([t.reshape(-1).to(torch.int64) if not t.is_floating_point() else t.reshape(-1).double()
+                      for t in tensors]) if len({t.is_floating_point() for t in tensors}) == 1 else None
+    if flat is None:   # mixed integer / float: two copies, still one wait (the second finds the stream idle)
+        return [t.tolist() for t in tensors]
+    vals, out, off = flat.tolist(), [], 0
+    for t in tensors:
+        out.append(vals[off:off + t.numel()])
+        off += t.numel()
+    return out
+
+
+class NeighborJob:
+    """A radius search whose count pass is enqueued; ``max_count`` (device int32[1]) is the width of the padded matrix."""
+    __slots__ = ("q", "q_elem", "origin_cs", "dims_c", "cell_start", "sorted_pts", "radius", "ns", "nq", "max_count",
+                 "counts")
+
+
+def neighbors_begin(q, s, ql, sl, radius, bounds):
+    """Enqueue the cell grid of the supports and the count pass.  bounds: (min xyz, max xyz) covering every support."""
+    dev = q.device
+    B, nq, ns = len(ql), q.shape[0], s.shape[0]
+    radius = float(np.float32(radius))
+    if nq == 0 or ns == 0:
+        raise RuntimeError("Error")  # the reference raises on an empty result (wrapper.cpp:201-205)
+    q_ptr, s_ptr = _ptr_tensor(ql, dev), _ptr_tensor(sl, dev)
+    lo, hi = list(bounds[:3]), list(bounds[3:])
+    cs = radius * 1.001
+    while True:
+        dims = [int(np.floor((h - l) / cs)) + 1 for l, h in zip(lo, hi)]
+        if B * dims[0] * dims[1] * dims[2] <= MAX_CELLS:
+            break
+        cs *= 2.0  # coarser cells stay correct for as long as cell >= radius
+    job = NeighborJob()
+    job.origin_cs = (ctypes.c_float * 4)(lo[0], lo[1], lo[2], cs)
+    job.dims_c = (ctypes.c_int32 * 4)(dims[0], dims[1], dims[2], B)
+    cells = B * dims[0] * dims[1] * dims[2]
+    job.cell_start = torch.empty(cells + 1, dtype=torch.int32, device=dev)
+    cell_fill = torch.empty(cells + 1, dtype=torch.int32, device=dev)
+    cell_of = torch.empty(ns, dtype=torch.int32, device=dev)
+    job.sorted_pts = torch.empty(ns, 4, dtype=torch.float32, device=dev)
+    scratch = torch.empty(_lib.scan_scratch_elems(cells + 1), dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.call("agb_ball_grid_build", _P(s), ns, _P(s_ptr), job.origin_cs, job.dims_c, _P(job.cell_start),
+              _P(job.sorted_pts), _P(cell_of), _P(cell_fill), _P(scratch), _P(total), _lib.stream())
+    job.q, job.q_elem = q, _elem_of_row(q_ptr, B, nq, dev)
+    job.counts = torch.empty(nq, dtype=torch.int32, device=dev)
+    job.max_count = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.call("agb_ball_query_count", _P(q), nq, _P(job.q_elem), job.origin_cs, job.dims_c, _P(job.cell_start),
+              _P(job.sorted_pts), radius, _P(job.counts), _P(job.max_count), _lib.stream())
+    job.radius, job.ns, job.nq = radius, ns, nq
+    return job
+
+
+def neighbors_finish(job, width):
+    """Fill pass for a job whose ``max_count`` has been read back (``width``)."""
+    width = int(width)
+    if width == 0:
+        raise RuntimeError("Error")
+    if width > 1024:
+        raise _lib.AgbError("a neighbourhood holds more than 1024 points: beyond the kernel's LDS capacity")
+    out = torch.empty(job.nq, width, dtype=torch.int32, device=job.q.device)
+    status = torch.empty(4, dtype=torch.int32, device=job.q.device)
+    _lib.call("agb_ball_query_fill", _P(job.q), job.nq, _P(job.q_elem), job.origin_cs, job.dims_c, _P(job.cell_start),
+              _P(job.sorted_pts), job.radius, job.ns, width, _P(out), _P(status), _lib.stream())
+    return out
+
+
+def support_bounds(s, sl):
+    """(min xyz, max xyz) over all clouds: one host read."""
+    dev = s.device
+    bb = elem_bbox(s, _ptr_tensor(sl, dev), len(sl))
+    lo, hi = read_back(bb[:, :3].min(0).values, bb[:, 3:].max(0).values)
+    return tuple(lo) + tuple(hi)
+
+
 def batch_neighbors(queries, supports, q_batches, s_batches, radius, bounds=None):
     """bounds: optional float (min_x, min_y, min_z, max_x, max_y, max_z) covering every support (saves the
     bounding-box read-back)."""
@@ -93,49 +170,13 @@ def batch_neighbors(queries, supports, q_batches, s_batches, radius, bounds=None
     s, _ = _to_dev(supports, torch.float32)
     ql, sl = _lengths(q_batches), _lengths(s_batches)
     _check_shapes(q, s, ql, sl)
-    dev = q.device
-    B, nq, ns = len(ql), q.shape[0], s.shape[0]
-    radius = float(np.float32(radius))
-    if nq == 0 or ns == 0:
+    if q.shape[0] == 0 or s.shape[0] == 0:
         raise RuntimeError("Error")  # the reference raises on an empty result (wrapper.cpp:201-205)
-    q_ptr, s_ptr = _ptr_tensor(ql, dev), _ptr_tensor(sl, dev)
     if bounds is None:
-        bb = elem_bbox(s, s_ptr, B)
-        lo = bb[:, :3].min(0).values.tolist()   # one host read (pass `bounds` to avoid it)
-        hi = bb[:, 3:].max(0).values.tolist()
-    else:
-        lo, hi = list(bounds[:3]), list(bounds[3:])
-    cs = radius * 1.001
-    while True:
-        dims = [int(np.floor((h - l) / cs)) + 1 for l, h in zip(lo, hi)]
-        if B * dims[0] * dims[1] * dims[2] <= MAX_CELLS:
-            break
-        cs *= 2.0  # coarser cells stay correct for as long as cell >= radius
-    origin_cs = (ctypes.c_float * 4)(lo[0], lo[1], lo[2], cs)
-    dims_c = (ctypes.c_int32 * 4)(dims[0], dims[1], dims[2], B)
-    cells = B * dims[0] * dims[1] * dims[2]
-    cell_start = torch.empty(cells + 1, dtype=torch.int32, device=dev)
-    cell_fill = torch.empty(cells + 1, dtype=torch.int32, device=dev)
-    cell_of = torch.empty(ns, dtype=torch.int32, device=dev)
-    sorted_pts = torch.empty(ns, 4, dtype=torch.float32, device=dev)
-    scratch = torch.empty(_lib.scan_scratch_elems(cells + 1), dtype=torch.int32, device=dev)
-    total = torch.empty(1, dtype=torch.int32, device=dev)
-    _lib.call("agb_ball_grid_build", _P(s), ns, _P(s_ptr), origin_cs, dims_c, _P(cell_start), _P(sorted_pts),
-              _P(cell_of), _P(cell_fill), _P(scratch), _P(total), _lib.stream())
-    q_elem = _elem_of_row(q_ptr, B, nq, dev)
-    counts = torch.empty(nq, dtype=torch.int32, device=dev)
-    mx = torch.empty(1, dtype=torch.int32, device=dev)
-    _lib.call("agb_ball_query_count", _P(q), nq, _P(q_elem), origin_cs, dims_c, _P(cell_start), _P(sorted_pts),
-              radius, _P(counts), _P(mx), _lib.stream())
-    width = int(mx.item())  # the padded matrix the reference returns is as wide as the fullest neighbourhood
-    if width == 0:
-        raise RuntimeError("Error")
-    out = torch.empty(nq, width, dtype=torch.int32, device=dev)
-    status = torch.empty(4, dtype=torch.int32, device=dev)
-    _lib.call("agb_ball_query_fill", _P(q), nq, _P(q_elem), origin_cs, dims_c, _P(cell_start), _P(sorted_pts), radius,
-              ns, width, _P(out), _P(status), _lib.stream())
-    if width > 1024 and int(status[0].item()):
-        raise _lib.AgbError("a neighbourhood holds more than 1024 points: beyond the kernel's LDS capacity")
+        bounds = support_bounds(s, sl)
+    job = neighbors_begin(q, s, ql, sl, radius, bounds)
+    # the padded matrix the reference returns is as wide as the fullest neighbourhood: one host read
+    out = neighbors_finish(job, int(job.max_count.item()))
     return out if q_is_t else out.cpu().numpy()
 
 
@@ -176,16 +217,17 @@ def _rotate(points, elem, R_dev, transpose):
     return out
 
 
-def _subsample_core(p, f, lens, dl, bounds_hint=None):
+class SubsampleJob:
+    __slots__ = ("out_p", "out_f", "out_ptr", "status", "elem", "B")
+
+
+def subsample_begin(p, f, lens, dl, ext):
+    """Enqueue the grid subsampling of stacked clouds; ext: upper bound of every cloud's extent per axis (sizes the cell
+    grid without a read-back).  ``subsample_finish`` needs ``out_ptr`` and ``status[:1]`` on the host."""
     dev = p.device
     B, n = len(lens), p.shape[0]
     ptr = _ptr_tensor(lens, dev)
     elem = _elem_of_row(ptr, B, n, dev)
-    if bounds_hint is None:
-        bb = elem_bbox(p, ptr, B)
-        ext = (bb[:, 3:] - bb[:, :3]).max(0).values.tolist()   # one host read
-    else:
-        ext = list(bounds_hint)
     cap = 1
     for e in ext:
         cap *= int(np.floor(e / dl)) + 3
@@ -193,18 +235,45 @@ def _subsample_core(p, f, lens, dl, bounds_hint=None):
         raise _lib.AgbError(f"grid subsampling would need {B * cap} cells: sampleDl too small for these clouds")
     i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
     ws = torch.empty(_lib.size_call("agb_grid_subsample_workspace_bytes", n, B, cap), dtype=torch.uint8, device=dev)
-    out_p = torch.empty(max(n, 1), 3, dtype=torch.float32, device=dev)
+    job = SubsampleJob()
+    job.out_p = torch.empty(max(n, 1), 3, dtype=torch.float32, device=dev)
     fdim = 0 if f is None else f.shape[1]
-    out_f = torch.empty(max(n, 1), fdim, dtype=torch.float32, device=dev) if f is not None else None
-    out_ptr, n_out, status = i32(B + 1), i32(1), i32(4)
+    job.out_f = torch.empty(max(n, 1), fdim, dtype=torch.float32, device=dev) if f is not None else None
+    job.out_ptr, n_out, job.status = i32(B + 1), i32(1), i32(4)
+    job.elem, job.B = elem, B
     _lib.call("agb_grid_subsample_ws", _P(p), _P(f), fdim, n, _P(ptr), _P(elem), B, float(np.float32(dl)), cap, _P(ws),
-              _P(out_p), _P(out_f), _P(out_ptr), _P(n_out), _P(status), _lib.stream())
-    host = torch.cat([out_ptr, status[:1]]).tolist()   # one host read: sizes of the subsampled clouds
-    if host[-1]:
+              _P(job.out_p), _P(job.out_f), _P(job.out_ptr), _P(n_out), _P(job.status), _lib.stream())
+    return job
+
+
+def subsample_finish(job, out_ptr_host, status0):
+    if int(status0):
         raise _lib.AgbError("grid subsampling: a cloud exceeds the reserved cell capacity")
-    optr = np.asarray(host[:B + 1], dtype=np.int64)
+    optr = np.asarray(out_ptr_host, dtype=np.int64)
     m = int(optr[-1])
-    return out_p[:m], (None if out_f is None else out_f[:m]), np.diff(optr).astype(np.int32), elem
+    return job.out_p[:m], (None if job.out_f is None else job.out_f[:m]), np.diff(optr).astype(np.int32), job.elem
+
+
+def _subsample_core(p, f, lens, dl, bounds_hint=None):
+    dev = p.device
+    B, n = len(lens), p.shape[0]
+    if bounds_hint is None:
+        bb = elem_bbox(p, _ptr_tensor(lens, dev), B)
+        ext = (bb[:, 3:] - bb[:, :3]).max(0).values.tolist()   # one host read
+    else:
+        ext = list(bounds_hint)
+    job = subsample_begin(p, f, lens, dl, ext)
+    optr, st = read_back(job.out_ptr, job.status[:1])         # one host read: sizes of the subsampled clouds
+    return subsample_finish(job, optr, st[0])
+
+
+def rotate_points(points, lens, R, transpose):
+    """points @ R[cloud] (or its transpose) for stacked clouds; R float32 [B, 3, 3] (numpy)."""
+    dev = points.device
+    R_dev = torch.from_numpy(np.ascontiguousarray(R, dtype=np.float32)).to(dev)
+    ptr = _ptr_tensor(lens, dev)
+    elem = _elem_of_row(ptr, len(lens), points.shape[0], dev)
+    return _rotate(points.contiguous(), elem, R_dev, transpose)
 
 
 def batch_grid_subsampling(points, batches_len, features=None, labels=None, sampleDl=0.1, max_p=0, verbose=0,

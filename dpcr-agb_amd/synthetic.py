@@ -102,6 +102,9 @@ class PlotBatch:
         out = PlotBatch(mv(self.batch), mv(self.coords), mv(self.x), mv(self.pos), None, None, self._n,
                         self.coord_bounds)
         out.y_reg, out.y_reg_mask, out.y_reg_mask_all = mv(self.y_reg), mv(self.y_reg_mask), self.y_reg_mask_all
+        for extra in ("pos_bounds", "area_name"):
+            if hasattr(self, extra):
+                setattr(out, extra, getattr(self, extra))
         return out
 
     @property
@@ -138,9 +141,15 @@ def make_point_batch(seeds: List[int], n_points: int = 6144, extra_feature: bool
         xs.append(x)
         ps.append(pos)
         ys.append(y)
-    return PlotBatch(torch.from_numpy(np.concatenate(bs)), None, torch.from_numpy(np.concatenate(xs)),
-                     torch.from_numpy(np.concatenate(ps)), torch.from_numpy(np.stack(ys)),
-                     torch.ones(len(seeds), 2, dtype=torch.bool), len(seeds))
+    allp = np.concatenate(ps)
+    out = PlotBatch(torch.from_numpy(np.concatenate(bs)), None, torch.from_numpy(np.concatenate(xs)),
+                    torch.from_numpy(allp), torch.from_numpy(np.stack(ys)),
+                    torch.ones(len(seeds), 2, dtype=torch.bool), len(seeds))
+    # bounding box of the positions, known for free where the batch is assembled (saves the KPConv input pyramid its one
+    # bounding-box read-back); slightly widened so that float32 round trips cannot put a point outside
+    lo, hi = allp.min(0).astype(np.float64), allp.max(0).astype(np.float64)
+    out.pos_bounds = tuple(lo - 1e-5) + tuple(hi + 1e-5)
+    return out
 
 
 class SyntheticDataset:

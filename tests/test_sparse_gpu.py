@@ -508,7 +508,10 @@ def test_mpointnet_matches_oracle(device, pool):
     sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
     model.to(device).train()
     captured = {}
-    hook = model.model.mlp[0].register_forward_hook(lambda m, inp, out: captured.setdefault("pooled", inp[0].F))
+    def keep_pooled(module, inp, out):      # (a forward hook that returns a value would replace the module's output)
+        captured["pooled"] = inp[0].F
+
+    hook = model.model.mlp[0].register_forward_hook(keep_pooled)
     model.set_input(batch, device)
     model.forward()
     hook.remove()
