@@ -116,11 +116,12 @@ class KPConvModel(InstanceBase):
             if "global" in block or "upsample" in block:
                 break
         if pool_job is not None:     # (an architecture that ends on a strided block)
-            pools[-1] = self._crop(kp_index.neighbors_finish(pool_job, int(pool_job.max_count.item())), len(points) - 1)
+            pools[-1] = self._crop(kp_index.neighbors_finish(pool_job, kp_index.read_back(pool_job.max_count)[0][0]),
+                                   len(points) - 1)
         ptr = np.zeros(len(lengths[-1]) + 1, dtype=np.int32)
         np.cumsum(lengths[-1].numpy(), out=ptr[1:])
         return dict(points=points, neighbors=neighbors, pools=pools, lengths=lengths, features=feats,
-                    last_ptr=torch.from_numpy(ptr).to(device))
+                    last_ptr=kp_index.h2d_small(ptr, device))
 
     def _pyramid(self, data, device):
         ptr = data.ptr

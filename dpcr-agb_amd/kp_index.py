@@ -53,10 +53,71 @@ def _lengths(v):
     return np.asarray(v, dtype=np.int64).reshape(-1)
 
 
+class _PinnedRing:
+    """Small host <-> device transfers through a ring of pinned buffers: a copy from / to PAGEABLE memory makes the
+    runtime wait for the whole device (every stream) — with the training step of the previous batch queued on the compute
+    stream that stalled the input pyramid's side stream for whole steps (50-150 ms hiccups in the KPConv loop).  A slot
+    is reused only after the device has executed the copy that used it (one event per slot)."""
+    SLOTS, BYTES = 128, 8192
+
+    def __init__(self):
+        self.buf = torch.empty(self.SLOTS, self.BYTES, dtype=torch.uint8).pin_memory()
+        self.done = [None] * self.SLOTS
+        self.next = 0
+
+    def slot(self):
+        i = self.next % self.SLOTS
+        self.next += 1
+        if self.done[i] is not None:
+            self.done[i].synchronize()
+        return i
+
+    def h2d(self, arr, device):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > self.BYTES or arr.nbytes == 0:
+            return torch.from_numpy(arr).to(device)
+        i = self.slot()
+        host = self.buf[i, :arr.nbytes].view(torch.from_numpy(arr).dtype).reshape(arr.shape)
+        host.copy_(torch.from_numpy(arr))
+        out = host.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[i] = ev
+        return out
+
+    def d2h(self, t):
+        """Values of a small device tensor as a list; waits only for the stream it was produced on."""
+        nbytes = t.numel() * t.element_size()
+        if nbytes > self.BYTES or nbytes == 0:
+            return t.tolist()
+        i = self.slot()
+        host = self.buf[i, :nbytes].view(t.dtype).reshape(t.shape)
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
+        self.done[i] = None
+        return host.tolist()
+
+
+_RING = None
+
+
+def _ring():
+    global _RING
+    if _RING is None:
+        _RING = _PinnedRing()
+    return _RING
+
+
+def h2d_small(arr, device):
+    return _ring().h2d(arr, device) if torch.device(device).type == "cuda" else torch.from_numpy(np.asarray(arr)).to(device)
+
+
 def _ptr_tensor(lens, device):
     p = np.zeros(len(lens) + 1, dtype=np.int32)
     np.cumsum(lens, out=p[1:])
-    return torch.from_numpy(p).to(device)
+    return h2d_small(p, device)
 
 
 def elem_bbox(points, ptr, B):
@@ -87,12 +148,16 @@ def _check_shapes(queries, supports, q_batches, s_batches):
 
 
 def read_back(*tensors):
-    """ONE host synchronisation for several small device tensors: returns their values as lists, in order."""
-    flat = torch.cat([t.reshape(-1).to(torch.int64) if not t.is_floating_point() else t.reshape(-1).double()
-                      for t in tensors]) if len({t.is_floating_point() for t in tensors}) == 1 else None
-    if flat is None:   # mixed integer / float: two copies, still one wait (the second finds the stream idle)
-        return [t.tolist() for t in tensors]
-    vals, out, off = flat.tolist(), [], 0
+    """ONE host synchronisation (of the current stream only) for several small device tensors: their values as lists."""
+    if not tensors:
+        return []
+    if all(not t.is_floating_point() for t in tensors):
+        flat = torch.cat([t.reshape(-1).to(torch.int64) for t in tensors])
+    elif all(t.is_floating_point() for t in tensors):
+        flat = torch.cat([t.reshape(-1).double() for t in tensors])
+    else:
+        return [_ring().d2h(t.reshape(-1)) for t in tensors]
+    vals, out, off = _ring().d2h(flat), [], 0
     for t in tensors:
         out.append(vals[off:off + t.numel()])
         off += t.numel()
@@ -176,7 +241,7 @@ def batch_neighbors(queries, supports, q_batches, s_batches, radius, bounds=None
         bounds = support_bounds(s, sl)
     job = neighbors_begin(q, s, ql, sl, radius, bounds)
     # the padded matrix the reference returns is as wide as the fullest neighbourhood: one host read
-    out = neighbors_finish(job, int(job.max_count.item()))
+    out = neighbors_finish(job, read_back(job.max_count)[0][0])
     return out if q_is_t else out.cpu().numpy()
 
 
@@ -270,7 +335,7 @@ def _subsample_core(p, f, lens, dl, bounds_hint=None):
 def rotate_points(points, lens, R, transpose):
     """points @ R[cloud] (or its transpose) for stacked clouds; R float32 [B, 3, 3] (numpy)."""
     dev = points.device
-    R_dev = torch.from_numpy(np.ascontiguousarray(R, dtype=np.float32)).to(dev)
+    R_dev = h2d_small(np.ascontiguousarray(R, dtype=np.float32), dev)
     ptr = _ptr_tensor(lens, dev)
     elem = _elem_of_row(ptr, len(lens), points.shape[0], dev)
     return _rotate(points.contiguous(), elem, R_dev, transpose)
@@ -292,7 +357,7 @@ def batch_grid_subsampling(points, batches_len, features=None, labels=None, samp
     R = None
     if random_grid_orient:
         R = random_grid_rotations(B) if rotations is None else np.asarray(rotations, dtype=np.float32)
-        R_dev = torch.from_numpy(np.ascontiguousarray(R)).to(p.device)
+        R_dev = h2d_small(np.ascontiguousarray(R), p.device)
         ptr = _ptr_tensor(lens, p.device)
         elem = _elem_of_row(ptr, B, p.shape[0], p.device)
         p = _rotate(p, elem, R_dev, False)

@@ -114,6 +114,7 @@ def timed_loop(step, steps, warmup):
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     evs = []
     for i in range(steps):
@@ -124,6 +125,12 @@ def timed_loop(step, steps, warmup):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gc.enable()
+    ms1 = torch.cuda.memory_stats()
+    log("caching allocator over the timed region: "
+        f"{ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)} device allocations, "
+        f"{ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0)} device frees, "
+        f"{ms1.get('num_alloc_retries', 0) - ms0.get('num_alloc_retries', 0)} retries; "
+        f"{torch.cuda.memory_reserved() / 2**30:.2f} GiB reserved, {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB peak")
     gaps = sorted(evs[j].elapsed_time(evs[j + 1]) for j in range(len(evs) - 1))
     return dt, gaps
 
@@ -226,12 +233,22 @@ def run_kpconv(a):
     model.to(dev).train()
     model.init_train_objects(TRAINING_NFI)
 
+    host = dict(set_input=[], optimize=[], prefetch=[])
+
     def step(i):
+        t0 = time.perf_counter()
         model.set_input(pool[i % 2], dev)
+        t1 = time.perf_counter()
         model.optimize_parameters(epoch=0, batch_size=B, num_batches=133)
+        t2 = time.perf_counter()
         model.prefetch_input(pool[(i + 1) % 2], dev)
+        t3 = time.perf_counter()
+        host["set_input"].append(t1 - t0); host["optimize"].append(t2 - t1); host["prefetch"].append(t3 - t2)
 
     dt, gaps = timed_loop(step, a.steps, a.warmup)
+    for k, v in host.items():
+        v = sorted(v[-a.steps:])
+        log(f"host time in {k}: median {v[len(v) // 2] * 1e3:.2f} ms, max {v[-1] * 1e3:.2f} ms")
     # the instrumented steps run the input pyramid on the compute stream (the events are recorded there)
     with CallTimer() as ct:
         for i in range(3):
