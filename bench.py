@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="build each batch's coordinate plan inside set_input")
     ap.add_argument("--cpu-plots", type=int, default=1)
+    ap.add_argument("--reserve-gib", type=int, default=12, help="allocator pool reserved up front on the compute stream "
+                    "(half of it again on the input pipeline's side stream); 0 = grow on demand")
     return ap.parse_args()
 
 
@@ -313,6 +315,8 @@ def main():
             # step ago) and stages the levels of batch i+2 — the host never waits for a device read-back
             model.prefetch_input(pool[(i + 2) % len(pool)], dev)
 
+    # allocator pools grown up front (per stream): no device allocation inside the timed region
+    model.reserve_workspace(dev, main_bytes=args.reserve_gib << 30, side_bytes=(args.reserve_gib << 30) // 2)
     if not args.no_prefetch and len(pool) >= 3:
         model.prefetch_input(pool[0], dev)
         model.prefetch_input(pool[1], dev)

@@ -171,6 +171,21 @@ class InstanceBase(torch.nn.Module):
             for _ in range(batch_size):
                 self._lr_scheduler.step(epoch)
 
+    def reserve_workspace(self, device, main_bytes=0, side_bytes=0):
+        """Grow the caching allocator's pools of the compute stream and of the input pipeline's side stream up front (one
+        big block each, handed straight back to the cache, which then carves every later request out of it): a
+        hipMalloc in the middle of a step waits for the whole device, and the pools are per stream.  MI355X has 288 GB:
+        a few GiB of head-room cost nothing.  Creates the side stream ``prefetch_input`` uses."""
+        if not hasattr(self, "_side_stream"):
+            self._side_stream = torch.cuda.Stream(device=device)
+            self._staged = None
+        for stream, nbytes in ((torch.cuda.current_stream(device), main_bytes), (self._side_stream, side_bytes)):
+            if nbytes > 0:
+                with torch.cuda.stream(stream):
+                    block = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                    del block
+        torch.cuda.synchronize(device)
+
     @torch.no_grad()
     def calibrate_bn(self, batches, device, epochs=1):
         """Forward-only passes in train mode to refresh the BatchNorm running statistics — the reference's

@@ -154,6 +154,7 @@ def run_pointnet(a):
     pool = [synthetic.make_sparse_batch(list(range(i * B, (i + 1) * B)), n_points=a.points).to(dev) for i in range(3)]
     model.to(dev).train()
     model.init_train_objects(TRAINING_NFI)
+    model.reserve_workspace(dev, main_bytes=16 << 30, side_bytes=2 << 30)
     voxels = sum(int(b.coords.shape[0]) for b in pool) / len(pool) / B
 
     def step(i):
@@ -232,6 +233,7 @@ def run_kpconv(a):
         b.pos, b.x = b.pos.to(dev), b.x.to(dev)
     model.to(dev).train()
     model.init_train_objects(TRAINING_NFI)
+    model.reserve_workspace(dev, main_bytes=12 << 30, side_bytes=6 << 30)
 
     host = dict(set_input=[], optimize=[], prefetch=[])
 
