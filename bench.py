@@ -100,10 +100,14 @@ def kernel_of(rec):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/collect_pmc.sh -> profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        data = json.load(open(path))["kernels"]
-    except Exception:
+    data = None
+    for tag in ("r02", "r01"):      # the newest committed PMC pass (tools/collect_pmc.sh <tag>)
+        try:
+            data = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))["kernels"]
+            break
+        except Exception:
+            continue
+    if data is None:
         return None
     for name, v in data.items():
         if name.replace("void ", "").strip() == kernel:
@@ -268,7 +272,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    import dpcr_agb_amd
     from dpcr_agb_amd import sparse_ops, synthetic
+    dpcr_agb_amd.limit_host_threads()     # (the cpu_baseline leg sets its own thread count afterwards)
     global PRECISION
     PRECISION = args.precision
     sparse_ops.set_conv_precision(args.precision)

@@ -16,3 +16,18 @@ The directory name carries a hyphen (it mirrors the reference's repository name)
 ``dpcr_agb_amd`` through the shim module at the repository root.
 """
 __version__ = "0.1.0"
+
+
+def limit_host_threads(n=None):
+    """Cap torch's intra-op CPU thread pool for a training / serving process whose device work is all on the GPU.
+
+    The host side of a step only issues launches and touches a few small CPU tensors.  torch sizes its OpenMP pool from the
+    VISIBLE cores (256 on an MI355X host) even when a cgroup quota allows far fewer (16 on the GPU boxes of this project):
+    the spinning workers exhaust the quota and the kernel throttles the whole process for the rest of the scheduling
+    period — measured as 50-150 ms host stalls in the KPConv loop (the step rate doubled once the pool was capped).
+    n: thread count (default: the AGB_HOST_THREADS environment variable, else 4).  Returns the previous setting."""
+    import os
+    import torch
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, int(n if n is not None else os.environ.get("AGB_HOST_THREADS", "4"))))
+    return old

@@ -331,6 +331,12 @@ def main():
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device")
+    # The host side of a step only issues launches and shuffles a few small CPU tensors: keep torch's intra-op pool small.
+    # With one OpenMP thread per VISIBLE core (256 on the GPU box, 16 allowed by the cgroup quota) the spinning workers
+    # exhaust the CPU quota and the kernel throttles the whole process for the rest of the 100 ms period (the 50-150 ms
+    # hiccups of the KPConv loop: host stalls with zero device allocations and no pageable copy in flight).
+    import dpcr_agb_amd
+    dpcr_agb_amd.limit_host_threads()
     (run_pointnet if a.which == "pointnet" else run_kpconv)(a)
 
 

@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+import dpcr_agb_amd  # noqa: E402
+
+dpcr_agb_amd.limit_host_threads()
 
 
 def acceptance_gpu_leg(cfg, dev, log=None, keep=None):
