@@ -53,7 +53,8 @@ class KPConv(nn.Module):
         w2d = self.weights.view(-1, self.out_channels)
         if wf.is_cuda and DenseConvFunction.supported(w2d.shape[0], w2d.shape[1]):
             return DenseConvFunction.apply(wf.view(wf.shape[0], -1), w2d, None)
-        return wf.view(wf.shape[0], -1) @ w2d
+        # odd widths (the 3-feature input layer: K * Cin = 45): the zero-padding Linear form of the same kernels
+        return dense_linear(wf.view(wf.shape[0], -1), w2d.t().contiguous())
 
     def __repr__(self):
         return f"KPConv(radius: {self.radius:.2f}, in_feat: {self.in_channels:d}, out_feat: {self.out_channels:d})"

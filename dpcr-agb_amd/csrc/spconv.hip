@@ -344,14 +344,17 @@ struct ConvArgs {
     int cmp_il;     // log2 of the interleave block of its tiles (0 = contiguous, -1 = by level size)
 };
 
-template <int TM, bool PERM>
+// CW: output columns per workgroup (64, or 128 for wide dense layers: the staged A tile serves twice the columns)
+template <int TM, bool PERM, int CW = 64>
 __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
     constexpr int WAVES_M = TM / 32;       // 2 or 4
     constexpr int WAVES_N = 4 / WAVES_M;   // 2 or 1
-    constexpr int NT = 2 / WAVES_N;        // 32-col accumulators per wave: 1 or 2
+    constexpr int NT = (CW / 32) / WAVES_N;   // 32-col accumulators per wave: 1, 2 or 4
+    constexpr int BJ = CW / 32;               // float4 weight loads per thread per chunk
+    constexpr int BT = CW / 4;                // threads per weight row
     constexpr int AJ = TM / 32;            // float4 A gathers per thread per chunk
     __shared__ __attribute__((aligned(16))) float As[TM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * CW];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -362,10 +365,10 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
     // dispatched last it ran on a mostly empty chip; heavy tiles first, the one-offset tiles fill the tail
     const int tile = PERM ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int row0 = tile * TM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * CW;
     const int li = lane & 31, lh = lane >> 5;
     const int a_r = tid >> 3, a_c = (tid & 7) * 4;     // A: row (+32j), channel offset in chunk
-    const int b_r = tid >> 4, b_c = (tid & 15) * 4;    // B: k row (+16j), output offset
+    const int b_r = tid / BT, b_c = (tid % BT) * 4;    // B: k row (+ (256 / BT) j), output offset
     const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
 
     int noff = K3;
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
     }
 
     int idx_cur[AJ], idx_nxt[AJ];
-    float4 a_reg[AJ], b_reg[2];
+    float4 a_reg[AJ], b_reg[BJ];
 
     auto offset_of = [&](int ch) {
         int ko = ch / cpk;
@@ -421,8 +424,8 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
                 a_reg[j] = *reinterpret_cast<const float4*>(a.X + (long long)idx[j] * a.ldx + c0 + a_c);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int kr = b_r + 16 * j;
+        for (int j = 0; j < BJ; ++j) {
+            int kr = b_r + (256 / BT) * j;
             b_reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c0 + kr < Cin && n0 + b_c < Cout)
                 b_reg[j] = *reinterpret_cast<const float4*>(a.W + ((long long)k * Cin + c0 + kr) * Cout + n0 + b_c);
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
         for (int j = 0; j < AJ; ++j)
             *reinterpret_cast<float4*>(&As[(a_r + 32 * j) * LDA + a_c]) = a_reg[j];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&Bs[(b_r + 16 * j) * LDB + b_c]) = b_reg[j];
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<float4*>(&Bs[(b_r + (256 / BT) * j) * CW + b_c]) = b_reg[j];
         __syncthreads();
         if (ch + 1 < ch_end) {
 #pragma unroll
@@ -456,10 +459,10 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float* bcol = &Bs[(wn * NT + nt) * 32 + li];
-                float b0 = bcol[(kb + 0) * LDB];
-                float b1 = bcol[(kb + 1) * LDB];
-                float b2 = bcol[(kb + 2) * LDB];
-                float b3 = bcol[(kb + 3) * LDB];
+                float b0 = bcol[(kb + 0) * CW];
+                float b1 = bcol[(kb + 1) * CW];
+                float b2 = bcol[(kb + 2) * CW];
+                float b3 = bcol[(kb + 3) * CW];
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc[nt], 0, 0, 0);
@@ -1607,9 +1610,16 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
         if (R == 128) hipLaunchKernelGGL((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
         else hipLaunchKernelGGL((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
     } else if (conv_tile_rows(a.n_out, a.Cin, a.Cout) == 128) {
-        // 128-row tiles: the W tile is reused by twice as many rows (layers with many rows, or W-heavy layers)
-        hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
-                           block, 0, s, a);
+        // 128-row tiles: the W tile is reused by twice as many rows (layers with many rows, or W-heavy layers);
+        // 128-column tiles on top where the layer is wide and still fills the chip (the A tile — re-read from L2 once
+        // per column tile — serves twice the columns: the dense products are bound by that traffic)
+        const bool wide = a.Cout >= 128 && (long long)agb_cdiv(a.n_out, 128) * agb_cdiv(a.Cout, 128) * a.ksplit >= 512;
+        if (wide)
+            hipLaunchKernelGGL((k_spconv_pipe<128, false, 128>),
+                               dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, 128), a.ksplit), block, 0, s, a);
+        else
+            hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
+                               block, 0, s, a);
     } else {
         hipLaunchKernelGGL((k_spconv_pipe<64, false>), dim3(agb_cdiv(a.n_out, 64), agb_cdiv(a.Cout, BN), a.ksplit),
                            block, 0, s, a);
