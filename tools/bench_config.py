@@ -183,30 +183,9 @@ def run_pointnet(a):
                 entry_points_ms_per_step={n: round(g["ms"] / 3, 3) for n, g in
                                           sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:8]})
     if not a.no_cpu_baseline:
-        from oracle import sparse_ref as R
-        from dpcr_agb_amd.optim import AdaBelief
-        cores = usable_cores()
-        torch.set_num_threads(cores)
-        nb = 4
-        cb = synthetic.make_sparse_batch(list(range(900_000, 900_000 + nb)), n_points=a.points)
-        sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd_cpu.items()}
-        params = [v for v in sd.values() if v.requires_grad]
-        opt = AdaBelief(params, lr=0.005, weight_decay=1e-2)
-        feats = torch.cat([cb.pos, cb.x], 1)
-        center, scale, w = model.reg_center_targets.cpu(), model.reg_scale_targets.cpu(), model.reg_weights.cpu()
-        t0, n = time.time(), 0
-        while n < 2 or (time.time() - t0 < 12 and n < 40):
-            out = R.pointnet_forward(sd, cb.batch, feats, nb)
-            loss = R.reg_loss(out, cb.y_reg, center, scale, w)
-            opt.zero_grad()
-            loss.backward()
-            torch.nn.utils.clip_grad_value_(params, 100)
-            opt.step()
-            n += 1
-        d = time.time() - t0
-        line["cpu_baseline"] = dict(value=round(nb * n / d, 3), unit="plots/s", cores=cores, kind="port",
-                                    sample=f"{n} training steps of MPointNet on {nb} synthetic {a.points}-pt plots "
-                                           f"(oracle/sparse_ref.py, torch-CPU fp32, {cores} threads), {d:.1f} s")
+        import bench      # the oracle is only ever imported by bench.py's cpu_baseline legs
+        stats = (model.reg_center_targets.cpu(), model.reg_scale_targets.cpu(), model.reg_weights.cpu())
+        line["cpu_baseline"] = bench.cpu_baseline_pointnet(sd_cpu, stats, a.points)
     print(json.dumps(line), flush=True)
 
 
@@ -278,46 +257,9 @@ def run_kpconv(a):
                 entry_points_ms_per_step={n: round(g["ms"] / 3, 3) for n, g in
                                           sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:10]})
     if not a.no_cpu_baseline:
-        line["cpu_baseline"] = kpconv_cpu_index(pool[0], B, a.points)
+        import bench      # the oracle is only ever imported by bench.py's cpu_baseline legs
+        line["cpu_baseline"] = bench.cpu_baseline_kpconv_index(pool[0], B, a.points)
     print(json.dumps(line), flush=True)
-
-
-def kpconv_cpu_index(batch, B, points):
-    """The index path of one batch on the C++ restatement: single thread, then one plot per task on all cores."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import kpconv_index as O
-    from dpcr_agb_amd.config import kpconv_config
-    cfg = kpconv_config()
-    pos = batch.pos.cpu().numpy().astype(np.float32)
-    nplots = min(B, 8)                       # a bounded sample: 8 plots (the reference does the whole batch per step)
-    per = [pos[i * points:(i + 1) * points] for i in range(nplots)]
-
-    def pyramid(pts_list):
-        pts = np.concatenate(pts_list)
-        lens = np.array([len(p) for p in pts_list], dtype=np.int32)
-        r = cfg.first_subsampling_dl * cfg.conv_radius
-        for level in range(5):
-            O.batch_neighbors(pts, pts, lens, lens, r)
-            if level == 4:
-                break
-            sub, sub_l = O.batch_grid_subsampling(pts, lens, sampleDl=2 * r / cfg.conv_radius)[:2]
-            O.batch_neighbors(sub, pts, sub_l, lens, r)
-            pts, lens, r = sub, sub_l, r * 2
-
-    t0 = time.time()
-    pyramid(per)
-    single = time.time() - t0
-    cores = usable_cores()
-    t0 = time.time()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda p: pyramid([p]), per))
-    multi = time.time() - t0
-    return dict(value=round(nplots / single, 3), unit="plots/s (index path only)", cores=1, kind="port",
-                all_cores=dict(value=round(nplots / multi, 3), cores=cores),
-                sample=f"the KPConv index path (5 x radius neighbours + 4 x grid subsampling + 4 x pooling neighbours) of "
-                       f"{nplots} synthetic {points}-pt plots on oracle/kpconv_index_ref.cpp: {single:.1f} s single thread "
-                       f"(how the reference runs it), {multi:.1f} s with one plot per task on {cores} threads; the GPU "
-                       f"number next to it is the WHOLE training step")
 
 
 def main():
