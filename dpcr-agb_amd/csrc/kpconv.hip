@@ -73,37 +73,61 @@ __global__ __launch_bounds__(256) void k_kpconv_gather(const float* __restrict__
             }
         }
 
-    // all lanes of a wave walk the same number of steps (shuffles inside): rows finished early just idle
-    for (int h = 0; h < H; ++h) {
-        int id = row_ok ? idx[(long long)n * H + h] : Ns;
-        bool live = id < Ns && id >= 0;
-        // rows are sorted by distance with the shadow padding at the end: stop once every row of the wave is done
-        if (__ballot(live) == 0ull) break;
-        float rel[3] = {0.f, 0.f, 0.f};
-        if (live) {
-            rel[0] = s[3 * (long long)id] - qx;
-            rel[1] = s[3 * (long long)id + 1] - qy;
-            rel[2] = s[3 * (long long)id + 2] - qz;
-        }
-        float w[KP_MAX];
-        kp_influences<LPR, CPL>(rel, s_kp, K, ext, lir, lane, w);
-        if (!live) continue;
-        if (!BWD) {
+    // The walk over a row's neighbours is a chain of dependent loads (index -> support position / feature row): one
+    // neighbour per iteration left every wave waiting ~1.5 us per step with nothing else in flight (0.95 ms for the
+    // 506 k rows of the first level at ~20 neighbours per row).  Neighbours are therefore taken NB at a time: one lane per
+    // neighbour loads its index (a coalesced run of the row), then the NB positions and feature pieces are all requested
+    // before the first one is used.  All lanes of a wave walk the same number of blocks (shuffles inside); rows are sorted
+    // by distance with the shadow padding at the end, so the walk stops at the first block whose FIRST entry is a shadow
+    // neighbour in every row of the wave.
+    constexpr int NB = 8;
+    const int grp = lane & ~15;
+    for (int h0 = 0; h0 < H; h0 += NB) {
+        int myid = Ns;
+        if (row_ok && (lir & 15) < NB && h0 + (lir & 15) < H) myid = idx[(long long)n * H + h0 + (lir & 15)];
+        int ids[NB];
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                int c = lir + LPR * j;
-                float xv = c < Cin ? x[(long long)id * ldx + c] : 0.f;
+        for (int j = 0; j < NB; ++j) ids[j] = __shfl(myid, grp + j, 64);
+        if (__ballot(ids[0] < Ns && ids[0] >= 0) == 0ull) break;
+        float rel[NB][3];
+        float xv[NB][CPL];
 #pragma unroll
-                for (int k = 0; k < KP_MAX; ++k) acc[k][j] += w[k] * xv;
+        for (int j = 0; j < NB; ++j) {
+            const bool live = ids[j] < Ns && ids[j] >= 0;
+            const long long ic = live ? ids[j] : 0;      // clamped: the loads are unconditional, the use is masked
+            rel[j][0] = s[3 * ic] - qx;
+            rel[j][1] = s[3 * ic + 1] - qy;
+            rel[j][2] = s[3 * ic + 2] - qz;
+            if (!BWD) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int ch = lir + LPR * c;
+                    xv[j][c] = ch < Cin ? x[ic * ldx + ch] : 0.f;
+                }
             }
-        } else {
+        }
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                int c = lir + LPR * j;
-                float g = 0.f;
+        for (int j = 0; j < NB; ++j) {
+            const bool live = ids[j] < Ns && ids[j] >= 0;
+            if (__ballot(live) == 0ull) break;           // (uniform: sorted rows, nothing live further on in this block)
+            float w[KP_MAX];
+            kp_influences<LPR, CPL>(rel[j], s_kp, K, ext, lir, lane, w);
+            if (!live) continue;
+            if (!BWD) {
 #pragma unroll
-                for (int k = 0; k < KP_MAX; ++k) g += w[k] * acc[k][j];
-                if (c < Cin) atomicAdd(&dx[(long long)id * ldx + c], g);
+                for (int c = 0; c < CPL; ++c) {
+#pragma unroll
+                    for (int k = 0; k < KP_MAX; ++k) acc[k][c] += w[k] * xv[j][c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int ch = lir + LPR * c;
+                    float g = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KP_MAX; ++k) g += w[k] * acc[k][c];
+                    if (ch < Cin) atomicAdd(&dx[(long long)ids[j] * ldx + ch], g);
+                }
             }
         }
     }

@@ -59,3 +59,25 @@ def test_product_path_refuses_cpu_tensors():
         ME.SparseTensor(torch.zeros(2, 3), coordinates=torch.tensor([[0, 0, 0, 0], [0, 1, 0, 0]]), device="cpu")
     with pytest.raises(_lib.AgbError):
         _lib.ptr(torch.zeros(3))
+
+
+def test_host_helpers_without_gpu():
+    """Sizing helpers and the process-level knobs are pure host code."""
+    import torch
+    import dpcr_agb_amd
+    from dpcr_agb_amd import _lib
+    import dpcr_agb_amd.norm_ops, dpcr_agb_amd.kp_index, dpcr_agb_amd.voxelize, dpcr_agb_amd.transforms  # noqa: F401,E401
+    assert _lib.size_call("agb_plot_workspace_bytes", 1000, 4) > 1000 * 5 * 4
+    small, big = (_lib.size_call("agb_grid_subsample_workspace_bytes", 1000, 2, c) for c in (100, 10000))
+    assert big > small > 0
+    assert _lib.size_call("agb_pointnet_mlp_workspace_bytes", 1000, 2, 64, 128, 1024) >= 1000 * (2 * 64 + 2 * 128 + 1024) * 4
+    assert _lib.load().agb_pointnet_pool_splits(64 * 13000, 64) >= 8
+    old = dpcr_agb_amd.limit_host_threads(3)
+    try:
+        assert torch.get_num_threads() == 3
+    finally:
+        torch.set_num_threads(old)
+    # option validation of the per-call kernel knobs happens before any launch
+    rc = _lib.load().agb_spconv_fwd_opt(None, 4, None, None, 0, 0, None, None, 4, 10, 27, 4, 4, None, None, None, 0, 1, None,
+                                        7, -1, None)
+    assert rc == -1 and b"cmp_mode" in _lib.load().agb_last_error()

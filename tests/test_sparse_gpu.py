@@ -738,3 +738,54 @@ def test_pointnet_fused_tail_and_c_chain(device, pool):
             continue
         e = float((named[k].grad.detach().cpu().double() - v.grad).abs().max()) / max(float(v.grad.abs().max()), 1e-3 * gmax)
         assert e < RTOL, (k, e)
+
+
+@pytest.mark.parametrize("mode", ["sum", "avg", "max"])
+def test_pointnet_pool_edge_cases(device, mode):
+    """Fused BN + act + pooling with ragged plots: an EMPTY plot in the middle, a one-row plot, a channel count that is
+    not a multiple of the 64-channel slab (80), enough rows for several row splits — forward and backward vs fp64."""
+    from dpcr_agb_amd.norm_ops import batch_norm_act_pool
+    torch.manual_seed(9)
+    lens = [700, 0, 1, 2300, 64]
+    n, C, B = sum(lens), 80, len(lens)
+    bidx = torch.repeat_interleave(torch.arange(B), torch.tensor(lens))
+    coords = torch.zeros(n, 4, dtype=torch.int32)
+    coords[:, 0] = bidx.int()
+    ptr = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    bn = torch.nn.BatchNorm1d(C).to(device)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    z = torch.randn(n, C) * 1.5 + 0.3
+    zg = z.to(device).requires_grad_(True)
+    out = batch_norm_act_pool(zg, bn, "gelu", coords.to(device), ptr.to(device), B, mode)
+    g = torch.randn(B, C)
+    out.backward(g.to(device))
+    zr = z.double().requires_grad_(True)
+    w, b = bn.weight.detach().cpu().double().requires_grad_(True), bn.bias.detach().cpu().double().requires_grad_(True)
+    y = torch.nn.functional.gelu(torch.nn.functional.batch_norm(zr, None, None, w, b, True, 0.1, 1e-5))
+    ref = R.global_pool(y, bidx, B, mode)
+    ref.backward(g.double())
+    assert out.shape == (B, C) and float(out[1].abs().max()) == 0.0          # the empty plot pools to zero
+    assert rel_err(out, ref) < 1e-5
+    assert rel_err(zg.grad, zr.grad) < RTOL
+    assert rel_err(bn.weight.grad, w.grad) < RTOL and rel_err(bn.bias.grad, b.grad) < RTOL
+
+
+@pytest.mark.parametrize("n,cin,cout", [(1, 5, 7), (3, 6, 64), (1000, 45, 32), (64, 1024, 512)])
+def test_dense_linear_odd_shapes(device, n, cin, cout):
+    """nn.Linear semantics on the own kernels for widths that need zero padding (the 6-feature PointNet input, KPConv's
+    45-wide input contraction) and for a handful of rows (the head MLP on B rows)."""
+    from dpcr_agb_amd.sparse_ops import dense_linear
+    torch.manual_seed(n + cin)
+    lin = torch.nn.Linear(cin, cout, bias=True).to(device)
+    x = torch.randn(n, cin)
+    xg = x.to(device).requires_grad_(True)
+    y = dense_linear(xg, lin.weight, lin.bias)
+    g = torch.randn(n, cout)
+    y.backward(g.to(device))
+    xr = x.double().requires_grad_(True)
+    wr, br = lin.weight.detach().cpu().double().requires_grad_(True), lin.bias.detach().cpu().double().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(g.double())
+    assert rel_err(y, yr) < RTOL and rel_err(xg.grad, xr.grad) < RTOL
+    assert rel_err(lin.weight.grad, wr.grad) < RTOL and rel_err(lin.bias.grad, br.grad) < RTOL
