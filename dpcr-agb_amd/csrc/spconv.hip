@@ -1359,148 +1359,6 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     }
 }
 
-// Weight gradient of a DENSE product (identity map): dW [Cin, Cout] += X[rows]^T dY[rows] over a row chunk, 128 x 128
-// output tiles (four waves, each 64 x 64 = 2 x 2 accumulators).  The 64 x 64 tiles of k_spconv_dw_cmp re-read X once per
-// column tile and dY once per row tile: traffic N * 4 * Cin * Cout * (1/64 + 1/64) bytes — 13.5 GB for PointNet's
-// 1024 x 128 gradient over 823 k rows, L2 / HBM-bound; 128 x 128 tiles halve it.  No pair lists: rows are consecutive.
-//   PREC 0: fp32 MFMA, 32 rows per step;  PREC 1 / 2: bf16 / split-bf16x3, 64 rows per step, rows transposed and packed
-//   to bf16 pairs while staged (the swizzled layout of k_spconv_dw_cmp, one 64-channel half at a time).
-template <int PREC>
-__global__ __launch_bounds__(256) void k_dense_dw(const float* __restrict__ X, int ldx, const float* __restrict__ dY,
-                                                  int ldy, float* __restrict__ dW, int n, int Cin, int Cout,
-                                                  int rows_per_wg) {
-    constexpr int KS = PREC == 0 ? 32 : 64;
-    constexpr int NP = PREC == 2 ? 2 : 1;
-    constexpr int NR = PREC == 0 ? 4 : 8;          // float4 loads per thread, operand and step
-    __shared__ __attribute__((aligned(16))) float As[PREC == 0 ? KS * 128 : NP * 128 * DWT_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[PREC == 0 ? KS * 128 : NP * 128 * DWT_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
-    const int r_begin = blockIdx.x * rows_per_wg, r_end = min(n, r_begin + rows_per_wg);
-    if (r_begin >= r_end) return;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    float4 a_reg[NR], b_reg[NR];
-    // fp32: thread -> (row t_r + 8 j, columns 4 (tid & 31) ..);  bf16: register 4 half + 2 jj + e -> row 2 (u + 16 jj) + e,
-    // columns 64 half + 4 (tid & 15) .. (u = tid >> 4)
-    auto row_of = [&](int j) { return PREC == 0 ? (tid >> 5) + 8 * j : 2 * ((tid >> 4) + 16 * ((j >> 1) & 1)) + (j & 1); };
-    auto col_of = [&](int j) { return PREC == 0 ? (tid & 31) * 4 : 64 * (j >> 2) + (tid & 15) * 4; };
-    auto load_data = [&](int rb) {
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int r = min(rb + row_of(j), r_end - 1);
-            const int ca = min(m0 + col_of(j), Cin - 4), cb = min(n0 + col_of(j), Cout - 4);
-            a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)r * ldx + ca);
-            b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + cb);
-        }
-    };
-    load_data(r_begin);
-    for (int rb = r_begin; rb < r_end; rb += KS) {
-        if constexpr (PREC == 0) {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const bool live = rb + row_of(j) < r_end;
-                float4 av = a_reg[j], bv = b_reg[j];
-                if (!(live && m0 + col_of(j) < Cin)) av = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(live && n0 + col_of(j) < Cout)) bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(&As[row_of(j) * 128 + col_of(j)]) = av;
-                *reinterpret_cast<float4*>(&Bs[row_of(j) * 128 + col_of(j)]) = bv;
-            }
-        } else {
-            unsigned* At = reinterpret_cast<unsigned*>(As);
-            unsigned* Bt = reinterpret_cast<unsigned*>(Bs);
-#pragma unroll
-            for (int jp = 0; jp < NR / 2; ++jp) {            // register pairs (two consecutive rows, same columns)
-                float av[2][4], bv[2][4];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int j = 2 * jp + e;
-                    const bool live = rb + row_of(j) < r_end;
-                    const bool la = live && m0 + col_of(j) < Cin, lb = live && n0 + col_of(j) < Cout;
-                    const float4 a4 = a_reg[j], b4 = b_reg[j];
-                    av[e][0] = la ? a4.x : 0.f; av[e][1] = la ? a4.y : 0.f; av[e][2] = la ? a4.z : 0.f; av[e][3] = la ? a4.w : 0.f;
-                    bv[e][0] = lb ? b4.x : 0.f; bv[e][1] = lb ? b4.y : 0.f; bv[e][2] = lb ? b4.z : 0.f; bv[e][3] = lb ? b4.w : 0.f;
-                }
-                const int pp = row_of(2 * jp) >> 1;          // pair-pair (dword column) 0..31
-                const int c = col_of(2 * jp);                // first of the 4 channels (0..124)
-                const int col = (((pp >> 2) ^ ((c >> 2) & 7)) << 2) | (pp & 3);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    At[(c + i) * DWT_LD + col] = pack_bf16(av[0][i], av[1][i]);
-                    Bt[(c + i) * DWT_LD + col] = pack_bf16(bv[0][i], bv[1][i]);
-                    if constexpr (PREC == 2) {
-                        At[(128 + c + i) * DWT_LD + col] = pack_bf16_lo(av[0][i], av[1][i]);
-                        Bt[(128 + c + i) * DWT_LD + col] = pack_bf16_lo(bv[0][i], bv[1][i]);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (rb + KS < r_end) load_data(rb + KS);   // in flight during the MFMAs below
-        if constexpr (PREC == 0) {
-            const float* ap = &As[wr * 64 + li];
-            const float* bp = &Bs[wc * 64 + li];
-#pragma unroll
-            for (int s2 = 0; s2 < KS / 2; ++s2) {
-                const float a0 = ap[(2 * s2 + lh) * 128], a1 = ap[(2 * s2 + lh) * 128 + 32];
-                const float b0 = bp[(2 * s2 + lh) * 128], b1 = bp[(2 * s2 + lh) * 128 + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-        } else {
-            const unsigned* At = reinterpret_cast<const unsigned*>(As);
-            const unsigned* Bt = reinterpret_cast<const unsigned*>(Bs);
-#pragma unroll
-            for (int s2 = 0; s2 < KS / 16; ++s2) {
-                const int q = 2 * s2 + lh;
-                bf16x8 ah[2], bh[2], al[2], bl[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int ar = wr * 64 + 32 * i + li, br = wc * 64 + 32 * i + li;
-                    ah[i] = *reinterpret_cast<const bf16x8*>(&At[ar * DWT_LD + ((q ^ ((ar >> 2) & 7)) << 2)]);
-                    bh[i] = *reinterpret_cast<const bf16x8*>(&Bt[br * DWT_LD + ((q ^ ((br >> 2) & 7)) << 2)]);
-                    if constexpr (PREC == 2) {
-                        al[i] = *reinterpret_cast<const bf16x8*>(&At[(128 + ar) * DWT_LD + ((q ^ ((ar >> 2) & 7)) << 2)]);
-                        bl[i] = *reinterpret_cast<const bf16x8*>(&Bt[(128 + br) * DWT_LD + ((q ^ ((br >> 2) & 7)) << 2)]);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        if constexpr (PREC == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        }
-                    }
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + 32 * j + li;
-            if (col >= Cout) continue;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = m0 + wr * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                if (m < Cin) atomicAdd(&dW[(long long)m * Cout + col], acc[i][j][reg]);
-            }
-        }
-}
-
 // Weight gradient of the small-Cin (stem) path, ROW-COMPACTED: an M tile covers 64/CPAD kernel offsets; a row whose
 // neighbours at ALL of those offsets are absent contributes nothing (7^3 stem map: 35 % of the rows of a 16-offset
 // tile).  The workgroup compacts its row chunk to the rows with at least one present neighbour, then walks them 32 at a
@@ -1964,19 +1822,7 @@ int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, 
     else if (Cin == 8)
         hipLaunchKernelGGL(k_spconv_dw_small_cmp<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                            Cout, (int)rows, chunks, m_tiles);
-    else if (nbr == nullptr && (Cin > 64 || Cout > 64)) {
-        // dense product with a wide side: 128 x 128 tiles (k_dense_dw), ~2048 workgroups
-        const int mt = agb_cdiv(Cin, 128), nt = agb_cdiv(Cout, 128);
-        long long want = 2048 / ((long long)mt * nt);
-        if (want < 1) want = 1;
-        long long rpw = (n_out + want - 1) / want;
-        if (rpw < 256) rpw = 256;
-        rpw = (rpw + 63) / 64 * 64;
-        dim3 gridd(agb_cdiv(n_out, rpw), mt, nt);
-        if (precision == 1) hipLaunchKernelGGL(k_dense_dw<1>, gridd, block, 0, s, X, ldx, dY, ldy, dW, n_out, Cin, Cout, (int)rpw);
-        else if (precision == 2) hipLaunchKernelGGL(k_dense_dw<2>, gridd, block, 0, s, X, ldx, dY, ldy, dW, n_out, Cin, Cout, (int)rpw);
-        else hipLaunchKernelGGL(k_dense_dw<0>, gridd, block, 0, s, X, ldx, dY, ldy, dW, n_out, Cin, Cout, (int)rpw);
-    } else {
+    else {
         // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
         if (rows > DW_MAXROWS) rows = DW_MAXROWS;
         chunks = agb_cdiv(n_out, rows);
