@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..kp_dispositions import kernel_disposition
-from ..kpconv_ops import KPGatherFunction, KPMaxPoolFunction, as_index
+from ..kpconv_ops import KPConvSymmetricFunction, KPGatherFunction, KPMaxPoolFunction, as_index
 from ..norm_ops import ACT_IDS, AddActFunction, batch_norm_act
 from ..sparse_ops import DenseConvFunction, dense_linear, segment_reduce
 
@@ -48,6 +48,11 @@ class KPConv(nn.Module):
 
     def forward(self, q_pts, s_pts, neighb_inds, x):
         idx = as_index(neighb_inds)
+        # same point set on both sides with a symmetric neighbour relation (marked by the input pyramid on uncropped
+        # self-searches): the scatter-free backward
+        if q_pts is s_pts and getattr(neighb_inds, "agb_symmetric", False) and x.is_cuda and \
+                KPConvSymmetricFunction.supported(self.K, self.in_channels, self.out_channels):
+            return KPConvSymmetricFunction.apply(x, q_pts, idx, self.kernel_points, self.KP_extent, self.weights)
         wf = KPGatherFunction.apply(x, q_pts, s_pts, idx, self.kernel_points, self.KP_extent)
         # dense feature x kernel-weight contraction [N, K*Cin] @ [K*Cin, Cout] on the library's own MFMA kernels
         w2d = self.weights.view(-1, self.out_channels)

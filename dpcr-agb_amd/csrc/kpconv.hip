@@ -1,145 +1,163 @@
 // kpconv.hip — rigid kernel-point convolution (KPConv.forward, torch_points3d/modules/KPConv/blocks.py:264-400)
 // split the MI355X way:
-//   (1) k_kpconv_gather_fwd : wf[n,k,:] = sum_h max(0, 1 - |(s[idx[n,h]] - q[n]) - kp[k]| / extent) * x[idx[n,h],:]
+//   (1) gather fwd : wf[n,k,:] = sum_h max(0, 1 - |(s[idx[n,h]] - q[n]) - kp[k]| / extent) * x[idx[n,h],:]
 //       one fused pass over the neighbour matrix — the reference materialises [N,H,15,3] differences, [N,H,15]
-//       weights and [N,H,Cin] gathered features in HBM; here neighbour rows are read once as coalesced
-//       Cin-wide pieces, the 15 influences of a neighbour are computed by 15 lanes and shuffled to the row's lanes,
-//       and the loop stops at the first shadow neighbour (rows are distance-sorted, padding sits at the end).
-//   (2) the dense contraction out = wf[N, 15*Cin] @ W[15*Cin, Cout] is a plain GEMM (MFMA, via rocBLAS).
-//   (3) k_kpconv_gather_bwd : dx[idx[n,h],:] += sum_k infl(n,h,k) * dwf[n,k,:]   (fp32 atomics, 4*LPR-byte pieces)
+//       weights and [N,H,Cin] gathered features in HBM; here the neighbour rows are read once as coalesced 64-byte
+//       pieces and the walk stops after the last real neighbour (rows are distance-sorted, padding sits at the end).
+//   (2) the dense contraction out = wf[N, 15*Cin] @ W[15*Cin, Cout]: the identity-map kernels of spconv.hip.
+//   (3) gather bwd : dx[idx[n,h],:] += sum_k infl(n,h,k) * dwf[n,k,:]   (fp32 atomics, 64-byte pieces) — only for
+//       layers whose query and support sets differ (strided blocks); a layer on ONE point set with a symmetric
+//       neighbour relation runs its backward as pass (1) on dy with mirrored kernel points (kpconv_ops.py).
 // plus the max-pooled shortcut of strided blocks (blocks.py:98-114: the zero "shadow" row takes part in the max).
 #include "agb_common.h"
 #include <float.h>
 
 #define KP_MAX 16
 
-template <int LPR, int CPL>
-__device__ __forceinline__ void kp_influences(const float rel[3], const float* __restrict__ s_kp, int K, float ext,
-                                              int lir, int lane, float w[KP_MAX]) {
-    if constexpr (LPR >= 16) {
-        // lane (lir % 16) of every 16-lane group evaluates one kernel point, then the values are shuffled around
-        int k = lir & 15;
-        float mine = 0.f;
-        if (k < K) {
-            float dx = rel[0] - s_kp[3 * k], dy = rel[1] - s_kp[3 * k + 1], dz = rel[2] - s_kp[3 * k + 2];
-            float d = sqrtf((dx * dx + dy * dy) + dz * dz);
-            mine = fmaxf(1.f - d / ext, 0.f);
-        }
-        int base = lane & ~15;
+// ------------------------------------------------------------------ the two gather passes on the matrix cores
+// Per query row the gather is a small matrix product over the row's neighbours h:
+//     wf[n]  (K x Cin) = W^T (K x H) . X (H x Cin)        W[h,k] = influence of kernel point k on neighbour h,
+//     g      (H x Cin) = W   (H x K) . dwf[n] (K x Cin)   X[h,:]  = x[idx[n,h],:],  dx[idx[n,h],:] += g[h,:]
+// and v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation) has exactly the operand shape for it with K = 15
+// kernel points padded to 16: in the forward pass lane (k, j) of a wave evaluates ONE influence — kernel point k, the
+// j-th neighbour of a block of four — which IS its A operand, and loads x[idx[h_j], c] as its B operand (a coalesced
+// 64-byte piece per neighbour); nothing is exchanged between lanes.  One wave per (query row, chunk of 16*NC channels).
+//
+// History (profiles/r02_kpconv_pmc.txt): the first form gave every lane one channel and broadcast the 15 influences of
+// a neighbour to the row's lanes — 16 cross-lane moves + 16 multiply-adds + an influence evaluation per neighbour on
+// every lane, 14 wave instructions per row-neighbour at Cin = 16; with ds_bpermute the LDS pipe was 57 % busy, with DPP
+// row_share moves the VALU was the limit (fwd 5.9 -> 4.5 ms per KPConv step).  This form needs about 5 (-> 2.2 ms).
+// Combining the backward scatter in an LDS table (32 consecutive rows share ~75 % of their support rows) was built and
+// measured SLOWER: ds_add_f32 retires one 64-lane instruction per ~194 cycles on gfx950 (ds_add_u32: 4.6,
+// read+add+write: 14.6 — tools/micro/lds_atomic_bench.hip), so the LDS pipe became the bound.
+typedef float kp_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float kp_influence(float rx, float ry, float rz, float kx, float ky, float kz, float ext) {
+    const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
+    const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+    return fmaxf(1.f - d / ext, 0.f);
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_kpconv_gather_mm_fwd(const float* __restrict__ q, const float* __restrict__ s,
+                                                              const int32_t* __restrict__ idx, int H, int Ns,
+                                                              const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ kp, int K, float ext,
+                                                              float* __restrict__ wf, int N, int Cin, int chunks) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long long)N * chunks) return;            // (whole waves leave: no barrier in this kernel)
+    const int n = (int)(item / chunks);
+    const int cbase = (int)(item % chunks) * (16 * NC);
+    const int m = lane & 15, g = lane >> 4;               // A: (kernel point m, neighbour g)   B/D: (.., channel m)
+    const float kx = m < K ? kp[3 * m] : 0.f, ky = m < K ? kp[3 * m + 1] : 0.f, kz = m < K ? kp[3 * m + 2] : 0.f;
+    const float qx = q[3 * (long long)n], qy = q[3 * (long long)n + 1], qz = q[3 * (long long)n + 2];
+    kp_f32x4 acc[NC];
 #pragma unroll
-        for (int j = 0; j < KP_MAX; ++j) w[j] = __shfl(mine, base + j, 64);
-    } else {
+    for (int t = 0; t < NC; ++t) acc[t] = kp_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int32_t* row = idx + (long long)n * H;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        const int myid = h0 + lane < H ? row[h0 + lane] : Ns;
+        const unsigned long long valid = __ballot(myid >= 0 && myid < Ns);
+        if (valid == 0ull) break;                          // rows are sorted by distance: the rest is shadow padding
+        // two blocks of four neighbours per trip: both blocks' loads are requested before either is used
+        const int nblk = (64 - __builtin_clzll(valid) + 7) >> 3;
+        for (int b = 0; b < nblk; ++b) {
+            int id[2];
+            bool live[2];
+            float rx[2], ry[2], rz[2], xb[2][NC];
 #pragma unroll
-        for (int j = 0; j < KP_MAX; ++j) {
-            w[j] = 0.f;
-            if (j < K) {
-                float dx = rel[0] - s_kp[3 * j], dy = rel[1] - s_kp[3 * j + 1], dz = rel[2] - s_kp[3 * j + 2];
-                float d = sqrtf((dx * dx + dy * dy) + dz * dz);
-                w[j] = fmaxf(1.f - d / ext, 0.f);
+            for (int u = 0; u < 2; ++u) {
+                id[u] = __shfl(myid, 8 * b + 4 * u + g, 64);
+                live[u] = id[u] >= 0 && id[u] < Ns;
+                const long long ic = live[u] ? id[u] : 0;
+                rx[u] = s[3 * ic] - qx, ry[u] = s[3 * ic + 1] - qy, rz[u] = s[3 * ic + 2] - qz;
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    const int c = cbase + 16 * t + m;
+                    xb[u][t] = (live[u] && c < Cin) ? x[ic * ldx + c] : 0.f;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float a = (live[u] && m < K) ? kp_influence(rx[u], ry[u], rz[u], kx, ky, kz, ext) : 0.f;
+#pragma unroll
+                for (int t = 0; t < NC; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[u][t], acc[t], 0, 0, 0);
+            }
+        }
+        if (valid != ~0ull) break;
+    }
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+        const int c = cbase + 16 * t + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 4 * g + i;
+            if (k < K && c < Cin) wf[((long long)n * K + k) * Cin + c] = acc[t][i];
         }
     }
 }
 
-// LPR lanes per query row, each lane owns channels lir, lir+LPR, ... (CPL of them)
-template <int LPR, int CPL, bool BWD>
-__global__ __launch_bounds__(256) void k_kpconv_gather(const float* __restrict__ q, const float* __restrict__ s,
-                                                       const int32_t* __restrict__ idx, int H, int Ns,
-                                                       const float* __restrict__ x, int ldx,
-                                                       const float* __restrict__ kp, int K, float ext,
-                                                       float* __restrict__ wf,         // fwd: out [N,K,Cin]
-                                                       const float* __restrict__ dwf,  // bwd: in  [N,K,Cin]
-                                                       float* __restrict__ dx,         // bwd: out [Ns,Cin] (atomics)
-                                                       int N, int Cin) {
-    __shared__ float s_kp[3 * KP_MAX];
-    if (threadIdx.x < 3 * K) s_kp[threadIdx.x] = kp[threadIdx.x];
-    __syncthreads();
+// backward: blocks of 16 neighbours; lane (h, j) evaluates the influences of kernel points j, 4+j, 8+j, 12+j on
+// neighbour h (its A operands of the four k-steps); dwf[n] stays in registers as the B operands for the whole row.
+template <int NC>
+__global__ __launch_bounds__(256) void k_kpconv_gather_mm_bwd(const float* __restrict__ q, const float* __restrict__ s,
+                                                              const int32_t* __restrict__ idx, int H, int Ns,
+                                                              const float* __restrict__ kp, int K, float ext,
+                                                              const float* __restrict__ dwf, float* __restrict__ dx,
+                                                              int ldx, int N, int Cin, int chunks) {
     const int lane = threadIdx.x & 63;
-    const int lir = threadIdx.x % LPR;
-    const int n = (blockIdx.x * 256 + threadIdx.x) / LPR;
-    const bool row_ok = n < N;
-    const int nn = row_ok ? n : 0;
-    const float qx = q[3 * (long long)nn], qy = q[3 * (long long)nn + 1], qz = q[3 * (long long)nn + 2];
-
-    float acc[KP_MAX][CPL];
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long long)N * chunks) return;
+    const int n = (int)(item / chunks);
+    const int cbase = (int)(item % chunks) * (16 * NC);
+    const int m = lane & 15, g = lane >> 4;               // A: (neighbour m, kernel point 4*step+g)  B/D: (.., channel m)
+    float kx[4], ky[4], kz[4];
+    float db[4][NC];
 #pragma unroll
-    for (int k = 0; k < KP_MAX; ++k)
+    for (int st = 0; st < 4; ++st) {
+        const int k = 4 * st + g;
+        kx[st] = k < K ? kp[3 * k] : 0.f;
+        ky[st] = k < K ? kp[3 * k + 1] : 0.f;
+        kz[st] = k < K ? kp[3 * k + 2] : 0.f;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            acc[k][j] = 0.f;
-            if (BWD && row_ok && k < K) {
-                int c = lir + LPR * j;
-                if (c < Cin) acc[k][j] = dwf[((long long)n * K + k) * Cin + c];
-            }
-        }
-
-    // The walk over a row's neighbours is a chain of dependent loads (index -> support position / feature row): one
-    // neighbour per iteration left every wave waiting ~1.5 us per step with nothing else in flight (0.95 ms for the
-    // 506 k rows of the first level at ~20 neighbours per row).  Neighbours are therefore taken NB at a time: one lane per
-    // neighbour loads its index (a coalesced run of the row), then the NB positions and feature pieces are all requested
-    // before the first one is used.  All lanes of a wave walk the same number of blocks (shuffles inside); rows are sorted
-    // by distance with the shadow padding at the end, so the walk stops at the first block whose FIRST entry is a shadow
-    // neighbour in every row of the wave.
-    constexpr int NB = 8;
-    const int grp = lane & ~15;
-    for (int h0 = 0; h0 < H; h0 += NB) {
-        int myid = Ns;
-        if (row_ok && (lir & 15) < NB && h0 + (lir & 15) < H) myid = idx[(long long)n * H + h0 + (lir & 15)];
-        int ids[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) ids[j] = __shfl(myid, grp + j, 64);
-        if (__ballot(ids[0] < Ns && ids[0] >= 0) == 0ull) break;
-        float rel[NB][3];
-        float xv[NB][CPL];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const bool live = ids[j] < Ns && ids[j] >= 0;
-            const long long ic = live ? ids[j] : 0;      // clamped: the loads are unconditional, the use is masked
-            rel[j][0] = s[3 * ic] - qx;
-            rel[j][1] = s[3 * ic + 1] - qy;
-            rel[j][2] = s[3 * ic + 2] - qz;
-            if (!BWD) {
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const int ch = lir + LPR * c;
-                    xv[j][c] = ch < Cin ? x[ic * ldx + ch] : 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const bool live = ids[j] < Ns && ids[j] >= 0;
-            if (__ballot(live) == 0ull) break;           // (uniform: sorted rows, nothing live further on in this block)
-            float w[KP_MAX];
-            kp_influences<LPR, CPL>(rel[j], s_kp, K, ext, lir, lane, w);
-            if (!live) continue;
-            if (!BWD) {
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-#pragma unroll
-                    for (int k = 0; k < KP_MAX; ++k) acc[k][c] += w[k] * xv[j][c];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const int ch = lir + LPR * c;
-                    float g = 0.f;
-#pragma unroll
-                    for (int k = 0; k < KP_MAX; ++k) g += w[k] * acc[k][c];
-                    if (ch < Cin) atomicAdd(&dx[(long long)ids[j] * ldx + ch], g);
-                }
-            }
+        for (int t = 0; t < NC; ++t) {
+            const int c = cbase + 16 * t + m;
+            db[st][t] = (k < K && c < Cin) ? dwf[((long long)n * K + k) * Cin + c] : 0.f;
         }
     }
-    if (!BWD && row_ok) {
+    const float qx = q[3 * (long long)n], qy = q[3 * (long long)n + 1], qz = q[3 * (long long)n + 2];
+    const int32_t* row = idx + (long long)n * H;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        const int myid = h0 + lane < H ? row[h0 + lane] : Ns;
+        const unsigned long long valid = __ballot(myid >= 0 && myid < Ns);
+        if (valid == 0ull) break;
+        const int nblk = (64 - __builtin_clzll(valid) + 15) >> 4;
+        for (int b = 0; b < nblk; ++b) {
+            const int id = __shfl(myid, 16 * b + m, 64);
+            const bool live = id >= 0 && id < Ns;
+            const long long ic = live ? id : 0;
+            const float rx = s[3 * ic] - qx, ry = s[3 * ic + 1] - qy, rz = s[3 * ic + 2] - qz;
+            float a[4];
 #pragma unroll
-        for (int k = 0; k < KP_MAX; ++k)
-            if (k < K)
+            for (int st = 0; st < 4; ++st)
+                a[st] = (live && 4 * st + g < K) ? kp_influence(rx, ry, rz, kx[st], ky[st], kz[st], ext) : 0.f;
+            int ido[4];
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    int c = lir + LPR * j;
-                    if (c < Cin) wf[((long long)n * K + k) * Cin + c] = acc[k][j];
-                }
+            for (int i = 0; i < 4; ++i) ido[i] = __shfl(myid, 16 * b + 4 * g + i, 64);
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                kp_f32x4 d = kp_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 4; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], db[st][t], d, 0, 0, 0);
+                const int c = cbase + 16 * t + m;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c < Cin && ido[i] >= 0 && ido[i] < Ns) atomicAdd(&dx[(long long)ido[i] * ldx + c], d[i]);
+            }
+        }
+        if (valid != ~0ull) break;
     }
 }
 
@@ -211,21 +229,21 @@ template <bool BWD>
 static int launch_gather(const float* q, const float* s, const int32_t* idx, int H, int Ns, const float* x, int ldx,
                          const float* kp, int K, float ext, float* wf, const float* dwf, float* dx, int N, int Cin,
                          hipStream_t st) {
-#define AGB_KP_LAUNCH(LPR, CPL)                                                                                      \
-    hipLaunchKernelGGL((k_kpconv_gather<LPR, CPL, BWD>), dim3(agb_cdiv((long long)N * LPR, 256)), dim3(256), 0, st, \
-                       q, s, idx, H, Ns, x, ldx, kp, K, ext, wf, dwf, dx, N, Cin)
-    // (Cin <= 4 — the 3-feature input layer — takes the 16-lane form too: one lane per kernel point evaluates its
-    // influence once per neighbour; with 4 lanes per row every lane evaluated all 15 square roots itself)
-    if (Cin <= 16) AGB_KP_LAUNCH(16, 1);
-    else if (Cin <= 32) AGB_KP_LAUNCH(16, 2);
-    else if (Cin <= 64) AGB_KP_LAUNCH(64, 1);
-    else if (Cin <= 128) AGB_KP_LAUNCH(64, 2);
-    else if (Cin <= 256) AGB_KP_LAUNCH(64, 4);
-    else {
-        agb_set_error("agb_kpconv_gather: Cin %d > 256 is not supported", Cin);
-        return AGB_EUNSUPPORTED;
-    }
-#undef AGB_KP_LAUNCH
+    // one wave per (row, chunk of 16*NC channels)
+    const int nc = Cin <= 16 ? 1 : Cin <= 32 ? 2 : 4;
+    const int chunks = agb_cdiv(Cin, 16 * nc);
+    const dim3 grid(agb_cdiv((long long)N * chunks, 4)), block(256);
+#define AGB_KP_MM(NC)                                                                                                 \
+    do {                                                                                                              \
+        if (BWD) hipLaunchKernelGGL((k_kpconv_gather_mm_bwd<NC>), grid, block, 0, st, q, s, idx, H, Ns, kp, K, ext,   \
+                                    dwf, dx, ldx, N, Cin, chunks);                                                    \
+        else hipLaunchKernelGGL((k_kpconv_gather_mm_fwd<NC>), grid, block, 0, st, q, s, idx, H, Ns, x, ldx, kp, K,    \
+                                ext, wf, N, Cin, chunks);                                                             \
+    } while (0)
+    if (nc == 1) AGB_KP_MM(1);
+    else if (nc == 2) AGB_KP_MM(2);
+    else AGB_KP_MM(4);
+#undef AGB_KP_MM
     return AGB_OK;
 }
 

@@ -106,7 +106,11 @@ class KPConvModel(InstanceBase):
             else:
                 pool_i, pool_p, pool_b = empty_i, torch.zeros(0, 3, device=device), np.zeros(0, dtype=np.int64)
             points.append(pts)
-            neighbors.append(self._crop(conv_i, len(points) - 1))
+            nb = self._crop(conv_i, len(points) - 1)
+            # an uncropped radius search of a point set against itself is symmetric (d2(a, b) is computed from the same
+            # differences either way): KPConv layers on it take the scatter-free backward (KPConvSymmetricFunction)
+            nb.agb_symmetric = conv_job is not None and nb.shape[1] == conv_i.shape[1]
+            neighbors.append(nb)
             pools.append(pool_i if pool_i is None else self._crop(pool_i, len(points) - 1))
             lengths.append(torch.from_numpy(lens.copy()))
             pts, lens = pool_p, pool_b

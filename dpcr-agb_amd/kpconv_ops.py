@@ -28,9 +28,7 @@ class KPGatherFunction(torch.autograd.Function):
         N, H = idx.shape
         Ns, cin = x.shape
         K = kernel_points.shape[0]
-        wf = torch.empty(N, K, cin, dtype=torch.float32, device=x.device)
-        _lib.call("agb_kpconv_gather_fwd", _P(q_pts), _P(s_pts), _P(idx), H, Ns, _P(x), x.stride(0),
-                  _P(kernel_points), K, float(extent), _P(wf), N, cin, _lib.stream())
+        wf = _gather(x, q_pts, s_pts, idx, kernel_points, extent)
         ctx.save_for_backward(q_pts, s_pts, idx, kernel_points)
         ctx.cfg = (float(extent), Ns, cin)
         return wf
@@ -46,6 +44,58 @@ class KPGatherFunction(torch.autograd.Function):
         _lib.call("agb_kpconv_gather_bwd", _P(q_pts), _P(s_pts), _P(idx), H, Ns, _P(dwf), _P(kernel_points), K, extent,
                   _P(dx), dx.stride(0), N, cin, _lib.stream())
         return dx, None, None, None, None, None
+
+
+def _gather(x, q_pts, s_pts, idx, kernel_points, extent):
+    N, H = idx.shape
+    Ns, cin = x.shape
+    K = kernel_points.shape[0]
+    wf = torch.empty(N, K, cin, dtype=torch.float32, device=x.device)
+    _lib.call("agb_kpconv_gather_fwd", _P(q_pts), _P(s_pts), _P(idx), H, Ns, _P(x), x.stride(0), _P(kernel_points), K,
+              float(extent), _P(wf), N, cin, _lib.stream())
+    return wf
+
+
+class KPConvSymmetricFunction(torch.autograd.Function):
+    """The whole rigid KPConv (gather + kernel-weight contraction, blocks.py:264-400) of a layer whose query and support
+    sets are THE SAME points with a symmetric neighbour relation (j in N(n) <=> n in N(j): an uncropped radius search
+    of a point set against itself — every non-strided block of the network).
+
+    Backward without a scatter: dx[j] = sum_{n: j in N(n)} sum_k infl_k(s_j - q_n) W_k dy[n]; with N symmetric the sum
+    runs over j's OWN neighbour row, and infl_k(s_j - q_n) = max(0, 1 - |(s_n - q_j) - (-kp_k)| / extent): the forward
+    gather applied to dy with the kernel points mirrored, followed by the dense product with W_k^T.  The scatter form
+    (agb_kpconv_gather_bwd) issues one 64-byte fp32 atomic per (row, neighbour, 16 channels); those execute at the memory
+    side of the fabric at ~19 G requests/s and made the backward gather 2.6x the forward one."""
+
+    @staticmethod
+    def supported(K, cin, cout):
+        from .sparse_ops import DenseConvFunction
+        return DenseConvFunction.supported(K * cin, cout) and DenseConvFunction.supported(K * cout, cin)
+
+    @staticmethod
+    def forward(ctx, x, pts, idx, kernel_points, extent, weights):
+        from .sparse_ops import dense_product
+        x, pts, kernel_points = x.contiguous(), pts.contiguous(), kernel_points.contiguous()
+        K, cin, cout = weights.shape
+        wf = _gather(x, pts, pts, idx, kernel_points, extent).view(-1, K * cin)
+        out = dense_product(wf, weights.reshape(K * cin, cout))
+        ctx.save_for_backward(wf, pts, idx, kernel_points, weights)
+        ctx.extent = float(extent)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .sparse_ops import dense_product, dense_weight_grad
+        wf, pts, idx, kernel_points, weights = ctx.saved_tensors
+        K, cin, cout = weights.shape
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[5]:
+            dw = dense_weight_grad(wf, dy).view(K, cin, cout)
+        if ctx.needs_input_grad[0]:
+            wfd = _gather(dy, pts, pts, idx, (-kernel_points).contiguous(), ctx.extent).view(-1, K * cout)
+            dx = dense_product(wfd, weights.permute(0, 2, 1).reshape(K * cout, cin), "dgrad1x1")
+        return dx, None, None, None, None, dw
 
 
 class KPMaxPoolFunction(torch.autograd.Function):

@@ -323,6 +323,28 @@ class DenseConvFunction(torch.autograd.Function):
         return dx, dk, db
 
 
+def dense_product(x, w, kind="fwd1x1"):
+    """x [n, cin] @ w [cin, cout] on the identity-map convolution kernels in the operand precision of ``CONV_PRECISION``
+    (no autograd: building block of the fused Functions).  Widths as in ``DenseConvFunction.supported``."""
+    cin, cout = w.shape
+    w = w.contiguous()
+    if CONV_PRECISION in _PREC_ID:
+        return spconv_forward_raw(x, None, None, 0, None, x.shape[0], 1, cin, cout, kind, None, None, w.t().contiguous())
+    return spconv_forward_raw(x, w, None, 0, None, x.shape[0], 1, cin, cout, kind)
+
+
+def dense_weight_grad(x, dy):
+    """x^T [cin, n] @ dy [n, cout] (no autograd)."""
+    n, cin = x.shape
+    cout = dy.shape[1]
+    dk = torch.zeros(cin, cout, dtype=torch.float32, device=x.device)
+    ev = _prof_begin("wgrad1x1", 1, cin, cout, n)
+    _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), None, 0, _P(dk), n, 1, cin, cout,
+              _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
+    _prof_end(ev, "wgrad1x1", 1, cin, cout, n, int(n))
+    return dk
+
+
 class DenseLinearFunction(torch.autograd.Function):
     """y = x @ weight.T + bias with nn.Linear's parameter layout (weight [out, in]) on this library's own MFMA kernels
     (the identity-map convolution kernels of csrc/spconv.hip), in the operand precision of ``CONV_PRECISION``: the shared

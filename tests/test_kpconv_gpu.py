@@ -51,6 +51,55 @@ def test_kpconv_layer_matches_reference(device, g):
     assert rel(y64, g["L_y"]) < RTOL
 
 
+def _is_symmetric(nb, ns):
+    pairs = {(i, int(j)) for i, row in enumerate(nb) for j in row if j < ns}
+    return all((j, i) in pairs for i, j in pairs)
+
+
+def test_kpconv_symmetric_backward(device, g):
+    """A layer on ONE point set with a symmetric neighbour relation runs its backward without the scatter (the forward
+    gather on dy with mirrored kernel points): same gradients as the reference's, and as the scatter form's."""
+    from dpcr_agb_amd.backbones.kpconv import KPConv
+    from dpcr_agb_amd.kpconv_ops import KPConvSymmetricFunction
+    assert _is_symmetric(g["neighbors0"], len(g["points0"]))      # the reference's own radius search, uncropped
+    cin, cout = 16, 12
+    rng = np.random.default_rng(5)
+    conv = KPConv(15, 3, cin, cout, float(g["L_ext"]), 0.08).to(device)
+    with torch.no_grad():
+        conv.kernel_points.copy_(D(g["L_kp"], device))
+    assert KPConvSymmetricFunction.supported(15, cin, cout)
+    pts = D(g["points0"], device)
+    xs = rng.standard_normal((len(g["points0"]), cin)).astype(np.float32)
+    gy = rng.standard_normal((len(g["points0"]), cout)).astype(np.float32)
+    res = {}
+    for sym in (False, True):
+        idx = D(g["neighbors0"], device)
+        idx.agb_symmetric = sym
+        calls = []
+        from dpcr_agb_amd import _lib
+        orig = _lib.call
+        _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            conv.zero_grad()
+            x = D(xs, device, True)
+            y = conv(pts, pts, idx, x)
+            y.backward(D(gy, device))
+        finally:
+            _lib.call = orig
+        assert ("agb_kpconv_gather_bwd" in calls) == (not sym), calls
+        res[sym] = (y.detach(), x.grad.clone(), conv.weights.grad.clone())
+    # fp64 evaluation of the reference formula
+    xr = torch.from_numpy(xs).double().requires_grad_(True)
+    wr = conv.weights.detach().cpu().double().requires_grad_(True)
+    yr = R.kpconv(torch.from_numpy(g["points0"]).double(), torch.from_numpy(g["points0"]).double(),
+                  torch.from_numpy(g["neighbors0"]).long(), xr, torch.from_numpy(g["L_kp"]).double(), wr, float(g["L_ext"]))
+    yr.backward(torch.from_numpy(gy).double())
+    for sym in (False, True):
+        assert rel(res[sym][0], yr) < RTOL
+        assert rel(res[sym][1], xr.grad) < RTOL, sym
+        assert rel(res[sym][2], wr.grad) < RTOL, sym
+
+
 def test_pool_helpers_match_reference(device, g):
     from dpcr_agb_amd.backbones.kpconv import GlobalSumBlock
     from dpcr_agb_amd.kpconv_ops import KPMaxPoolFunction
@@ -150,6 +199,24 @@ def test_input_pyramid_and_network_vs_oracle(device):
                 batch_norm_momentum=cfg.batch_norm_momentum)
     ref = R.kpcnn_forward(sd, ocfg, ob, training=True)
     assert rel(out, ref) < RTOL
+    # every self-search of the pyramid is marked symmetric (and is); the scatter-free backward they select gives the
+    # same parameter gradients as the scatter form
+    for lvl, nb in enumerate(inp["neighbors"]):
+        assert nb.agb_symmetric
+        if lvl >= 3:
+            assert _is_symmetric(nb.cpu().numpy(), len(inp["points"][lvl]))
+    grads = {}
+    gy = torch.randn_like(out)
+    for sym in (True, False):
+        for nb in inp["neighbors"]:
+            nb.agb_symmetric = sym
+        model.model.zero_grad()
+        model.model(O(inp)).backward(gy)
+        grads[sym] = {k: p.grad.clone() for k, p in model.model.named_parameters() if p.grad is not None}
+    gmax = max(float(v.abs().max()) for v in grads[False].values())
+    for k, v in grads[False].items():
+        err = float((grads[True][k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gmax)
+        assert err < RTOL, (k, err)
 
 
 def test_kpconv_training_step(device):

@@ -90,6 +90,29 @@ def wgrad_call_cost(args):
     return 2.0 * n * cin * cout, (n * (cin + cout) + K3 * cin * cout) * 4.0
 
 
+def shape_table(groups):
+    """Per distinct (rows, Cin, Cout) of the dense products and weight gradients: time, TFLOP/s and GB/s of 3 steps."""
+    for name, cost, sig in (("agb_spconv_fwd_opt", conv_call_cost, lambda x: (x[9], (x[10], x[11], x[12]))),
+                            ("agb_spconv_bwd_weight_lp", wgrad_call_cost, lambda x: (x[7], (x[8], x[9], x[10]))),
+                            ("agb_kpconv_gather_fwd", None, lambda x: (x[11], (x[12],))),
+                            ("agb_kpconv_gather_bwd", None, lambda x: (x[11], (x[12],)))):
+        if name not in groups:
+            continue
+        acc = {}
+        for args, ms in groups[name]["calls"]:
+            rows, key = sig(args)
+            key = (len(str(rows)),) + key              # (row counts differ a little from batch to batch: group by magnitude)
+            e = acc.setdefault(key, [0.0, 0, 0.0, 0.0, 0])
+            e[0] += ms; e[1] += 1; e[4] += rows
+            if cost:
+                fl, by = cost(args)
+                e[2] += fl; e[3] += by
+        log(f"--- {name}: mean rows, (K3, Cin, Cout | Cin) -> ms per step, calls per step, TFLOP/s, GB/s")
+        for k, (ms, n, fl, by, rows) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
+            log(f"    {rows // n:8d} {str(k[1:]):18s}: {ms / 3:8.3f} ms {n / 3:5.1f} calls  {fl / ms / 1e9 if fl else 0:7.1f} TF"
+                f"  {by / ms / 1e6 if by else 0:7.0f} GB/s")
+
+
 def roofline_entry(name, g, cost):
     flops = sum(cost(a)[0] for a, _ in g["calls"])
     byts = sum(cost(a)[1] for a, _ in g["calls"])
@@ -237,6 +260,8 @@ def run_kpconv(a):
             model.optimize_parameters(epoch=0, batch_size=B, num_batches=133)
     groups = ct.by_name()
     top_table(groups, 12)
+    if a.shapes:
+        shape_table(groups)
     costs = {"agb_ball_query_fill": ballquery_cost, "agb_spconv_fwd_opt": conv_call_cost,
              "agb_spconv_bwd_weight_lp": wgrad_call_cost}
     dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
@@ -270,6 +295,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--points", type=int, default=16000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="per-shape table of the dense products / gathers")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device")
