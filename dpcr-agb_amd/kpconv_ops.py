@@ -79,6 +79,8 @@ class KPConvSymmetricFunction(torch.autograd.Function):
         K, cin, cout = weights.shape
         wf = _gather(x, pts, pts, idx, kernel_points, extent).view(-1, K * cin)
         out = dense_product(wf, weights.reshape(K * cin, cout))
+        # (by the same symmetry dW[k,c,o] = sum_j x[j,c] wfd[j,k,o] with the mirrored gather of dy, which would let the
+        # backward keep x instead of the 15x larger wf; measured 0.1 ms/step slower in the [N,16]^T [N,240] product shape)
         ctx.save_for_backward(wf, pts, idx, kernel_points, weights)
         ctx.extent = float(extent)
         return out
