@@ -11,24 +11,43 @@
 // pre-activation from the saved conv output instead of storing it.
 #include "agb_common.h"
 
-// block = 256 threads = 16 row lanes x 16 column groups of 4 channels (one 64-channel slab, 16 rows / pass)
+// block = 256 threads = RL row lanes x CGS column groups of 4 channels.  64 channels and more: 16 x 16 (one 64-channel
+// slab, 16 rows per pass).  Narrower matrices (the 16/32-channel levels of KPConv and of the sparse stem) would leave 3/4
+// or 1/2 of those threads without a column: they take CGS = C/4 groups and 256/CGS row lanes instead (1.2-1.5 TB/s ->
+// see DESIGN.md section 5 for the figures).
 #define NB_ROWS 16
+struct BnLanes {
+    int cgs, rl_n;     // column groups per block, row lanes in use
+    int cg, rl;        // this thread's; rl >= rl_n: idle (CGS does not divide 256)
+};
+__device__ __forceinline__ BnLanes bn_lanes(int C) {
+    BnLanes L;
+    L.cgs = C >= 64 ? 16 : (C >> 2);
+    L.rl_n = 256 / L.cgs;
+    L.cg = threadIdx.x % L.cgs;
+    L.rl = threadIdx.x / L.cgs;
+    return L;
+}
+static inline int bn_slab(int C) { return C >= 64 ? 64 : C; }              // channels per workgroup
+static inline int bn_row_lanes(int C) { return C >= 64 ? 16 : 256 / (C >> 2); }
 
 // ---------------------------------------------------------------- statistics
 // grid (chunks, ceil(C/64)); part[chunk][3][C] = (count, mean, M2) of the chunk's rows
 __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ X, int ldx, int n, int C,
                                                           int rows_per_chunk, float* __restrict__ part) {
-    __shared__ float s_mean[NB_ROWS][64];
-    __shared__ float s_m2[NB_ROWS][64];
-    __shared__ float s_cnt[NB_ROWS];
-    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.y * 64 + cg * 4;
+    __shared__ float s_mean[1024];         // [row lane][slab channel]
+    __shared__ float s_m2[1024];
+    __shared__ float s_cnt[256];
+    const BnLanes L = bn_lanes(C);
+    const int cg = L.cg, rl = L.rl, slab = L.cgs * 4;
+    const int c = blockIdx.y * slab + cg * 4;
     const int r_beg = blockIdx.x * rows_per_chunk;
     const int r_end = min(n, r_beg + rows_per_chunk);
     float mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
     float cnt = 0.f;
-    if (c < C) {
-        for (int r = r_beg + rl; r < r_end; r += NB_ROWS) {
+    if (rl >= L.rl_n) {
+    } else if (c < C) {
+        for (int r = r_beg + rl; r < r_end; r += L.rl_n) {
             float4 v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
             cnt += 1.f;
             float inv = 1.f / cnt;
@@ -41,22 +60,24 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
             }
         }
     } else {
-        for (int r = r_beg + rl; r < r_end; r += NB_ROWS) cnt += 1.f;
+        for (int r = r_beg + rl; r < r_end; r += L.rl_n) cnt += 1.f;
     }
+    if (rl < L.rl_n) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s_mean[rl][cg * 4 + j] = mean[j];
-        s_m2[rl][cg * 4 + j] = m2[j];
+        for (int j = 0; j < 4; ++j) {
+            s_mean[rl * slab + cg * 4 + j] = mean[j];
+            s_m2[rl * slab + cg * 4 + j] = m2[j];
+        }
+        if (cg == 0) s_cnt[rl] = cnt;
     }
-    if (cg == 0) s_cnt[rl] = cnt;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        int cc = blockIdx.y * 64 + threadIdx.x;
+    if (threadIdx.x < slab) {
+        int cc = blockIdx.y * slab + threadIdx.x;
         float na = 0.f, ma = 0.f, qa = 0.f;
-        for (int j = 0; j < NB_ROWS; ++j) {  // fixed order
+        for (int j = 0; j < L.rl_n; ++j) {  // fixed order
             float nb = s_cnt[j];
             if (nb == 0.f) continue;
-            float mb = s_mean[j][threadIdx.x], qb = s_m2[j][threadIdx.x];
+            float mb = s_mean[j * slab + threadIdx.x], qb = s_m2[j * slab + threadIdx.x];
             float nt = na + nb, d = mb - ma;
             ma += d * (nb / nt);
             qa += qb + d * d * (na * nb / nt);
@@ -156,27 +177,29 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
 // thread keeps the per-channel parameters of its 4 channels in registers and streams EW_ROWS/16 rows (independent
 // 16-B loads in flight) — no per-element 64-bit index division, no per-element parameter reloads.
 #define EW_ROWS 128
+#define EW_PER (EW_ROWS / 16)      // rows per thread of the BatchNorm element-wise kernels
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ X, int ldx, int n, int C,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     int act, float* __restrict__ Y, int ldy) {
-    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.y * 64 + cg * 4;
-    if (c >= C) return;
+    const BnLanes L = bn_lanes(C);
+    const int cg = L.cg, rl = L.rl;
+    const int c = blockIdx.y * (L.cgs * 4) + cg * 4;
+    if (c >= C || rl >= L.rl_n) return;
     const float4 m = *reinterpret_cast<const float4*>(mean + c);
     const float4 s = *reinterpret_cast<const float4*>(rstd + c);
     const float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 b = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int r0 = blockIdx.x * EW_ROWS + rl;
-    float4 v[EW_ROWS / 16];
+    const int r0 = blockIdx.x * (EW_PER * L.rl_n) + rl;
+    float4 v[EW_PER];
 #pragma unroll
-    for (int j = 0; j < EW_ROWS / 16; ++j) {
-        const int r = r0 + 16 * j;
+    for (int j = 0; j < EW_PER; ++j) {
+        const int r = r0 + L.rl_n * j;
         if (r < n) v[j] = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
     }
 #pragma unroll
-    for (int j = 0; j < EW_ROWS / 16; ++j) {
-        const int r = r0 + 16 * j;
+    for (int j = 0; j < EW_PER; ++j) {
+        const int r = r0 + L.rl_n * j;
         if (r >= n) continue;
         float4 o;
         o.x = act_fwd((v[j].x - m.x) * s.x * g.x + b.x, act);
@@ -196,14 +219,15 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int act,
                                                             float* __restrict__ part) {
-    __shared__ float s_a[NB_ROWS][64];
-    __shared__ float s_b[NB_ROWS][64];
-    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.y * 64 + cg * 4;
+    __shared__ float s_a[1024];
+    __shared__ float s_b[1024];
+    const BnLanes L = bn_lanes(C);
+    const int cg = L.cg, rl = L.rl, slab = L.cgs * 4;
+    const int c = blockIdx.y * slab + cg * 4;
     const int r_beg = blockIdx.x * rows_per_chunk;
     const int r_end = min(n, r_beg + rows_per_chunk);
     float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < C) {
+    if (c < C && rl < L.rl_n) {
         float m[4], s[4], g[4], b[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -212,7 +236,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
             g[j] = gamma ? gamma[c + j] : 1.f;
             b[j] = beta ? beta[c + j] : 0.f;
         }
-        for (int r = r_beg + rl; r < r_end; r += NB_ROWS) {
+        for (int r = r_beg + rl; r < r_end; r += L.rl_n) {
             float4 xv = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
             float4 dv = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
             float x[4] = {xv.x, xv.y, xv.z, xv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -225,18 +249,20 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
             }
         }
     }
+    if (rl < L.rl_n) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s_a[rl][cg * 4 + j] = sa[j];
-        s_b[rl][cg * 4 + j] = sb[j];
+        for (int j = 0; j < 4; ++j) {
+            s_a[rl * slab + cg * 4 + j] = sa[j];
+            s_b[rl * slab + cg * 4 + j] = sb[j];
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-        int cc = blockIdx.y * 64 + threadIdx.x;
+    if (threadIdx.x < slab) {
+        int cc = blockIdx.y * slab + threadIdx.x;
         float a = 0.f, b = 0.f;
-        for (int j = 0; j < NB_ROWS; ++j) {
-            a += s_a[j][threadIdx.x];
-            b += s_b[j][threadIdx.x];
+        for (int j = 0; j < L.rl_n; ++j) {
+            a += s_a[j * slab + threadIdx.x];
+            b += s_b[j * slab + threadIdx.x];
         }
         if (cc < C) {
             float* p = part + (long long)blockIdx.x * 2 * C;
@@ -303,8 +329,10 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restric
                                                           int act, const float* __restrict__ dbeta,
                                                           const float* __restrict__ dgamma, int training,
                                                           float* __restrict__ dX, int lddx) {
-    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = min(blockIdx.y * 64 + cg * 4, C - 4);   // a partial last slab recomputes its last group (C % 4 == 0)
+    const BnLanes L = bn_lanes(C);
+    const int cg = L.cg, rl = L.rl;
+    if (rl >= L.rl_n) return;
+    const int c = min(blockIdx.y * (L.cgs * 4) + cg * 4, C - 4);   // a partial last slab recomputes its last group (C % 4 == 0)
     float m[4], s[4], g[4], b[4], db[4], dg[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -316,14 +344,14 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restric
         dg[j] = dgamma[c + j];
     }
     const float inv_n = training ? 1.f / (float)n : 0.f;
-    const int r0 = blockIdx.x * EW_ROWS + rl;
-    constexpr int NR = EW_ROWS / 16, HALF = NR / 2;
+    const int r0 = blockIdx.x * (EW_PER * L.rl_n) + rl;
+    constexpr int NR = EW_PER, HALF = NR / 2;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float4 xv[HALF], dv[HALF];
 #pragma unroll
         for (int j = 0; j < HALF; ++j) {
-            const int r = r0 + 16 * (h * HALF + j);
+            const int r = r0 + L.rl_n * (h * HALF + j);
             if (r < n) {
                 xv[j] = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
                 dv[j] = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
@@ -331,7 +359,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restric
         }
 #pragma unroll
         for (int j = 0; j < HALF; ++j) {
-            const int r = r0 + 16 * (h * HALF + j);
+            const int r = r0 + L.rl_n * (h * HALF + j);
             if (r >= n) continue;
             const float x[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, d[4] = {dv[j].x, dv[j].y, dv[j].z, dv[j].w};
             float o[4];
@@ -435,6 +463,13 @@ int agb_bn_chunks(int n) {
 
 static int rows_per_chunk(int n, int chunks) { return agb_cdiv(n > 0 ? n : 1, chunks); }
 
+// chunks actually used (<= agb_bn_chunks(n), which sizes the callers' scratch): every row lane of a workgroup gets at
+// least 8 rows, so the narrow layouts (32 / 64 row lanes) do not pay their longer in-block fold for two rows each
+static int bn_chunks_for(int n, int C) {
+    const int cap = agb_bn_chunks(n), want = agb_cdiv(n > 0 ? n : 1, 8 * bn_row_lanes(C));
+    return want < cap ? want : cap;
+}
+
 // training != 0: batch statistics of X (and running-stat update if the pointers are given); else mean/rstd from the
 // running statistics.  part: float[agb_bn_chunks(n) * 3 * C] scratch.  mean, rstd: float[C] out.
 // num_batches_tracked: the layer's int64 counter (device), incremented by the fold kernel in training mode; or NULL.
@@ -448,8 +483,8 @@ int agb_bn_stats_tracked(const float* X, int ldx, int n, int C, float eps, float
         hipLaunchKernelGGL(k_bn_eval_stats, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, C, eps,
                            mean, rstd);
     } else {
-        int chunks = agb_bn_chunks(n);
-        hipLaunchKernelGGL(k_bn_stats_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, n, C,
+        int chunks = bn_chunks_for(n, C);
+        hipLaunchKernelGGL(k_bn_stats_partial, dim3(chunks, agb_cdiv(C, bn_slab(C))), dim3(256), 0, s, X, ldx, n, C,
                            rows_per_chunk(n, chunks), part);
         hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, eps, momentum,
                            mean, rstd, running_mean, running_var, num_batches_tracked);
@@ -469,7 +504,8 @@ int agb_bn_act_fwd(const float* X, int ldx, int n, int C, const float* mean, con
     AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_bn_act_fwd: C/ld must be multiples of 4");
     AGB_CHECK_ARG(act >= 0 && act <= 2, "agb_bn_act_fwd: activation %d", act);
     if (n == 0) return AGB_OK;
-    hipLaunchKernelGGL(k_bn_act_fwd, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, X,
+    hipLaunchKernelGGL(k_bn_act_fwd, dim3(agb_cdiv(n, EW_PER * bn_row_lanes(C)), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
+                       (hipStream_t)stream, X,
                        ldx, n, C, mean, rstd, gamma, beta, act, Y, ldy);
     AGB_CHECK_LAUNCH("agb_bn_act_fwd");
     return AGB_OK;
@@ -485,13 +521,15 @@ int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int
                   "agb_bn_act_bwd: C/ld must be multiples of 4");
     AGB_CHECK_ARG(colsum == nullptr || dX != nullptr, "agb_bn_act_bwd: colsum needs dX");
     hipStream_t s = (hipStream_t)stream;
-    int chunks = agb_bn_chunks(n);
-    hipLaunchKernelGGL(k_bn_act_bwd_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY, ldy, n, C,
+    int chunks = bn_chunks_for(n, C);
+    hipLaunchKernelGGL(k_bn_act_bwd_partial, dim3(chunks, agb_cdiv(C, bn_slab(C))), dim3(256), 0, s, X, ldx, dY, ldy, n,
+                       C,
                        rows_per_chunk(n, chunks), mean, rstd, gamma, beta, act, part);
     hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, dbeta, dgamma, colsum,
                        gamma, rstd, training);
     if (n > 0 && dX) {
-        hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, s, X, ldx, dY,
+        hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(n, EW_PER * bn_row_lanes(C)), agb_cdiv(C, bn_slab(C))),
+                           dim3(256), 0, s, X, ldx, dY,
                            ldy, n, C, mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx);
     }
     AGB_CHECK_LAUNCH("agb_bn_act_bwd");

@@ -15,7 +15,9 @@ def rel(a, b):
 ACTS = {"none": lambda z: z, "relu": F.relu, "gelu": F.gelu}
 
 
-@pytest.mark.parametrize("n,c", [(1, 64), (37, 4), (5000, 64), (70001, 128), (333, 1024), (300017, 64)])
+@pytest.mark.parametrize("n,c", [(1, 64), (37, 4), (5000, 64), (70001, 128), (333, 1024), (300017, 64),
+                                 # narrower than one 64-channel slab: the threads regroup (csrc/norm.hip: bn_lanes)
+                                 (50021, 16), (40003, 32), (9001, 48), (777, 12), (200, 8)])
 @pytest.mark.parametrize("act", ["none", "relu", "gelu"])
 def test_bn_act_training(device, n, c, act):
     from dpcr_agb_amd.norm_ops import batch_norm_act

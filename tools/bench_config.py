@@ -94,6 +94,9 @@ def shape_table(groups):
     """Per distinct (rows, Cin, Cout) of the dense products and weight gradients: time, TFLOP/s and GB/s of 3 steps."""
     for name, cost, sig in (("agb_spconv_fwd_opt", conv_call_cost, lambda x: (x[9], (x[10], x[11], x[12]))),
                             ("agb_spconv_bwd_weight_lp", wgrad_call_cost, lambda x: (x[7], (x[8], x[9], x[10]))),
+                            ("agb_bn_stats_tracked", lambda x: (0.0, x[2] * x[3] * 4.0), lambda x: (x[2], (x[3],))),
+                            ("agb_bn_act_fwd", lambda x: (0.0, 2.0 * x[2] * x[3] * 4.0), lambda x: (x[2], (x[3],))),
+                            ("agb_bn_act_bwd_colsum", lambda x: (0.0, 3.0 * x[4] * x[5] * 4.0), lambda x: (x[4], (x[5],))),
                             ("agb_kpconv_gather_fwd", None, lambda x: (x[11], (x[12],))),
                             ("agb_kpconv_gather_bwd", None, lambda x: (x[11], (x[12],)))):
         if name not in groups:
