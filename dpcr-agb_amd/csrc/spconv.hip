@@ -1668,6 +1668,19 @@ int agb_spconv_split_hint_opt(int n_out, int K3, int Cin, int Cout, int cmp_mode
     return (int)(s < 1 ? 1 : s);
 }
 
+// The same for the identity map (nbr == NULL: a dense [n, Cin] x [Cin, Cout] product): the reduction dimension is split
+// over workgroups when the output tiles alone leave most of the chip idle and Cin is long enough to pay for the partial
+// buffer (KPConv's deepest level: 2860 rows x 3840 -> 256 is 92 tiles of a 256-CU chip; 0.19 -> 0.07 ms with 8 splits).
+int agb_dense_split_hint(int n_out, int Cin, int Cout) {
+    if (Cin < 512 || n_out <= 0) return 1;
+    long long tiles = (long long)agb_cdiv(n_out, conv_tile_rows(n_out, Cin, Cout)) * agb_cdiv(Cout, BN);
+    if (tiles >= 512) return 1;
+    long long s = (1024 + tiles - 1) / tiles, cap = Cin / 128;      // at least 128 input channels per split
+    if (s > 8) s = 8;
+    if (s > cap) s = cap;
+    return (int)(s < 1 ? 1 : s);
+}
+
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
     return agb_spconv_split_hint_opt(n_out, K3, Cin, Cout, 1);
 }

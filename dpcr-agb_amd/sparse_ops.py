@@ -41,6 +41,7 @@ _lib.declare("agb_spconv_fwd_opt", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _l
                                     _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
                                     _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p])
 _lib.declare("agb_spconv_split_hint_opt", [_lib.c_int] * 5)
+_lib.declare("agb_dense_split_hint", [_lib.c_int] * 3)
 _lib.declare("agb_spconv_bwd_weight_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
                                           _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                           _lib.c_void_p])
@@ -112,8 +113,12 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
     w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes."""
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
-    split = _lib.load().agb_spconv_split_hint_opt(n_out, K3, cin, cout, CMP_MODE) if (plan is None and nbr is not None) \
-        else 1
+    if plan is not None:
+        split = 1
+    elif nbr is not None:
+        split = _lib.load().agb_spconv_split_hint_opt(n_out, K3, cin, cout, CMP_MODE)
+    else:
+        split = _lib.load().agb_dense_split_hint(n_out, cin, cout)
     partial = torch.empty(split, n_out, cout, dtype=torch.float32, device=x.device) if split > 1 else None
     perm = tile_cls = cls_tab = None
     n_tiles = 0

@@ -106,6 +106,8 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                       float* partial, void* stream);
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper (automatic kernel choice) */
+/* the same for the identity map (nbr == NULL, a dense product): splits of the reduction dimension Cin */
+int agb_dense_split_hint(int n_out, int Cin, int Cout);
 /* The same product with the kernel choice as per-call arguments (the library keeps no tuning state):
  * cmp_mode: 1 = automatic (the pair-compacted LDS-accumulating kernel for many-row layers with Cin % 64 == 0, the
  * register-accumulator kernels otherwise; what agb_spconv_fwd / _ex use), 0 = never the pair-compacted kernel,

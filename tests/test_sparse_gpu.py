@@ -595,7 +595,9 @@ def test_conv_low_precision_operands(device, precision, tol, cin, cout, K, strid
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 2e-2), ("bf16x3", 1e-4)])
 @pytest.mark.parametrize("cin,cout,n", [(64, 256, 5000), (256, 64, 3001), (128, 512, 700), (512, 2048, 90), (16, 12, 333),
-                                        (96, 80, 1)])
+                                        (96, 80, 1),
+                                        # few rows, long reduction: split over workgroups (agb_dense_split_hint > 1)
+                                        (3840, 256, 2861), (1024, 256, 300), (640, 16, 77)])
 def test_dense_1x1_conv(device, precision, tol, cin, cout, n):
     """1x1 stride-1 convolutions (ME's use_mm case; two thirds of SENet50's layers) run on this library's own kernels
     with the identity map: forward, data gradient, weight gradient and bias gradient vs fp64, in all operand modes."""
@@ -603,6 +605,9 @@ def test_dense_1x1_conv(device, precision, tol, cin, cout, n):
     from dpcr_agb_amd import sparse_ops
     from dpcr_agb_amd.sparse_ops import DenseConvFunction
     torch.manual_seed(cin + cout + n)
+    if cin >= 640:
+        from dpcr_agb_amd import _lib
+        assert _lib.load().agb_dense_split_hint(n, cin, cout) > 1
     conv = ME.MinkowskiConvolution(cin, cout, kernel_size=1, stride=1, bias=True, dimension=3).to(device)
     assert conv.use_mm and conv.kernel.shape == (cin, cout) and DenseConvFunction.supported(cin, cout)
     x = torch.randn(n, cin)
