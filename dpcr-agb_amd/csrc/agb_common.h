@@ -40,6 +40,14 @@ void agb_set_error(const char* fmt, ...);
 
 static inline int agb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// dense_stream.hip: HBM-bound dense products (many rows, small weight matrix), taken from the identity-map entry points
+bool agb_dense_stream_ok(int n, int Cin, int Cout);
+bool agb_dense_stream_wgrad_ok(int n, int Cin, int Cout);
+int agb_dense_stream_launch(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int n, int Cin,
+                            int Cout, hipStream_t st);
+int agb_dense_stream_wgrad_launch(const float* X, int ldx, const float* dY, int ldy, float* dW, int n, int Cin, int Cout,
+                                  hipStream_t st);
+
 // ---- coordinate key packing -------------------------------------------------
 // [b | z | y | x], 16 bits each, spatial components biased by 32768 so that
 // negative voxel coordinates (ME allows them) order correctly.

@@ -1704,6 +1704,13 @@ int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* n
     AGB_CHECK_ARG(perm == nullptr || (tile_cls != nullptr && cls_tab != nullptr && n_tiles > 0),
                   "agb_spconv_fwd_ex: perm needs tile_cls, cls_tab and n_tiles");
     if (n_out == 0) return AGB_OK;
+    // HBM-bound dense products (many rows, a weight matrix that fits LDS): the streaming kernels of dense_stream.hip
+    if (nbr == nullptr && ksplit == 1 && agb_dense_stream_ok(n_out, Cin, Cout)) {
+        int rc = agb_dense_stream_launch(X, ldx, W, bias, Y, ldy, n_out, Cin, Cout, (hipStream_t)stream);
+        if (rc) return rc;
+        AGB_CHECK_LAUNCH("agb_spconv_fwd (dense, streaming)");
+        return AGB_OK;
+    }
     ConvArgs a{X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit,
                partial, cmp_mode, cmp_interleave_shift};
     int rc = launch_conv(a, n_tiles, (hipStream_t)stream);
@@ -1807,6 +1814,12 @@ int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, 
                   "agb_spconv_bwd_weight: Cin (%d), Cout (%d), ldx, ldy must be multiples of 4", Cin, Cout);
     if (n_out == 0) return AGB_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (nbr == nullptr && precision == 0 && agb_dense_stream_wgrad_ok(n_out, Cin, Cout)) {
+        int rc = agb_dense_stream_wgrad_launch(X, ldx, dY, ldy, dW, n_out, Cin, Cout, s);
+        if (rc) return rc;
+        AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (dense, streaming)");
+        return AGB_OK;
+    }
     int m_tiles, cin_tiles = 1;
     if (Cin == 4 || Cin == 8) {
         m_tiles = agb_cdiv(K3, 64 / Cin);

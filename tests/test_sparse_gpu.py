@@ -630,6 +630,31 @@ def test_dense_1x1_conv(device, precision, tol, cin, cout, n):
     assert rel_err(conv.bias.grad, br.grad) < RTOL
 
 
+@pytest.mark.parametrize("cin,cout,n", [(240, 16, 40001), (480, 32, 20000), (16, 240, 33333), (32, 480, 17000),
+                                        (32, 128, 50000), (128, 32, 16384), (64, 16, 30011), (16, 64, 70000),
+                                        (48, 32, 25000), (64, 64, 16400), (16, 12, 20000), (1008, 12, 16385)])
+def test_dense_streaming_products(device, cin, cout, n):
+    """Many rows x a small weight matrix (KPConv's first levels, the narrow front of the point MLP): the identity-map
+    entry points hand these HBM-bound products to the streaming kernels of csrc/dense_stream.hip — forward, data gradient
+    (the transposed shape) and weight gradient vs fp64, bias included; ragged last row block."""
+    from dpcr_agb_amd.sparse_ops import DenseConvFunction
+    torch.manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin)
+    w = torch.randn(cin, cout) / cin ** 0.5
+    b = torch.randn(cout)
+    g = torch.randn(n, cout)
+    xg, wg, bg = (t.to(device).requires_grad_(True) for t in (x, w, b))
+    out = DenseConvFunction.apply(xg, wg, bg)
+    out.backward(g.to(device))
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    outr = xr @ wr + br
+    outr.backward(g.double())
+    assert rel_err(out, outr) < RTOL
+    assert rel_err(xg.grad, xr.grad) < RTOL
+    assert rel_err(wg.grad, wr.grad) < RTOL
+    assert rel_err(bg.grad, br.grad) < RTOL
+
+
 @pytest.mark.parametrize("precision,out_tol,grad_tol,cos_tol", [("bf16", 3e-2, 0.5, 2e-2), ("bf16x3", 1e-4, 1e-3, 1e-7)])
 def test_senet50_low_precision_matches_oracle(device, precision, out_tol, grad_tol, cos_tol):
     """BASELINE config 5's single-GPU leg: MSENet50 (SEBottleneck x (3,4,6,3), two targets) with bf16 operands / fp32
