@@ -32,17 +32,21 @@
 // read+add+write: 14.6 — tools/micro/lds_atomic_bench.hip), so the LDS pipe became the bound.
 typedef float kp_f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float kp_influence(float rx, float ry, float rz, float kx, float ky, float kz, float ext) {
+// max(0, 1 - |rel - kp| / extent) (blocks.py:339-350).  `inv_ext` = 1 / extent: the quotient becomes one multiply-add
+// and the root one v_sqrt_f32 (1 ulp) instead of the ~18 instructions of IEEE division + correctly rounded sqrtf — this
+// function is evaluated once per (neighbour, kernel point) and was a third of the gather's instructions.  The
+// influence moves by < 2e-7 absolute (outputs: 1e-4 bar of the parity tests, floor re-measured in DESIGN.md section 3).
+__device__ __forceinline__ float kp_influence(float rx, float ry, float rz, float kx, float ky, float kz, float inv_ext) {
     const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
-    const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
-    return fmaxf(1.f - d / ext, 0.f);
+    const float d = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    return fmaxf(fmaf(-d, inv_ext, 1.f), 0.f);
 }
 
 template <int NC>
 __global__ __launch_bounds__(256) void k_kpconv_gather_mm_fwd(const float* __restrict__ q, const float* __restrict__ s,
                                                               const int32_t* __restrict__ idx, int H, int Ns,
                                                               const float* __restrict__ x, int ldx,
-                                                              const float* __restrict__ kp, int K, float ext,
+                                                              const float* __restrict__ kp, int K, float inv_ext,
                                                               float* __restrict__ wf, int N, int Cin, int chunks) {
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void k_kpconv_gather_mm_fwd(const float* __res
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float a = (live[u] && m < K) ? kp_influence(rx[u], ry[u], rz[u], kx, ky, kz, ext) : 0.f;
+                const float a = (live[u] && m < K) ? kp_influence(rx[u], ry[u], rz[u], kx, ky, kz, inv_ext) : 0.f;
 #pragma unroll
                 for (int t = 0; t < NC; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[u][t], acc[t], 0, 0, 0);
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void k_kpconv_gather_mm_fwd(const float* __res
 template <int NC>
 __global__ __launch_bounds__(256) void k_kpconv_gather_mm_bwd(const float* __restrict__ q, const float* __restrict__ s,
                                                               const int32_t* __restrict__ idx, int H, int Ns,
-                                                              const float* __restrict__ kp, int K, float ext,
+                                                              const float* __restrict__ kp, int K, float inv_ext,
                                                               const float* __restrict__ dwf, float* __restrict__ dx,
                                                               int ldx, int N, int Cin, int chunks) {
     const int lane = threadIdx.x & 63;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void k_kpconv_gather_mm_bwd(const float* __res
             float a[4];
 #pragma unroll
             for (int st = 0; st < 4; ++st)
-                a[st] = (live && 4 * st + g < K) ? kp_influence(rx, ry, rz, kx[st], ky[st], kz[st], ext) : 0.f;
+                a[st] = (live && 4 * st + g < K) ? kp_influence(rx, ry, rz, kx[st], ky[st], kz[st], inv_ext) : 0.f;
             int ido[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) ido[i] = __shfl(myid, 16 * b + 4 * g + i, 64);
@@ -232,13 +236,14 @@ static int launch_gather(const float* q, const float* s, const int32_t* idx, int
     // one wave per (row, chunk of 16*NC channels)
     const int nc = Cin <= 16 ? 1 : Cin <= 32 ? 2 : 4;
     const int chunks = agb_cdiv(Cin, 16 * nc);
+    const float inv_ext = 1.f / ext;
     const dim3 grid(agb_cdiv((long long)N * chunks, 4)), block(256);
 #define AGB_KP_MM(NC)                                                                                                 \
     do {                                                                                                              \
-        if (BWD) hipLaunchKernelGGL((k_kpconv_gather_mm_bwd<NC>), grid, block, 0, st, q, s, idx, H, Ns, kp, K, ext,   \
+        if (BWD) hipLaunchKernelGGL((k_kpconv_gather_mm_bwd<NC>), grid, block, 0, st, q, s, idx, H, Ns, kp, K, inv_ext, \
                                     dwf, dx, ldx, N, Cin, chunks);                                                    \
         else hipLaunchKernelGGL((k_kpconv_gather_mm_fwd<NC>), grid, block, 0, st, q, s, idx, H, Ns, x, ldx, kp, K,    \
-                                ext, wf, N, Cin, chunks);                                                             \
+                                inv_ext, wf, N, Cin, chunks);                                                         \
     } while (0)
     if (nc == 1) AGB_KP_MM(1);
     else if (nc == 2) AGB_KP_MM(2);
