@@ -115,3 +115,77 @@ def test_strided_conv_adjointness_and_pools(full, device):
     assert mp.F.shape[0] == cm.level(4).n and bool((mp.F == 1).all())
     xs = ME.SparseTensor(x.detach(), coordinate_map_key=ME.CoordinateMapKey(2), coordinate_manager=cm)
     assert bool((ME.MinkowskiGlobalMaxPooling()(xs).F >= ME.MinkowskiGlobalAvgPooling()(xs).F).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# KPConv path (BASELINE config 3) at 16 000-point plots: the CPU oracle needs seconds per PLOT for the index path and
+# minutes for the layers here, so the full-size checks are properties — symmetry of every self-search of the pyramid,
+# and the bilinear form <KPConv_W(x), g> seen from its three sides (forward, data gradient, weight gradient) in both
+# backward forms (atomic scatter / mirrored gather).
+@pytest.fixture(scope="module")
+def kp_full(device):
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import KPConvModel
+    np.random.seed(11)
+    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_016))
+    model = KPConvModel(Opt(MODEL_OPTIONS["KPConv"]), "kpconv", ds).to(device)
+    b = synthetic.make_point_batch(list(range(8)), n_points=16000)
+    lens = np.bincount(b.batch.numpy()).astype(np.int64)
+    return model, model.prepare_inputs(b.pos, b.x, lens, device), lens
+
+
+def test_kpconv_pyramid_symmetry_full_size(kp_full):
+    model, inp, lens = kp_full
+    assert len(inp["points"]) == 5 and inp["points"][0].shape[0] == int(lens.sum())
+    for lvl, (pts, nb) in enumerate(zip(inp["points"], inp["neighbors"])):
+        n, h = nb.shape
+        assert n == pts.shape[0] and nb.agb_symmetric
+        valid = nb < n
+        rows = torch.arange(n, device=nb.device).view(-1, 1).expand(n, h)
+        fwd = (rows[valid].long() * n + nb[valid].long()).sort().values
+        rev = (nb[valid].long() * n + rows[valid].long()).sort().values
+        assert torch.equal(fwd, rev), f"level {lvl}: the self-search is not symmetric"
+        # rows sorted by distance, padding (== n) only at the end, the point itself first
+        assert bool((valid[:, 1:] <= valid[:, :-1]).all())
+        assert torch.equal(nb[:, 0].long(), torch.arange(n, device=nb.device))
+        # batch elements do not mix
+        ptr = np.concatenate([[0], np.cumsum(inp["lengths"][lvl].numpy())])
+        elem = torch.from_numpy(np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))).to(nb.device)
+        assert bool((elem[nb.clamp(max=n - 1).long()][valid] == elem.view(-1, 1).expand(n, h)[valid]).all())
+
+
+@pytest.mark.parametrize("lvl,cin,cout", [(0, 16, 16), (1, 32, 32), (2, 64, 64)])
+def test_kpconv_bilinear_form_full_size(kp_full, device, lvl, cin, cout):
+    import dpcr_agb_amd.backbones.kpconv as KB
+    model, inp, _ = kp_full
+    pts, nb = inp["points"][lvl], inp["neighbors"][lvl]
+    n = pts.shape[0]
+    cfg = model.config
+    r = cfg.first_subsampling_dl * cfg.conv_radius * 2 ** lvl
+    conv = KB.KPConv(15, 3, cin, cout, r * cfg.KP_extent / cfg.conv_radius, r).to(device)
+    g = torch.Generator(device="cpu").manual_seed(lvl)
+    x1, x2 = (torch.randn(n, cin, generator=g).to(device) for _ in range(2))
+    gy = torch.randn(n, cout, generator=g).to(device)
+    res = {}
+    for form in ("scatter", "symmetric"):
+        nb.agb_symmetric = form == "symmetric"
+        conv.zero_grad()
+        x = x1.clone().requires_grad_(True)
+        y = conv(pts, pts, nb, x)
+        y.backward(gy)
+        res[form] = (y.detach(), x.grad, conv.weights.grad.clone())
+        # linear in x
+        with torch.no_grad():
+            y12 = conv(pts, pts, nb, 0.5 * x1 - 2.0 * x2)
+            y2 = conv(pts, pts, nb, x2)
+        assert float((y12 - (0.5 * y.detach() - 2.0 * y2)).abs().max()) < 1e-4 * float(y.detach().abs().max())
+        # <y, g> = <x, dx> = <W, dW>   (float64 sums of fp32 products)
+        form_y = float((y.detach().double() * gy.double()).sum())
+        form_x = float((x1.double() * x.grad.double()).sum())
+        form_w = float((conv.weights.detach().double() * conv.weights.grad.double()).sum())
+        scale = float((y.detach().double().abs() * gy.double().abs()).sum())
+        assert abs(form_y - form_x) < 1e-5 * scale and abs(form_y - form_w) < 1e-5 * scale, (form, form_y, form_x, form_w)
+    nb.agb_symmetric = True
+    for a, b in zip(res["scatter"], res["symmetric"]):
+        assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
