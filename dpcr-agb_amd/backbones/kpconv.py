@@ -20,7 +20,7 @@ from .. import _lib
 from ..kp_dispositions import kernel_disposition
 from ..kpconv_ops import KPConvSymmetricFunction, KPGatherFunction, KPMaxPoolFunction, as_index
 from ..norm_ops import ACT_IDS, AddActFunction, batch_norm_act
-from ..sparse_ops import DenseConvFunction, dense_linear, segment_reduce
+from ..sparse_ops import DenseConvFunction, dense_linear, segment_reduce, take_bn_hint
 
 ACTIVATION_NAMES = {"relu": "relu", "gelu": "gelu"}
 
@@ -52,12 +52,13 @@ class KPConv(nn.Module):
         # self-searches): the scatter-free backward
         if q_pts is s_pts and getattr(neighb_inds, "agb_symmetric", False) and x.is_cuda and \
                 KPConvSymmetricFunction.supported(self.K, self.in_channels, self.out_channels):
-            return KPConvSymmetricFunction.apply(x, q_pts, idx, self.kernel_points, self.KP_extent, self.weights)
+            return take_bn_hint(KPConvSymmetricFunction.apply(x, q_pts, idx, self.kernel_points, self.KP_extent,
+                                                              self.weights))
         wf = KPGatherFunction.apply(x, q_pts, s_pts, idx, self.kernel_points, self.KP_extent)
         # dense feature x kernel-weight contraction [N, K*Cin] @ [K*Cin, Cout] on the library's own MFMA kernels
         w2d = self.weights.view(-1, self.out_channels)
         if wf.is_cuda and DenseConvFunction.supported(w2d.shape[0], w2d.shape[1]):
-            return DenseConvFunction.apply(wf.view(wf.shape[0], -1), w2d, None)
+            return take_bn_hint(DenseConvFunction.apply(wf.view(wf.shape[0], -1), w2d, None))
         # odd widths (the 3-feature input layer: K * Cin = 45): the zero-padding Linear form of the same kernels
         return dense_linear(wf.view(wf.shape[0], -1), w2d.t().contiguous())
 

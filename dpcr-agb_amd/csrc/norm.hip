@@ -493,6 +493,17 @@ int agb_bn_stats_tracked(const float* X, int ldx, int n, int C, float eps, float
     return AGB_OK;
 }
 
+// The second half of agb_bn_stats_tracked on partials produced elsewhere (agb_dense_fwd_bn: the epilogue of the product
+// that wrote X): part float[chunks][3][C] = (count, mean, M2) per chunk and column.
+int agb_bn_stats_fold(const float* part, int chunks, int C, float eps, float momentum, float* mean, float* rstd,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, void* stream) {
+    AGB_CHECK_ARG(part != nullptr && chunks >= 1 && C >= 1, "agb_bn_stats_fold: %d chunks, %d columns", chunks, C);
+    hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, (hipStream_t)stream, part, chunks, C,
+                       eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
+    AGB_CHECK_LAUNCH("agb_bn_stats_fold");
+    return AGB_OK;
+}
+
 int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
                  float* mean, float* rstd, float* running_mean, float* running_var, void* stream) {
     return agb_bn_stats_tracked(X, ldx, n, C, eps, momentum, training, part, mean, rstd, running_mean, running_var,

@@ -342,6 +342,8 @@ struct ConvArgs {
     int ksplit; float* partial;
     int cmp_mode;   // pair-compacted kernel: 1 = automatic, 0 = never, 64 / 128 = always with that tile height
     int cmp_il;     // log2 of the interleave block of its tiles (0 = contiguous, -1 = by level size)
+    float* bn_part; // optional [row tiles][3][Cout]: (count, mean, M2) of every output column over the tile's rows —
+                    // the partial statistics of the BatchNorm that follows (register-accumulator kernels, no split)
 };
 
 // CW: output columns per workgroup (64, or 128 for wide dense layers: the staged A tile serves twice the columns)
@@ -497,6 +499,61 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + (wn * NT + nt) * 32 + li;
             if (col < Cout) out[(long long)row * ldo + col] = acc[nt][reg] + bvs[nt];
+        }
+    }
+    // Partial BatchNorm statistics of the tile while it is still in registers: the statistics pass of the BatchNorm
+    // that follows (one more read of the [N, Cout] output: 4.2 GB for the 1024-wide layer of the point MLP) becomes a
+    // fold of these partials.  Two-pass inside the tile (sum -> mean -> squared deviations), Chan's combine across tiles.
+    if (!PERM && a.bn_part != nullptr && a.ksplit == 1) {
+        float* red = As;                               // [WAVES_M][CW] (the K loop is over: the staging tiles are free)
+        const int cnt_rows = min(TM, a.n_out - row0);
+        float s[NT], q[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            s[nt] = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (rows[reg] >= 0) s[nt] += acc[nt][reg] + bvs[nt];
+            s[nt] += __shfl_xor(s[nt], 32, 64);
+            if (lh == 0) red[wm * CW + (wn * NT + nt) * 32 + li] = s[nt];
+        }
+        __syncthreads();
+        float mean[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) t += red[w * CW + (wn * NT + nt) * 32 + li];
+            mean[nt] = t / (float)cnt_rows;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            q[nt] = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (rows[reg] >= 0) {
+                    const float d = acc[nt][reg] + bvs[nt] - mean[nt];
+                    q[nt] += d * d;
+                }
+            q[nt] += __shfl_xor(q[nt], 32, 64);
+            if (lh == 0) red[wm * CW + (wn * NT + nt) * 32 + li] = q[nt];
+        }
+        __syncthreads();
+        if (wm == 0 && lh == 0) {
+            float* p = a.bn_part + (long long)blockIdx.x * 3 * Cout;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = n0 + (wn * NT + nt) * 32 + li;
+                if (col < Cout) {
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WAVES_M; ++w) m2 += red[w * CW + (wn * NT + nt) * 32 + li];
+                    p[col] = (float)cnt_rows;
+                    p[Cout + col] = mean[nt];
+                    p[2 * Cout + col] = m2;
+                }
+            }
         }
     }
 }
@@ -1679,6 +1736,30 @@ int agb_dense_split_hint(int n_out, int Cin, int Cout) {
     if (s > 8) s = 8;
     if (s > cap) s = cap;
     return (int)(s < 1 ? 1 : s);
+}
+
+// Row tiles of a dense fp32 product that can deliver partial BatchNorm statistics from its epilogue
+// (agb_dense_fwd_bn), 0 when this shape takes a path that cannot (streaming kernels, split reduction).
+int agb_dense_bn_chunks(int n_out, int Cin, int Cout) {
+    if (n_out <= 0 || Cin < 12 || Cin % 4 != 0 || Cout % 4 != 0) return 0;
+    if (agb_dense_stream_ok(n_out, Cin, Cout) || agb_dense_split_hint(n_out, Cin, Cout) > 1) return 0;
+    return agb_cdiv(n_out, conv_tile_rows(n_out, Cin, Cout));
+}
+
+// Y = X W + bias (identity map, fp32) and bn_part float[agb_dense_bn_chunks][3][Cout] = (count, mean, M2) of every
+// column of Y over each row tile: the input of agb_bn_stats_fold.
+int agb_dense_fwd_bn(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int n_out, int Cin,
+                     int Cout, float* bn_part, void* stream) {
+    AGB_CHECK_ARG(bn_part != nullptr && agb_dense_bn_chunks(n_out, Cin, Cout) > 0,
+                  "agb_dense_fwd_bn: no statistics from this shape (n %d, Cin %d, Cout %d): see agb_dense_bn_chunks", n_out,
+                  Cin, Cout);
+    AGB_CHECK_ARG(ldx % 4 == 0 && ldy >= Cout, "agb_dense_fwd_bn: ldx %d (a multiple of 4), ldy %d", ldx, ldy);
+    ConvArgs a{X, ldx, W, nullptr, 0, 0, bias, Y, ldy, n_out, 1, Cin, Cout, nullptr, nullptr, nullptr, 1, nullptr, 0, -1,
+               bn_part};
+    int rc = launch_conv(a, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    AGB_CHECK_LAUNCH("agb_dense_fwd_bn");
+    return AGB_OK;
 }
 
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {

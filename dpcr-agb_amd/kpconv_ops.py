@@ -78,7 +78,7 @@ class KPConvSymmetricFunction(torch.autograd.Function):
         x, pts, kernel_points = x.contiguous(), pts.contiguous(), kernel_points.contiguous()
         K, cin, cout = weights.shape
         wf = _gather(x, pts, pts, idx, kernel_points, extent).view(-1, K * cin)
-        out = dense_product(wf, weights.reshape(K * cin, cout))
+        out = dense_product(wf, weights.reshape(K * cin, cout), bn_stats=any(ctx.needs_input_grad))
         # (by the same symmetry dW[k,c,o] = sum_j x[j,c] wfd[j,k,o] with the mirrored gather of dy, which would let the
         # backward keep x instead of the 15x larger wf; measured 0.1 ms/step slower in the [N,16]^T [N,240] product shape)
         ctx.save_for_backward(wf, pts, idx, kernel_points, weights)

@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import _lib
 from .coords import CoordinateManager, CoordinateMapKey, _as_int
 from .norm_ops import ACT_IDS, AddActFunction, batch_norm_act
-from .sparse_ops import (BroadcastMulFunction, DenseConvFunction, GlobalPoolFunction, MaxPoolFunction,
+from .sparse_ops import (BroadcastMulFunction, DenseConvFunction, take_bn_hint, GlobalPoolFunction, MaxPoolFunction,
                          SparseConvFunction, dense_linear)
 
 
@@ -170,7 +170,7 @@ class MinkowskiConvolution(nn.Module):
         if self.use_mm:
             if input.F.is_cuda and DenseConvFunction.supported(self.in_channels, self.out_channels):
                 # 1x1 stride-1: this library's own MFMA kernels on the identity map (csrc/spconv.hip), not a BLAS call
-                return input._like(DenseConvFunction.apply(input.F, self.kernel, self.bias))
+                return input._like(take_bn_hint(DenseConvFunction.apply(input.F, self.kernel, self.bias)))
             out = input.F @ self.kernel     # odd channel counts (not used by the NFI models)
             if self.bias is not None:
                 out = out + self.bias

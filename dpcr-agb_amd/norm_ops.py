@@ -31,6 +31,25 @@ _lib.declare("agb_add_act_bwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.
                                  _lib.c_void_p, _lib.c_void_p])
 
 
+_lib.declare("agb_bn_stats_fold", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_float, _lib.c_float, _lib.c_void_p,
+                                   _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p])
+
+
+def _statistics(x, n, c, eps, momentum, training, running_mean, running_var, counter, hint):
+    """mean / rstd [2, C]: batch statistics of x (from the partials the producing kernel left, when it did) or the
+    running ones."""
+    stats = torch.empty(2, c, dtype=torch.float32, device=x.device)
+    if training and hint is not None:
+        part, chunks = hint
+        _lib.call("agb_bn_stats_fold", _P(part), chunks, c, float(eps), float(momentum), _P(stats[0]), _P(stats[1]),
+                  _P(running_mean), _P(running_var), _P(counter), _lib.stream())
+        return stats
+    part = torch.empty(bn_chunks(n) * 3 * c, dtype=torch.float32, device=x.device) if training else None
+    _lib.call("agb_bn_stats_tracked", _P(x), x.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
+              _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter), _lib.stream())
+    return stats
+
+
 def bn_chunks(n):
     return _lib.load().agb_bn_chunks(int(n))
 
@@ -39,16 +58,13 @@ class BatchNormActFunction(torch.autograd.Function):
     """y = act(gamma * (x - mean) * rstd + beta) over the rows of x [N, C] (C % 4 == 0)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act_id, training, counter=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act_id, training, counter=None,
+                hint=None):
         x = x.contiguous()
         n, c = x.shape
         if c % 4 != 0:
             raise _lib.AgbError("fused batch norm needs a channel count that is a multiple of 4")
-        dev = x.device
-        stats = torch.empty(2, c, dtype=torch.float32, device=dev)
-        part = torch.empty(bn_chunks(n) * 3 * c, dtype=torch.float32, device=dev) if training else None
-        _lib.call("agb_bn_stats_tracked", _P(x), x.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
-                  _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter), _lib.stream())
+        stats = _statistics(x, n, c, eps, momentum, training, running_mean, running_var, counter, hint)
         y = torch.empty_like(x)
         _lib.call("agb_bn_act_fwd", _P(x), x.stride(0), n, c, _P(stats[0]), _P(stats[1]), _P(gamma), _P(beta),
                   act_id, _P(y), y.stride(0), _lib.stream())
@@ -78,7 +94,8 @@ class BatchNormActFunction(torch.autograd.Function):
             # The hint is tied to the tensor's version: if autograd accumulates another consumer's gradient into this
             # buffer in place, the version moves and the convolution's backward recomputes the sum itself.
             dx.agb_colsum = (dgb[2], dx._version)
-        return dx, (dgb[0] if has_g else None), (dgb[1] if has_b else None), None, None, None, None, None, None, None
+        return dx, (dgb[0] if has_g else None), (dgb[1] if has_b else None), None, None, None, None, None, None, None, \
+            None
 
 
 def batch_norm_act(x, bn: torch.nn.BatchNorm1d, act=None):
@@ -96,8 +113,10 @@ def batch_norm_act(x, bn: torch.nn.BatchNorm1d, act=None):
             momentum = 1.0 / float(bn.num_batches_tracked)
     # training + tracked: batch stats, running stats updated in the fold kernel; eval + tracked: running stats;
     # untracked: batch stats, nothing to update
+    from .sparse_ops import bn_hint
+    hint = bn_hint(x, x.shape[1]) if (use_batch_stats and x.dim() == 2) else None
     return BatchNormActFunction.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, ACT_IDS[act], use_batch_stats,
-                                      counter)
+                                      counter, hint)
 
 
 class AddActFunction(torch.autograd.Function):
@@ -147,16 +166,13 @@ class BatchNormActPoolFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, act_id, training, counter, coords, ptr,
-                B, mode):
+                B, mode, hint=None):
         z = z.contiguous()
         n, c = z.shape
         if c % 4 != 0:
             raise _lib.AgbError("fused batch norm + pooling needs a channel count that is a multiple of 4")
         dev = z.device
-        stats = torch.empty(2, c, dtype=torch.float32, device=dev)
-        part = torch.empty(bn_chunks(n) * 3 * c, dtype=torch.float32, device=dev) if training else None
-        _lib.call("agb_bn_stats_tracked", _P(z), z.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
-                  _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter), _lib.stream())
+        stats = _statistics(z, n, c, eps, momentum, training, running_mean, running_var, counter, hint)
         sp = _lib.load().agb_pointnet_pool_splits(n, B)
         pooled = torch.empty(B, c, dtype=torch.float32, device=dev)
         arg = torch.empty(B, c, dtype=torch.int32, device=dev) if mode == 2 else None
@@ -184,7 +200,7 @@ class BatchNormActPoolFunction(torch.autograd.Function):
                   _P(arg) if mode == 2 else None, mode, _P(stats[0]), _P(stats[1]), _P(gamma) if has_g else None,
                   _P(beta) if has_b else None, act_id, int(training), _P(part), _P(dz),
                   0 if dz is None else dz.stride(0), _P(dgb[0]), _P(dgb[1]), _lib.stream())
-        return (dz, dgb[0] if has_g else None, dgb[1] if has_b else None) + (None,) * 11
+        return (dz, dgb[0] if has_g else None, dgb[1] if has_b else None) + (None,) * 12
 
 
 def batch_norm_act_pool(z, bn: torch.nn.BatchNorm1d, act, coords, ptr, B, mode):
@@ -198,8 +214,10 @@ def batch_norm_act_pool(z, bn: torch.nn.BatchNorm1d, act, coords, ptr, B, mode):
         else:
             bn.num_batches_tracked.add_(1)
             momentum = 1.0 / float(bn.num_batches_tracked)
+    from .sparse_ops import bn_hint
+    hint = bn_hint(z, z.shape[1]) if (use_batch_stats and z.dim() == 2) else None
     return BatchNormActPoolFunction.apply(z, bn.weight, bn.bias, rm, rv, momentum, bn.eps, ACT_IDS[act], use_batch_stats,
-                                          counter, coords, ptr, B, POOL_MODES[mode])
+                                          counter, coords, ptr, B, POOL_MODES[mode], hint)
 
 
 _lib.declare("agb_pointnet_mlp_workspace_bytes", [_I] * 5)

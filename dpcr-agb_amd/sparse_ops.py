@@ -42,6 +42,9 @@ _lib.declare("agb_spconv_fwd_opt", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _l
                                     _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p])
 _lib.declare("agb_spconv_split_hint_opt", [_lib.c_int] * 5)
 _lib.declare("agb_dense_split_hint", [_lib.c_int] * 3)
+_lib.declare("agb_dense_bn_chunks", [_lib.c_int] * 3)
+_lib.declare("agb_dense_fwd_bn", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int,
+                                  _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p])
 _lib.declare("agb_spconv_bwd_weight_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
                                           _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                           _lib.c_void_p])
@@ -107,8 +110,33 @@ def _small_cin_pad(cin):
     return (cin + 3) // 4 * 4
 
 
+# Partial BatchNorm statistics from the epilogue of the forward dense products (agb_dense_fwd_bn); the product's caller
+# moves them onto the tensor it returns (take_bn_hint), norm_ops.batch_norm_act picks them up from there.
+BN_STATS_IN_EPILOGUE = True
+_LAST_BN_PART = None
+
+
+def take_bn_hint(out):
+    """Attach the statistics partials of the dense product that just produced `out` (if it left any) to `out`."""
+    global _LAST_BN_PART
+    last, _LAST_BN_PART = _LAST_BN_PART, None
+    if last is not None and isinstance(out, torch.Tensor):
+        part, chunks, y = last
+        if out.data_ptr() == y.data_ptr() and out.shape == y.shape and out.is_contiguous():
+            out.agb_bn_part = (part, chunks, out._version)
+    return out
+
+
+def bn_hint(x, c):
+    """(part, chunks) of a still-valid statistics hint on x, or None."""
+    h = getattr(x, "agb_bn_part", None)
+    if h is None or h[2] != x._version or h[0].numel() != h[1] * 3 * c:
+        return None
+    return h[0], h[1]
+
+
 def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None, plan=None,
-                       w_kmajor=None):
+                       w_kmajor=None, bn_stats=False):
     """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout].
     plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
     w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes."""
@@ -128,7 +156,17 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
         pairs = int(n_out)        # dense product: one (in, out) pair per row
     ev = _prof_begin(kind, K3, cin, cout, n_out, plan is not None, split, x.shape[0])
     prec = _PREC_ID.get(CONV_PRECISION, 0) if (w_kmajor is not None and cin >= 12) else 0
-    if prec:
+    global _LAST_BN_PART
+    bn_chunks = 0
+    if BN_STATS_IN_EPILOGUE and bn_stats and nbr is None and not prec and split == 1:
+        bn_chunks = _lib.load().agb_dense_bn_chunks(n_out, cin, cout)
+    if bn_chunks > 0:
+        # forward dense product in training: the BatchNorm that follows takes its statistics from this epilogue
+        part = torch.empty(bn_chunks * 3 * cout, dtype=torch.float32, device=x.device)
+        _lib.call("agb_dense_fwd_bn", _P(x), x.stride(0), _P(w2d), _P(bias), _P(y), y.stride(0), n_out, cin, cout, _P(part),
+                  _lib.stream())
+        _LAST_BN_PART = (part, bn_chunks, y)
+    elif prec:
         _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip),
                   _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
                   split, _P(partial), prec, _lib.stream())
@@ -292,7 +330,9 @@ class DenseConvFunction(torch.autograd.Function):
         b = None if bias is None else bias.reshape(-1).contiguous()
         lp = CONV_PRECISION in _PREC_ID
         wkm = w.t().contiguous() if lp else None          # K-major [Cout][Cin]
-        y = spconv_forward_raw(x, w, None, 0, b, n, 1, cin, cout, "fwd1x1", None, None, wkm)
+        # (a forward pass that will be differentiated = training: the BatchNorm behind it wants batch statistics)
+        y = spconv_forward_raw(x, w, None, 0, b, n, 1, cin, cout, "fwd1x1", None, None, wkm,
+                               bn_stats=any(ctx.needs_input_grad))
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bias_shape = None if bias is None else bias.shape
@@ -328,14 +368,14 @@ class DenseConvFunction(torch.autograd.Function):
         return dx, dk, db
 
 
-def dense_product(x, w, kind="fwd1x1"):
+def dense_product(x, w, kind="fwd1x1", bn_stats=False):
     """x [n, cin] @ w [cin, cout] on the identity-map convolution kernels in the operand precision of ``CONV_PRECISION``
     (no autograd: building block of the fused Functions).  Widths as in ``DenseConvFunction.supported``."""
     cin, cout = w.shape
     w = w.contiguous()
     if CONV_PRECISION in _PREC_ID:
         return spconv_forward_raw(x, None, None, 0, None, x.shape[0], 1, cin, cout, kind, None, None, w.t().contiguous())
-    return spconv_forward_raw(x, w, None, 0, None, x.shape[0], 1, cin, cout, kind)
+    return spconv_forward_raw(x, w, None, 0, None, x.shape[0], 1, cin, cout, kind, bn_stats=bn_stats)
 
 
 def dense_weight_grad(x, dy):
@@ -373,7 +413,8 @@ class DenseLinearFunction(torch.autograd.Function):
         else:
             wt = torch.empty(cin_p, cout_p, dtype=torch.float32, device=x.device)
             _lib.call("agb_spconv_weight_transpose", _P(wp), _P(wt), 1, cout_p, cin_p, _lib.stream())
-            y = spconv_forward_raw(xp, wt, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1")
+            y = spconv_forward_raw(xp, wt, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1",
+                                   bn_stats=any(ctx.needs_input_grad) and cout_p == cout)
         ctx.save_for_backward(xp, wp)
         ctx.dims = (cin, cout, cin_p, cout_p, bias is not None)
         return y if cout_p == cout else y[:, :cout].contiguous()
@@ -412,7 +453,7 @@ class DenseLinearFunction(torch.autograd.Function):
 def dense_linear(x, weight, bias=None):
     """nn.Linear semantics on the library's own kernels for device tensors with >= 1 row; plain F.linear otherwise."""
     if x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.dtype == torch.float32:
-        return DenseLinearFunction.apply(x, weight, bias)
+        return take_bn_hint(DenseLinearFunction.apply(x, weight, bias))
     return F.linear(x, weight, bias)
 
 

@@ -108,6 +108,13 @@ int agb_spconv_fwd_ex(const float* X, int ldx, const float* W, const int32_t* nb
 int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout);  /* host helper (automatic kernel choice) */
 /* the same for the identity map (nbr == NULL, a dense product): splits of the reduction dimension Cin */
 int agb_dense_split_hint(int n_out, int Cin, int Cout);
+/* Dense fp32 product Y = X W + bias that also leaves the partial BatchNorm statistics of its output — (count, mean, M2)
+ * of every column per row tile, bn_part float[agb_dense_bn_chunks(...)][3][Cout] — for agb_bn_stats_fold: the
+ * BatchNorm behind a Linear / 1x1 layer (PointNet.py:16-28, blocks.py:499-535) then never re-reads the layer output for
+ * its statistics.  agb_dense_bn_chunks returns 0 for shapes that take a path without that epilogue. */
+int agb_dense_bn_chunks(int n_out, int Cin, int Cout);
+int agb_dense_fwd_bn(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int n_out, int Cin,
+                     int Cout, float* bn_part, void* stream);
 /* The same product with the kernel choice as per-call arguments (the library keeps no tuning state):
  * cmp_mode: 1 = automatic (the pair-compacted LDS-accumulating kernel for many-row layers with Cin % 64 == 0, the
  * register-accumulator kernels otherwise; what agb_spconv_fwd / _ex use), 0 = never the pair-compacted kernel,
@@ -205,6 +212,9 @@ int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentu
 int agb_bn_stats_tracked(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
                          float* mean, float* rstd, float* running_mean, float* running_var,
                          long long* num_batches_tracked, void* stream);
+/* the fold half of agb_bn_stats_tracked on partials produced by agb_dense_fwd_bn */
+int agb_bn_stats_fold(const float* part, int chunks, int C, float eps, float momentum, float* mean, float* rstd,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, void* stream);
 int agb_bn_act_fwd(const float* X, int ldx, int n, int C, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, int act, float* Y, int ldy, void* stream);
 /* part: float[agb_bn_chunks(n)*2*C] scratch; dgamma, dbeta: float[C] out; dX may be NULL */

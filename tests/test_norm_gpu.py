@@ -226,3 +226,44 @@ def test_se_layer_one_node(device, act, C):
     assert rel(xg.grad, xr.grad) < 1e-4
     for a, b in ((l1.weight, r1.weight), (l1.bias, r1.bias), (l2.weight, r2.weight), (l2.bias, r2.bias)):
         assert rel(a.grad, b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("n,cin,cout", [(70001, 128, 1024), (5000, 64, 256), (3001, 256, 64), (130, 32, 128)])
+def test_bn_statistics_from_the_product_epilogue(device, n, cin, cout):
+    """Linear -> BatchNorm in training: the dense product leaves (count, mean, M2) per row tile and column in its epilogue
+    (agb_dense_fwd_bn) and the BatchNorm folds those instead of reading the layer output again — same output, same
+    running statistics, same gradients as the separate statistics pass and as torch in fp64."""
+    from dpcr_agb_amd import _lib, sparse_ops
+    from dpcr_agb_amd.norm_ops import batch_norm_act
+    from dpcr_agb_amd.sparse_ops import dense_linear
+    torch.manual_seed(n + cout)
+    x = torch.randn(n, cin) + 3.0
+    lin = torch.nn.Linear(cin, cout)
+    bn0 = torch.nn.BatchNorm1d(cout, momentum=0.1)
+    g = torch.randn(n, cout)
+    res = {}
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm1d(cout, momentum=0.1)
+        bn.load_state_dict(bn0.state_dict())
+        bn = bn.to(device).train()
+        w, b = lin.weight.detach().clone().to(device).requires_grad_(True), lin.bias.detach().clone().to(device)
+        calls = []
+        orig, flag = _lib.call, sparse_ops.BN_STATS_IN_EPILOGUE
+        _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        sparse_ops.BN_STATS_IN_EPILOGUE = fused
+        try:
+            xg = x.to(device).requires_grad_(True)
+            z = dense_linear(xg, w, b)
+            y = batch_norm_act(z, bn, "gelu")   # (smooth: a ReLU kink element flipping between the two roundings moves its gradient)
+            y.backward(g.to(device))
+        finally:
+            _lib.call, sparse_ops.BN_STATS_IN_EPILOGUE = orig, flag
+        assert ("agb_bn_stats_fold" in calls) == fused and ("agb_bn_stats_tracked" in calls) == (not fused), calls
+        res[fused] = (y.detach(), bn.running_mean.clone(), bn.running_var.clone(), xg.grad.clone(), w.grad.clone())
+    for a, b_ in zip(res[True], res[False]):
+        assert rel(a, b_) < 1e-5      # (two fp32 roundings of the same statistics)
+    ref = torch.nn.BatchNorm1d(cout, momentum=0.1).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn0.state_dict().items()})
+    yr = F.gelu(ref(x.double() @ lin.weight.detach().double().t() + lin.bias.detach().double()))
+    assert rel(res[True][0], yr) < 1e-4
+    assert rel(res[True][1], ref.running_mean) < 1e-5 and rel(res[True][2], ref.running_var) < 1e-4
