@@ -25,9 +25,37 @@ def limit_host_threads(n=None):
     VISIBLE cores (256 on an MI355X host) even when a cgroup quota allows far fewer (16 on the GPU boxes of this project):
     the spinning workers exhaust the quota and the kernel throttles the whole process for the rest of the scheduling
     period — measured as 50-150 ms host stalls in the KPConv loop (the step rate doubled once the pool was capped).
-    n: thread count (default: the AGB_HOST_THREADS environment variable, else 4).  Returns the previous setting."""
+    n: thread count (default: the AGB_HOST_THREADS environment variable, else 4 — fewer when the cgroup's CPU quota
+    divided among the ranks of this node (LOCAL_WORLD_SIZE) is smaller: eight ranks of four spinning threads would
+    exhaust a 16-core quota just the same).  Returns the previous setting."""
     import os
     import torch
     old = torch.get_num_threads()
-    torch.set_num_threads(max(1, int(n if n is not None else os.environ.get("AGB_HOST_THREADS", "4"))))
+    if n is None:
+        n = os.environ.get("AGB_HOST_THREADS")
+    if n is None:
+        n = 4
+        quota = cpu_quota()
+        if quota is not None:
+            ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+            n = max(1, min(4, int(quota // ranks)))
+    torch.set_num_threads(max(1, int(n)))
     return old
+
+
+def cpu_quota():
+    """CPU cores the cgroup of this process may use (cgroup v2 cpu.max or v1 cfs quota), or None when unlimited/unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
