@@ -193,6 +193,26 @@ class SELayer(nn.Module):
         return self.broadcast_mul(x, self.fc(pooled))
 
 
+def _se_block_forward(block, x, z, last_norm):
+    """Everything behind the last convolution of an SE block (its output z before `last_norm`): the one-node fused tail
+    (se_ops.SEBlockTailFunction) when the pieces are the plain ones, the module-by-module path otherwise."""
+    import dpcr_agb_amd.se_ops as se_ops
+    se, dp = block.se, block.drop_path
+    lin1, act, lin2, gate = se.fc[0], se.fc[1], se.fc[2], se.fc[3]
+    se_name, act_name = getattr(act, "act_name", None), getattr(block.relu, "act_name", None)
+    residual = block.downsample(x)
+    if (se_ops.FUSED_TAIL and isinstance(last_norm, ME.MinkowskiBatchNorm) and z.F.is_cuda and z.F.shape[1] % 4 == 0
+            and se_name in ("relu", "gelu") and act_name in ("relu", "gelu") and isinstance(gate, ME.MinkowskiSigmoid)
+            and lin1.linear.out_features <= MAX_SE_HIDDEN and z._ts != 0
+            and isinstance(dp, (MinkowskiDropPath, nn.Identity))):
+        z._check_same_map(residual)
+        cm, ts = z.coordinate_manager, z._ts
+        keep = dp.scale_vector(z) if isinstance(dp, MinkowskiDropPath) else None
+        return z._like(se_ops.se_block_tail(z.F, residual.F, last_norm.bn, cm.level(ts).coords, cm.batch_ptr(ts),
+                                            cm.batch_size, lin1.linear, se_name, lin2.linear, keep, act_name))
+    return _residual_tail(block, se(last_norm(z)), residual)
+
+
 class SEBasicBlock(BasicBlock):
     def __init__(self, inplanes, planes, act_fn, norm_layer, stride=1, dilation=1, downsample=None, reduction=16,
                  drop_path=0.0, bias=True, dimension=-1):
@@ -202,6 +222,10 @@ class SEBasicBlock(BasicBlock):
 
     def _main(self, x):
         return self.se(super()._main(x))
+
+    def forward(self, x):
+        out = ME.fused_norm_act(self.norm1, self.relu, self.conv1(x))
+        return _se_block_forward(self, x, self.conv2(out), self.norm2)
 
 
 class SEBottleneck(Bottleneck):
@@ -213,6 +237,11 @@ class SEBottleneck(Bottleneck):
 
     def _main(self, x):
         return self.se(super()._main(x))
+
+    def forward(self, x):
+        out = ME.fused_norm_act(self.norm1, self.relu, self.conv1(x))
+        out = ME.fused_norm_act(self.norm2, self.relu, self.conv2(out))
+        return _se_block_forward(self, x, self.conv3(out), self.norm3)
 
 
 class ResNetBase(nn.Module):

@@ -451,6 +451,316 @@ __global__ __launch_bounds__(256) void k_add_act_bwd(const float* __restrict__ A
     }
 }
 
+// ---------------------------------------------------------------- squeeze-excite block tail, fused
+// The tail of an SE residual block (senet_block.py:83-96, 126-147; resnet_block.py:70-73)
+//     t = BatchNorm(z);  s = sigmoid(W2 act(W1 avgpool_plot(t) + b1) + b2);  y = act(t * s[plot] * keep[plot] + r)
+// ran as BatchNorm (statistics + apply), per-plot pooling, excitation MLP, broadcast multiplication and residual kernel:
+// 9 passes over [N, C] forward and 14 backward.  Here t and t*s never exist in memory:
+//   forward : ONE pass over z for the BatchNorm partials AND the per-plot column sums (the pooled input of the MLP is an
+//             affine function of the plot mean of z), then y from (z, r) in one pass                     — 4 passes
+//   backward: one pass for the per-plot sums of da = dy act'(.) and da*xhat (they give the gradient of s, and — once the MLP
+//             backward has produced the pooled gradient — dbeta / dgamma in closed form per plot), one pass for dz and dr
+//                                                                                                           — 8 passes
+// Rows of a plot are contiguous.  The row chunks of the reduction kernels are PLOT-ALIGNED — plot b gets
+// ceil(rows_b / R) chunks of its own — so every chunk partial belongs to one plot, per-plot quantities are folds of the
+// plot's chunk range in a fixed order (no atomics: results are bitwise reproducible, like the BatchNorm statistics), and
+// the per-plot mean of z falls out of the BatchNorm partials themselves (Chan's combine over the plot's chunks).
+// The grid is sized for the worst case ceil(n / R) + B chunks; the surplus writes empty partials.
+struct PlotChunk { int b, r_beg, r_end; };
+__device__ __forceinline__ PlotChunk plot_chunk(const int32_t* __restrict__ ptr, int B, int R, int g) {
+    int acc = 0;
+    for (int b = 0; b < B; ++b) {
+        const int lo = ptr[b], hi = ptr[b + 1];
+        const int nb = (hi - lo + R - 1) / R;
+        if (g < acc + nb) {
+            const int rb = lo + (g - acc) * R;
+            return PlotChunk{b, rb, min(hi, rb + R)};
+        }
+        acc += nb;
+    }
+    return PlotChunk{-1, 0, 0};
+}
+// first chunk and number of chunks of plot b
+__device__ __forceinline__ void plot_chunks_of(const int32_t* __restrict__ ptr, int R, int b, int* first, int* count) {
+    int acc = 0;
+    for (int i = 0; i < b; ++i) acc += (ptr[i + 1] - ptr[i] + R - 1) / R;
+    *first = acc;
+    *count = (ptr[b + 1] - ptr[b] + R - 1) / R;
+}
+
+// grid (max chunks, slabs): part[chunk][3][C] = (count, mean, M2) of the chunk's rows, as k_bn_stats_partial
+__global__ __launch_bounds__(256) void k_tail_stats(const float* __restrict__ X, int ldx, const int32_t* __restrict__ ptr,
+                                                    int B, int C, int R, float* __restrict__ part) {
+    __shared__ float s_mean[1024];
+    __shared__ float s_m2[1024];
+    __shared__ float s_cnt[256];
+    const BnLanes L = bn_lanes(C);
+    const int cg = L.cg, rl = L.rl, slab = L.cgs * 4;
+    const int c = blockIdx.y * slab + cg * 4;
+    const PlotChunk pc = plot_chunk(ptr, B, R, blockIdx.x);
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+    float cnt = 0.f;
+    if (rl < L.rl_n && c < C) {
+        for (int r = pc.r_beg + rl; r < pc.r_end; r += L.rl_n) {
+            const float4 v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+            cnt += 1.f;
+            const float inv = 1.f / cnt;
+            const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = x[j] - mean[j];
+                mean[j] += d * inv;
+                m2[j] += d * (x[j] - mean[j]);
+            }
+        }
+    } else if (rl < L.rl_n) {
+        for (int r = pc.r_beg + rl; r < pc.r_end; r += L.rl_n) cnt += 1.f;
+    }
+    if (rl < L.rl_n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s_mean[rl * slab + cg * 4 + j] = mean[j];
+            s_m2[rl * slab + cg * 4 + j] = m2[j];
+        }
+        if (cg == 0) s_cnt[rl] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < slab) {
+        const int cc = blockIdx.y * slab + threadIdx.x;
+        float na = 0.f, ma = 0.f, qa = 0.f;
+        for (int j = 0; j < L.rl_n; ++j) {  // fixed order
+            const float nb = s_cnt[j];
+            if (nb == 0.f) continue;
+            const float mb = s_mean[j * slab + threadIdx.x], qb = s_m2[j * slab + threadIdx.x];
+            const float nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
+        }
+        if (cc < C) {
+            float* p = part + (long long)blockIdx.x * 3 * C;
+            p[cc] = na;
+            p[C + cc] = ma;
+            p[2 * C + cc] = qa;
+        }
+    }
+}
+
+// zbar[b,c] = plot mean of z (Chan's combine of the plot's chunk partials, fixed order) and
+// p[b,c] = BatchNorm(zbar) = (zbar - mean) rstd gamma + beta: the excitation MLP's input
+__global__ void k_tail_pool(const float* __restrict__ part, const int32_t* __restrict__ ptr, int B, int C, int R,
+                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ zbar,
+                            float* __restrict__ p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    const int b = t / C, c = t - b * C;
+    int first, count;
+    plot_chunks_of(ptr, R, b, &first, &count);
+    float na = 0.f, ma = 0.f;
+    for (int j = 0; j < count; ++j) {
+        const float* q = part + (long long)(first + j) * 3 * C;
+        const float nb = q[c];
+        if (nb == 0.f) continue;
+        const float nt = na + nb;
+        ma += (q[C + c] - ma) * (nb / nt);
+        na = nt;
+    }
+    const float zb = na > 0.f ? ma : mean[c];
+    zbar[t] = zb;
+    p[t] = (zb - mean[c]) * rstd[c] * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+}
+
+struct TailParams {
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    const float* s;      // [B, C] excitation
+    const float* keep;   // [B] drop-path factor or NULL
+};
+
+// y = act(((z - mean) rstd gamma + beta) * s[plot] * keep[plot] + r)
+__global__ __launch_bounds__(256) void k_tail_fwd(const float* __restrict__ Z, int ldz, const float* __restrict__ R, int ldr,
+                                                  const int4* __restrict__ coords, TailParams P, int act, int n, int C,
+                                                  float* __restrict__ Y, int ldy) {
+    const BnLanes L = bn_lanes(C);
+    if (L.rl >= L.rl_n) return;
+    const int c = min(blockIdx.y * (L.cgs * 4) + L.cg * 4, C - 4);
+    float m[4], sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m[j] = P.mean[c + j];
+        sc[j] = P.rstd[c + j] * (P.gamma ? P.gamma[c + j] : 1.f);
+        sh[j] = P.beta ? P.beta[c + j] : 0.f;
+    }
+    const int r0 = blockIdx.x * (EW_PER * L.rl_n) + L.rl;
+#pragma unroll
+    for (int j = 0; j < EW_PER; ++j) {
+        const int r = r0 + L.rl_n * j;
+        if (r >= n) continue;
+        const int b = coords[r].x;
+        const float kf = P.keep ? P.keep[b] : 1.f;
+        const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
+        const float4 r4 = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+        const float4 s4 = *reinterpret_cast<const float4*>(P.s + (long long)b * C + c);
+        const float z[4] = {z4.x, z4.y, z4.z, z4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = act_fwd(((z[q] - m[q]) * sc[q] + sh[q]) * (ss[q] * kf) + rr[q], act);
+        *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// chunk partials spart[chunk][2][C] = (sum da, sum da * xhat) over the chunk's rows, da = dy * act'(pre), pre recomputed
+__global__ __launch_bounds__(256) void k_tail_bwd_sums(const float* __restrict__ Z, int ldz, const float* __restrict__ R,
+                                                       int ldr, const float* __restrict__ dY, int ldy,
+                                                       const int32_t* __restrict__ ptr, int B, TailParams P, int act, int C,
+                                                       int RC, float* __restrict__ spart) {
+    __shared__ float s_a[1024];
+    __shared__ float s_b[1024];
+    const BnLanes L = bn_lanes(C);
+    const int cg = L.cg, rl = L.rl, slab = L.cgs * 4;
+    const int c = blockIdx.y * slab + cg * 4;
+    const PlotChunk pc = plot_chunk(ptr, B, RC, blockIdx.x);
+    float a2[4] = {0.f, 0.f, 0.f, 0.f}, a3[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < L.rl_n && c < C && pc.b >= 0) {
+        float m[4], rs[4], g[4], be[4], sk[4];
+        const float kf = P.keep ? P.keep[pc.b] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m[j] = P.mean[c + j];
+            rs[j] = P.rstd[c + j];
+            g[j] = P.gamma ? P.gamma[c + j] : 1.f;
+            be[j] = P.beta ? P.beta[c + j] : 0.f;
+            sk[j] = P.s[(long long)pc.b * C + c + j] * kf;
+        }
+        for (int r = pc.r_beg + rl; r < pc.r_end; r += L.rl_n) {
+            const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
+            const float4 r4 = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+            const float4 d4 = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+            const float z[4] = {z4.x, z4.y, z4.z, z4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xh = (z[q] - m[q]) * rs[q];
+                const float da = d[q] * act_grad((xh * g[q] + be[q]) * sk[q] + rr[q], act);
+                a2[q] += da;
+                a3[q] += da * xh;
+            }
+        }
+    }
+    if (rl < L.rl_n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s_a[rl * slab + cg * 4 + j] = a2[j]; s_b[rl * slab + cg * 4 + j] = a3[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < slab) {
+        const int cc = blockIdx.y * slab + threadIdx.x;
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < L.rl_n; ++j) { a += s_a[j * slab + threadIdx.x]; b += s_b[j * slab + threadIdx.x]; }
+        if (cc < C) {
+            float* p = spart + (long long)blockIdx.x * 2 * C;
+            p[cc] = a;
+            p[C + cc] = b;
+        }
+    }
+}
+
+// S2, S3 [B, C] = the plot's chunk partials summed in order; ds[b,c] = keep[b] * (gamma S3 + beta S2): the gradient of the
+// excitation s (sum over the plot's rows of da * t)
+__global__ void k_tail_bwd_ds(const float* __restrict__ spart, const int32_t* __restrict__ ptr, int RC,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              const float* __restrict__ keep, int B, int C, float* __restrict__ S2, float* __restrict__ S3,
+                              float* __restrict__ ds) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    const int b = t / C, c = t - b * C;
+    int first, count;
+    plot_chunks_of(ptr, RC, b, &first, &count);
+    float a = 0.f, q = 0.f;
+    for (int j = 0; j < count; ++j) {
+        const float* p = spart + (long long)(first + j) * 2 * C;
+        a += p[c];
+        q += p[C + c];
+    }
+    S2[t] = a;
+    S3[t] = q;
+    ds[t] = (keep ? keep[b] : 1.f) * ((gamma ? gamma[c] : 1.f) * q + (beta ? beta[c] : 0.f) * a);
+}
+
+// With dp[b,c] = gradient of the pooled MLP input: dte = dp / rows (the per-row share of the pooled gradient, in the space
+// of t), and the BatchNorm parameter gradients in closed form over the plots:
+//   dbeta  = sum_rows dt        = sum_b (s keep S2 + rows dte)
+//   dgamma = sum_rows dt * xhat = sum_b (s keep S3 + dte X1),  X1[b,c] = sum_plot xhat = rows (zbar - mean) rstd
+__global__ void k_tail_bwd_fold(const float* __restrict__ S2, const float* __restrict__ S3,
+                                const float* __restrict__ zbar, const int32_t* __restrict__ ptr,
+                                const float* __restrict__ dp, const float* __restrict__ s, const float* __restrict__ keep,
+                                const float* __restrict__ mean, const float* __restrict__ rstd, int B, int C,
+                                float* __restrict__ dte, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float db = 0.f, dg = 0.f;
+    for (int b = 0; b < B; ++b) {     // fixed order
+        const long long t = (long long)b * C + c;
+        const float rows = (float)(ptr[b + 1] - ptr[b]);
+        const float e = rows > 0.f ? dp[t] / rows : 0.f;
+        dte[t] = e;
+        const float sk = s[t] * (keep ? keep[b] : 1.f);
+        db += sk * S2[t] + rows * e;
+        dg += sk * S3[t] + e * rows * (zbar[t] - mean[c]) * rstd[c];
+    }
+    dbeta[c] = db;
+    dgamma[c] = dg;
+}
+
+// dz = gamma rstd (dt - [training](dbeta + xhat dgamma) / n),  dt = da s keep + dte[plot];   dr = da
+__global__ __launch_bounds__(256) void k_tail_bwd_apply(const float* __restrict__ Z, int ldz, const float* __restrict__ R,
+                                                        int ldr, const float* __restrict__ dY, int ldy,
+                                                        const int4* __restrict__ coords, TailParams P,
+                                                        const float* __restrict__ dte, const float* __restrict__ dbeta,
+                                                        const float* __restrict__ dgamma, int act, int training, int n,
+                                                        int C, float* __restrict__ dZ, int lddz, float* __restrict__ dR,
+                                                        int lddr) {
+    const BnLanes L = bn_lanes(C);
+    if (L.rl >= L.rl_n) return;
+    const int c = min(blockIdx.y * (L.cgs * 4) + L.cg * 4, C - 4);
+    float m[4], rs[4], g[4], be[4], db[4], dg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m[j] = P.mean[c + j];
+        rs[j] = P.rstd[c + j];
+        g[j] = P.gamma ? P.gamma[c + j] : 1.f;
+        be[j] = P.beta ? P.beta[c + j] : 0.f;
+        db[j] = dbeta[c + j];
+        dg[j] = dgamma[c + j];
+    }
+    const float inv_n = training ? 1.f / (float)n : 0.f;
+    const int r0 = blockIdx.x * (EW_PER * L.rl_n) + L.rl;
+#pragma unroll 2
+    for (int j = 0; j < EW_PER; ++j) {
+        const int r = r0 + L.rl_n * j;
+        if (r >= n) continue;
+        const int b = coords[r].x;
+        const float kf = P.keep ? P.keep[b] : 1.f;
+        const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
+        const float4 r4 = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+        const float4 d4 = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+        const float4 s4 = *reinterpret_cast<const float4*>(P.s + (long long)b * C + c);
+        const float4 e4 = *reinterpret_cast<const float4*>(dte + (long long)b * C + c);
+        const float z[4] = {z4.x, z4.y, z4.z, z4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w},
+                    ss[4] = {s4.x, s4.y, s4.z, s4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+        float oz[4], orr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (z[q] - m[q]) * rs[q];
+            const float sk = ss[q] * kf;
+            const float da = d[q] * act_grad((xh * g[q] + be[q]) * sk + rr[q], act);
+            const float dt = da * sk + ee[q];
+            oz[q] = g[q] * rs[q] * (dt - (db[q] + xh * dg[q]) * inv_n);
+            orr[q] = da;
+        }
+        if (dZ) *reinterpret_cast<float4*>(dZ + (long long)r * lddz + c) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+        if (dR) *reinterpret_cast<float4*>(dR + (long long)r * lddr + c) = make_float4(orr[0], orr[1], orr[2], orr[3]);
+    }
+}
+
 // =============================================================== C ABI
 extern "C" {
 
@@ -552,6 +862,106 @@ int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int
                    float* dX, int lddx, float* dgamma, float* dbeta, void* stream) {
     return agb_bn_act_bwd_colsum(X, ldx, dY, ldy, n, C, mean, rstd, gamma, beta, act, training, part, dX, lddx, dgamma,
                                  dbeta, nullptr, stream);
+}
+
+// ---- squeeze-excite block tail (see k_tail_*).  coords: int4[n] (batch index in .x), ptr: int32[B+1] row offsets.
+static int tail_rows(int n, int C) { return rows_per_chunk(n, bn_chunks_for(n, C)); }
+
+// Plot-aligned row chunks of the tail's reduction kernels (upper bound): sizes `part` (x 3 C floats) and `spart` (x 2 C)
+int agb_se_tail_chunks(int n, int C, int B) { return agb_cdiv(n > 0 ? n : 1, tail_rows(n, C)) + (B > 0 ? B : 0); }
+
+// Statistics of Z for the BatchNorm (as agb_bn_stats_tracked) from plot-aligned chunk partials, which stay in `part`
+// float[agb_se_tail_chunks * 3 * C] for agb_se_tail_pool.
+int agb_se_tail_stats(const float* Z, int ldz, const int32_t* ptr, int n, int C, int B, float eps, float momentum,
+                      int training, float* part, float* mean, float* rstd, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && n >= 1 && B >= 1, "agb_se_tail_stats: n %d, C %d, B %d, ld %d", n, C, B, ldz);
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = agb_se_tail_chunks(n, C, B);
+    hipLaunchKernelGGL(k_tail_stats, dim3(chunks, agb_cdiv(C, bn_slab(C))), dim3(256), 0, s, Z, ldz, ptr, B, C,
+                       tail_rows(n, C), part);
+    if (training) {
+        hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, eps, momentum,
+                           mean, rstd, running_mean, running_var, num_batches_tracked);
+    } else {
+        AGB_CHECK_ARG(running_mean && running_var, "agb_se_tail_stats: eval mode needs running statistics");
+        hipLaunchKernelGGL(k_bn_eval_stats, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, C, eps,
+                           mean, rstd);
+    }
+    AGB_CHECK_LAUNCH("agb_se_tail_stats");
+    return AGB_OK;
+}
+
+// zbar[b, c] = plot mean of z; pooled[b, c] = BatchNorm(zbar): the input of the excitation MLP (agb_se_mlp_fwd)
+int agb_se_tail_pool(const float* part, const int32_t* ptr, int n, int B, int C, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, float* zbar, float* pooled, void* stream) {
+    hipLaunchKernelGGL(k_tail_pool, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, part, ptr, B, C,
+                       tail_rows(n, C), mean, rstd, gamma, beta, zbar, pooled);
+    AGB_CHECK_LAUNCH("agb_se_tail_pool");
+    return AGB_OK;
+}
+
+// Y = act(BatchNorm(Z) * s[plot] * keep[plot] + R); s float[B, C], keep float[B] or NULL
+int agb_se_tail_fwd(const float* Z, int ldz, const float* R, int ldr, const int32_t* coords, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, const float* s, const float* keep, int act,
+                    int n, int C, float* Y, int ldy, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0, "agb_se_tail_fwd: C/ld must be multiples of 4");
+    AGB_CHECK_ARG(act >= 0 && act <= 2, "agb_se_tail_fwd: activation %d", act);
+    if (n == 0) return AGB_OK;
+    const TailParams P{mean, rstd, gamma, beta, s, keep};
+    hipLaunchKernelGGL(k_tail_fwd, dim3(agb_cdiv(n, EW_PER * bn_row_lanes(C)), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
+                       (hipStream_t)stream, Z, ldz, R, ldr, (const int4*)coords, P, act, n, C, Y, ldy);
+    AGB_CHECK_LAUNCH("agb_se_tail_fwd");
+    return AGB_OK;
+}
+
+// spart float[agb_se_tail_chunks * 2 * C]: chunk partials of sum da and sum da * xhat
+int agb_se_tail_bwd_sums(const float* Z, int ldz, const float* R, int ldr, const float* dY, int ldy, const int32_t* ptr,
+                         int B, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         const float* s, const float* keep, int act, int n, int C, float* spart, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0, "agb_se_tail_bwd_sums: C/ld multiples of 4");
+    if (n == 0) return AGB_OK;
+    const TailParams P{mean, rstd, gamma, beta, s, keep};
+    hipLaunchKernelGGL(k_tail_bwd_sums, dim3(agb_se_tail_chunks(n, C, B), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
+                       (hipStream_t)stream, Z, ldz, R, ldr, dY, ldy, ptr, B, P, act, C, tail_rows(n, C), spart);
+    AGB_CHECK_LAUNCH("agb_se_tail_bwd_sums");
+    return AGB_OK;
+}
+
+// S2, S3 float[B, C]: per-plot sums (the plot's chunk partials in order); ds float[B, C]: the gradient of the excitation
+// (input of agb_se_mlp_bwd)
+int agb_se_tail_bwd_ds(const float* spart, const int32_t* ptr, int n, const float* gamma, const float* beta,
+                       const float* keep, int B, int C, float* S2, float* S3, float* ds, void* stream) {
+    hipLaunchKernelGGL(k_tail_bwd_ds, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, spart, ptr,
+                       tail_rows(n, C), gamma, beta, keep, B, C, S2, S3, ds);
+    AGB_CHECK_LAUNCH("agb_se_tail_bwd_ds");
+    return AGB_OK;
+}
+
+// dp float[B, C]: gradient of the pooled MLP input (from agb_se_mlp_bwd) -> dte float[B, C], dbeta, dgamma float[C]
+int agb_se_tail_bwd_fold(const float* S2, const float* S3, const float* zbar, const int32_t* ptr, const float* dp,
+                         const float* s, const float* keep, const float* mean, const float* rstd, int B, int C, float* dte,
+                         float* dbeta, float* dgamma, void* stream) {
+    hipLaunchKernelGGL(k_tail_bwd_fold, dim3(agb_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, S2, S3, zbar, ptr, dp, s,
+                       keep, mean, rstd, B, C, dte, dbeta, dgamma);
+    AGB_CHECK_LAUNCH("agb_se_tail_bwd_fold");
+    return AGB_OK;
+}
+
+// dZ (gradient of the BatchNorm input) and dR (gradient of the residual); either may be NULL
+int agb_se_tail_bwd_apply(const float* Z, int ldz, const float* R, int ldr, const float* dY, int ldy, const int32_t* coords,
+                          const float* mean, const float* rstd, const float* gamma, const float* beta, const float* s,
+                          const float* keep, const float* dte, const float* dbeta, const float* dgamma, int act,
+                          int training, int n, int C, float* dZ, int lddz, float* dR, int lddr, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0 && lddr % 4 == 0,
+                  "agb_se_tail_bwd_apply: C/ld must be multiples of 4");
+    if (n == 0) return AGB_OK;
+    const TailParams P{mean, rstd, gamma, beta, s, keep};
+    hipLaunchKernelGGL(k_tail_bwd_apply, dim3(agb_cdiv(n, EW_PER * bn_row_lanes(C)), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
+                       (hipStream_t)stream, Z, ldz, R, ldr, dY, ldy, (const int4*)coords, P, dte, dbeta, dgamma, act,
+                       training, n, C, dZ, lddz, dR, lddr);
+    AGB_CHECK_LAUNCH("agb_se_tail_bwd_apply");
+    return AGB_OK;
 }
 
 // y = act(A * scale[batch(row)] + R); scale (float[B]) and coords may be NULL (no drop-path)

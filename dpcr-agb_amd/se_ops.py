@@ -105,3 +105,110 @@ def se_layer(x, coords, ptr, B, lin1: torch.nn.Linear, act_name: str, lin2: torc
 
 def se_excite(p, lin1: torch.nn.Linear, act_name: str, lin2: torch.nn.Linear):
     return SEExciteFunction.apply(p, lin1.weight, lin1.bias, lin2.weight, lin2.bias, ACT_IDS[act_name])
+
+
+# ---------------------------------------------------------------------------------------------- fused block tail
+_F = _lib.c_float
+_lib.declare("agb_se_tail_chunks", [_I, _I, _I])
+_lib.declare("agb_se_tail_stats", [_V, _I, _V, _I, _I, _I, _F, _F, _I, _V, _V, _V, _V, _V, _V, _V])
+_lib.declare("agb_se_tail_pool", [_V, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V])
+_lib.declare("agb_se_tail_fwd", [_V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V, _I, _V])
+_lib.declare("agb_se_tail_bwd_sums", [_V, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V, _V])
+_lib.declare("agb_se_tail_bwd_ds", [_V, _V, _I, _V, _V, _V, _I, _I, _V, _V, _V, _V])
+_lib.declare("agb_se_tail_bwd_fold", [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _V, _V, _V, _V])
+_lib.declare("agb_se_tail_bwd_apply", [_V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V,
+                                       _I, _V, _I, _V])
+FUSED_TAIL = True      # (tests compare the fused tail with the separate kernels)
+
+
+class SEBlockTailFunction(torch.autograd.Function):
+    """y = act(BatchNorm(z) * s[plot] * keep[plot] + r),  s = sigmoid(W2 act_se(W1 avgpool_plot(BatchNorm(z)) + b1) + b2):
+    everything behind the last convolution of an SE residual block (senet_block.py:83-96, 126-147 + resnet_block.py:70-73)
+    as one autograd node over csrc/norm.hip k_tail_*: neither BatchNorm(z) nor its product with s is written to memory;
+    four passes over [N, C] forward, eight backward (the separate kernels: 9 and 14)."""
+
+    @staticmethod
+    def forward(ctx, z, r, gamma, beta, running_mean, running_var, momentum, eps, training, counter, coords, ptr, B, w1,
+                b1, w2, b2, se_act, keep, act_id):
+        z, r, w1, w2 = z.contiguous(), r.contiguous(), w1.contiguous(), w2.contiguous()
+        n, C = z.shape
+        H = w1.shape[0]
+        dev = z.device
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # noqa: E731
+        stats = f32(2, C)
+        part = f32(_lib.load().agb_se_tail_chunks(n, C, B) * 3 * C)
+        _lib.call("agb_se_tail_stats", _P(z), z.stride(0), _P(ptr), n, C, B, float(eps), float(momentum),
+                  int(bool(training)), _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter),
+                  _lib.stream())
+        zbar, p, h_pre, s = f32(B, C), f32(B, C), f32(B, H), f32(B, C)
+        _lib.call("agb_se_tail_pool", _P(part), _P(ptr), n, B, C, _P(stats[0]), _P(stats[1]), _P(gamma), _P(beta), _P(zbar),
+                  _P(p), _lib.stream())
+        _lib.call("agb_se_mlp_fwd", _P(p), _P(w1), _P(b1), _P(w2), _P(b2), B, C, H, se_act, _P(h_pre), _P(s), _lib.stream())
+        y = torch.empty_like(z)
+        _lib.call("agb_se_tail_fwd", _P(z), z.stride(0), _P(r), r.stride(0), _P(coords), _P(stats[0]), _P(stats[1]),
+                  _P(gamma), _P(beta), _P(s), _P(keep), act_id, n, C, _P(y), y.stride(0), _lib.stream())
+        none = torch.empty(0)
+        ctx.save_for_backward(z, r, stats, zbar, p, h_pre, s, coords, ptr, w1, w2,
+                              gamma if gamma is not None else none, beta if beta is not None else none,
+                              keep if keep is not None else none)
+        ctx.cfg = (bool(training), B, se_act, act_id, gamma is not None, beta is not None, keep is not None,
+                   b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, r, stats, zbar, p, h_pre, s, coords, ptr, w1, w2, gamma, beta, keep = ctx.saved_tensors
+        training, B, se_act, act_id, has_g, has_b, has_keep, has_b1, has_b2 = ctx.cfg
+        gamma, beta, keep = (gamma if has_g else None), (beta if has_b else None), (keep if has_keep else None)
+        dy = dy.contiguous()
+        n, C = z.shape
+        H = w1.shape[0]
+        dev = z.device
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # noqa: E731
+        S = f32(2, B, C)
+        bn = (_P(stats[0]), _P(stats[1]), _P(gamma), _P(beta), _P(s), _P(keep))
+        common = (_P(coords),) + bn
+        spart = f32(_lib.load().agb_se_tail_chunks(n, C, B) * 2 * C)
+        _lib.call("agb_se_tail_bwd_sums", _P(z), z.stride(0), _P(r), r.stride(0), _P(dy), dy.stride(0), _P(ptr), B, *bn,
+                  act_id, n, C, _P(spart), _lib.stream())
+        ds = f32(B, C)
+        _lib.call("agb_se_tail_bwd_ds", _P(spart), _P(ptr), n, _P(gamma), _P(beta), _P(keep), B, C, _P(S[0]), _P(S[1]),
+                  _P(ds), _lib.stream())
+        dz2, dh, dp = f32((C + 511) // 512, B, C), f32(B, H), f32(B, C)
+        dw1, dw2 = f32(H, C), f32(C, H)
+        db1 = f32(H) if has_b1 else None
+        db2 = f32(C) if has_b2 else None
+        _lib.call("agb_se_mlp_bwd", _P(p), _P(w1), _P(w2), B, C, H, se_act, _P(h_pre), _P(s), _P(ds), _P(dz2), _P(dh),
+                  _P(dp), _P(dw1), _P(db1), _P(dw2), _P(db2), _lib.stream())
+        dte, dgb = f32(B, C), f32(2, C)
+        _lib.call("agb_se_tail_bwd_fold", _P(S[0]), _P(S[1]), _P(zbar), _P(ptr), _P(dp), _P(s), _P(keep), _P(stats[0]),
+                  _P(stats[1]), B, C, _P(dte), _P(dgb[0]), _P(dgb[1]), _lib.stream())
+        dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        dr = torch.empty_like(r) if ctx.needs_input_grad[1] else None
+        _lib.call("agb_se_tail_bwd_apply", _P(z), z.stride(0), _P(r), r.stride(0), _P(dy), dy.stride(0), *common, _P(dte),
+                  _P(dgb[0]), _P(dgb[1]), act_id, int(training), n, C, _P(dz), 0 if dz is None else dz.stride(0), _P(dr),
+                  0 if dr is None else dr.stride(0), _lib.stream())
+        if dz is not None:
+            # column sums of dz = the bias gradient of the convolution that produced z: 0 with batch statistics (the
+            # BatchNorm is blind to a constant), gamma * rstd * dbeta with the running ones (norm_ops.BatchNormActFunction)
+            colsum = torch.zeros(C, dtype=torch.float32, device=dev) if training else \
+                (stats[1] * dgb[0] * (gamma if gamma is not None else 1.0))
+            dz.agb_colsum = (colsum, dz._version)
+        return (dz, dr, dgb[1] if has_g else None, dgb[0] if has_b else None, None, None, None, None, None, None, None, None,
+                None, dw1, db1, dw2, db2, None, None, None)
+
+
+def se_block_tail(z, r, bn: torch.nn.BatchNorm1d, coords, ptr, B, lin1, se_act_name, lin2, keep, act_name):
+    """nn.BatchNorm1d semantics for `bn` (batch statistics + running update in training, running statistics in eval)."""
+    rm, rv = bn.running_mean, bn.running_var
+    use_batch_stats = bn.training or rm is None
+    momentum, counter = 0.0, None
+    if bn.training and rm is not None:
+        if bn.momentum is not None:
+            momentum, counter = bn.momentum, bn.num_batches_tracked
+        else:
+            bn.num_batches_tracked.add_(1)
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    return SEBlockTailFunction.apply(z, r, bn.weight, bn.bias, rm, rv, momentum, bn.eps, use_batch_stats, counter, coords,
+                                     ptr, B, lin1.weight, lin1.bias, lin2.weight, lin2.bias, ACT_IDS[se_act_name], keep,
+                                     ACT_IDS[act_name])

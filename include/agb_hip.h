@@ -228,6 +228,32 @@ int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int
 int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
                           const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
                           float* dX, int lddx, float* dgamma, float* dbeta, float* colsum, void* stream);
+/* The tail of a squeeze-excite residual block in four passes forward and eight backward instead of 9 + 14
+ * (senet_block.py:83-96,126-147; resnet_block.py:70-73):  y = act(BatchNorm(z) * s[plot] * keep[plot] + r) with
+ * s = excitation MLP of the plot means of BatchNorm(z).  coords int32[n][4] (batch index first), ptr int32[B+1].
+ * Reductions run over plot-aligned row chunks and are folded in a fixed order: no atomics, bitwise reproducible.
+ * Call order: _stats, _pool, agb_se_mlp_fwd, _fwd | _bwd_sums, _bwd_ds, agb_se_mlp_bwd, _bwd_fold, _bwd_apply. */
+int agb_se_tail_chunks(int n, int C, int B);   /* plot-aligned row chunks: sizes part (x 3 C floats) and spart (x 2 C) */
+int agb_se_tail_stats(const float* Z, int ldz, const int32_t* ptr, int n, int C, int B, float eps, float momentum,
+                      int training, float* part, float* mean, float* rstd, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, void* stream);
+int agb_se_tail_pool(const float* part, const int32_t* ptr, int n, int B, int C, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, float* zbar, float* pooled, void* stream);
+int agb_se_tail_fwd(const float* Z, int ldz, const float* R, int ldr, const int32_t* coords, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, const float* s, const float* keep, int act,
+                    int n, int C, float* Y, int ldy, void* stream);
+int agb_se_tail_bwd_sums(const float* Z, int ldz, const float* R, int ldr, const float* dY, int ldy, const int32_t* ptr,
+                         int B, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         const float* s, const float* keep, int act, int n, int C, float* spart, void* stream);
+int agb_se_tail_bwd_ds(const float* spart, const int32_t* ptr, int n, const float* gamma, const float* beta,
+                       const float* keep, int B, int C, float* S2, float* S3, float* ds, void* stream);
+int agb_se_tail_bwd_fold(const float* S2, const float* S3, const float* zbar, const int32_t* ptr, const float* dp,
+                         const float* s, const float* keep, const float* mean, const float* rstd, int B, int C, float* dte,
+                         float* dbeta, float* dgamma, void* stream);
+int agb_se_tail_bwd_apply(const float* Z, int ldz, const float* R, int ldr, const float* dY, int ldy, const int32_t* coords,
+                          const float* mean, const float* rstd, const float* gamma, const float* beta, const float* s,
+                          const float* keep, const float* dte, const float* dbeta, const float* dgamma, int act,
+                          int training, int n, int C, float* dZ, int lddz, float* dR, int lddr, void* stream);
 /* Y = act(A * scale[batch(row)] + R); scale float[B] (drop-path keep/(1-p)) and coords may be NULL */
 int agb_add_act_fwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords, int n,
                     int C, int act, float* Y, int ldy, void* stream);

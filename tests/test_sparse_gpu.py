@@ -819,3 +819,64 @@ def test_dense_linear_odd_shapes(device, n, cin, cout):
     yr.backward(g.double())
     assert rel_err(y, yr) < RTOL and rel_err(xg.grad, xr.grad) < RTOL
     assert rel_err(lin.weight.grad, wr.grad) < RTOL and rel_err(lin.bias.grad, br.grad) < RTOL
+
+
+@pytest.mark.parametrize("block_name,training,drop", [("SEBasicBlock", True, 0.0), ("SEBasicBlock", True, 0.5),
+                                                      ("SEBasicBlock", False, 0.0), ("SEBottleneck", True, 0.3)])
+def test_se_block_tail_fused_vs_separate(device, block_name, training, drop):
+    """Everything behind the last convolution of an SE residual block as one autograd node (se_ops.SEBlockTailFunction:
+    BatchNorm statistics + per-plot sums in one pass, no BatchNorm output / excitation product in memory) against the
+    module-by-module path: output, input gradient, every parameter gradient and the running statistics; training with and
+    without drop-path, and eval mode (running statistics) with gradients."""
+    import random
+    import dpcr_agb_amd.backbones.sparse as SP
+    import dpcr_agb_amd.me_compat as ME
+    import dpcr_agb_amd.se_ops as se_ops
+    torch.manual_seed(3)
+    rng = np.random.default_rng(1)
+    B, npts = 5, 700
+    coords = np.unique(np.concatenate([np.full((B * npts, 1), 0), rng.integers(0, 14, (B * npts, 3))], 1), axis=0)
+    coords = np.concatenate([np.concatenate([np.full((len(coords), 1), b), coords[:, 1:] + b], 1) for b in range(B)])
+    c = 32
+    cls = getattr(SP, block_name)
+    planes = c if block_name == "SEBasicBlock" else c // 4
+    act = ME.MinkowskiGELU()
+    blk = cls(c, planes, act, ME.MinkowskiBatchNorm, drop_path=drop, dimension=3).to(device)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-0.5, 0.5)
+                m.running_mean.uniform_(-0.2, 0.2), m.running_var.uniform_(0.5, 1.5)
+    blk.train(training)
+    state0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    x0 = torch.randn(len(coords), c)
+    g = torch.randn(len(coords), c)
+    res = {}
+    for fused in (True, False):
+        blk.load_state_dict(state0)
+        blk.zero_grad()
+        flag = se_ops.FUSED_TAIL
+        se_ops.FUSED_TAIL = fused
+        calls = []
+        from dpcr_agb_amd import _lib
+        orig = _lib.call
+        _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        random.seed(7)                     # (the drop-path draws)
+        try:
+            xf = x0.to(device).requires_grad_(True)
+            st = ME.SparseTensor(xf, coordinates=torch.from_numpy(coords).int(), device=device, batch_size=B)
+            y = blk(st).F
+            y.backward(g.to(device))
+        finally:
+            se_ops.FUSED_TAIL, _lib.call = flag, orig
+        assert ("agb_se_tail_fwd" in calls) == fused and ("agb_add_act_fwd" in calls) == (not fused), calls
+        res[fused] = dict(y=y.detach(), dx=xf.grad.clone(), **{"g/" + k: p.grad.clone() for k, p in blk.named_parameters()},
+                          **{"s/" + k: v.clone() for k, v in blk.state_dict().items() if "running" in k})
+    gmax = max(float(v.abs().max()) for k, v in res[False].items() if k.startswith("g/"))
+    import re
+    for k, v in res[False].items():
+        floor = 1e-3 * gmax if k.startswith("g/") else 1e-30
+        if training and re.search(r"conv\d\.bias$", k):
+            floor = 1e-2 * gmax     # exactly 0 in exact arithmetic (a BatchNorm in training mode follows): rounding noise
+        err = float((res[True][k] - v).abs().max()) / max(float(v.abs().max()), floor)
+        assert err < RTOL, (k, err)
