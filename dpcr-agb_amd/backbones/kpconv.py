@@ -19,10 +19,11 @@ import torch.nn as nn
 from .. import _lib
 from ..kp_dispositions import kernel_disposition
 from ..kpconv_ops import KPConvSymmetricFunction, KPGatherFunction, KPMaxPoolFunction, as_index
-from ..norm_ops import ACT_IDS, AddActFunction, batch_norm_act
+from ..norm_ops import ACT_IDS, AddActFunction, batch_norm_act, batch_norm_add_act
 from ..sparse_ops import DenseConvFunction, dense_linear, segment_reduce, take_bn_hint
 
 ACTIVATION_NAMES = {"relu": "relu", "gelu": "gelu"}
+FUSED_TAIL = True        # Linear -> BatchNorm -> + shortcut -> activation of the bottleneck blocks as one node
 
 
 def _act_module(name):
@@ -167,12 +168,18 @@ class ResnetBottleneckBlock(nn.Module):
         x = self.unary1(features)
         x = self.KPConv(q, s, idx, x)
         x = _post(self.batch_norm_conv, self.act_name, None if self._fused_act else self.act, x)
-        x = self.unary2(x)
         if "strided" in self.block_name:
             shortcut = KPMaxPoolFunction.apply(features, as_index(idx))
         else:
             shortcut = features
         shortcut = self.unary_shortcut(shortcut)
+        u2 = self.unary2
+        if (FUSED_TAIL and self._fused_act and x.is_cuda and u2.no_relu and u2.batch_norm.use_bn
+                and u2.out_dim % 4 == 0):
+            # Linear -> BatchNorm -> (+ shortcut) -> activation without the BatchNorm output in memory
+            z = dense_linear(x, u2.mlp.weight, u2.mlp.bias)
+            return batch_norm_add_act(z, shortcut, u2.batch_norm.batch_norm, self._fused_act)
+        x = u2(x)
         if self._fused_act and x.shape[1] % 4 == 0:
             return AddActFunction.apply(x, shortcut, None, None, ACT_IDS[self._fused_act])
         return self.act(x + shortcut)

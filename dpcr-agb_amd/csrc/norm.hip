@@ -468,6 +468,11 @@ __global__ __launch_bounds__(256) void k_add_act_bwd(const float* __restrict__ A
 // The grid is sized for the worst case ceil(n / R) + B chunks; the surplus writes empty partials.
 struct PlotChunk { int b, r_beg, r_end; };
 __device__ __forceinline__ PlotChunk plot_chunk(const int32_t* __restrict__ ptr, int B, int R, int g) {
+    if (ptr == nullptr) {                 // no plots: B carries the row count, plain consecutive chunks
+        const long long rb = (long long)g * R;
+        if (rb >= B) return PlotChunk{-1, 0, 0};
+        return PlotChunk{0, (int)rb, (int)min((long long)B, rb + R)};
+    }
     int acc = 0;
     for (int b = 0; b < B; ++b) {
         const int lo = ptr[b], hi = ptr[b + 1];
@@ -596,11 +601,11 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const float* __restrict__ Z, i
     for (int j = 0; j < EW_PER; ++j) {
         const int r = r0 + L.rl_n * j;
         if (r >= n) continue;
-        const int b = coords[r].x;
+        const int b = coords ? coords[r].x : 0;
         const float kf = P.keep ? P.keep[b] : 1.f;
         const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
         const float4 r4 = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
-        const float4 s4 = *reinterpret_cast<const float4*>(P.s + (long long)b * C + c);
+        const float4 s4 = P.s ? *reinterpret_cast<const float4*>(P.s + (long long)b * C + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float z[4] = {z4.x, z4.y, z4.z, z4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
         float o[4];
 #pragma unroll
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256) void k_tail_bwd_sums(const float* __restrict__
             rs[j] = P.rstd[c + j];
             g[j] = P.gamma ? P.gamma[c + j] : 1.f;
             be[j] = P.beta ? P.beta[c + j] : 0.f;
-            sk[j] = P.s[(long long)pc.b * C + c + j] * kf;
+            sk[j] = (P.s ? P.s[(long long)pc.b * C + c + j] : 1.f) * kf;
         }
         for (int r = pc.r_beg + rl; r < pc.r_end; r += L.rl_n) {
             const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
@@ -737,13 +742,13 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const float* __restrict_
     for (int j = 0; j < EW_PER; ++j) {
         const int r = r0 + L.rl_n * j;
         if (r >= n) continue;
-        const int b = coords[r].x;
+        const int b = coords ? coords[r].x : 0;
         const float kf = P.keep ? P.keep[b] : 1.f;
         const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
         const float4 r4 = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
         const float4 d4 = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
-        const float4 s4 = *reinterpret_cast<const float4*>(P.s + (long long)b * C + c);
-        const float4 e4 = *reinterpret_cast<const float4*>(dte + (long long)b * C + c);
+        const float4 s4 = P.s ? *reinterpret_cast<const float4*>(P.s + (long long)b * C + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 e4 = dte ? *reinterpret_cast<const float4*>(dte + (long long)b * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float z[4] = {z4.x, z4.y, z4.z, z4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w},
                     ss[4] = {s4.x, s4.y, s4.z, s4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
         float oz[4], orr[4];
@@ -857,6 +862,16 @@ int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int
     return AGB_OK;
 }
 
+// dbeta[c] = sum over chunks of part[chunk][0][c], dgamma[c] = ... part[chunk][1][c] (fixed order): the fold half of
+// agb_bn_act_bwd on partials produced by agb_se_tail_bwd_sums without plots
+int agb_bn_bwd_fold(const float* part, int chunks, int C, float* dbeta, float* dgamma, void* stream) {
+    AGB_CHECK_ARG(part && chunks >= 1 && C >= 1, "agb_bn_bwd_fold: %d chunks, %d columns", chunks, C);
+    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, (hipStream_t)stream, part, chunks, C, dbeta,
+                       dgamma, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1);
+    AGB_CHECK_LAUNCH("agb_bn_bwd_fold");
+    return AGB_OK;
+}
+
 int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
                    const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
                    float* dX, int lddx, float* dgamma, float* dbeta, void* stream) {
@@ -922,8 +937,10 @@ int agb_se_tail_bwd_sums(const float* Z, int ldz, const float* R, int ldr, const
     AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0, "agb_se_tail_bwd_sums: C/ld multiples of 4");
     if (n == 0) return AGB_OK;
     const TailParams P{mean, rstd, gamma, beta, s, keep};
-    hipLaunchKernelGGL(k_tail_bwd_sums, dim3(agb_se_tail_chunks(n, C, B), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
-                       (hipStream_t)stream, Z, ldz, R, ldr, dY, ldy, ptr, B, P, act, C, tail_rows(n, C), spart);
+    // ptr == NULL: no plots (s and keep must be NULL too): plain row chunks, the kernel's plot count carries n
+    AGB_CHECK_ARG(ptr != nullptr || (s == nullptr && keep == nullptr), "agb_se_tail_bwd_sums: s / keep need ptr");
+    hipLaunchKernelGGL(k_tail_bwd_sums, dim3(agb_se_tail_chunks(n, C, ptr ? B : 0), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
+                       (hipStream_t)stream, Z, ldz, R, ldr, dY, ldy, ptr, ptr ? B : n, P, act, C, tail_rows(n, C), spart);
     AGB_CHECK_LAUNCH("agb_se_tail_bwd_sums");
     return AGB_OK;
 }

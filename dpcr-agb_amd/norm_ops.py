@@ -3,6 +3,7 @@ activation, and the fused residual tail act(a * drop_path_scale[batch] + r)."""
 import torch
 
 from . import _lib
+from . import se_ops as _se_ops  # noqa: F401  (declares the agb_se_tail_* entry points used below)
 
 _P = _lib.ptr
 ACT_IDS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
@@ -48,6 +49,9 @@ def _statistics(x, n, c, eps, momentum, training, running_mean, running_var, cou
     _lib.call("agb_bn_stats_tracked", _P(x), x.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
               _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter), _lib.stream())
     return stats
+
+
+_lib.declare("agb_bn_bwd_fold", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p])
 
 
 def bn_chunks(n):
@@ -149,6 +153,71 @@ class AddActFunction(torch.autograd.Function):
         _lib.call("agb_add_act_bwd", _P(a), a.stride(0), _P(r), r.stride(0), _P(scale) if has_s else None,
                   _P(coords) if has_s else None, _P(dy), dy.stride(0), n, c, act_id, _P(da), _P(dr), _lib.stream())
         return da, (da if shared else dr), None, None, None
+
+
+class BatchNormAddActFunction(torch.autograd.Function):
+    """y = act(BatchNorm(z) + r): the tail of a residual block whose last layer is Linear / conv -> BatchNorm (KPConv
+    blocks.py:640-668) without the BatchNorm output in memory: 2 passes + statistics forward (the statistics come from the
+    producing product's epilogue where it left them), 8 passes backward instead of 10."""
+
+    @staticmethod
+    def forward(ctx, z, r, gamma, beta, running_mean, running_var, momentum, eps, act_id, training, counter, hint):
+        z, r = z.contiguous(), r.contiguous()
+        n, c = z.shape
+        if c % 4 != 0:
+            raise _lib.AgbError("fused batch norm + residual needs a channel count that is a multiple of 4")
+        stats = _statistics(z, n, c, eps, momentum, training, running_mean, running_var, counter, hint)
+        y = torch.empty_like(z)
+        _lib.call("agb_se_tail_fwd", _P(z), z.stride(0), _P(r), r.stride(0), None, _P(stats[0]), _P(stats[1]), _P(gamma),
+                  _P(beta), None, None, act_id, n, c, _P(y), y.stride(0), _lib.stream())
+        none = torch.empty(0)
+        ctx.save_for_backward(z, r, stats, gamma if gamma is not None else none, beta if beta is not None else none)
+        ctx.cfg = (act_id, bool(training), gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, r, stats, gamma, beta = ctx.saved_tensors
+        act_id, training, has_g, has_b = ctx.cfg
+        gamma, beta = (gamma if has_g else None), (beta if has_b else None)
+        dy = dy.contiguous()
+        n, c = z.shape
+        dev = z.device
+        chunks = _lib.load().agb_se_tail_chunks(n, c, 0)
+        spart = torch.empty(chunks * 2 * c, dtype=torch.float32, device=dev)
+        bn = (_P(stats[0]), _P(stats[1]), _P(gamma), _P(beta), None, None)
+        _lib.call("agb_se_tail_bwd_sums", _P(z), z.stride(0), _P(r), r.stride(0), _P(dy), dy.stride(0), None, 0, *bn, act_id,
+                  n, c, _P(spart), _lib.stream())
+        dgb = torch.empty(2, c, dtype=torch.float32, device=dev)
+        _lib.call("agb_bn_bwd_fold", _P(spart), chunks, c, _P(dgb[0]), _P(dgb[1]), _lib.stream())
+        dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        dr = torch.empty_like(r) if ctx.needs_input_grad[1] else None
+        _lib.call("agb_se_tail_bwd_apply", _P(z), z.stride(0), _P(r), r.stride(0), _P(dy), dy.stride(0), None, *bn, None,
+                  _P(dgb[0]), _P(dgb[1]), act_id, int(training), n, c, _P(dz), 0 if dz is None else dz.stride(0), _P(dr),
+                  0 if dr is None else dr.stride(0), _lib.stream())
+        if dz is not None:
+            colsum = torch.zeros(c, dtype=torch.float32, device=dev) if training else \
+                (stats[1] * dgb[0] * (gamma if gamma is not None else 1.0))
+            dz.agb_colsum = (colsum, dz._version)
+        return dz, dr, (dgb[1] if has_g else None), (dgb[0] if has_b else None), None, None, None, None, None, None, None, \
+            None
+
+
+def batch_norm_add_act(z, r, bn: torch.nn.BatchNorm1d, act):
+    """act(bn(z) + r) with nn.BatchNorm1d semantics for `bn` (as batch_norm_act)."""
+    rm, rv = bn.running_mean, bn.running_var
+    use_batch_stats = bn.training or rm is None
+    momentum, counter = 0.0, None
+    if bn.training and rm is not None:
+        if bn.momentum is not None:
+            momentum, counter = bn.momentum, bn.num_batches_tracked
+        else:
+            bn.num_batches_tracked.add_(1)
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    from .sparse_ops import bn_hint
+    hint = bn_hint(z, z.shape[1]) if (use_batch_stats and z.dim() == 2) else None
+    return BatchNormAddActFunction.apply(z, r, bn.weight, bn.bias, rm, rv, momentum, bn.eps, ACT_IDS[act], use_batch_stats,
+                                         counter, hint)
 
 
 _V, _I = _lib.c_void_p, _lib.c_int

@@ -233,6 +233,9 @@ int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int
  * s = excitation MLP of the plot means of BatchNorm(z).  coords int32[n][4] (batch index first), ptr int32[B+1].
  * Reductions run over plot-aligned row chunks and are folded in a fixed order: no atomics, bitwise reproducible.
  * Call order: _stats, _pool, agb_se_mlp_fwd, _fwd | _bwd_sums, _bwd_ds, agb_se_mlp_bwd, _bwd_fold, _bwd_apply. */
+/* Without an excitation (s == NULL, keep == NULL, coords == NULL, ptr == NULL) the same entry points are the tail of a
+ * plain residual block, y = act(BatchNorm(z) + r) (KPConv blocks.py:640-668): _fwd | _bwd_sums, agb_bn_bwd_fold, _bwd_apply. */
+int agb_bn_bwd_fold(const float* part, int chunks, int C, float* dbeta, float* dgamma, void* stream);
 int agb_se_tail_chunks(int n, int C, int B);   /* plot-aligned row chunks: sizes part (x 3 C floats) and spart (x 2 C) */
 int agb_se_tail_stats(const float* Z, int ldz, const int32_t* ptr, int n, int C, int B, float eps, float momentum,
                       int training, float* part, float* mean, float* rstd, float* running_mean, float* running_var,

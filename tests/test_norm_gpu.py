@@ -267,3 +267,41 @@ def test_bn_statistics_from_the_product_epilogue(device, n, cin, cout):
     yr = F.gelu(ref(x.double() @ lin.weight.detach().double().t() + lin.bias.detach().double()))
     assert rel(res[True][0], yr) < 1e-4
     assert rel(res[True][1], ref.running_mean) < 1e-5 and rel(res[True][2], ref.running_var) < 1e-4
+
+
+@pytest.mark.parametrize("n,c", [(50021, 64), (4099, 16), (333, 256)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_add_act_fused(device, n, c, training):
+    """act(BatchNorm(z) + r) as one node (the tail of KPConv's bottleneck blocks; csrc/norm.hip k_tail_* without an
+    excitation) against batch_norm_act + the residual kernel and against torch in fp64."""
+    from dpcr_agb_amd.norm_ops import ACT_IDS, AddActFunction, batch_norm_act, batch_norm_add_act
+    torch.manual_seed(n + c)
+    z0, r0, g = torch.randn(n, c) * 0.7 + 2.0, torch.randn(n, c), torch.randn(n, c)
+    bn0 = torch.nn.BatchNorm1d(c, momentum=0.1)
+    with torch.no_grad():
+        bn0.weight.uniform_(0.5, 1.5), bn0.bias.uniform_(-0.5, 0.5)
+        bn0.running_mean.uniform_(1.5, 2.5), bn0.running_var.uniform_(0.3, 0.8)
+    res = {}
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm1d(c, momentum=0.1)
+        bn.load_state_dict(bn0.state_dict())
+        bn = bn.to(device).train(training)
+        z, r = z0.to(device).requires_grad_(True), r0.to(device).requires_grad_(True)
+        if fused:
+            y = batch_norm_add_act(z, r, bn, "gelu")
+        else:
+            y = AddActFunction.apply(batch_norm_act(z, bn, None), r, None, None, ACT_IDS["gelu"])
+        y.backward(g.to(device))
+        res[fused] = (y.detach(), z.grad.clone(), r.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                      bn.running_mean.clone(), bn.running_var.clone())
+    for a, b in zip(res[True], res[False]):
+        assert rel(a, b) < 2e-5
+    ref = torch.nn.BatchNorm1d(c, momentum=0.1).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn0.state_dict().items()})
+    ref.train(training)
+    zr, rr = z0.double().requires_grad_(True), r0.double().requires_grad_(True)
+    yr = F.gelu(ref(zr) + rr)
+    yr.backward(g.double())
+    assert rel(res[True][0], yr) < 5e-5
+    assert rel(res[True][1], zr.grad) < 2e-4 and rel(res[True][2], rr.grad) < 2e-4
+    assert rel(res[True][3], ref.weight.grad) < 2e-4 and rel(res[True][4], ref.bias.grad) < 2e-4
