@@ -694,25 +694,38 @@ __global__ void k_tail_bwd_ds(const float* __restrict__ spart, const int32_t* __
 // of t), and the BatchNorm parameter gradients in closed form over the plots:
 //   dbeta  = sum_rows dt        = sum_b (s keep S2 + rows dte)
 //   dgamma = sum_rows dt * xhat = sum_b (s keep S3 + dte X1),  X1[b,c] = sum_plot xhat = rows (zbar - mean) rstd
-__global__ void k_tail_bwd_fold(const float* __restrict__ S2, const float* __restrict__ S3,
-                                const float* __restrict__ zbar, const int32_t* __restrict__ ptr,
-                                const float* __restrict__ dp, const float* __restrict__ s, const float* __restrict__ keep,
-                                const float* __restrict__ mean, const float* __restrict__ rstd, int B, int C,
-                                float* __restrict__ dte, float* __restrict__ dbeta, float* __restrict__ dgamma) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void k_tail_bwd_fold(const float* __restrict__ S2, const float* __restrict__ S3,
+                                                       const float* __restrict__ zbar, const int32_t* __restrict__ ptr,
+                                                       const float* __restrict__ dp, const float* __restrict__ s,
+                                                       const float* __restrict__ keep, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int B, int C,
+                                                       float* __restrict__ dte, float* __restrict__ dbeta,
+                                                       float* __restrict__ dgamma) {
+    // 64 columns x 4 plot lanes per workgroup (one thread walking all the plots of a column made this tiny kernel 23 us
+    // of dependent loads); lane partials meet in LDS in a fixed order
+    __shared__ float s_db[4][64], s_dg[4][64];
+    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float db = 0.f, dg = 0.f;
-    for (int b = 0; b < B; ++b) {     // fixed order
-        const long long t = (long long)b * C + c;
-        const float rows = (float)(ptr[b + 1] - ptr[b]);
-        const float e = rows > 0.f ? dp[t] / rows : 0.f;
-        dte[t] = e;
-        const float sk = s[t] * (keep ? keep[b] : 1.f);
-        db += sk * S2[t] + rows * e;
-        dg += sk * S3[t] + e * rows * (zbar[t] - mean[c]) * rstd[c];
+    if (c < C) {
+        const float mu = mean[c], rs = rstd[c];
+        for (int b = bl; b < B; b += 4) {
+            const long long t = (long long)b * C + c;
+            const float rows = (float)(ptr[b + 1] - ptr[b]);
+            const float e = rows > 0.f ? dp[t] / rows : 0.f;
+            dte[t] = e;
+            const float sk = s[t] * (keep ? keep[b] : 1.f);
+            db += sk * S2[t] + rows * e;
+            dg += sk * S3[t] + e * rows * (zbar[t] - mu) * rs;
+        }
     }
-    dbeta[c] = db;
-    dgamma[c] = dg;
+    s_db[bl][cl] = db;
+    s_dg[bl][cl] = dg;
+    __syncthreads();
+    if (bl == 0 && c < C) {
+        dbeta[c] = (s_db[0][cl] + s_db[1][cl]) + (s_db[2][cl] + s_db[3][cl]);
+        dgamma[c] = (s_dg[0][cl] + s_dg[1][cl]) + (s_dg[2][cl] + s_dg[3][cl]);
+    }
 }
 
 // dz = gamma rstd (dt - [training](dbeta + xhat dgamma) / n),  dt = da s keep + dte[plot];   dr = da
@@ -959,7 +972,7 @@ int agb_se_tail_bwd_ds(const float* spart, const int32_t* ptr, int n, const floa
 int agb_se_tail_bwd_fold(const float* S2, const float* S3, const float* zbar, const int32_t* ptr, const float* dp,
                          const float* s, const float* keep, const float* mean, const float* rstd, int B, int C, float* dte,
                          float* dbeta, float* dgamma, void* stream) {
-    hipLaunchKernelGGL(k_tail_bwd_fold, dim3(agb_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, S2, S3, zbar, ptr, dp, s,
+    hipLaunchKernelGGL(k_tail_bwd_fold, dim3(agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, S2, S3, zbar, ptr, dp, s,
                        keep, mean, rstd, B, C, dte, dbeta, dgamma);
     AGB_CHECK_LAUNCH("agb_se_tail_bwd_fold");
     return AGB_OK;
