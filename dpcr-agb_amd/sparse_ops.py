@@ -3,6 +3,8 @@
 Each Function only marshals pointers/sizes into the C ABI on torch's current stream; all arithmetic of the
 sparse path happens in libagbhip.so.  Host tensors are refused (see _lib.ptr).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -112,7 +114,7 @@ def _small_cin_pad(cin):
 
 # Partial BatchNorm statistics from the epilogue of the forward dense products (agb_dense_fwd_bn); the product's caller
 # moves them onto the tensor it returns (take_bn_hint), norm_ops.batch_norm_act picks them up from there.
-BN_STATS_IN_EPILOGUE = True
+BN_STATS_IN_EPILOGUE = os.environ.get("AGB_BN_EPILOGUE", "1") != "0"   # (host-side tuning knob: measurements with / without)
 _LAST_BN_PART = None
 
 
