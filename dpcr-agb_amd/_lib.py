@@ -112,15 +112,29 @@ def ptr(t):
     return t.data_ptr()
 
 
+# torch.cuda.current_stream() builds a Stream object through four Python layers (~9 us): at ~170 launches per training
+# step and direction that was 0.8 ms of host time per step.  The raw handle of the current stream of the current device is
+# one C call.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
+_FN = {}     # entry point name -> ctypes function (one dictionary lookup per launch instead of load() + getattr)
+
+
 def call(name, *args):
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
-        raise AgbError(f"{name} failed ({rc}): {lib.agb_last_error().decode()}")
+        raise AgbError(f"{name} failed ({rc}): {load().agb_last_error().decode()}")
     return rc
 
 
