@@ -16,8 +16,7 @@ _P = _lib.ptr
 #   "fp32"   exact fp32 MFMA (default; what bench.py's headline number uses)
 #   "bf16"   bf16 operands, fp32 accumulate (BASELINE.json config 5)
 #   "bf16x3" split-bf16 (hi+lo) operands, three MFMAs per product: fp32-level accuracy at 3/16 of the fp32 MFMA cost
-import os as _os
-CONV_PRECISION = _os.environ.get("AGB_CONV_PRECISION", "fp32")
+CONV_PRECISION = os.environ.get("AGB_CONV_PRECISION", "fp32")
 _PREC_ID = {"bf16": 1, "bf16x3": 2}
 
 
