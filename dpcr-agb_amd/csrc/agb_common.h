@@ -86,6 +86,18 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
     if (act == ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
     return z;
 }
+// value and derivative at once (the GELU pair shares its erf)
+__device__ __forceinline__ void act_fwd_grad(float z, int act, float* val, float* grad) {
+    if (act == ACT_RELU) { *val = z > 0.f ? z : 0.f; *grad = z > 0.f ? 1.f : 0.f; return; }
+    if (act == ACT_GELU) {
+        const float e = erff(z * 0.70710678118654752440f);
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+        *val = 0.5f * z * (1.f + e);                  // (the expressions of act_fwd / act_grad: same rounding)
+        *grad = 0.5f * (1.f + e) + z * pdf;
+        return;
+    }
+    *val = z; *grad = 1.f;
+}
 __device__ __forceinline__ float act_grad(float z, int act) {
     if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
     if (act == ACT_GELU) {

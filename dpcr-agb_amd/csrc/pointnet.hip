@@ -20,9 +20,12 @@ __global__ __launch_bounds__(256) void k_pn_pool_fwd(const float* __restrict__ Z
                                                      int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int act, int mode, int S, float* __restrict__ Y,
-                                                     int32_t* __restrict__ arg) {
+                                                     int32_t* __restrict__ arg, float* __restrict__ AUX, int B) {
+    // AUX (sum / avg pooling, optional): [2][B * S][C] per-plot sums of act'(.) and act'(.) * zhat — everything the
+    // BatchNorm parameter gradients need from z, so that the backward pass does not read the [n, C] matrix for them
     __shared__ float s_val[PN_ROWS][64];
     __shared__ int s_arg[PN_ROWS][64];
+    __shared__ float s_x1[PN_ROWS][64], s_x2[PN_ROWS][64];
     const int b = blockIdx.x;
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = min(blockIdx.y * 64 + cg * 4, C - 4);
@@ -37,8 +40,9 @@ __global__ __launch_bounds__(256) void k_pn_pool_fwd(const float* __restrict__ Z
         m[j] = mean[c + j]; sd[j] = rstd[c + j];
         g[j] = gamma ? gamma[c + j] : 1.f; bb[j] = beta ? beta[c + j] : 0.f;
     }
-    float acc[4];
+    float acc[4], x1[4] = {0.f, 0.f, 0.f, 0.f}, x2[4] = {0.f, 0.f, 0.f, 0.f};
     int ai[4] = {-1, -1, -1, -1};
+    const bool aux = AUX != nullptr && mode != 2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (mode == 2) ? -FLT_MAX : 0.f;
     // four rows in flight per thread
@@ -57,7 +61,16 @@ __global__ __launch_bounds__(256) void k_pn_pool_fwd(const float* __restrict__ Z
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // (z - mean) * rstd * gamma + beta evaluated like the unfused kernel (k_bn_act_fwd): same rounding
-                const float y = act_fwd((v[j] - m[j]) * sd[j] * g[j] + bb[j], act);
+                const float zh = (v[j] - m[j]) * sd[j];
+                if (aux) {
+                    float y, dy;
+                    act_fwd_grad(zh * g[j] + bb[j], act, &y, &dy);
+                    acc[j] += y;
+                    x1[j] += dy;
+                    x2[j] += dy * zh;
+                    continue;
+                }
+                const float y = act_fwd(zh * g[j] + bb[j], act);
                 if (mode == 2) {
                     if (y > acc[j]) { acc[j] = y; ai[j] = r; }
                 } else {
@@ -70,10 +83,19 @@ __global__ __launch_bounds__(256) void k_pn_pool_fwd(const float* __restrict__ Z
     for (int j = 0; j < 4; ++j) {
         s_val[rl][cg * 4 + j] = acc[j];
         s_arg[rl][cg * 4 + j] = ai[j];
+        s_x1[rl][cg * 4 + j] = x1[j];
+        s_x2[rl][cg * 4 + j] = x2[j];
     }
     __syncthreads();
     const int l = threadIdx.x;
     const int cc = blockIdx.y * 64 + l;
+    if (aux && l < 64 && cc < C) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int j = 0; j < PN_ROWS; ++j) { a1 += s_x1[j][l]; a2 += s_x2[j][l]; }
+        const long long slot = ((long long)b * S + blockIdx.z) * C + cc;
+        AUX[slot] = a1;
+        AUX[(long long)B * S * C + slot] = a2;
+    }
     // (threads of a partial last slab past C recomputed the last channel group; their columns are not written out)
     if (l < 64 && cc < C) {
         const int src = l;
@@ -119,6 +141,39 @@ __global__ void k_pn_pool_fold(const float* __restrict__ part, const int32_t* __
         if (mode == 1) a = len > 0 ? a / (float)len : 0.f;
         Y[t] = a;
     }
+}
+
+// aux[2][B][C] = the row splits of aux_part[2][B * S][C] summed in split order
+__global__ void k_pn_aux_fold(const float* __restrict__ aux_part, int B, int C, int S, float* __restrict__ aux) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2LL * B * C) return;
+    const int which = (int)(t / ((long long)B * C));
+    const long long u = t - (long long)which * B * C;
+    const int b = (int)(u / C), c = (int)(u % C);
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += aux_part[((long long)which * B * S + (long long)b * S + s) * C + c];
+    aux[t] = a;
+}
+
+// sum / avg pooling with the forward's per-plot sums: dbeta[c] = sum_b g_b A1[b,c], dgamma[c] = sum_b g_b A2[b,c],
+// g_b = dpooled[b,c] (/ rows of the plot for avg) — B terms per channel instead of a pass over [n, C]
+__global__ void k_pn_bwd_sums_aux(const float* __restrict__ dP, const float* __restrict__ aux,
+                                  const int32_t* __restrict__ ptr, int B, int C, int mode, float* __restrict__ dbeta,
+                                  float* __restrict__ dgamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, q = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float g = dP[(long long)b * C + c];
+        if (mode == 1) {
+            const int len = ptr[b + 1] - ptr[b];
+            g = len > 0 ? g / (float)len : 0.f;
+        }
+        a += g * aux[(long long)b * C + c];
+        q += g * aux[((long long)B + b) * C + c];
+    }
+    dbeta[c] = a;
+    dgamma[c] = q;
 }
 
 // upstream gradient of element (r, c .. c+3): the pooled gradient of the row's plot, routed by the pooling mode
@@ -217,6 +272,39 @@ __global__ void k_pn_bwd_fold(const float* __restrict__ part, int chunks, int C,
     dgamma[c] = (b[0] + b[1]) + (b[2] + b[3]);
 }
 
+// Max pooling: the upstream gradient is non-zero at ONE row per (plot, channel) — the winner — so the two sums are B terms
+// per channel gathered through argmax, not a pass over the [n, C] matrix (4.2 GB for the 1024-wide layer of the point MLP):
+// dbeta[c] = sum_b g, dgamma[c] = sum_b g zhat with g = dpooled[b,c] act'(.) at row argmax[b,c].  Fixed order over the plots.
+__global__ __launch_bounds__(256) void k_pn_bwd_sums_max(const float* __restrict__ Z, int ldz, int C, int B,
+                                                         const float* __restrict__ dP, const int32_t* __restrict__ arg,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int act, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float m = mean[c], s = rstd[c], g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    float a = 0.f, q = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float z[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {            // eight independent gathers in flight
+            const int b = b0 + u;
+            const int r = b < B ? arg[(long long)b * C + c] : -1;
+            z[u] = r >= 0 ? Z[(long long)r * ldz + c] : 0.f;
+            d[u] = r >= 0 ? dP[(long long)b * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float zh = (z[u] - m) * s;
+            const float gz = d[u] * act_grad(zh * g + bb, act);
+            a += gz;
+            q += gz * zh;
+        }
+    }
+    dbeta[c] = a;
+    dgamma[c] = q;
+}
+
 // pass 2: dz = gamma rstd (g - [training] (dbeta + zhat dgamma) / n)
 __global__ __launch_bounds__(256) void k_pn_bwd_apply(const float* __restrict__ Z, int ldz, int n, int C,
                                                       const int4* __restrict__ coords, const int32_t* __restrict__ ptr,
@@ -266,6 +354,14 @@ __global__ __launch_bounds__(256) void k_pn_bwd_apply(const float* __restrict__ 
 }
 
 extern "C" {
+int agb_pointnet_pool_fwd_aux(const float* Z, int ldz, int n, int C, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, const int32_t* ptr, int B, int mode,
+                              int splits, float* part, int32_t* part_arg, float* pooled, int32_t* argmax, float* aux_part,
+                              float* aux, void* stream);
+int agb_pointnet_pool_bwd_aux(const float* Z, int ldz, int n, int C, const int32_t* coords, const int32_t* ptr, int B,
+                              const float* dpooled, const int32_t* argmax, int mode, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, int training, float* part, const float* aux,
+                              float* dZ, int lddz, float* dgamma, float* dbeta, void* stream);
 
 int agb_bn_chunks(int n);
 int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
@@ -289,6 +385,16 @@ int agb_pointnet_pool_splits(int n, int B) {
 int agb_pointnet_pool_fwd(const float* Z, int ldz, int n, int C, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, int act, const int32_t* ptr, int B, int mode, int splits, float* part,
                           int32_t* part_arg, float* pooled, int32_t* argmax, void* stream) {
+    return agb_pointnet_pool_fwd_aux(Z, ldz, n, C, mean, rstd, gamma, beta, act, ptr, B, mode, splits, part, part_arg,
+                                     pooled, argmax, nullptr, nullptr, stream);
+}
+
+// The same, and (sum / avg pooling) aux float[2][B][C]: per-plot sums of act'(.) and act'(.) * zhat for
+// agb_pointnet_pool_bwd_aux.  aux_part: float[2][B * splits][C] scratch when splits > 1.
+int agb_pointnet_pool_fwd_aux(const float* Z, int ldz, int n, int C, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, const int32_t* ptr, int B, int mode,
+                              int splits, float* part, int32_t* part_arg, float* pooled, int32_t* argmax, float* aux_part,
+                              float* aux, void* stream) {
     AGB_CHECK_ARG(C % 4 == 0 && C >= 4 && ldz % 4 == 0, "agb_pointnet_pool_fwd: C (%d), ldz must be multiples of 4", C);
     AGB_CHECK_ARG(mode >= 0 && mode <= 2 && act >= 0 && act <= 2, "agb_pointnet_pool_fwd: mode %d, act %d", mode, act);
     AGB_CHECK_ARG(mode != 2 || argmax != nullptr, "agb_pointnet_pool_fwd: max pooling needs an argmax buffer");
@@ -296,11 +402,17 @@ int agb_pointnet_pool_fwd(const float* Z, int ldz, int n, int C, const float* me
                   "agb_pointnet_pool_fwd: splits %d needs scratch buffers", splits);
     if (B == 0) return AGB_OK;
     hipStream_t s = (hipStream_t)stream;
+    AGB_CHECK_ARG(aux == nullptr || splits == 1 || aux_part != nullptr, "agb_pointnet_pool_fwd_aux: splits need aux_part");
+    float* aux_out = (aux && mode != 2) ? (splits == 1 ? aux : aux_part) : nullptr;
     hipLaunchKernelGGL(k_pn_pool_fwd, dim3(B, agb_cdiv(C, 64), splits), dim3(256), 0, s, Z, ldz, ptr, C, mean, rstd, gamma,
-                       beta, act, mode, splits, splits == 1 ? pooled : part, splits == 1 ? argmax : part_arg);
-    if (splits > 1)
+                       beta, act, mode, splits, splits == 1 ? pooled : part, splits == 1 ? argmax : part_arg, aux_out, B);
+    if (splits > 1) {
         hipLaunchKernelGGL(k_pn_pool_fold, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, s, part, part_arg, ptr, B,
                            C, mode, splits, pooled, argmax);
+        if (aux_out)
+            hipLaunchKernelGGL(k_pn_aux_fold, dim3(agb_cdiv(2LL * B * C, 256)), dim3(256), 0, s, aux_part, B, C, splits,
+                               aux);
+    }
     AGB_CHECK_LAUNCH("agb_pointnet_pool_fwd");
     return AGB_OK;
 }
@@ -312,14 +424,33 @@ int agb_pointnet_pool_bwd(const float* Z, int ldz, int n, int C, const int32_t* 
                           const float* dpooled, const int32_t* argmax, int mode, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int act, int training, float* part, float* dZ, int lddz,
                           float* dgamma, float* dbeta, void* stream) {
+    return agb_pointnet_pool_bwd_aux(Z, ldz, n, C, coords, ptr, B, dpooled, argmax, mode, mean, rstd, gamma, beta, act,
+                                     training, part, nullptr, dZ, lddz, dgamma, dbeta, stream);
+}
+
+// aux: the forward's per-plot sums (agb_pointnet_pool_fwd_aux) or NULL; with them (and for max pooling anyway) the
+// parameter gradients need no pass over Z and `part` may be NULL.
+int agb_pointnet_pool_bwd_aux(const float* Z, int ldz, int n, int C, const int32_t* coords, const int32_t* ptr, int B,
+                              const float* dpooled, const int32_t* argmax, int mode, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, int training, float* part, const float* aux,
+                              float* dZ, int lddz, float* dgamma, float* dbeta, void* stream) {
     AGB_CHECK_ARG(C % 4 == 0 && C >= 4 && ldz % 4 == 0 && lddz % 4 == 0, "agb_pointnet_pool_bwd: C/ld multiples of 4");
     AGB_CHECK_ARG(mode >= 0 && mode <= 2 && (mode != 2 || argmax), "agb_pointnet_pool_bwd: mode %d", mode);
     hipStream_t s = (hipStream_t)stream;
     const int chunks = agb_bn_chunks(n);
     const int rpc = agb_cdiv(n > 0 ? n : 1, chunks);
-    hipLaunchKernelGGL(k_pn_bwd_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, Z, ldz, n, C, rpc,
-                       (const int4*)coords, ptr, dpooled, argmax, mode, mean, rstd, gamma, beta, act, part);
-    hipLaunchKernelGGL(k_pn_bwd_fold, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, part, chunks, C, dbeta, dgamma);
+    if (mode == 2) {
+        hipLaunchKernelGGL(k_pn_bwd_sums_max, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, Z, ldz, C, B, dpooled, argmax, mean,
+                           rstd, gamma, beta, act, dbeta, dgamma);
+    } else if (aux != nullptr) {
+        hipLaunchKernelGGL(k_pn_bwd_sums_aux, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, dpooled, aux, ptr, B, C, mode, dbeta,
+                           dgamma);
+    } else {
+        AGB_CHECK_ARG(part != nullptr, "agb_pointnet_pool_bwd: sum / avg pooling without aux needs the scratch `part`");
+        hipLaunchKernelGGL(k_pn_bwd_partial, dim3(chunks, agb_cdiv(C, 64)), dim3(256), 0, s, Z, ldz, n, C, rpc,
+                           (const int4*)coords, ptr, dpooled, argmax, mode, mean, rstd, gamma, beta, act, part);
+        hipLaunchKernelGGL(k_pn_bwd_fold, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, part, chunks, C, dbeta, dgamma);
+    }
     if (n > 0 && dZ)
         hipLaunchKernelGGL(k_pn_bwd_apply, dim3(agb_cdiv(n, 128), agb_cdiv(C, 64)), dim3(256), 0, s, Z, ldz, n, C,
                            (const int4*)coords, ptr, dpooled, argmax, mode, mean, rstd, gamma, beta, act, dbeta, dgamma,

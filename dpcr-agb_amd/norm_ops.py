@@ -225,6 +225,9 @@ _lib.declare("agb_pointnet_pool_splits", [_I, _I])
 _lib.declare("agb_pointnet_pool_fwd", [_V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _I, _I, _I, _V, _V, _V, _V, _V])
 _lib.declare("agb_pointnet_pool_bwd", [_V, _I, _I, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V, _I, _I, _V, _V, _I, _V, _V,
                                        _V])
+_lib.declare("agb_pointnet_pool_fwd_aux", [_V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V])
+_lib.declare("agb_pointnet_pool_bwd_aux", [_V, _I, _I, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V, _I, _I, _V, _V, _V, _I, _V,
+                                           _V, _V])
 POOL_MODES = {"sum": 0, "avg": 1, "mean": 1, "max": 2}
 
 
@@ -247,27 +250,31 @@ class BatchNormActPoolFunction(torch.autograd.Function):
         arg = torch.empty(B, c, dtype=torch.int32, device=dev) if mode == 2 else None
         ppart = torch.empty(B * sp, c, dtype=torch.float32, device=dev) if sp > 1 else None
         parg = torch.empty(B * sp, c, dtype=torch.int32, device=dev) if (sp > 1 and mode == 2) else None
-        _lib.call("agb_pointnet_pool_fwd", _P(z), z.stride(0), n, c, _P(stats[0]), _P(stats[1]), _P(gamma), _P(beta),
-                  act_id, _P(ptr), B, mode, sp, _P(ppart), _P(parg), _P(pooled), _P(arg), _lib.stream())
+        # sum / avg pooling: the per-plot sums of act'(.) and act'(.) * zhat ride along (the backward's parameter gradients
+        # then need no pass over z: 4.2 GB for the 1024-wide layer)
+        aux = torch.empty(2, B, c, dtype=torch.float32, device=dev) if mode != 2 else None
+        aux_part = torch.empty(2, B * sp, c, dtype=torch.float32, device=dev) if (mode != 2 and sp > 1) else None
+        _lib.call("agb_pointnet_pool_fwd_aux", _P(z), z.stride(0), n, c, _P(stats[0]), _P(stats[1]), _P(gamma), _P(beta),
+                  act_id, _P(ptr), B, mode, sp, _P(ppart), _P(parg), _P(pooled), _P(arg), _P(aux_part), _P(aux),
+                  _lib.stream())
         ctx.save_for_backward(z, stats, gamma if gamma is not None else torch.empty(0),
                               beta if beta is not None else torch.empty(0), coords, ptr,
-                              arg if arg is not None else torch.empty(0))
+                              arg if arg is not None else torch.empty(0), aux if aux is not None else torch.empty(0))
         ctx.cfg = (act_id, bool(training), gamma is not None, beta is not None, B, mode)
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        z, stats, gamma, beta, coords, ptr, arg = ctx.saved_tensors
+        z, stats, gamma, beta, coords, ptr, arg, aux = ctx.saved_tensors
         act_id, training, has_g, has_b, B, mode = ctx.cfg
         dpooled = dpooled.contiguous()
         n, c = z.shape
         dev = z.device
-        part = torch.empty(bn_chunks(n) * 2 * c, dtype=torch.float32, device=dev)
         dgb = torch.empty(2, c, dtype=torch.float32, device=dev)
         dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
-        _lib.call("agb_pointnet_pool_bwd", _P(z), z.stride(0), n, c, _P(coords), _P(ptr), B, _P(dpooled),
+        _lib.call("agb_pointnet_pool_bwd_aux", _P(z), z.stride(0), n, c, _P(coords), _P(ptr), B, _P(dpooled),
                   _P(arg) if mode == 2 else None, mode, _P(stats[0]), _P(stats[1]), _P(gamma) if has_g else None,
-                  _P(beta) if has_b else None, act_id, int(training), _P(part), _P(dz),
+                  _P(beta) if has_b else None, act_id, int(training), None, _P(aux) if mode != 2 else None, _P(dz),
                   0 if dz is None else dz.stride(0), _P(dgb[0]), _P(dgb[1]), _lib.stream())
         return (dz, dgb[0] if has_g else None, dgb[1] if has_b else None) + (None,) * 12
 

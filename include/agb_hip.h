@@ -408,6 +408,17 @@ int agb_pointnet_pool_bwd(const float* Z, int ldz, int n, int C, const int32_t* 
                           const float* dpooled, const int32_t* argmax, int mode, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int act, int training, float* part, float* dZ, int lddz,
                           float* dgamma, float* dbeta, void* stream);
+/* The same two with the forward's per-plot sums of act'(.) and act'(.) * zhat (aux float[2][B][C], sum / avg pooling;
+ * aux_part float[2][B * splits][C] scratch when splits > 1): the backward then takes dgamma / dbeta from B terms per channel
+ * instead of a pass over Z (`part` may be NULL).  Max pooling needs no aux: its sums are gathered through argmax. */
+int agb_pointnet_pool_fwd_aux(const float* Z, int ldz, int n, int C, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, const int32_t* ptr, int B, int mode,
+                              int splits, float* part, int32_t* part_arg, float* pooled, int32_t* argmax, float* aux_part,
+                              float* aux, void* stream);
+int agb_pointnet_pool_bwd_aux(const float* Z, int ldz, int n, int C, const int32_t* coords, const int32_t* ptr, int B,
+                              const float* dpooled, const int32_t* argmax, int mode, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, int training, float* part, const float* aux,
+                              float* dZ, int lddz, float* dgamma, float* dbeta, void* stream);
 size_t agb_pointnet_mlp_workspace_bytes(int n, int B, int c1, int c2, int c3);
 int agb_pointnet_mlp_fwd(const float* x, int ldx, int n, int cin_pad, const float* W1, const float* const* bn1, int c1,
                          const float* W2, const float* const* bn2, int c2, const float* W3, const float* const* bn3,
