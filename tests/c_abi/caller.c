@@ -1,5 +1,6 @@
 /* A plain-C caller of libagbhip.so (include/agb_hip.h): coordinate hash insert -> kernel map -> sparse convolution on a
- * 3-voxel input, checked against a brute-force evaluation on the host.  Built by tests/c_abi/Makefile (gcc + the HIP
+ * 3-voxel input, then Linear -> BatchNorm -> ReLU with the statistics taken from the product's epilogue; both checked
+ * against a brute-force evaluation on the host.  Built by tests/c_abi/Makefile (gcc + the HIP
  * runtime API for device memory only), run by tests/test_c_caller.py on a GPU box.  Exit code 0 = all values match. */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -88,5 +89,62 @@ int main(void) {
     /* the error path is part of the contract: a bad argument returns AGB_EINVAL and leaves a message */
     if (agb_spconv_fwd(d_X, 3, d_W, d_nbr, N, 0, d_b, d_Y, COUT, N, K3, CIN, COUT, NULL) != AGB_EINVAL ||
         strlen(agb_last_error()) == 0) { fprintf(stderr, "error path\n"); return 7; }
-    return worst < 1e-5 ? 0 : 1;
+    if (!(worst < 1e-5)) return 1;
+
+    /* ---- Linear -> BatchNorm (training) -> ReLU through the fused entry points: the dense product leaves the partial
+     * statistics of its output (agb_dense_fwd_bn), agb_bn_stats_fold turns them into mean / rstd, agb_bn_act_fwd applies */
+    enum { M = 300, DI = 16, DO = 32 };
+    static float A[M][DI], V[DI][DO], Z[M][DO], Zr[M][DO], Yb[M][DO], gamma[DO], beta[DO], mean_h[DO], rstd_h[DO];
+    for (int r = 0; r < M; ++r) for (int c = 0; c < DI; ++c) A[r][c] = (float)(((r * 13 + c * 7) % 29) - 14) * 0.0625f;
+    for (int c = 0; c < DI; ++c) for (int o = 0; o < DO; ++o) V[c][o] = (float)(((c * 5 + o * 3) % 17) - 8) * 0.03125f;
+    for (int o = 0; o < DO; ++o) { gamma[o] = 1.f + 0.01f * (float)o; beta[o] = 0.1f * (float)(o % 3); }
+    const int chunks = agb_dense_bn_chunks(M, DI, DO);
+    if (chunks < 1) { fprintf(stderr, "agb_dense_bn_chunks(%d, %d, %d) = %d\n", M, DI, DO, chunks); return 8; }
+    float *d_A, *d_V, *d_Z, *d_part, *d_mean, *d_rstd, *d_g, *d_be, *d_Yb;
+    CHECK_HIP(hipMalloc((void**)&d_A, sizeof(A)));
+    CHECK_HIP(hipMalloc((void**)&d_V, sizeof(V)));
+    CHECK_HIP(hipMalloc((void**)&d_Z, sizeof(Z)));
+    CHECK_HIP(hipMalloc((void**)&d_Yb, sizeof(Yb)));
+    CHECK_HIP(hipMalloc((void**)&d_part, sizeof(float) * chunks * 3 * DO));
+    CHECK_HIP(hipMalloc((void**)&d_mean, sizeof(float) * DO));
+    CHECK_HIP(hipMalloc((void**)&d_rstd, sizeof(float) * DO));
+    CHECK_HIP(hipMalloc((void**)&d_g, sizeof(gamma)));
+    CHECK_HIP(hipMalloc((void**)&d_be, sizeof(beta)));
+    CHECK_HIP(hipMemcpy(d_A, A, sizeof(A), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_V, V, sizeof(V), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_g, gamma, sizeof(gamma), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_be, beta, sizeof(beta), hipMemcpyHostToDevice));
+    CHECK_AGB(agb_dense_fwd_bn(d_A, DI, d_V, NULL, d_Z, DO, M, DI, DO, d_part, NULL));
+    CHECK_AGB(agb_bn_stats_fold(d_part, chunks, DO, 1e-5f, 0.f, d_mean, d_rstd, NULL, NULL, NULL, NULL));
+    CHECK_AGB(agb_bn_act_fwd(d_Z, DO, M, DO, d_mean, d_rstd, d_g, d_be, 1 /* ReLU */, d_Yb, DO, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(Z, d_Z, sizeof(Z), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(Yb, d_Yb, sizeof(Yb), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(mean_h, d_mean, sizeof(mean_h), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(rstd_h, d_rstd, sizeof(rstd_h), hipMemcpyDeviceToHost));
+    double worst2 = 0.0;
+    for (int o = 0; o < DO; ++o) {
+        double mu = 0.0, var = 0.0;
+        for (int r = 0; r < M; ++r) {
+            double z = 0.0;
+            for (int c = 0; c < DI; ++c) z += (double)A[r][c] * (double)V[c][o];
+            Zr[r][o] = (float)z;
+            mu += z;
+        }
+        mu /= M;
+        for (int r = 0; r < M; ++r) var += ((double)Zr[r][o] - mu) * ((double)Zr[r][o] - mu);
+        var /= M;
+        const double rs = 1.0 / sqrt(var + 1e-5);
+        if (fabs(mean_h[o] - mu) > worst2) worst2 = fabs(mean_h[o] - mu);
+        if (fabs(rstd_h[o] - rs) / rs > worst2) worst2 = fabs(rstd_h[o] - rs) / rs;
+        for (int r = 0; r < M; ++r) {
+            double y = ((double)Zr[r][o] - mu) * rs * gamma[o] + beta[o];
+            if (y < 0.0) y = 0.0;
+            if (fabs((double)Z[r][o] - (double)Zr[r][o]) > worst2) worst2 = fabs((double)Z[r][o] - (double)Zr[r][o]);
+            if (fabs((double)Yb[r][o] - y) > worst2) worst2 = fabs((double)Yb[r][o] - y);
+        }
+    }
+    printf("c caller: Linear -> BatchNorm -> ReLU (statistics from the product's epilogue, %d row tiles): max error %.3g\n",
+           chunks, worst2);
+    return worst2 < 2e-5 ? 0 : 9;
 }
