@@ -47,6 +47,8 @@ _SIGNATURES = {
                               c_void_p],
     "agb_spconv_fwd3_grid": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                              c_int, c_int, c_void_p, c_ll, c_void_p],
+    "agb_spconv_fwd3_grid_lp": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                c_int, c_int, c_void_p, c_ll, c_int, c_void_p],
     "agb_maxpool_fwd": [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "agb_maxpool_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "agb_maxpool_fwd_k": [c_void_p, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],

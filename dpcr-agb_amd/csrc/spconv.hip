@@ -1416,6 +1416,125 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 3-channel grid-probing stem forward with bf16 / split-bf16x3 operands (operand modes "bf16" / "bf16x3" only: the
+// fp32 mode keeps k_spconv_fwd3).  Five sixths of the dense-over-offsets products multiply absent neighbours; on
+// v_mfma_f32_32x32x16_bf16 those zeros cost 1/16 (bf16) or 3/16 (bf16x3) of what they cost the fp32 MFMA.  With the MFMA
+// cheap the staging is what counts: 16 offsets x 4 (padded) channels per 64-deep K-chunk, so that a gathered row goes to LDS
+// as ONE 8-byte write of four bf16 (21 x 3 packed channels needed three 2-byte writes per pair: 550 us; this form: see
+// DESIGN.md section 5).  Same probing, same by-product map, same software pipeline (indices two chunks ahead, rows and
+// weights one chunk ahead) as k_spconv_fwd3<true>.
+template <bool X3>
+__global__ __launch_bounds__(256) void k_spconv_fwd3_lp(const float* __restrict__ X, int ldx,
+                                                        const float* __restrict__ W,  // [K3*3, Cout]
+                                                        const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                        int n_out, int K3, int Cout, GridProbe gp) {
+    constexpr int OPC = 16, NP = X3 ? 2 : 1, NJ = 4, NW = 4;
+    __shared__ __attribute__((aligned(16))) unsigned short As[NP][BM * LLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][BN * LLD];
+    __shared__ int s_delta[736];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int row0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k = tid; k < K3; k += 256) s_delta[k] = probe_delta(gp, k);
+    const int myrow = row0 + (tid & (BM - 1));
+    const bool row_ok = myrow < n_out;
+    const int base = probe_base(gp, min(myrow, n_out - 1));
+    __syncthreads();
+    const int nchunks = (K3 + OPC - 1) / OPC;
+    int idxn[NJ], idxc[NJ];
+    f32x4 xv[NJ];
+    float4 wv[NW];
+    auto load_idx = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int off = (tid + 256 * j) >> 6;                       // 0 .. 15
+            const int k = min(ch * OPC + off, K3 - 1);
+            idxn[j] = gp.grid[base + s_delta[k]];
+        }
+    };
+    auto gather = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            idxc[j] = idxn[j] == INT_MAX ? -1 : idxn[j];
+            xv[j] = *reinterpret_cast<const f32x4*>(X + (long long)max(idxc[j], 0) * ldx);
+            if (gp.nbr_out && blockIdx.y == 0) {
+                const int off = (tid + 256 * j) >> 6, k = ch * OPC + off;
+                if (off < OPC && k < K3 && row_ok) gp.nbr_out[(long long)k * gp.nbr_out_stride + myrow] = idxc[j];
+            }
+        }
+    };
+    // weights of a chunk: K row kr = 4 * offset + channel (channel 3: zero), float4 pieces along the 64 columns
+    auto load_w = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int e = tid + 256 * j, kr = e >> 4, c4 = (e & 15) * 4;     // kr 0 .. 63
+            const long long wrow = min(((long long)ch * OPC + (kr >> 2)) * 3 + min(kr & 3, 2), (long long)K3 * 3 - 1);
+            wv[j] = *reinterpret_cast<const float4*>(W + wrow * Cout + min(n0 + c4, Cout - 4));
+        }
+    };
+    auto put = [&](unsigned short (*T)[BM * LLD], int at, float v) {
+        const unsigned short h = f2bf(v);
+        T[0][at] = h;
+        if (X3) T[NP - 1][at] = f2bf(v - bf2f(h));
+    };
+    load_idx(0);
+    gather(0);
+    load_w(0);
+    load_idx(nchunks > 1 ? 1 : 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = ch * OPC;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = tid + 256 * j, off = e >> 6, r = e & (BM - 1);
+            const bool ok = idxc[j] >= 0 && k0 + off < K3 && row0 + r < n_out;
+            asm volatile("" : "+v"(xv[j]));
+            // (x rows are 4 floats wide with a zero in the fourth: the padded channel multiplies a zero weight row anyway)
+            const float4 v = ok ? make_float4(xv[j][0], xv[j][1], xv[j][2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            stage_bf16<X3>(As[0], As[NP - 1], r * LLD + off * 4, v);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int e = tid + 256 * j, kr = e >> 4, c4 = (e & 15) * 4;
+            const bool ok = (kr & 3) < 3 && k0 + (kr >> 2) < K3 && n0 + c4 < Cout;
+            const float w4[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) put(Bs, (c4 + c) * LLD + kr, ok ? w4[c] : 0.f);
+        }
+        __syncthreads();
+        gather(min(ch + 1, nchunks - 1));
+        load_w(min(ch + 1, nchunks - 1));
+        load_idx(min(ch + 2, nchunks - 1));
+        const int aoff = (wr * 32 + li) * LLD + 8 * lh, boff = (wc * 32 + li) * LLD + 8 * lh;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][aoff + 16 * s2]);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][boff + 16 * s2]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            if (X3) {
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[NP - 1][aoff + 16 * s2]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[NP - 1][boff + 16 * s2]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + li;
+    if (col < Cout) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (row < n_out) Y[(long long)row * ldy + col] = acc[reg] + bv;
+        }
+    }
+}
+
 // Weight gradient of the small-Cin (stem) path, ROW-COMPACTED: an M tile covers 64/CPAD kernel offsets; a row whose
 // neighbours at ALL of those offsets are absent contributes nothing (7^3 stem map: 35 % of the rows of a 16-offset
 // tile).  The workgroup compacts its row chunk to the rows with at least one present neighbour, then walks them 32 at a
@@ -1559,6 +1678,9 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
 
 // =============================================================== C ABI
 extern "C" {
+int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                            const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                            int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream);
 
 // tile height of the generic kernel: 128 rows when there are plenty of tiles anyway, or when the layer is W-heavy
 // (Cin >= 256: every workgroup streams Cin x 64 weights per offset, so halving the number of row tiles halves the
@@ -1965,6 +2087,16 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
 int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
                          const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
                          int32_t* nbr_out, long long nbr_out_stride, void* stream) {
+    return agb_spconv_fwd3_grid_lp(X, ldx, W, coords, grid, desc, K, bias, Y, ldy, n_out, Cout, nbr_out, nbr_out_stride, 0,
+                                   stream);
+}
+
+// precision: 0 fp32 MFMA, 1 bf16 operands (k_spconv_fwd3_lp), 2 split-bf16x3 requested: served by the fp32 kernel
+int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                            const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                            int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream) {
+    AGB_CHECK_ARG(precision >= 0 && precision <= 2, "agb_spconv_fwd3_grid_lp: precision %d (0 fp32, 1 bf16, 2 bf16x3)",
+                  precision);
     AGB_CHECK_ARG(n_out >= 0 && Cout >= 4 && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout, "agb_spconv_fwd3_grid: bad sizes");
     AGB_CHECK_ARG(coords && grid && desc, "agb_spconv_fwd3_grid: coords, grid and desc are required");
     AGB_CHECK_ARG(K >= 1 && K <= 9 && (K & 1), "agb_spconv_fwd3_grid: kernel size %d (odd, <= 9)", K);
@@ -1978,8 +2110,15 @@ int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t*
     gp.coords = (const int4*)coords; gp.grid = grid;
     gp.ox = desc[0]; gp.oy = desc[1]; gp.oz = desc[2]; gp.X = desc[3]; gp.Y = desc[4]; gp.Z = desc[5];
     gp.ts = desc[6]; gp.K = K; gp.nbr_out = nbr_out; gp.nbr_out_stride = nbr_out_stride;
-    hipLaunchKernelGGL(k_spconv_fwd3<true>, dim3(agb_cdiv(n_out, BM), agb_cdiv(Cout, BN)), dim3(256), 0,
-                       (hipStream_t)stream, X, ldx, W, nullptr, 0LL, 0, bias, Y, ldy, n_out, K * K * K, Cout, gp);
+    const dim3 grid3(agb_cdiv(n_out, BM), agb_cdiv(Cout, BN));
+    // (split-bf16x3 measured SLOWER than the fp32 kernel here — two LDS planes to stage, three MFMAs: 740 vs 683 us —
+    // so precision 2 takes the exact fp32 kernel)
+    if (precision == 1)
+        hipLaunchKernelGGL(k_spconv_fwd3_lp<false>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy, n_out,
+                           K * K * K, Cout, gp);
+    else
+        hipLaunchKernelGGL(k_spconv_fwd3<true>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, nullptr, 0LL, 0, bias, Y,
+                           ldy, n_out, K * K * K, Cout, gp);
     AGB_CHECK_LAUNCH("agb_spconv_fwd3_grid");
     return AGB_OK;
 }

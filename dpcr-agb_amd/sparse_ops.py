@@ -230,8 +230,9 @@ class SparseConvFunction(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]   # (grad mode is off inside Function.forward)
         nbr = torch.empty(K3, max(n_out, 1), dtype=torch.int32, device=x.device) if need_w else None
         ev = _prof_begin("fwd", K3, 3, cout, n_out)
-        _lib.call("agb_spconv_fwd3_grid", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
-                  _P(b), _P(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0), _lib.stream())
+        _lib.call("agb_spconv_fwd3_grid_lp", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
+                  _P(b), _P(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0),
+                  _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
         _prof_end(ev, "fwd", K3, 3, cout, n_out, None)
         if ev is not None and nbr is not None:   # profiling only: the kernel-map size, after the closing event
             PROFILE[-1]["pairs"] = (nbr >= 0).sum()

@@ -136,6 +136,12 @@ int agb_spconv_split_hint_opt(int n_out, int K3, int Cin, int Cout, int cmp_mode
 int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
                          const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
                          int32_t* nbr_out, long long nbr_out_stride, void* stream);
+/* the same with bf16 operands (precision 1): 16 offsets x 4 padded channels per 64-deep K-chunk on
+ * v_mfma_f32_32x32x16_bf16 — the absent neighbours of the dense-over-offsets product cost 1/16 of the fp32 MFMA;
+ * precision 0 and 2 (split-bf16x3 measured slower than fp32 here) run the exact fp32 kernel */
+int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                            const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                            int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream);
 /* WT [K3][C][R] = per-offset transpose of W [K3][R][C] (R, C multiples of 4): the operand of the data gradient
  * dX = sum_k dY[nbrT[k]] @ W[k]^T, rebuilt once per layer per step (ME does the same inside its backward GEMMs with
  * a transposed-operand flag: MinkowskiEngine/src/convolution_kernel.cu ConvolutionBackwardKernelGPU). */
