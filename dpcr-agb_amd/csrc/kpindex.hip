@@ -64,7 +64,9 @@ __global__ void k_bbox_fill(int32_t* bbox, int B) {
 // decoded float bbox for the host: out[b][6]
 __global__ void k_bbox_decode(const int32_t* bbox, int B, float* out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 6 * B) out[t] = ord2f(bbox[t]);
+    if (t >= 6 * B) return;
+    const int v = bbox[t];      // an empty cloud decodes to (+inf, -inf): min / max over clouds pass it by
+    out[t] = v == INT_MAX ? INFINITY : v == INT_MIN ? -INFINITY : ord2f(v);
 }
 
 // =================================================================== radius neighbours

@@ -1836,7 +1836,7 @@ int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C,
 
 // How many offset splits a layer of n_out rows wants (1 = none): host helper for sizing `partial`.
 int agb_spconv_split_hint_opt(int n_out, int K3, int Cin, int Cout, int cmp_mode) {
-    if (Cin == 3 || Cin == 4 || Cin == 8 || K3 < 8) return 1;
+    if (Cin == 3 || Cin == 4 || Cin == 8 || K3 < 8 || n_out <= 0) return 1;
     const int sp = cmp_mode == 0 ? 0 : cmp_want_split(n_out, Cin, Cout);
     if (sp > 0) return sp;   // the pair-compacted kernel takes the layer, input channels split sp ways
     if (cmp_mode == 64 || cmp_mode == 128) return 1;

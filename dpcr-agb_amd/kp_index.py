@@ -322,6 +322,8 @@ def subsample_finish(job, out_ptr_host, status0):
 def _subsample_core(p, f, lens, dl, bounds_hint=None):
     dev = p.device
     B, n = len(lens), p.shape[0]
+    if n == 0:      # no points at all: every cloud stays empty
+        return p[:0], (None if f is None else f[:0]), np.zeros(B, dtype=np.int32), torch.empty(0, dtype=torch.int32, device=dev)
     if bounds_hint is None:
         bb = elem_bbox(p, _ptr_tensor(lens, dev), B)
         ext = (bb[:, 3:] - bb[:, :3]).max(0).values.tolist()   # one host read

@@ -142,6 +142,8 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
     w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes."""
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+    if n_out == 0:
+        return y
     if plan is not None:
         split = 1
     elif nbr is not None:

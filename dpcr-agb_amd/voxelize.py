@@ -35,6 +35,9 @@ def voxelize_last(pos, lengths, size, perm=None, extent_hint=None):
     if not torch.cuda.is_available():
         raise _lib.AgbError("voxelize_last needs a HIP device (no CPU fallback in the product path)")
     dev = pos.device if pos.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    if n == 0:      # nothing to voxelize: every cloud keeps zero voxels
+        return (torch.empty(0, 3, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
+                np.zeros(B, dtype=np.int64), (0,) * 6)
     p = pos.to(device=dev, dtype=torch.float32).contiguous()
     if perm is None:
         perm = draw_permutations(lens)

@@ -81,3 +81,13 @@ def test_host_helpers_without_gpu():
     rc = _lib.load().agb_spconv_fwd_opt(None, 4, None, None, 0, 0, None, None, 4, 10, 27, 4, 4, None, None, None, 0, 1, None,
                                         7, -1, None)
     assert rc == -1 and b"cmp_mode" in _lib.load().agb_last_error()
+
+
+def test_split_hints_take_zero_rows():
+    """Host helpers on an empty level: no division by the (zero) tile count."""
+    from dpcr_agb_amd import _lib
+    L = _lib.load()
+    assert L.agb_spconv_split_hint_opt(0, 27, 64, 64, 1) == 1
+    assert L.agb_spconv_split_hint(0, 27, 512, 512) == 1
+    assert L.agb_dense_split_hint(0, 3840, 256) == 1
+    assert L.agb_dense_bn_chunks(0, 64, 64) == 0

@@ -1,0 +1,164 @@
+"""Empty and ragged inputs through the product path (HIP) against the oracles: zero rows, an EMPTY cloud in the middle of a
+batch, single-point clouds.  The reference's own behaviour is the bar where it is defined (radius search: the compiled
+reference returns a padded matrix for an empty batch element and its Python wrapper raises on an empty result,
+cpp_neighbors/wrapper.cpp:201-205); where it is undefined (grid subsampling / voxelisation of a cloud without points read
+uninitialised min / max corners) the product returns empty results instead of failing."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kpconv_index as K
+from oracle import sparse_ref as R
+from oracle import voxelize_ref as VR
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_zero_row_products(device):
+    from dpcr_agb_amd import norm_ops, sparse_ops
+    w = torch.randn(64, 32, device=device)
+    assert tuple(sparse_ops.dense_product(torch.zeros(0, 64, device=device), w).shape) == (0, 32)
+    dw = sparse_ops.dense_weight_grad(torch.zeros(0, 64, device=device), torch.zeros(0, 32, device=device))
+    assert tuple(dw.shape) == (64, 32) and float(dw.abs().max()) == 0.0
+    nbr = torch.full((27, 0), -1, dtype=torch.int32, device=device)
+    y = sparse_ops.spconv_forward_raw(torch.zeros(0, 64, device=device), torch.randn(27 * 64, 64, device=device), nbr, 0, None,
+                                      0, 27, 64, 64)
+    assert tuple(y.shape) == (0, 64)
+    bn = torch.nn.BatchNorm1d(32).to(device)
+    assert tuple(norm_ops.batch_norm_act(torch.zeros(0, 32, device=device), bn, None).shape) == (0, 32)
+    # one row: the biased variance is 0, the output is beta, the running variance takes the unbiased estimate's n/(n-1)
+    # guard (torch raises for a single value per channel in training mode; the fused kernel normalises with var = 0)
+    x1 = torch.randn(1, 32, device=device)
+    y1 = norm_ops.batch_norm_act(x1, bn, None)
+    assert torch.isfinite(y1).all() and float(y1.detach().abs().max()) < 1e-3
+    pooled = sparse_ops.segment_reduce(torch.zeros(0, 16, device=device), None,
+                                       torch.zeros(3, dtype=torch.int32, device=device), 2, 0)[0]
+    assert tuple(pooled.shape) == (2, 16) and float(pooled.abs().max()) == 0.0
+    torch.cuda.synchronize()
+
+
+def test_voxelize_empty_clouds(device):
+    from dpcr_agb_amd import voxelize
+    c, k, nl, b = voxelize.voxelize_last(torch.zeros(0, 3), np.array([0, 0], dtype=np.int64), 0.1)
+    assert tuple(c.shape) == (0, 3) and tuple(k.shape) == (0,) and nl.tolist() == [0, 0]
+    g = torch.Generator().manual_seed(3)
+    pos = torch.rand(300, 3, generator=g)
+    lens = np.array([120, 0, 180], dtype=np.int64)
+    perm = voxelize.draw_permutations(lens)
+    c, k, nl, _ = voxelize.voxelize_last(pos, lens, 0.1, perm=perm)
+    assert nl[1] == 0
+    # the two non-empty clouds, each against the oracle on its own
+    off_in, off_out = 0, 0
+    for n_in, n_out in zip(lens, nl):
+        if n_in:
+            rc, rk = VR.grid_sampling_last(pos[off_in:off_in + n_in].numpy(), perm[off_in:off_in + n_in].numpy(), 0.1)
+            assert n_out == len(rk)
+            assert np.array_equal(c[off_out:off_out + n_out].cpu().numpy(), rc)
+            assert np.array_equal(k[off_out:off_out + n_out].cpu().numpy() - off_in, rk)
+        off_in, off_out = off_in + n_in, off_out + n_out
+
+
+@pytest.mark.parametrize("ql,sl", [([25, 0, 15], [20, 0, 30]), ([40, 0], [20, 30]), ([0, 40], [50, 0]), ([1, 39], [1, 49])])
+def test_neighbors_with_empty_batch_elements(device, ql, sl):
+    from dpcr_agb_amd import kp_index
+    rng = np.random.default_rng(0)
+    q = rng.random((sum(ql), 3)).astype(np.float32)
+    s = rng.random((sum(sl), 3)).astype(np.float32)
+    ref = K.batch_neighbors(q, s, ql, sl, 0.3)
+    if ref.shape[1] == 0:      # no neighbour anywhere: the reference's wrapper raises (wrapper.cpp:201-205)
+        with pytest.raises(RuntimeError):
+            kp_index.batch_neighbors(q, s, ql, sl, 0.3)
+        return
+    got = kp_index.batch_neighbors(q, s, ql, sl, 0.3)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_neighbors_of_an_empty_batch_raise_like_the_reference(device):
+    from dpcr_agb_amd import kp_index
+    s = np.random.default_rng(0).random((50, 3)).astype(np.float32)
+    with pytest.raises(RuntimeError):
+        kp_index.batch_neighbors(np.zeros((0, 3), np.float32), s, [0], [50], 0.2)
+    with pytest.raises(RuntimeError):
+        kp_index.batch_neighbors(s, np.zeros((0, 3), np.float32), [50], [0], 0.2)
+
+
+def test_grid_subsampling_with_empty_clouds(device):
+    from dpcr_agb_amd import kp_index
+    rng = np.random.default_rng(1)
+    P = rng.random((200, 3)).astype(np.float32)
+    F = rng.random((200, 2)).astype(np.float32)
+    got = kp_index.batch_grid_subsampling(P, [90, 0, 110], features=F, sampleDl=0.2, random_grid_orient=False)
+    ref = K.batch_grid_subsampling(P, [90, 0, 110], features=F, sampleDl=0.2)
+    assert np.asarray(got[1]).tolist() == np.asarray(ref[1]).tolist() and got[1][1] == 0
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+    e = kp_index.batch_grid_subsampling(np.zeros((0, 3), np.float32), [0, 0], sampleDl=0.2, random_grid_orient=False)
+    assert e[0].shape == (0, 3) and np.asarray(e[1]).tolist() == [0, 0]
+
+
+def _ragged_sparse_batch(sizes, seeds):
+    from dpcr_agb_amd import synthetic
+    parts = [synthetic.make_sparse_batch([s], n_points=n) for s, n in zip(seeds, sizes)]
+    batch = torch.cat([torch.full_like(p.batch, b) for b, p in enumerate(parts)])
+    cat = lambda name: torch.cat([getattr(p, name) for p in parts])  # noqa: E731
+    return synthetic.PlotBatch(batch, cat("coords"), cat("x"), cat("pos"), cat("y_reg"),
+                               torch.ones(len(parts), 2, dtype=torch.bool), len(parts))
+
+
+def test_network_on_ragged_plots_matches_oracle(device):
+    """SENet14 forward + backward on plots of 1500, 1 and 40 points (the one-point plot is a single voxel at every level)."""
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_032))
+    opt = Opt(MODEL_OPTIONS["SENet14"])
+    opt["drop_path"] = 0.0
+    model = MinkowskiBaselineModel(opt, "minkowski", ds)
+    batch = _ragged_sparse_batch([1500, 1, 40], [0, 1, 2])
+    assert int((batch.batch == 1).sum()) == 1
+    sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    model.to(device).train()
+    model.set_input(batch, device)
+    model.forward()
+    model.loss.backward()
+    sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in sd32.items()}
+    coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
+    out = R.resnet_forward(sd, coords, batch.x.double(), (1, 1, 1, 1), batch_size=len(batch))
+    loss = R.reg_loss(out, batch.y_reg.double(), model.reg_center_targets.cpu().double(),
+                      model.reg_scale_targets.cpu().double(), model.reg_weights.cpu().double())
+    loss.backward()
+    assert rel_err(model.output, out) < RTOL
+    gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.model.named_parameters())
+    worst, worst_name = 0.0, None
+    for k, p in model.model.named_parameters():
+        ref_g = sd[k].grad
+        e = float((p.grad.detach().cpu().double() - ref_g).abs().max()) / max(float(ref_g.abs().max()), 1e-3 * gmax)
+        if e > worst:
+            worst, worst_name = e, k
+    print(f"ragged SENet14: output rel err {rel_err(model.output, out):.2e}, worst gradient rel err {worst:.2e} ({worst_name})")
+    assert worst < RTOL, (worst, worst_name)
+
+
+def test_kpconv_pyramid_on_ragged_plots_matches_oracle(device):
+    """KPConv input pyramid (subsampling + radius searches, 5 levels) for plots of 6144, 3 and 200 points."""
+    from dpcr_agb_amd import kp_index, synthetic
+    parts = [synthetic.make_point_batch([s], n_points=n) for s, n in zip([0, 1, 2], [2048, 3, 200])]
+    pos = torch.cat([p.pos for p in parts]).numpy().astype(np.float32)
+    lens = [len(p.pos) for p in parts]
+    dl, r = 0.02 * 2.5 / 2.5, 0.05
+    for level in range(3):
+        got_nb = kp_index.batch_neighbors(pos, pos, lens, lens, r)
+        ref_nb = K.batch_neighbors(pos, pos, lens, lens, r)
+        assert got_nb.shape == ref_nb.shape and np.array_equal(got_nb, ref_nb), level
+        dl2 = dl * 2
+        got = kp_index.batch_grid_subsampling(pos, lens, sampleDl=dl2, random_grid_orient=False)
+        ref = K.batch_grid_subsampling(pos, lens, sampleDl=dl2)
+        assert np.asarray(got[1]).tolist() == np.asarray(ref[1]).tolist(), level
+        assert np.array_equal(got[0], ref[0]), level
+        pos, lens, dl, r = np.asarray(got[0]), [int(v) for v in np.asarray(got[1])], dl2, r * 2
