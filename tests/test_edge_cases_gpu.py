@@ -162,3 +162,57 @@ def test_kpconv_pyramid_on_ragged_plots_matches_oracle(device):
         assert np.asarray(got[1]).tolist() == np.asarray(ref[1]).tolist(), level
         assert np.array_equal(got[0], ref[0]), level
         pos, lens, dl, r = np.asarray(got[0]), [int(v) for v in np.asarray(got[1])], dl2, r * 2
+
+
+def test_kpconv_model_on_ragged_plots_matches_oracle(device):
+    """Full KPConv model (5-level pyramid with the reference configuration) on plots of 3000, 5 and 250 points: pyramid vs
+    the pinned index oracle with the same grid orientations, network output vs the fp64 layer oracle, finite gradients."""
+    from oracle import kpconv_ref as KR
+    from dpcr_agb_amd import kp_index, synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import KPConvModel
+    torch.manual_seed(0)
+    np.random.seed(3)
+    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_016))
+    opt = Opt(MODEL_OPTIONS["KPConv"])
+    model = KPConvModel(opt, "kpconv", ds).to(device).train()
+    parts = [synthetic.make_point_batch([s], n_points=n) for s, n in zip([40, 41, 42], [3000, 5, 250])]
+    pos = torch.cat([p.pos for p in parts])
+    x = torch.cat([p.x for p in parts])
+    lens = np.array([len(p.pos) for p in parts], dtype=np.int64)
+    rots = [kp_index.random_grid_rotations(3) for _ in range(4)]
+    inp = model.prepare_inputs(pos, x, lens, device, rotations=rots)
+    cfg = opt.config
+    pts, ln, r = pos.numpy(), lens, cfg.first_subsampling_dl * cfg.conv_radius
+    for lvl in range(5):
+        assert np.array_equal(inp["points"][lvl].cpu().numpy(), pts), lvl
+        assert np.array_equal(inp["neighbors"][lvl].cpu().numpy(), K.batch_neighbors(pts, pts, ln, ln, r)), lvl
+        assert [int(v) for v in inp["lengths"][lvl]] == [int(v) for v in ln], lvl
+        if lvl == 4:
+            break
+        rot = pts.copy()
+        i0 = 0
+        for bi, n in enumerate(ln):
+            rot[i0:i0 + n] = np.sum(np.expand_dims(pts[i0:i0 + n], 2) * rots[lvl][bi], axis=1)
+            i0 += n
+        sp, sb = K.batch_grid_subsampling(rot, ln, sampleDl=2 * r / cfg.conv_radius, order="canonical")
+        i0 = 0
+        for bi, n in enumerate(sb):
+            sp[i0:i0 + n] = np.sum(np.expand_dims(sp[i0:i0 + n], 2) * rots[lvl][bi].T, axis=1)
+            i0 += n
+        assert K.same_up_to_ties(inp["pools"][lvl].cpu().numpy(), K.batch_neighbors(sp, pts, sb, ln, r), sp, pts), lvl
+        pts, ln, r = sp, sb.astype(np.int64), r * 2
+    assert min(int(v) for v in inp["lengths"][4]) >= 1
+    out = model.model(Opt(inp))
+    sd = {k: v.detach().cpu().double() for k, v in model.model.state_dict().items()}
+    ob = dict(features=x.double(), points=[p.cpu().double() for p in inp["points"]],
+              neighbors=[n.cpu().long() for n in inp["neighbors"]], pools=[p.cpu().long() for p in inp["pools"]],
+              lengths=[l.numpy() for l in inp["lengths"]])
+    ocfg = dict(first_subsampling_dl=cfg.first_subsampling_dl, conv_radius=cfg.conv_radius, KP_extent=cfg.KP_extent,
+                in_features_dim=3, first_features_dim=cfg.first_features_dim, architecture=list(cfg.architecture),
+                batch_norm_momentum=cfg.batch_norm_momentum)
+    ref = KR.kpcnn_forward(sd, ocfg, ob, training=True)
+    assert tuple(out.shape) == (3, ref.shape[1])
+    assert rel_err(out, ref) < RTOL
+    out.backward(torch.randn_like(out))
+    assert all(torch.isfinite(p.grad).all() for p in model.model.parameters() if p.grad is not None)
