@@ -216,3 +216,60 @@ def test_kpconv_model_on_ragged_plots_matches_oracle(device):
     assert rel_err(out, ref) < RTOL
     out.backward(torch.randn_like(out))
     assert all(torch.isfinite(p.grad).all() for p in model.model.parameters() if p.grad is not None)
+
+
+def test_tensors_beyond_two_giga_elements(device):
+    """Maximum sizes: a [2.2 M, 1024] activation (2.25e9 elements, 9 GB) through the dense product, the fused BatchNorm +
+    activation, per-plot pooling and their backward passes — every row offset is a 64-bit product.  Checked on row blocks
+    at the start, across the 2^31-element boundary (row 2 097 152) and at the end."""
+    from dpcr_agb_amd import norm_ops, sparse_ops
+    if torch.cuda.get_device_properties(0).total_memory < 80 * 2**30:
+        pytest.skip("needs ~45 GB of device memory")
+    torch.manual_seed(0)
+    n, cin, cout = 2_200_000, 16, 1024
+    x = torch.randn(n, cin, device=device)
+    w = (torch.randn(cout, cin, device=device) * 0.2)
+    blocks = (0, 1_000_000, 2_097_152 - 8, n - 64)
+    y = sparse_ops.dense_product(x, w.t().contiguous())
+    for r0 in blocks:
+        ref = x[r0:r0 + 64].double() @ w.double().t()
+        assert rel_err(y[r0:r0 + 64], ref) < 1e-5, r0
+    bn = torch.nn.BatchNorm1d(cout).to(device).train()
+    z = norm_ops.batch_norm_act(y, bn, "relu")
+    mean = torch.zeros(cout, dtype=torch.float64, device=device)
+    sq = torch.zeros_like(mean)
+    for r0 in range(0, n, 200_000):
+        blk = y[r0:r0 + 200_000].double()
+        mean += blk.sum(0)
+        sq += (blk * blk).sum(0)
+    mean /= n
+    var = sq / n - mean * mean
+    for r0 in blocks:
+        ref = torch.relu((y[r0:r0 + 64].double() - mean) / torch.sqrt(var + bn.eps))
+        assert rel_err(z[r0:r0 + 64], ref) < 1e-5, r0
+    assert float((bn.running_mean.double() - 0.1 * mean).abs().max()) < 1e-6
+    del y, z
+    # backward: linear -> BatchNorm + ReLU -> sum pooling per plot, two plots of n/2 rows
+    xg, wg = x.requires_grad_(True), w.requires_grad_(True)
+    lin = sparse_ops.dense_linear(xg, wg)
+    lin.retain_grad()
+    z = norm_ops.batch_norm_act(lin, bn, "relu")
+    ptr = torch.tensor([0, n // 2, n], dtype=torch.int32, device=device)
+    pooled = sparse_ops.segment_reduce(z.detach(), None, ptr, 2, 0)[0]
+    ref_pool = torch.stack([z[:n // 2].detach().double().sum(0), z[n // 2:].detach().double().sum(0)])
+    assert rel_err(pooled, ref_pool) < 1e-5
+    gz = torch.zeros(cout, device=device)
+    gz[::7] = 1e-3
+    z.backward(gz.expand(n, cout))
+    dy = lin.grad
+    # BatchNorm's backward removes the column mean of the gradient: sums over ALL rows vanish (a mis-addressed region
+    # would not), and so do the column sums of dx = dy W
+    scale = float(dy.abs().max())
+    assert float(dy.double().sum(0).abs().max()) < 1e-4 * scale * np.sqrt(n)
+    # dx = dy W on the row blocks, dW = dy^T x accumulated over every row in fp64
+    for r0 in blocks:
+        assert rel_err(xg.grad[r0:r0 + 64], dy[r0:r0 + 64].double() @ w.detach().double()) < 1e-5, r0
+    dw = torch.zeros(cout, cin, dtype=torch.float64, device=device)
+    for r0 in range(0, n, 200_000):
+        dw += dy[r0:r0 + 200_000].double().t() @ x.detach()[r0:r0 + 200_000].double()
+    assert rel_err(wg.grad, dw) < 1e-4
