@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void k_se_bwd_a(const float* __restrict__ W1, 
                                                   float* __restrict__ dP) {
     __shared__ float s_dh[SE_MAX_H];
     __shared__ float s_red[8][32];
+    __shared__ __attribute__((aligned(16))) float s_part[1024];   // [256 / (H/4) lane groups][H]
     const int b = blockIdx.x;
     // every workgroup of the plot needs the whole dz2 vector for the hidden-layer gradient: each keeps a private copy in
     // the scratch slice dz2[blockIdx.y][b] (slice 0 is the one pass B reads)
@@ -109,7 +110,35 @@ __global__ __launch_bounds__(256) void k_se_bwd_a(const float* __restrict__ W1, 
     }
     __syncthreads();   // read back below by other threads of the workgroup
     const float* z = zw;
-    // dh[j] = act'(h[j]) * sum_c z[c] W2[c][j]: thread (slice, j) with j fastest — the 32 lanes of a slice read one
+    // dh[j] = act'(h[j]) * sum_c z[c] W2[c][j].  H % 4 == 0: H/4 lanes cover one row of W2 with a float4 each and the
+    // 256 / (H/4) lane groups take rows c = group, group + groups, ...: every load instruction of the workgroup covers
+    // 4 KB of W2 and the loop is C / groups trips of independent loads (C = 2048, H = 128: 256 trips, eight in flight —
+    // the lane-per-column form walked W2 four times with one 4-byte load per trip and ran 50 us); partials meet in LDS.
+    if ((H & 3) == 0) {
+        const int lj = H >> 2, groups = 256 / lj;          // H <= 128: lj <= 32, a power of two or not — any divisor works
+        const int jl = threadIdx.x % lj, grp = threadIdx.x / lj;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp < groups) {
+#pragma unroll 8
+            for (int c = grp; c < C; c += groups) {
+                const float4 wv = *reinterpret_cast<const float4*>(W2 + (long long)c * H + 4 * jl);
+                const float zc = z[c];
+                acc.x += zc * wv.x; acc.y += zc * wv.y; acc.z += zc * wv.z; acc.w += zc * wv.w;
+            }
+            *reinterpret_cast<float4*>(&s_part[grp * H + 4 * jl]) = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < H) {
+            const int j = threadIdx.x;
+            float t = 0.f;
+            for (int u = 0; u < groups; ++u) t += s_part[u * H + j];      // fixed order
+            float g = t * se_act_grad(h_pre[(long long)b * H + j], act);
+            if (blockIdx.y == 0) dh[(long long)b * H + j] = g;
+            s_dh[j] = g;
+        }
+        __syncthreads();
+    } else {
+    // thread (slice, j) with j fastest — the 32 lanes of a slice read one
     // contiguous piece of row c of W2; 8 slices take rows c = slice, slice + 8, ...; partials meet in LDS
     const int jl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     for (int j0 = 0; j0 < H; j0 += 32) {
@@ -130,6 +159,7 @@ __global__ __launch_bounds__(256) void k_se_bwd_a(const float* __restrict__ W1, 
             s_dh[j] = g;
         }
         __syncthreads();
+    }
     }
     for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {
         float acc = 0.f;
