@@ -330,7 +330,11 @@ class ResNetBase(nn.Module):
                 return ts
             k, s, d = conv.kernel_size, conv.stride, conv.dilation
             # a 3-channel layer whose input needs no gradient probes the dense grid itself when it can
-            specs.append((ts, k, s, d, needs_dx and not (s == 1 and k % 2 == 1), conv.in_channels == 3 and not needs_dx))
+            widths = None
+            if conv.in_channels >= 12:      # padded widths as SparseConvFunction hands them over
+                widths = (-(-conv.in_channels // 4) * 4, -(-conv.out_channels // 4) * 4)
+            specs.append((ts, k, s, d, needs_dx and not (s == 1 and k % 2 == 1), conv.in_channels == 3 and not needs_dx,
+                          widths))
             return ts * s
 
         stem, pool = self.blocks[0][0], self.blocks[0][1]

@@ -344,6 +344,8 @@ struct ConvArgs {
     int cmp_il;     // log2 of the interleave block of its tiles (0 = contiguous, -1 = by level size)
     float* bn_part; // optional [row tiles][3][Cout]: (count, mean, M2) of every output column over the tile's rows —
                     // the partial statistics of the BatchNorm that follows (register-accumulator kernels, no split)
+    const int32_t* tile_blocks;   // optional [tiles][rows per tile >> il]: the row blocks of every tile of the pair-compacted
+                                  // kernel (work-balanced tiles, agb_spconv_balance_tiles) instead of the fixed interleave
 };
 
 // CW: output columns per workgroup (64, or 128 for wide dense layers: the staged A tile serves twice the columns)
@@ -778,6 +780,7 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     __shared__ __attribute__((aligned(16))) float Ys[(R + 1) * CMP_YS];
     __shared__ __attribute__((aligned(16))) int pl_in[2][R + 16];
     __shared__ __attribute__((aligned(16))) int pl_out[2][R + 16];
+    __shared__ int s_row[R];      // row of the level behind every local row of the tile (-1: none)
     const int lane = threadIdx.x;
     const int m = lane & 15, q = lane >> 4;
     // workgroup id -> (XCD, row tile, input-channel split, column tile); csplit > 1: the 64-channel steps of every
@@ -795,9 +798,17 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     auto grow = [&](int rl) -> int {
         if (il_shift == 0) return row0 + rl < row_end ? row0 + rl : -1;
         if (rl >= rows_per_tile) return -1;
-        const int r = ((((rl >> il_shift) * ntiles + tile) << il_shift) | (rl & ((1 << il_shift) - 1)));
-        return r < a.n_out ? r : -1;
+        const int blk = a.tile_blocks ? a.tile_blocks[tile * (rows_per_tile >> il_shift) + (rl >> il_shift)]
+                                      : (rl >> il_shift) * ntiles + tile;
+        const int r = (blk << il_shift) | (rl & ((1 << il_shift) - 1));
+        return (blk >= 0 && r < a.n_out) ? r : -1;
     };
+    int myrow[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        myrow[j] = grow(64 * j + lane);
+        s_row[64 * j + lane] = myrow[j];
+    }
     const int n0 = ct0 * 64;
     const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
     const int NSB = Cin / (CB * 16) / csplit;            // 64-channel steps per offset handled here
@@ -816,7 +827,7 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
         const int kn = a.kflip ? (K3 - 1 - k) : k;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int r = grow(64 * j + lane);
+            const int r = myrow[j];
             nv[j] = r >= 0 ? a.nbr[(long long)kn * a.nbr_stride + r] : -1;
         }
     };
@@ -958,7 +969,7 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     float* out = csplit > 1 ? a.partial + (long long)sp * a.n_out * Cout : a.Y;
     const int ldo = csplit > 1 ? Cout : a.ldy;
     for (int r = lane >> 4; r < rows_per_tile; r += 4) {
-        const int row = grow(r);
+        const int row = s_row[r];
         if (row >= 0 && n0 + c4 < Cout) {
             float4 y = *reinterpret_cast<const float4*>(&Ys[r * CMP_YS + c4]);
             y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
@@ -1919,6 +1930,50 @@ int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* n
     int rc = launch_conv(a, n_tiles, (hipStream_t)stream);
     if (rc) return rc;
     AGB_CHECK_LAUNCH("agb_spconv_fwd");
+    return AGB_OK;
+}
+
+// Tile geometry the pair-compacted kernel uses for this call: out[0] = tile height R (0: another kernel takes the layer),
+// out[1] = rows per tile, out[2] = tiles, out[3] = log2 of the interleave block (0: contiguous tiles, no block table).
+int agb_spconv_cmp_geometry(int n_out, int Cin, int Cout, int ldx, int ldy, int ksplit, int cmp_mode,
+                            int cmp_interleave_shift, int32_t* out) {
+    AGB_CHECK_ARG(out != nullptr, "agb_spconv_cmp_geometry: out required");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (n_out <= 0 || Cin < 1 || Cout < 1 || ksplit < 1) return AGB_OK;
+    ConvArgs a{};
+    float dummy = 0.f;
+    a.n_out = n_out; a.Cin = Cin; a.Cout = Cout; a.ldx = ldx; a.ldy = ldy; a.ksplit = ksplit;
+    a.partial = ksplit > 1 ? &dummy : nullptr;
+    a.cmp_mode = cmp_mode; a.cmp_il = cmp_interleave_shift;
+    if (cmp_rows(a) == 0) return AGB_OK;
+    int R, rpt, ntiles, nct, il;
+    cmp_geometry(a, &R, &rpt, &ntiles, &nct, &il);
+    out[0] = R; out[1] = rpt; out[2] = ntiles; out[3] = il;
+    return AGB_OK;
+}
+
+// agb_spconv_fwd_opt with WORK-BALANCED tiles for the pair-compacted kernel: tile_blocks int32[tb_tiles][tb_blocks] from
+// agb_spconv_balance_tiles for the geometry agb_spconv_cmp_geometry reports for this call (checked).  Same sums, bit for
+// bit, as without the table: a row's sum does not depend on the tile it is computed in.
+int agb_spconv_fwd_tiles(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                         const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, int ksplit,
+                         float* partial, int cmp_mode, int cmp_interleave_shift, const int32_t* tile_blocks, int tb_tiles,
+                         int tb_blocks, void* stream) {
+    AGB_CHECK_ARG(tile_blocks != nullptr && nbr != nullptr, "agb_spconv_fwd_tiles: tile_blocks and nbr required");
+    int32_t g[4];
+    int rc = agb_spconv_cmp_geometry(n_out, Cin, Cout, ldx, ldy, ksplit, cmp_mode, cmp_interleave_shift, g);
+    if (rc) return rc;
+    AGB_CHECK_ARG(g[0] > 0 && g[3] > 0 && g[2] == tb_tiles && (g[1] >> g[3]) == tb_blocks,
+                  "agb_spconv_fwd_tiles: the table (%d tiles x %d blocks) does not match this call's geometry (%d tiles x %d "
+                  "blocks of %d rows; 0 = the pair-compacted kernel does not take this layer)", tb_tiles, tb_blocks, g[2],
+                  g[3] > 0 ? g[1] >> g[3] : 0, 1 << g[3]);
+    AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && nbr_stride >= n_out && ldy >= Cout, "agb_spconv_fwd_tiles: bad sizes");
+    AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_tiles: ksplit needs `partial`");
+    ConvArgs a{X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, nullptr, nullptr, nullptr, ksplit,
+               partial, cmp_mode, cmp_interleave_shift, nullptr, tile_blocks};
+    rc = launch_conv(a, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    AGB_CHECK_LAUNCH("agb_spconv_fwd_tiles");
     return AGB_OK;
 }
 

@@ -3,6 +3,7 @@
 Each Function only marshals pointers/sizes into the C ABI on torch's current stream; all arithmetic of the
 sparse path happens in libagbhip.so.  Host tensors are refused (see _lib.ptr).
 """
+import ctypes
 import os
 
 import torch
@@ -42,6 +43,42 @@ _lib.declare("agb_spconv_fwd_opt", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _l
                                     _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
                                     _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p])
 _lib.declare("agb_spconv_split_hint_opt", [_lib.c_int] * 5)
+_lib.declare("agb_spconv_cmp_geometry", [_lib.c_int] * 8 + [_lib.c_void_p])
+_lib.declare("agb_spconv_balance_tiles_workspace_bytes", [_lib.c_int] * 3)
+_lib.declare("agb_spconv_balance_tiles", [_lib.c_void_p, _lib.c_ll, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
+                                          _lib.c_void_p, _lib.c_void_p, _lib.c_void_p])
+_lib.declare("agb_spconv_fwd_tiles", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
+                                      _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
+                                      _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p,
+                                      _lib.c_int, _lib.c_int, _lib.c_void_p])
+# Work-balanced tiles for the pair-compacted kernel (csrc/tiles.hip): one table per (kernel map, tile geometry), kept on
+# the map tensor (`nbr.agb_tiles`), built on first use — on the side stream when the input pipeline prebuilds the maps.
+BALANCED_TILES = os.environ.get("AGB_BALANCED_TILES", "1") != "0"
+_GEO = (ctypes.c_int32 * 4)()
+
+
+def cmp_tile_table(nbr, n_out, K3, cin, cout, ldx, ldy):
+    """Tile table of the fp32 product on kernel map `nbr` for this shape (None: the call takes another kernel or
+    contiguous tiles).  Same sums with or without it; it only evens out the work per tile."""
+    if not BALANCED_TILES or n_out <= 0:
+        return None
+    split = _lib.load().agb_spconv_split_hint_opt(n_out, K3, cin, cout, CMP_MODE)
+    _lib.call("agb_spconv_cmp_geometry", n_out, cin, cout, ldx, ldy, split, CMP_MODE, CMP_INTERLEAVE, _GEO)
+    rpt, ntiles, il = _GEO[1], _GEO[2], _GEO[3]
+    if _GEO[0] == 0 or il == 0:
+        return None
+    cache = getattr(nbr, "agb_tiles", None)
+    if cache is None:
+        cache = nbr.agb_tiles = {}
+    tab = cache.get((rpt, ntiles, il))
+    if tab is None:
+        tab = torch.empty(ntiles, rpt >> il, dtype=torch.int32, device=nbr.device)
+        ws = torch.empty(_lib.size_call("agb_spconv_balance_tiles_workspace_bytes", n_out, K3, il), dtype=torch.uint8,
+                         device=nbr.device)
+        _lib.call("agb_spconv_balance_tiles", _P(nbr), nbr.stride(0), n_out, K3, il, ntiles, rpt >> il, _P(tab), _P(ws),
+                  _lib.stream())
+        cache[(rpt, ntiles, il)] = tab
+    return tab
 _lib.declare("agb_dense_split_hint", [_lib.c_int] * 3)
 _lib.declare("agb_dense_bn_chunks", [_lib.c_int] * 3)
 _lib.declare("agb_dense_fwd_bn", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int,
@@ -174,9 +211,18 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
                   _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
                   split, _P(partial), prec, _lib.stream())
     else:
-        _lib.call("agb_spconv_fwd_opt", _P(x), x.stride(0), _P(w2d), _P(nbr), 0 if nbr is None else nbr.stride(0),
-                  int(kflip), _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab),
-                  n_tiles, split, _P(partial), CMP_MODE, CMP_INTERLEAVE, _lib.stream())
+        # a table pays where it serves several launches: the stride-1 maps (every convolution of a level, forward and
+        # data gradient); a strided layer's forward map serves one
+        tiles = (cmp_tile_table(nbr, n_out, K3, cin, cout, x.stride(0), y.stride(0))
+                 if (nbr is not None and plan is None and x.shape[0] == n_out and K3 > 1) else None)
+        if tiles is not None:
+            _lib.call("agb_spconv_fwd_tiles", _P(x), x.stride(0), _P(w2d), _P(nbr), nbr.stride(0), int(kflip), _P(bias), _P(y),
+                      y.stride(0), n_out, K3, cin, cout, split, _P(partial), CMP_MODE, CMP_INTERLEAVE, _P(tiles),
+                      tiles.shape[0], tiles.shape[1], _lib.stream())
+        else:
+            _lib.call("agb_spconv_fwd_opt", _P(x), x.stride(0), _P(w2d), _P(nbr), 0 if nbr is None else nbr.stride(0),
+                      int(kflip), _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab),
+                      n_tiles, split, _P(partial), CMP_MODE, CMP_INTERLEAVE, _lib.stream())
     _prof_end(ev, kind, K3, cin, cout, n_out, pairs, plan is not None, split, x.shape[0])
     return y
 

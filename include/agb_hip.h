@@ -129,6 +129,26 @@ int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* n
                        const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                        float* partial, int cmp_mode, int cmp_interleave_shift, void* stream);
 int agb_spconv_split_hint_opt(int n_out, int K3, int Cin, int Cout, int cmp_mode);  /* host helper */
+/* WORK-BALANCED tiles for the pair-compacted kernel.  Its time is set by its fullest tiles (with one or two tiles per
+ * resident wave the kernel ends 13-26 % after a balanced schedule on the NFI plots); agb_spconv_balance_tiles orders the
+ * row blocks of a level by their pair count and deals them to the tiles so that all tiles hold the same number of
+ * blocks and, to ~1 %, of pairs.  No counterpart in the reference (ME schedules gather-GEMM-scatter per kernel offset);
+ * the sums are bit-identical to agb_spconv_fwd_opt's — a row's sum does not depend on the tile that computes it.
+ *   agb_spconv_cmp_geometry  host helper: out[0] = tile height (0: another kernel takes this call), out[1] = rows per
+ *                            tile, out[2] = tiles, out[3] = log2 rows per block (0: contiguous tiles, no table)
+ *   agb_spconv_balance_tiles tile_blocks int32[ntiles][bpt] (bpt = rows per tile >> il; -1 = no block) from the kernel map;
+ *                            workspace of agb_spconv_balance_tiles_workspace_bytes bytes.  One table serves every
+ *                            stride-1 convolution on that map with that geometry, forward and data gradient (kflip).
+ *   agb_spconv_fwd_tiles     agb_spconv_fwd_opt (no class partition) with that table; the geometry is checked. */
+int agb_spconv_cmp_geometry(int n_out, int Cin, int Cout, int ldx, int ldy, int ksplit, int cmp_mode,
+                            int cmp_interleave_shift, int32_t* out);
+size_t agb_spconv_balance_tiles_workspace_bytes(int n_out, int K3, int il);
+int agb_spconv_balance_tiles(const int32_t* nbr, long long nbr_stride, int n_out, int K3, int il, int ntiles, int bpt,
+                             int32_t* tile_blocks, void* workspace, void* stream);
+int agb_spconv_fwd_tiles(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                         const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, int ksplit,
+                         float* partial, int cmp_mode, int cmp_interleave_shift, const int32_t* tile_blocks, int tb_tiles,
+                         int tb_blocks, void* stream);
 /* Stride-1 odd-kernel convolution of a 3-channel input (the 7^3 stem; X rows 4 floats wide, W [K^3*3, Cout]) whose
  * neighbours are probed in the level's dense lookup grid (agb_grid_insert; halo >= K/2) instead of a pre-built [K^3][n]
  * kernel map.  nbr_out (optional) receives that map as a by-product — the values agb_grid_kernel_map would write — for

@@ -880,3 +880,55 @@ def test_se_block_tail_fused_vs_separate(device, block_name, training, drop):
             floor = 1e-2 * gmax     # exactly 0 in exact arithmetic (a BatchNorm in training mode follows): rounding noise
         err = float((res[True][k] - v).abs().max()) / max(float(v.abs().max()), floor)
         assert err < RTOL, (k, err)
+
+
+def test_work_balanced_tiles(device):
+    """csrc/tiles.hip: the tile table of the pair-compacted kernel holds every row block exactly once, evens out the pairs
+    per tile, and the convolution with it is BIT-identical to the one without (forward and flipped / data-gradient form),
+    at the row counts of the SENet14 pyramid's first two levels."""
+    import ctypes
+    from dpcr_agb_amd import _lib, sparse_ops, synthetic
+    from dpcr_agb_amd.coords import CoordinateManager
+    b = synthetic.make_sparse_batch(list(range(8)))
+    coords = torch.cat([b.batch[:, None].int(), b.coords.int()], 1).to(device)
+    cm = CoordinateManager(coords, device=device, batch_size=8, bounds=b.coord_bounds)
+    cm.stride(1, 2)
+    cm.stride(2, 2)
+    for ts_in, c in ((2, 64), (4, 128)):
+        n = cm.level(ts_in).n
+        nbr = cm.kernel_map(ts_in, 3, 1)
+        x = torch.randn(n, c, device=device)
+        w = torch.randn(27 * c, c, device=device) * 0.05
+        old = sparse_ops.BALANCED_TILES
+        try:
+            sparse_ops.BALANCED_TILES = False
+            y0 = sparse_ops.spconv_forward_raw(x, w, nbr, 0, None, n, 27, c, c)
+            y0f = sparse_ops.spconv_forward_raw(x, w, nbr, 1, None, n, 27, c, c)
+            sparse_ops.BALANCED_TILES = True
+            if hasattr(nbr, "agb_tiles"):
+                nbr.agb_tiles.clear()
+            y1 = sparse_ops.spconv_forward_raw(x, w, nbr, 0, None, n, 27, c, c)
+            y1f = sparse_ops.spconv_forward_raw(x, w, nbr, 1, None, n, 27, c, c)
+        finally:
+            sparse_ops.BALANCED_TILES = old
+        tabs = getattr(nbr, "agb_tiles", {})
+        assert len(tabs) == 1, (ts_in, list(tabs))            # both calls share one geometry, hence one table
+        (rpt, ntiles, il), tab = next(iter(tabs.items()))
+        assert torch.equal(y0, y1) and torch.equal(y0f, y1f)
+        t = tab.cpu().numpy().ravel()
+        nblk = (n + (1 << il) - 1) >> il
+        assert tab.shape == (ntiles, rpt >> il)
+        assert sorted(t[t >= 0].tolist()) == list(range(nblk))
+        cnt = (nbr[:, :n] >= 0).sum(0).float()
+        cnt = torch.nn.functional.pad(cnt, (0, nblk * (1 << il) - n)).view(nblk, 1 << il).sum(1).cpu().numpy()
+        work = np.where(tab.cpu().numpy() >= 0, cnt[np.maximum(tab.cpu().numpy(), 0)], 0).sum(1)
+        fixed = (np.arange(rpt >> il)[None, :] * ntiles + np.arange(ntiles)[:, None])
+        work_fixed = np.where(fixed < nblk, cnt[np.minimum(fixed, nblk - 1)], 0).sum(1)
+        print(f"ts {ts_in}: {ntiles} tiles of {rpt} rows; pairs per tile max/mean {work.max() / work.mean():.3f} "
+              f"(fixed interleave {work_fixed.max() / work_fixed.mean():.3f})")
+        assert work.max() / work.mean() < 1.05 and work.max() / work.mean() <= work_fixed.max() / work_fixed.mean()
+    # a table that does not match the call's geometry is refused
+    geo = (ctypes.c_int32 * 4)()
+    with pytest.raises(_lib.AgbError):
+        _lib.call("agb_spconv_fwd_tiles", x.data_ptr(), c, w.data_ptr(), nbr.data_ptr(), nbr.stride(0), 0, None, y1.data_ptr(), c,
+                  n, 27, c, c, 1, None, 1, -1, tab.data_ptr(), tab.shape[0] + 1, tab.shape[1], _lib.stream())
