@@ -968,12 +968,25 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     if (a.bias && csplit == 1 && n0 + c4 < Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + c4);
     float* out = csplit > 1 ? a.partial + (long long)sp * a.n_out * Cout : a.Y;
     const int ldo = csplit > 1 ? Cout : a.ldy;
-    for (int r = lane >> 4; r < rows_per_tile; r += 4) {
-        const int row = s_row[r];
-        if (row >= 0 && n0 + c4 < Cout) {
-            float4 y = *reinterpret_cast<const float4*>(&Ys[r * CMP_YS + c4]);
-            y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
-            *reinterpret_cast<float4*>(out + (long long)row * ldo + n0 + c4) = y;
+    // eight row quads per trip: the LDS reads of a trip are issued together (one exposed LDS latency per 32 rows instead
+    // of one per 4: the rolled loop was ~3 % of a wave's life)
+    const bool col_ok = n0 + c4 < Cout;
+    for (int r0 = lane >> 4; r0 < rows_per_tile; r0 += 32) {
+        int rows[8];
+        float4 ys[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u;
+            rows[u] = r < rows_per_tile ? s_row[r] : -1;
+            ys[u] = *reinterpret_cast<const float4*>(&Ys[min(r, R) * CMP_YS + c4]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (rows[u] >= 0 && col_ok) {
+                float4 y = ys[u];
+                y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+                *reinterpret_cast<float4*>(out + (long long)rows[u] * ldo + n0 + c4) = y;
+            }
         }
     }
 }
