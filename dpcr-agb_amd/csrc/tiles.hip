@@ -48,22 +48,32 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(const int32_t* __restrict
 }
 
 // rank p -> tile: round j = p / T gives tile p % T its j-th block in even rounds, tile T-1 - p % T in odd ones; the
-// ranks past the last block mark the empty slots
-__global__ __launch_bounds__(256) void k_tile_deal(const int32_t* __restrict__ work, int nblk, const int32_t* __restrict__ start,
-                                                   int32_t* __restrict__ cursor, int ntiles, int bpt,
-                                                   int32_t* __restrict__ tile_blocks) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= ntiles * bpt) return;
-    int p = b, v = -1;
+// ranks past the last block mark the empty slots.  Ranks inside a count bin: the workgroup counts its blocks per bin in
+// LDS and claims one range per non-empty bin from the global cursor (a thread-per-block claim is ~26 k atomics on ~100
+// addresses for the first level of the pyramid: 50 us).
+__global__ __launch_bounds__(1024) void k_tile_deal(const int32_t* __restrict__ work, int nblk, int nbins,
+                                                    const int32_t* __restrict__ start, int32_t* __restrict__ cursor, int ntiles,
+                                                    int bpt, int32_t* __restrict__ tile_blocks) {
+    __shared__ int s_cnt[1024];
+    __shared__ int s_base[1024];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x * 1024 + t;
+    s_cnt[t] = 0;
+    __syncthreads();
+    int w = 0, local = 0;
     if (b < nblk) {
-        const int w = work[b];
-        p = start[w] + atomicAdd(&cursor[w], 1);
-        v = b;
+        w = work[b];
+        local = atomicAdd(&s_cnt[w], 1);
     }
+    __syncthreads();
+    if (t < nbins && s_cnt[t] > 0) s_base[t] = start[t] + atomicAdd(&cursor[t], s_cnt[t]);
+    __syncthreads();
+    if (b >= ntiles * bpt) return;
+    const int p = b < nblk ? s_base[w] + local : b;
     const int j = p / ntiles;
-    int t = p - j * ntiles;
-    if (j & 1) t = ntiles - 1 - t;
-    tile_blocks[(long long)t * bpt + j] = v;
+    int tl = p - j * ntiles;
+    if (j & 1) tl = ntiles - 1 - tl;
+    tile_blocks[(long long)tl * bpt + j] = b < nblk ? b : -1;
 }
 
 extern "C" {
@@ -94,8 +104,8 @@ int agb_spconv_balance_tiles(const int32_t* nbr, long long nbr_stride, int n_out
     int32_t* cursor = start + nbins;
     hipLaunchKernelGGL(k_tile_work, dim3(agb_cdiv(n_out, 256)), dim3(256), 0, s, nbr, nbr_stride, n_out, K3, il, work);
     hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, work, nblk, nbins, start, cursor);
-    hipLaunchKernelGGL(k_tile_deal, dim3(agb_cdiv((long long)ntiles * bpt, 256)), dim3(256), 0, s, work, nblk, start, cursor,
-                       ntiles, bpt, tile_blocks);
+    hipLaunchKernelGGL(k_tile_deal, dim3(agb_cdiv((long long)ntiles * bpt, 1024)), dim3(1024), 0, s, work, nblk, nbins, start,
+                       cursor, ntiles, bpt, tile_blocks);
     AGB_CHECK_LAUNCH("agb_spconv_balance_tiles");
     return AGB_OK;
 }
