@@ -1,6 +1,6 @@
 /* A plain-C caller of libagbhip.so (include/agb_hip.h): coordinate hash insert -> kernel map -> sparse convolution on a
- * 3-voxel input, then Linear -> BatchNorm -> ReLU with the statistics taken from the product's epilogue; both checked
- * against a brute-force evaluation on the host.  Built by tests/c_abi/Makefile (gcc + the HIP
+ * 3-voxel input, then Linear -> BatchNorm -> ReLU with the statistics taken from the product's epilogue, then the
+ * pair-compacted kernel with a work-balanced tile table; all checked against a brute-force evaluation on the host.  Built by tests/c_abi/Makefile (gcc + the HIP
  * runtime API for device memory only), run by tests/test_c_caller.py on a GPU box.  Exit code 0 = all values match. */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -146,5 +146,87 @@ int main(void) {
     }
     printf("c caller: Linear -> BatchNorm -> ReLU (statistics from the product's epilogue, %d row tiles): max error %.3g\n",
            chunks, worst2);
-    return worst2 < 2e-5 ? 0 : 9;
+    if (!(worst2 < 2e-5)) return 9;
+
+    /* ---- work-balanced tiles: a 27-offset map over 20 000 rows of 64 channels whose pair density varies along the rows
+     * (offset k of row i present iff (i + 3k) % 7 < 2 + (i >> 12): 29 % at the start, 86 % at the end; neighbour = a nearby
+     * row), the pair-compacted kernel with the fixed interleave and with the table of agb_spconv_balance_tiles: same bits. */
+    enum { TN = 20000, TC = 64 };
+    int32_t geo[4];
+    CHECK_AGB(agb_spconv_cmp_geometry(TN, TC, TC, TC, TC, 1, 128, -1, geo));
+    if (geo[0] != 128 || geo[3] <= 0) { fprintf(stderr, "cmp geometry: R %d il %d\n", geo[0], geo[3]); return 10; }
+    const int t_tiles = geo[2], t_bpt = geo[1] >> geo[3];
+    int32_t* h_nbr = (int32_t*)malloc(sizeof(int32_t) * K3 * TN);
+    float* h_x = (float*)malloc(sizeof(float) * TN * TC);
+    float* h_w = (float*)malloc(sizeof(float) * K3 * TC * TC);
+    float* h_y0 = (float*)malloc(sizeof(float) * TN * TC);
+    float* h_y1 = (float*)malloc(sizeof(float) * TN * TC);
+    int32_t* h_tab = (int32_t*)malloc(sizeof(int32_t) * t_tiles * t_bpt);
+    long long t_pairs = 0;
+    for (int k = 0; k < K3; ++k)
+        for (int i = 0; i < TN; ++i) {
+            const int present = (i + 3 * k) % 7 < 2 + (i >> 12);
+            int j = i + (k - 13) * 5;
+            if (j < 0) j += TN;
+            if (j >= TN) j -= TN;
+            h_nbr[k * TN + i] = present ? j : -1;
+            t_pairs += present;
+        }
+    for (int i = 0; i < TN * TC; ++i) h_x[i] = (float)((i * 37 + 11) % 101 - 50) * 0.01f;
+    for (int i = 0; i < K3 * TC * TC; ++i) h_w[i] = (float)((i * 53 + 7) % 89 - 44) * 0.002f;
+    int32_t *d_tn, *d_tab;
+    float *d_tx, *d_tw, *d_ty;
+    void* d_ws;
+    CHECK_HIP(hipMalloc((void**)&d_tn, sizeof(int32_t) * K3 * TN));
+    CHECK_HIP(hipMalloc((void**)&d_tab, sizeof(int32_t) * t_tiles * t_bpt));
+    CHECK_HIP(hipMalloc((void**)&d_tx, sizeof(float) * TN * TC));
+    CHECK_HIP(hipMalloc((void**)&d_tw, sizeof(float) * K3 * TC * TC));
+    CHECK_HIP(hipMalloc((void**)&d_ty, sizeof(float) * TN * TC));
+    CHECK_HIP(hipMalloc(&d_ws, agb_spconv_balance_tiles_workspace_bytes(TN, K3, geo[3])));
+    CHECK_HIP(hipMemcpy(d_tn, h_nbr, sizeof(int32_t) * K3 * TN, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_tx, h_x, sizeof(float) * TN * TC, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_tw, h_w, sizeof(float) * K3 * TC * TC, hipMemcpyHostToDevice));
+    CHECK_AGB(agb_spconv_fwd_opt(d_tx, TC, d_tw, d_tn, TN, 0, NULL, d_ty, TC, TN, K3, TC, TC, NULL, NULL, NULL, 0, 1, NULL, 128, -1,
+                                 NULL));
+    CHECK_HIP(hipMemcpy(h_y0, d_ty, sizeof(float) * TN * TC, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemset(d_ty, 0, sizeof(float) * TN * TC));
+    CHECK_AGB(agb_spconv_balance_tiles(d_tn, TN, TN, K3, geo[3], t_tiles, t_bpt, d_tab, d_ws, NULL));
+    CHECK_AGB(agb_spconv_fwd_tiles(d_tx, TC, d_tw, d_tn, TN, 0, NULL, d_ty, TC, TN, K3, TC, TC, 1, NULL, 128, -1, d_tab, t_tiles,
+                                   t_bpt, NULL));
+    CHECK_HIP(hipMemcpy(h_y1, d_ty, sizeof(float) * TN * TC, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_tab, d_tab, sizeof(int32_t) * t_tiles * t_bpt, hipMemcpyDeviceToHost));
+    if (memcmp(h_y0, h_y1, sizeof(float) * TN * TC) != 0) { fprintf(stderr, "balanced tiles changed the sums\n"); return 11; }
+    /* a few rows against the host, and the spread of the pairs per tile with and without the table */
+    double worst3 = 0.0;
+    for (int i = 0; i < TN; i += 1999)
+        for (int o = 0; o < TC; o += 7) {
+            double acc = 0.0;
+            for (int k = 0; k < K3; ++k) {
+                const int j = h_nbr[k * TN + i];
+                if (j >= 0) for (int c = 0; c < TC; ++c) acc += (double)h_x[j * TC + c] * (double)h_w[(k * TC + c) * TC + o];
+            }
+            if (fabs(acc - (double)h_y1[i * TC + o]) > worst3) worst3 = fabs(acc - (double)h_y1[i * TC + o]);
+        }
+    const int bs = 1 << geo[3], nblk = (TN + bs - 1) / bs;
+    double mean_w = (double)t_pairs / t_tiles, max_bal = 0.0, max_fix = 0.0;
+    int seen = 0;
+    for (int t = 0; t < t_tiles; ++t) {
+        double wb = 0.0, wf = 0.0;
+        for (int j = 0; j < t_bpt; ++j) {
+            const int bb = h_tab[t * t_bpt + j], bf = j * t_tiles + t;
+            for (int which = 0; which < 2; ++which) {
+                const int blk = which ? bf : bb;
+                if (blk < 0 || blk >= nblk) continue;
+                if (!which) ++seen;
+                for (int r = blk * bs; r < (blk + 1) * bs && r < TN; ++r)
+                    for (int k = 0; k < K3; ++k) { if (h_nbr[k * TN + r] >= 0) { if (which) wf += 1.0; else wb += 1.0; } }
+            }
+        }
+        if (wb > max_bal) max_bal = wb;
+        if (wf > max_fix) max_fix = wf;
+    }
+    printf("c caller: balanced tiles (%d tiles x %d blocks of %d rows): identical sums, max error vs host %.3g, pairs per tile "
+           "max/mean %.3f (fixed interleave %.3f)\n", t_tiles, t_bpt, bs, worst3, max_bal / mean_w, max_fix / mean_w);
+    if (seen != nblk) { fprintf(stderr, "table holds %d of %d blocks\n", seen, nblk); return 12; }
+    return (worst3 < 1e-3 && max_bal / mean_w < 1.05) ? 0 : 13;
 }

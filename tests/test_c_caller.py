@@ -22,3 +22,4 @@ def test_c_caller_runs(device):
     r = subprocess.run([os.path.join(HERE, "caller")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "c caller: 9 pairs" in r.stdout     # 3 centres + 3 pairs of neighbours, both directions
+    assert "balanced tiles" in r.stdout and "identical sums" in r.stdout
