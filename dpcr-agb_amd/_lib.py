@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagbhip.so")
+# AGB_LIBRARY: another build of the same library (tools/wave_timeline.py loads the instrumented `make timeline` build)
+LIB_PATH = os.environ.get("AGB_LIBRARY") or os.path.join(_HERE, "libagbhip.so")
 
 c_int = ctypes.c_int
 c_ll = ctypes.c_longlong

@@ -763,6 +763,13 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
 // 1-D grid, XCD-aware: every XCD (workgroup id % 8) walks one contiguous range of row tiles, so the gathers of
 // neighbouring tiles share that XCD's L2.  rows_per_tile <= R is chosen by the host so that the number of workgroups is
 // a multiple of the resident-wave capacity (tiles of equal cost: no half-empty last round).
+// -DAGB_TIMELINE (make TIMELINE=1; tools/wave_timeline.py): every wave of k_spconv_cmp leaves its start / end time
+// (s_memrealtime, 100 MHz), its s_memtime ticks (shader clocks) and its 16-pair group count in g_cmp_timeline — the
+// measurement behind DESIGN.md section 5's clock x slots x in-wave decomposition.  Not part of the product build.
+#ifdef AGB_TIMELINE
+#define AGB_TIMELINE_SLOTS 8192
+__device__ unsigned long long g_cmp_timeline[4 * AGB_TIMELINE_SLOTS];
+#endif
 #define CMP_YS 68   // LDS row stride of the running sums (floats): 16-B aligned rows, 4-bank skew per row
 #define CMP_CB 4    // 16-channel blocks per step (64 input channels)
 
@@ -819,6 +826,10 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
     // clamped column: the weight loads are unconditional; columns past Cout hold sums that the epilogue never stores
     const int coff = colok ? 4 * m : 0;
 
+#ifdef AGB_TIMELINE
+    const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
+    unsigned long long tl_groups = 0;
+#endif
     for (int i = lane; i < (R + 1) * CMP_YS / 4; i += 64)
         reinterpret_cast<float4*>(Ys)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -905,6 +916,9 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
         const int xoff_cur = c_first + (step % NSB) * (CB * 16) + 4 * q;
         const int xoff_nxt = c_first + (nstep % NSB) * (CB * 16) + 4 * q;
 
+#ifdef AGB_TIMELINE
+        tl_groups += ng_cur;
+#endif
         for (int g = 0; g < ng_cur; ++g) {
             // D layout: MFMA col = lane & 15 (-> output column 4m + ct), row = 4 * (lane >> 4) + v.  The four rows of a
             // lane group are distinct (a row occurs once per offset) or the sink row.
@@ -989,6 +1003,12 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
             }
         }
     }
+#ifdef AGB_TIMELINE
+    if (lane == 0 && blockIdx.x < AGB_TIMELINE_SLOTS) {
+        unsigned long long* e = g_cmp_timeline + 4 * blockIdx.x;
+        e[0] = tl_t0; e[1] = wall_clock64(); e[2] = __builtin_readcyclecounter() - tl_c0; e[3] = tl_groups;
+    }
+#endif
 }
 
 // Y[r, :] = bias + sum_s partial[s][r, :]   (fixed order)
@@ -1834,6 +1854,20 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
     }
     return AGB_OK;
 }
+
+#ifdef AGB_TIMELINE
+// out: unsigned long long[4 * 8192] = (start, end [10 ns], shader clocks, groups) per workgroup of the last k_spconv_cmp
+// launches (slot = blockIdx.x); reset != 0 clears the table afterwards.
+int agb_debug_cmp_timeline(unsigned long long* out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cmp_timeline), sizeof(unsigned long long) * 4 * AGB_TIMELINE_SLOTS);
+    if (reset) {
+        void* p = nullptr;
+        (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_cmp_timeline));
+        (void)hipMemset(p, 0, sizeof(unsigned long long) * 4 * AGB_TIMELINE_SLOTS);
+    }
+    return AGB_OK;
+}
+#endif
 
 // Resident workgroups per CU of the pair-compacted kernel (R = 64 / 128), as the runtime computes it (tuning aid).
 int agb_spconv_cmp_occupancy(int R) {
