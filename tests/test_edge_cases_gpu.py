@@ -273,3 +273,42 @@ def test_tensors_beyond_two_giga_elements(device):
     for r0 in range(0, n, 200_000):
         dw += dy[r0:r0 + 200_000].double().t() @ x.detach()[r0:r0 + 200_000].double()
     assert rel_err(wg.grad, dw) < 1e-4
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_network_in_hash_mode_matches_grid_mode(device, prefetch, monkeypatch):
+    """Coordinate levels and kernel maps through the HASH tables (what a batch takes whose extent is too large for the dense
+    lookup grids) give the same training step as the grid mode: loss, output and every gradient, at 6 000-point plots (the
+    first level is large enough for interleaved / work-balanced tiles), with and without the side-stream input pipeline."""
+    import dpcr_agb_amd.coords as C
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+
+    def run(hash_mode):
+        monkeypatch.setattr(C, "GRID_MAX_CELLS", 0 if hash_mode else 1 << 28)
+        torch.manual_seed(0)
+        ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_032))
+        opt = Opt(MODEL_OPTIONS["SENet14"])
+        opt["drop_path"] = 0.0
+        model = MinkowskiBaselineModel(opt, "minkowski", ds).to(device).train()
+        batch = synthetic.make_sparse_batch([0, 1, 2, 3], n_points=6000)
+        if prefetch:
+            model.prefetch_input(batch, device)
+        model.set_input(batch, device)
+        modes = {lvl_ts: model.input.coordinate_manager.mode for lvl_ts in (1,)}
+        model.forward()
+        model.loss.backward()
+        torch.cuda.synchronize()
+        return (modes[1], float(model.loss.detach()), model.output.detach().clone(),
+                {k: p.grad.detach().clone() for k, p in model.model.named_parameters() if p.grad is not None})
+
+    mode_g, loss_g, out_g, grads_g = run(False)
+    mode_h, loss_h, out_h, grads_h = run(True)
+    assert (mode_g, mode_h) == ("grid", "hash")
+    assert abs(loss_g - loss_h) < 1e-5 * max(1.0, abs(loss_g))
+    assert rel_err(out_h, out_g) < 1e-5
+    gmax = max(float(v.abs().max()) for v in grads_g.values())
+    bad = {k: float((grads_h[k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gmax) for k, v in grads_g.items()}
+    bad = {k: e for k, e in bad.items() if e >= RTOL}
+    assert not bad, bad
