@@ -117,6 +117,7 @@ CONV_CASES = [
     (64, 64, 3, 1, 2),
     (64, 128, 3, 2, 2),
     (64, 128, 1, 2, 2),
+    (64, 256, 3, 2, 1),      # strided data gradient with a long reduction: split four ways
     (128, 128, 3, 1, 4),
     (96, 80, 3, 1, 1),
     (16, 8, 3, 2, 1),
