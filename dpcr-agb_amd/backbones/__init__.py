@@ -6,7 +6,9 @@ from .sparse import *  # noqa: F401,F403
 from .pointnet import MinkowskiPointNet  # noqa: F401
 from .kpconv import KPCNN, KPConv  # noqa: F401
 
-_REGISTRY = {name: getattr(_sparse, name) for name in _sparse.__all__ if name[0].isupper()}
+_REGISTRY = {name: getattr(_sparse, name) for name in _sparse.__all__
+             if isinstance(getattr(_sparse, name), type) and issubclass(getattr(_sparse, name), _sparse.ResNetBase)
+             and getattr(_sparse, name) is not _sparse.ResNetBase}
 _REGISTRY["MinkowskiPointNet"] = MinkowskiPointNet
 
 

@@ -87,6 +87,19 @@ class MinkowskiDropPath(nn.Module):
         return ME.MinkowskiBroadcastMultiplication()(x, glob)
 
 
+class MinkowskiLayerNorm(nn.Module):
+    """Channel-wise layer normalisation of a sparse tensor's rows (common.py:369-386: nn.LayerNorm(C, eps=1e-6) on .F;
+    state_dict keys ``ln.weight`` / ``ln.bias``), on csrc/layernorm.hip."""
+
+    def __init__(self, normalized_shape, eps=1e-6):
+        super().__init__()
+        self.ln = nn.LayerNorm(normalized_shape, eps=eps)
+
+    def forward(self, input):
+        from ..norm_ops import layer_norm
+        return input._like(layer_norm(input.F, self.ln))
+
+
 def _residual_tail(block, out, residual):
     """relu(drop_path(out) + residual) (resnet_block.py:70-73) as one fused kernel."""
     dp = block.drop_path
@@ -264,8 +277,10 @@ class ResNetBase(nn.Module):
             self.norm_layer = partial(ME.MinkowskiBatchNorm, momentum=bn_momentum, affine=False)
         elif norm_type == "in":
             self.norm_layer = ME.MinkowskiInstanceNorm
+        elif norm_type == "ln":
+            self.norm_layer = MinkowskiLayerNorm
         else:
-            raise NotImplementedError(f"norm_type '{norm_type}': choose 'bn', 'bn_no_affine' or 'in'")
+            raise NotImplementedError(f"Choose either 'bn', 'in', or 'ln'. Given: {norm_type}")
 
         # tensor strides the forward pass will visit (lets set_input build the whole coordinate pyramid at once)
         ts, self.tensor_strides = first_stride * 2, [first_stride, first_stride * 2]
@@ -380,5 +395,6 @@ SENet17_5deep = _variant("SENet17_5deep", SEBasicBlock, (1, 1, 1, 2, 2), (1, 2, 
 
 __all__ = ["ResNetBase", "ResNet14_", "ResNet18_", "ResNet34_", "ResNet50_", "ResNet101_", "SENet14", "SENet18",
            "SENet34", "SENet50", "SENet101", "SENet17_6deep", "SENet17_5deep", "BasicBlock", "Bottleneck",
-           "SEBasicBlock", "SEBottleneck", "SELayer", "ConvNormActivation", "MinkowskiDropPath", "ACTIVATIONS",
+           "SEBasicBlock", "SEBottleneck", "SELayer", "ConvNormActivation", "MinkowskiDropPath", "MinkowskiLayerNorm",
+           "ACTIVATIONS",
            "GLOBAL_POOL"]

@@ -11,6 +11,7 @@ known-answer tests, see DESIGN.md "parity unpinned"):
   * kernel [K^3, Cin, Cout] ([Cin, Cout] when K^3 == 1 and stride == 1), bias [1, Cout]
   * max pooling over present inputs only; global pooling per batch index; MinkowskiGlobalPooling = average
 """
+import enum
 import math
 from typing import List, Optional
 
@@ -350,6 +351,57 @@ MinkowskiTanh = _pointwise("MinkowskiTanh", nn.Tanh)
 MinkowskiLeakyReLU = _pointwise("MinkowskiLeakyReLU", nn.LeakyReLU)
 
 
+class MinkowskiSinusoidal(nn.Module):
+    """ME.MinkowskiSinusoidal (the "siren" entry of the reference's ACTIVATIONS table, common.py:40; no AGB
+    configuration selects it): coef * sin(F @ kernel + bias)."""
+
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.in_channel, self.out_channel = in_channel, out_channel
+        self.kernel = nn.Parameter(torch.rand(in_channel, out_channel))
+        self.bias = nn.Parameter(torch.rand(1, out_channel))
+        self.coef = nn.Parameter(torch.rand(1, out_channel))
+
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        return input._like(self.coef * torch.sin(input.F.mm(self.kernel) + self.bias))
+
+
+class RegionType(enum.Enum):
+    """ME.RegionType: the reference's common.py:75-86 builds lookup tables from these at import time.  Only HYPER_CUBE
+    kernels exist in this library (the AGB models use no other)."""
+    HYPER_CUBE = 0
+    HYPER_CROSS = 1
+    CUSTOM = 2
+
+
+class KernelGenerator:
+    """ME.KernelGenerator as far as the reference's helper constructors (common.py:135-212) use it: carries the
+    geometry; anything but a hypercube region is refused."""
+
+    def __init__(self, kernel_size=-1, stride=1, dilation=1, is_transpose=False, region_type=RegionType.HYPER_CUBE,
+                 region_offsets=None, expand_coordinates=False, axis_types=None, dimension=-1):
+        if region_type != RegionType.HYPER_CUBE or axis_types is not None:
+            raise NotImplementedError("only HYPER_CUBE kernel regions are implemented")
+        self.kernel_size, self.kernel_stride, self.kernel_dilation = kernel_size, stride, dilation
+        self.region_type, self.dimension = region_type, dimension
+
+
+def _unsupported(name):
+    class _Unsupported(nn.Module):
+        def __init__(self, *args, **kwargs):
+            raise NotImplementedError(f"ME.{name} is not used by the AGB encoder path and is not implemented")
+
+    _Unsupported.__name__ = _Unsupported.__qualname__ = name
+    return _Unsupported
+
+
+# named by helper functions of the reference's common.py that no AGB model calls (U-Net decoders, average / sum pooling)
+MinkowskiConvolutionTranspose = _unsupported("MinkowskiConvolutionTranspose")
+MinkowskiAvgPooling = _unsupported("MinkowskiAvgPooling")
+MinkowskiSumPooling = _unsupported("MinkowskiSumPooling")
+MinkowskiAvgUnpooling = _unsupported("MinkowskiAvgUnpooling")
+
+
 def fused_norm_act(norm, act, x: SparseTensor) -> SparseTensor:
     """act(norm(x)) in one fused BatchNorm+activation kernel pair when norm is a MinkowskiBatchNorm and act a plain
     ReLU/GELU (the reference's ConvNormActivation / block wiring); otherwise the modules are applied one by one."""
@@ -384,8 +436,9 @@ MinkowskiNormalization = _Namespace()
 MinkowskiNormalization.MinkowskiBatchNorm = MinkowskiBatchNorm
 MinkowskiNormalization.MinkowskiInstanceNorm = MinkowskiInstanceNorm
 MinkowskiNonlinearity = _Namespace()
-for _n in ("ReLU", "GELU", "CELU", "SiLU", "ELU", "Sigmoid", "Tanh", "LeakyReLU"):
+for _n in ("ReLU", "GELU", "CELU", "SiLU", "ELU", "Sigmoid", "Tanh", "LeakyReLU", "Sinusoidal"):
     setattr(MinkowskiNonlinearity, "Minkowski" + _n, globals()["Minkowski" + _n])
 
 __all__ = [n for n in dir() if n.startswith("Minkowski")] + ["SparseTensor", "CoordinateManager", "CoordinateMapKey",
-                                                              "fused_norm_act", "fused_residual"]
+                                                              "RegionType", "KernelGenerator", "fused_norm_act",
+                                                              "fused_residual"]

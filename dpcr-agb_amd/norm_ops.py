@@ -331,3 +331,49 @@ def pointnet_mlp_forward(x, layers, act, ptr, B, mode, training=False, momentum=
               _P(ws_[2]), bns[2], c3, ACT_IDS[act], float(layers[0][1].eps), float(momentum), int(bool(training)), _P(ptr),
               B, m, _P(work), _P(pooled), _P(arg), _lib.stream())
     return pooled, arg
+
+
+# ----------------------------------------------------------------------------------------------------- LayerNorm
+_lib.declare("agb_layernorm_chunks", [_lib.c_int])
+_lib.declare("agb_layernorm_fwd", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
+                                   _lib.c_float, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p])
+_lib.declare("agb_layernorm_bwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int,
+                                   _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
+                                   _lib.c_void_p, _lib.c_void_p])
+
+
+class LayerNormFunction(torch.autograd.Function):
+    """nn.LayerNorm(C) over the rows of x [N, C] (the reference's MinkowskiLayerNorm, common.py:369-386)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        n, c = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(n, 2, dtype=torch.float32, device=x.device)
+        _lib.call("agb_layernorm_fwd", _P(x), x.stride(0), n, c, _P(gamma), _P(beta), float(eps), _P(y), y.stride(0),
+                  _P(stats), _lib.stream())
+        ctx.save_for_backward(x, stats, gamma if gamma is not None else torch.empty(0))
+        ctx.has = (gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma = ctx.saved_tensors
+        has_g, has_b = ctx.has
+        dy = dy.contiguous()
+        n, c = x.shape
+        chunks = _lib.load().agb_layernorm_chunks(int(n))
+        part = torch.empty(chunks, 2, c, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dg = torch.empty(c, dtype=torch.float32, device=x.device) if has_g else None
+        db = torch.empty(c, dtype=torch.float32, device=x.device) if has_b else None
+        _lib.call("agb_layernorm_bwd", _P(x), x.stride(0), _P(dy), dy.stride(0), n, c, _P(gamma) if has_g else None,
+                  _P(stats), _P(dx), c if dx is None else dx.stride(0), _P(part), _P(dg), _P(db), _lib.stream())
+        return dx, dg, db, None
+
+
+def layer_norm(x, ln: torch.nn.LayerNorm):
+    if len(ln.normalized_shape) != 1 or ln.normalized_shape[0] != x.shape[1]:
+        raise ValueError("layer_norm: the module normalises one channel axis of the row matrix")
+    return LayerNormFunction.apply(x, ln.weight, ln.bias, ln.eps)

@@ -288,6 +288,15 @@ int agb_add_act_fwd(const float* A, int lda, const float* R, int ldr, const floa
                     int C, int act, float* Y, int ldy, void* stream);
 int agb_add_act_bwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords,
                     const float* dY, int ldy, int n, int C, int act, float* dA, float* dR, void* stream);
+/* Channel-wise LayerNorm of every row (norm_type="ln": SENet.py:40-41 -> common.py:369-386 MinkowskiLayerNorm =
+ * nn.LayerNorm(C, eps=1e-6) on .F).  stats float[n][2] = (mean, rstd) per row, written by _fwd and read by _bwd.
+ * _bwd: dX may be NULL; part float[agb_layernorm_chunks(n)][2][C] scratch for the fixed-order column sums behind
+ * dgamma / dbeta (either may be NULL).  C <= 2048. */
+int agb_layernorm_chunks(int n);       /* host helper */
+int agb_layernorm_fwd(const float* X, int ldx, int n, int C, const float* gamma, const float* beta, float eps, float* Y,
+                      int ldy, float* stats, void* stream);
+int agb_layernorm_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* gamma,
+                      const float* stats, float* dX, int lddx, float* part, float* dgamma, float* dbeta, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * KPConv index path.  Replaces the CPython extensions behind modules/KPConv/common.py:
