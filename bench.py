@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="build each batch's coordinate plan inside set_input")
     ap.add_argument("--cpu-plots", type=int, default=1)
-    ap.add_argument("--reserve-gib", type=int, default=12, help="allocator pool reserved up front on the compute stream "
+    ap.add_argument("--reserve-gib", type=int, default=16, help="allocator pool reserved up front on the compute stream "
                     "(half of it again on the input pipeline's side stream); 0 = grow on demand")
     return ap.parse_args()
 
@@ -99,20 +99,19 @@ def kernel_of(rec):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/collect_pmc.sh -> profiles/), or None."""
-    data = None
-    for tag in ("r02", "r01"):      # the newest committed PMC pass (tools/collect_pmc.sh <tag>)
+    """(HBM bytes per launch of `kernel`, file it was read from) from the newest committed PMC pass
+    (tools/collect_pmc.sh <tag> -> profiles/<tag>_pmc_traffic.json; separate --pmc runs of this same command, corrected as
+    MI355X_MICROARCH.md prescribes) — counters cannot be collected from inside a running benchmark — or (None, None)."""
+    for tag in ("r03", "r02", "r01"):
+        rel = os.path.join("profiles", f"{tag}_pmc_traffic.json")
         try:
-            data = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))["kernels"]
-            break
+            data = json.load(open(os.path.join(ROOT, rel)))["kernels"]
         except Exception:
             continue
-    if data is None:
-        return None
-    for name, v in data.items():
-        if name.replace("void ", "").strip() == kernel:
-            return round(v["hbm_bytes_per_launch"])
-    return None
+        for name, v in data.items():
+            if name.replace("void ", "").strip() == kernel:
+                return round(v["hbm_bytes_per_launch"]), rel
+    return None, None
 
 
 def group_profile(prof, table=False):
@@ -174,14 +173,15 @@ def roofline_of(dom, g):
     peak = mfma_peak_tf()
     intensity = g["flops"] / g["comp"]
     ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    traffic, traffic_src = pmc_traffic(dom)
     if intensity >= ridge:
         ach = g["flops"] / secs / 1e12
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s",
-                    frac=round(ach / peak, 4), traffic=pmc_traffic(dom))
+                    frac=round(ach / peak, 4), traffic=traffic, traffic_source=traffic_src)
     else:
         ach = g["comp"] / secs / 1e9
         roof = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom))
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src)
     roof.update(kernel=dom, launches=g["n"], avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2),
                 alg_bytes_per_launch=round(g["bytes"] / g["n"]), compulsory_bytes_per_launch=round(g["comp"] / g["n"]),
                 alg_flops_per_launch=round(g["flops"] / g["n"]), flop_per_compulsory_byte=round(intensity, 1),
@@ -347,7 +347,6 @@ def main():
     dpcr_agb_amd.limit_host_threads()     # (the cpu_baseline leg sets its own thread count afterwards)
     global PRECISION
     PRECISION = args.precision
-    sparse_ops.set_conv_precision(args.precision)
     from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
     from dpcr_agb_amd.dist import GradAllReduce, broadcast_parameters, shard_seeds
     from dpcr_agb_amd.instance import MinkowskiBaselineModel
@@ -357,6 +356,7 @@ def main():
     model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS[args.model]), "minkowski", ds)
     model_sd_cpu = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
     model.to(dev).train()
+    model.set_kernel_options(precision=args.precision)     # carried by the model, not by the process
     broadcast_parameters(model)
     model.init_train_objects(TRAINING_NFI)
     sync = None
@@ -374,12 +374,13 @@ def main():
     voxels = sum(int(b.coords.shape[0]) for b in pool) / len(pool) / args.batch
     steps_per_epoch = 133  # 4271 train plots / 32
 
-    host_ms = []
+    host_ms, host_cpu_ms = [], []
 
     def step(i):
-        t_h = time.perf_counter()
+        t_h, c_h = time.perf_counter(), time.process_time()
         _step(i)
         host_ms.append((time.perf_counter() - t_h) * 1e3)
+        host_cpu_ms.append((time.process_time() - c_h) * 1e3)     # CPU time of ALL threads of this rank
 
     def _step(i):
         # software pipeline of the input path: this step's coordinate pyramid was built on a side stream while the
@@ -452,6 +453,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(model.loss.detach())
+    # what the exchange looked like, for the driver's scaling run: backend, ranks, buckets and bytes per step; a checksum
+    # of every rank's parameters after the timed steps (identical on all ranks when the gradients were averaged) and each
+    # rank's host CPU time per step (all threads of the process: what N ranks ask of the node's cores)
+    checksum = torch.zeros(1, dtype=torch.float64, device=dev)
+    for p in model.parameters():
+        checksum += p.detach().double().sum()
+    hc = sorted(host_cpu_ms[-args.steps:])
+    slots = torch.zeros(world, 3, dtype=torch.float64, device=dev)
+    slots[rank] = torch.tensor([float(checksum.item()), hc[len(hc) // 2], sorted(host_ms[-args.steps:])[len(hc) // 2]],
+                               dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(slots, op=dist.ReduceOp.SUM)     # (a gather written as a sum: every backend has all_reduce)
+    gathered = list(slots)
+    comm = dict(backend=(dist.get_backend() if world > 1 else None), world=world,
+                buckets=len(sync.buckets) if sync is not None else 0,
+                bytes_per_step=int(sum(b["flat"].numel() * b["flat"].element_size() for b in sync.buckets)) if sync else 0,
+                param_checksums=[float(g[0].item()) for g in gathered],
+                host_cpu_ms_per_step_p50=[round(float(g[1].item()), 3) for g in gathered],
+                host_enqueue_ms_p50=[round(float(g[2].item()), 3) for g in gathered])
     gaps = []
     if len(step_events) > 1:
         gaps = [step_events[j].elapsed_time(step_events[j + 1]) for j in range(len(step_events) - 1)]
@@ -498,6 +518,8 @@ def main():
             "step_ms_p90": round(sorted(gaps)[int(len(gaps) * 0.9)], 3) if gaps else None,
             "step_ms_min": round(min(gaps), 3) if gaps else None,
             "device_allocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+            "host_enqueue_ms_p50": round(hm[len(hm) // 2], 3), "host_cpu_ms_per_step_p50": round(hc[len(hc) // 2], 3),
+            "comm": comm,
             "kernels": summary, "kernels_from": f"{n_instr} fully bracketed warmup step(s), outside the timed region",
         }
         if world == 1 and not args.no_cpu_baseline:

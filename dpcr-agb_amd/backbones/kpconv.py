@@ -20,10 +20,11 @@ from .. import _lib
 from ..kp_dispositions import kernel_disposition
 from ..kpconv_ops import KPConvSymmetricFunction, KPGatherFunction, KPMaxPoolFunction, as_index
 from ..norm_ops import ACT_IDS, AddActFunction, batch_norm_act, batch_norm_add_act
-from ..sparse_ops import DenseConvFunction, dense_linear, segment_reduce, take_bn_hint
+from ..sparse_ops import DenseConvFunction, current as current_options, dense_linear, model_scope, segment_reduce, \
+    take_bn_hint
 
 ACTIVATION_NAMES = {"relu": "relu", "gelu": "gelu"}
-FUSED_TAIL = True        # Linear -> BatchNorm -> + shortcut -> activation of the bottleneck blocks as one node
+# (Linear -> BatchNorm -> + shortcut -> activation of the bottleneck blocks as one node: KernelOptions.fused_tail)
 
 
 def _act_module(name):
@@ -174,7 +175,7 @@ class ResnetBottleneckBlock(nn.Module):
             shortcut = features
         shortcut = self.unary_shortcut(shortcut)
         u2 = self.unary2
-        if (FUSED_TAIL and self._fused_act and x.is_cuda and u2.no_relu and u2.batch_norm.use_bn
+        if (current_options().fused_tail and self._fused_act and x.is_cuda and u2.no_relu and u2.batch_norm.use_bn
                 and u2.out_dim % 4 == 0):
             # Linear -> BatchNorm -> (+ shortcut) -> activation without the BatchNorm output in memory
             z = dense_linear(x, u2.mlp.weight, u2.mlp.bias)
@@ -271,11 +272,14 @@ class KPCNN(nn.Module):
                 out_dim *= 2
         self.head_mlp = UnaryBlock(out_dim, 1024, config.activation, False, 0)
 
+    kernel_options = None      # sparse_ops.KernelOptions of this model (None: the ones in force / the defaults)
+
     def forward(self, batch):
-        x = batch.features.clone().detach()
-        for op in self.block_ops:
-            x = op(x, batch)
-        return self.head_mlp(x, batch)
+        with model_scope(self):
+            x = batch.features.clone().detach()
+            for op in self.block_ops:
+                x = op(x, batch)
+            return self.head_mlp(x, batch)
 
 
 __all__ = ["KPConv", "KPCNN", "UnaryBlock", "BatchNormBlock", "SimpleBlock", "ResnetBottleneckBlock",

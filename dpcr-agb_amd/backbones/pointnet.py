@@ -15,6 +15,7 @@ from .. import me_compat as ME
 import torch
 
 from ..norm_ops import POOL_MODES, batch_norm_act_pool, pointnet_mlp_forward
+from ..sparse_ops import model_scope
 from .sparse import ACTIVATIONS, GLOBAL_POOL
 
 # (Sequential name, layer widths relative to the constructor arguments); each width adds Linear(no bias) + BN + act
@@ -70,8 +71,11 @@ class MinkowskiPointNet(nn.Module):
             return ME.SparseTensor(pooled, coordinate_map_key=ME.CoordinateMapKey(0), coordinate_manager=cm)
         return self.global_pool(ME.fused_norm_act(norm, act, z))
 
+    kernel_options = None      # sparse_ops.KernelOptions of this model (None: the ones in force / the defaults)
+
     def forward(self, x):
-        x = self._embed(x)
-        x = self._run(list(self.mlp), x)
-        x = self.dp1(x)
-        return self.final(x)
+        with model_scope(self):
+            x = self._embed(x)
+            x = self._run(list(self.mlp), x)
+            x = self.dp1(x)
+            return self.final(x)

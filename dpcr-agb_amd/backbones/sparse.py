@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import me_compat as ME
 from ..se_ops import MAX_HIDDEN as MAX_SE_HIDDEN, se_layer
+from ..sparse_ops import current as current_options, model_scope
 
 ACTIVATIONS = {
     "relu": ME.MinkowskiReLU,
@@ -214,7 +215,7 @@ def _se_block_forward(block, x, z, last_norm):
     lin1, act, lin2, gate = se.fc[0], se.fc[1], se.fc[2], se.fc[3]
     se_name, act_name = getattr(act, "act_name", None), getattr(block.relu, "act_name", None)
     residual = block.downsample(x)
-    if (se_ops.FUSED_TAIL and isinstance(last_norm, ME.MinkowskiBatchNorm) and z.F.is_cuda and z.F.shape[1] % 4 == 0
+    if (current_options().fused_tail and isinstance(last_norm, ME.MinkowskiBatchNorm) and z.F.is_cuda and z.F.shape[1] % 4 == 0
             and se_name in ("relu", "gelu") and act_name in ("relu", "gelu") and isinstance(gate, ME.MinkowskiSigmoid)
             and lin1.linear.out_features <= MAX_SE_HIDDEN and z._ts != 0
             and isinstance(dp, (MinkowskiDropPath, nn.Identity))):
@@ -366,11 +367,14 @@ class ResNetBase(nn.Module):
                     visit(blk.downsample[0], ts_in, True)
         return specs
 
+    kernel_options = None      # sparse_ops.KernelOptions of this model (None: the ones in force / the defaults)
+
     def forward(self, x):
-        for block in self.blocks:
-            x = block(x)
-        x = self.glob_avg(x)
-        return self.final(x)
+        with model_scope(self):
+            for block in self.blocks:
+                x = block(x)
+            x = self.glob_avg(x)
+            return self.final(x)
 
 
 def _variant(name, block, layers, strides=(1, 2, 2, 2), init_dim=64, planes=(64, 128, 256, 512)):

@@ -319,8 +319,8 @@ class CoordinateManager:
             return None
         return lvl.coords, lvl.grid, lvl.desc_host
 
-    def prebuild(self, specs):
-        """Build kernel maps ahead of the forward pass. specs: iterable of (ts_in, K, stride, dilation, need_T[, probe
+    def prebuild(self, specs, opts=None):
+        """Build kernel maps ahead of the forward pass (opts: the model's KernelOptions, for the tile tables). specs: iterable of (ts_in, K, stride, dilation, need_T[, probe
         [, (cin, cout)]]): probe = True marks a layer that reads the dense grid itself when it can (it writes its own map
         then); (cin, cout) = padded widths of a stride-1 layer on the map, whose work-balanced tile tables (forward and
         data gradient) are built here too instead of inside the first convolution that uses them."""
@@ -331,11 +331,12 @@ class CoordinateManager:
             nbr = self.kernel_map(ts_in, K, s, d)
             if len(spec) > 6 and spec[6] is not None and _as_int(s) == 1 and _as_int(K) % 2 == 1 and _as_int(K) > 1:
                 from . import sparse_ops
-                if sparse_ops.CONV_PRECISION not in sparse_ops._PREC_ID:      # (the bf16 kernels do not take the tables)
+                opts = opts or sparse_ops.current()
+                if not opts.low_precision:      # (the bf16 kernels do not take the tables)
                     cin, cout = spec[6]
                     n = self.levels[int(ts_in)].n
-                    sparse_ops.cmp_tile_table(nbr, n, _as_int(K) ** 3, cin, cout, cin, cout)
-                    sparse_ops.cmp_tile_table(nbr, n, _as_int(K) ** 3, cout, cin, cout, cin)   # data gradient: same map, flipped
+                    sparse_ops.cmp_tile_table(nbr, n, _as_int(K) ** 3, cin, cout, cin, cout, opts)
+                    sparse_ops.cmp_tile_table(nbr, n, _as_int(K) ** 3, cout, cin, cout, cin, opts)   # data gradient: same map, flipped
             if need_t:
                 self.transposed_map(ts_in, K, s, d)
                 if s > 1:

@@ -197,16 +197,14 @@ template <int NTB, bool NT_LOADS>
 static int launch_stream(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int n, int Cin,
                          int Cout, hipStream_t st) {
     const int ldw = ((Cout + 15) / 16) * 16 + 4, lds = Cin * ldw * 4;
-    static int attr_bytes = 0;                                     // (per instantiation; only ever raised)
     auto kern = k_dense_stream<NTB, NT_LOADS>;
-    if (lds > 48 * 1024 && lds > attr_bytes) {
+    if (lds > 48 * 1024) {      // (per device and cheap: set on every such launch rather than cached in a static)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            96 * 1024);
         if (e != hipSuccess) {
             agb_set_error("dense product: %d bytes of LDS refused: %s", lds, hipGetErrorString(e));
             return AGB_ELAUNCH;
         }
-        attr_bytes = 96 * 1024;
     }
     const int items = agb_cdiv(n, 16);
     const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;   // 8-wave workgroups

@@ -80,9 +80,10 @@ extern "C" {
 
 // Scratch of agb_spconv_balance_tiles in bytes (int32: work[blocks], start / cursor[(K3 << il) + 1]).
 size_t agb_spconv_balance_tiles_workspace_bytes(int n_out, int K3, int il) {
-    if (n_out < 0 || K3 < 1 || il < 0 || il > 5) return 0;
+    if (n_out < 0 || K3 < 1 || il < 1 || il > 5) return 0;      // (the entry point's own contract: il 1..5)
     const size_t nblk = ((size_t)n_out + ((size_t)1 << il) - 1) >> il, nbins = ((size_t)K3 << il) + 1;
-    return 4 * (nblk + 3 * nbins + 16);
+    if (nbins > 1024) return 0;                                  // more pairs per block than the counting sort has bins
+    return 4 * (nblk + 2 * nbins + 16);
 }
 
 // tile_blocks int32[ntiles][bpt] (out): the row blocks (2^il rows each; -1 = none) of every tile, for agb_spconv_fwd_tiles.

@@ -86,6 +86,14 @@ class InstanceBase(torch.nn.Module):
                          if "train" in area], dtype=np.float64)
         return float(np.nanmean(vals))
 
+    def set_kernel_options(self, **kw):
+        """Operand precision / kernel-choice knobs of THIS model (sparse_ops.KernelOptions fields, e.g.
+        ``precision="bf16"``): carried by its backbone, applied to its forward pass and kept by its autograd nodes."""
+        from ..sparse_ops import KernelOptions
+        base = getattr(self.model, "kernel_options", None)
+        self.model.kernel_options = KernelOptions(base=base, **kw) if base is not None else KernelOptions(**kw)
+        return self.model.kernel_options
+
     # ----------------------------------------------------------- contract
     @property
     def conv_type(self):
@@ -171,7 +179,7 @@ class InstanceBase(torch.nn.Module):
             for _ in range(batch_size):
                 self._lr_scheduler.step(epoch)
 
-    def reserve_workspace(self, device, main_bytes=0, side_bytes=0):
+    def reserve_workspace(self, device, main_bytes=0, side_bytes=0, small_bytes=256 << 20):
         """Grow the caching allocator's pools of the compute stream and of the input pipeline's side stream up front (one
         big block each, handed straight back to the cache, which then carves every later request out of it): a
         hipMalloc in the middle of a step waits for the whole device, and the pools are per stream.  MI355X has 288 GB:
@@ -184,6 +192,13 @@ class InstanceBase(torch.nn.Module):
                 with torch.cuda.stream(stream):
                     block = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
                     del block
+            if small_bytes > 0:
+                # requests of up to 1 MiB come from a pool of their own (2 MiB segments) that the big block does not
+                # feed: park the same head-room there (per-plot vectors, statistics, tile tables, drop-path rows)
+                with torch.cuda.stream(stream):
+                    blocks = [torch.empty(1 << 20, dtype=torch.uint8, device=device)
+                              for _ in range(int(small_bytes) >> 20)]
+                    del blocks
         torch.cuda.synchronize(device)
 
     @torch.no_grad()

@@ -67,7 +67,7 @@ class MinkowskiBaselineModel(InstanceBase):
         cm = inp.coordinate_manager
         cm.finish_prefetch()
         if hasattr(self.model, "plan_spec"):
-            cm.prebuild(self.model.plan_spec(input_requires_grad=False))
+            cm.prebuild(self.model.plan_spec(input_requires_grad=False), getattr(self.model, "kernel_options", None))
         return inp
 
     def _build_input(self, data, device):

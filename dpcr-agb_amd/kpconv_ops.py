@@ -74,11 +74,12 @@ class KPConvSymmetricFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pts, idx, kernel_points, extent, weights):
-        from .sparse_ops import dense_product
+        from .sparse_ops import current, dense_product
         x, pts, kernel_points = x.contiguous(), pts.contiguous(), kernel_points.contiguous()
         K, cin, cout = weights.shape
+        ctx.opts = current()
         wf = _gather(x, pts, pts, idx, kernel_points, extent).view(-1, K * cin)
-        out = dense_product(wf, weights.reshape(K * cin, cout), bn_stats=any(ctx.needs_input_grad))
+        out = dense_product(wf, weights.reshape(K * cin, cout), bn_stats=any(ctx.needs_input_grad), opts=ctx.opts)
         # (by the same symmetry dW[k,c,o] = sum_j x[j,c] wfd[j,k,o] with the mirrored gather of dy, which would let the
         # backward keep x instead of the 15x larger wf; measured 0.1 ms/step slower in the [N,16]^T [N,240] product shape)
         ctx.save_for_backward(wf, pts, idx, kernel_points, weights)
@@ -93,10 +94,10 @@ class KPConvSymmetricFunction(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[5]:
-            dw = dense_weight_grad(wf, dy).view(K, cin, cout)
+            dw = dense_weight_grad(wf, dy, ctx.opts).view(K, cin, cout)
         if ctx.needs_input_grad[0]:
             wfd = _gather(dy, pts, pts, idx, (-kernel_points).contiguous(), ctx.extent).view(-1, K * cout)
-            dx = dense_product(wfd, weights.permute(0, 2, 1).reshape(K * cout, cin), "dgrad1x1")
+            dx = dense_product(wfd, weights.permute(0, 2, 1).reshape(K * cout, cin), "dgrad1x1", opts=ctx.opts)
         return dx, None, None, None, None, dw
 
 

@@ -118,7 +118,7 @@ _lib.declare("agb_se_tail_bwd_ds", [_V, _V, _I, _V, _V, _V, _I, _I, _V, _V, _V, 
 _lib.declare("agb_se_tail_bwd_fold", [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _V, _V, _V, _V])
 _lib.declare("agb_se_tail_bwd_apply", [_V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V,
                                        _I, _V, _I, _V])
-FUSED_TAIL = True      # (tests compare the fused tail with the separate kernels)
+# (whether the blocks take this fused tail is sparse_ops.KernelOptions.fused_tail; tests compare both forms)
 
 
 class SEBlockTailFunction(torch.autograd.Function):

@@ -3,8 +3,11 @@
 Each Function only marshals pointers/sizes into the C ABI on torch's current stream; all arithmetic of the
 sparse path happens in libagbhip.so.  Host tensors are refused (see _lib.ptr).
 """
+import contextlib
 import ctypes
 import os
+import threading
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -13,31 +16,102 @@ from . import _lib
 
 _P = _lib.ptr
 
-# Operand precision of the sparse-conv forward / data-gradient MFMAs (weight gradient and all I/O stay fp32):
-#   "fp32"   exact fp32 MFMA (default; what bench.py's headline number uses)
-#   "bf16"   bf16 operands, fp32 accumulate (BASELINE.json config 5)
-#   "bf16x3" split-bf16 (hi+lo) operands, three MFMAs per product: fp32-level accuracy at 3/16 of the fp32 MFMA cost
-CONV_PRECISION = os.environ.get("AGB_CONV_PRECISION", "fp32")
+class KernelOptions:
+    """Operand precision and kernel-choice knobs of ONE model (or one call) — carried by the model / its modules, not by
+    the process: two models of different precision coexist.  The library itself keeps no state: every value travels as a
+    per-call argument of the C ABI.
+
+      precision            operand precision of the sparse / 1x1 convolution MFMAs (forward, data and weight gradient;
+                           accumulation, I/O, the 3-channel stem in bf16x3, BatchNorm, SE and the index kernels stay fp32):
+                             "fp32"   exact fp32 MFMA (default; bench.py's headline)
+                             "bf16"   bf16 operands, fp32 accumulate (BASELINE.json config 5)
+                             "bf16x3" split-bf16 (hi+lo), three MFMAs per product: fp32-level accuracy
+      cmp_mode             fp32 forward / data-gradient kernel: 1 = automatic (pair-compacted kernel for many-row layers),
+                           0 = never, 64 / 128 = always with that tile height (tests, tuning)
+      cmp_interleave       log2 of the row-block size of its interleaved tiles (-1: by the level's size, 0: contiguous)
+      balanced_tiles       work-balanced tile tables for that kernel (csrc/tiles.hip)
+      bn_stats_in_epilogue forward dense products leave BatchNorm statistics partials (agb_dense_fwd_bn)
+      fused_tail           SE / bottleneck block tails as one autograd node (se_ops, backbones)
+
+    Use: ``model.kernel_options = KernelOptions(precision="bf16")`` (the backbones run their forward pass inside it), or
+    ``with KernelOptions(cmp_mode=128): ...`` around direct calls.  Autograd nodes keep the options they were created
+    under for their backward pass.  ``DEFAULTS`` (environment-initialised) applies where nothing else is set."""
+    __slots__ = ("precision", "cmp_mode", "cmp_interleave", "balanced_tiles", "bn_stats_in_epilogue", "fused_tail")
+    PRECISIONS = ("fp32", "bf16", "bf16x3")
+
+    def __init__(self, precision=None, cmp_mode=None, cmp_interleave=None, balanced_tiles=None,
+                 bn_stats_in_epilogue=None, fused_tail=None, base=None):
+        base = base if base is not None else (current() if "DEFAULTS" in globals() else None)
+        pick = lambda v, name, dflt: v if v is not None else (getattr(base, name) if base is not None else dflt)  # noqa: E731
+        self.precision = pick(precision, "precision", "fp32")
+        if self.precision not in self.PRECISIONS:
+            raise ValueError(f"conv precision '{self.precision}': choose fp32, bf16 or bf16x3")
+        self.cmp_mode = int(pick(cmp_mode, "cmp_mode", 1))
+        self.cmp_interleave = int(pick(cmp_interleave, "cmp_interleave", -1))
+        self.balanced_tiles = bool(pick(balanced_tiles, "balanced_tiles", True))
+        self.bn_stats_in_epilogue = bool(pick(bn_stats_in_epilogue, "bn_stats_in_epilogue", True))
+        self.fused_tail = bool(pick(fused_tail, "fused_tail", True))
+
+    def replace(self, **kw):
+        return KernelOptions(base=self, **kw)
+
+    @property
+    def prec_id(self):
+        return _PREC_ID.get(self.precision, 0)
+
+    @property
+    def low_precision(self):
+        return self.precision in _PREC_ID
+
+    def __enter__(self):
+        _scope().append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _scope().pop()
+        return False
+
+    def __repr__(self):
+        return "KernelOptions(" + ", ".join(f"{k}={getattr(self, k)!r}" for k in self.__slots__) + ")"
+
+
 _PREC_ID = {"bf16": 1, "bf16x3": 2}
+_TLS = threading.local()
+
+
+def _scope():
+    st = getattr(_TLS, "stack", None)
+    if st is None:
+        st = _TLS.stack = []
+    return st
+
+
+def current():
+    """The options in force here: the innermost ``with KernelOptions(...)`` / model scope of this thread, else DEFAULTS."""
+    st = getattr(_TLS, "stack", None)
+    return st[-1] if st else DEFAULTS
+
+
+DEFAULTS = KernelOptions(precision=os.environ.get("AGB_CONV_PRECISION", "fp32"), cmp_mode=1, cmp_interleave=-1,
+                         balanced_tiles=os.environ.get("AGB_BALANCED_TILES", "1") != "0",
+                         bn_stats_in_epilogue=os.environ.get("AGB_BN_EPILOGUE", "1") != "0", fused_tail=True)
 
 
 def set_conv_precision(name):
-    """Operand precision of the sparse / 1x1 convolution MFMAs from now on: "fp32", "bf16" or "bf16x3" (forward, data
-    gradient and weight gradient; accumulation, I/O, the 3-channel stem, BatchNorm, SE and the index kernels stay fp32).
-    Returns the previous setting."""
-    global CONV_PRECISION
-    if name not in ("fp32", "bf16", "bf16x3"):
+    """Process DEFAULT operand precision (command-line tools; a model's own ``kernel_options`` wins).  Returns the previous
+    default."""
+    if name not in KernelOptions.PRECISIONS:
         raise ValueError(f"conv precision '{name}': choose fp32, bf16 or bf16x3")
-    old, CONV_PRECISION = CONV_PRECISION, name
+    old, DEFAULTS.precision = DEFAULTS.precision, name
     return old
 
 
-# Kernel choice of the fp32 forward / data-gradient product, handed to the library with every call (the library itself
-# keeps no state): CMP_MODE 1 = automatic (the pair-compacted kernel for many-row layers), 0 = never, 64 / 128 = always
-# with that tile height (tests, tuning); CMP_INTERLEAVE = log2 of the row-block size of its interleaved tiles
-# (-1: chosen by the level's size, 0: contiguous tiles).
-CMP_MODE = 1
-CMP_INTERLEAVE = -1
+def model_scope(module):
+    """Context of a model's forward pass: its own ``kernel_options`` when it carries some, else whatever is in force."""
+    opts = getattr(module, "kernel_options", None)
+    return opts if opts is not None else contextlib.nullcontext()
+
+
 _lib.declare("agb_spconv_fwd_opt", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
                                     _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                     _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
@@ -53,20 +127,20 @@ _lib.declare("agb_spconv_fwd_tiles", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, 
                                       _lib.c_int, _lib.c_int, _lib.c_void_p])
 # Work-balanced tiles for the pair-compacted kernel (csrc/tiles.hip): one table per (kernel map, tile geometry), kept on
 # the map tensor (`nbr.agb_tiles`), built on first use — on the side stream when the input pipeline prebuilds the maps.
-BALANCED_TILES = os.environ.get("AGB_BALANCED_TILES", "1") != "0"
 _GEO = (ctypes.c_int32 * 4)()
 
 
-def cmp_tile_table(nbr, n_out, K3, cin, cout, ldx, ldy):
+def cmp_tile_table(nbr, n_out, K3, cin, cout, ldx, ldy, opts=None):
     """Tile table of the fp32 product on kernel map `nbr` for this shape (None: the call takes another kernel or
     contiguous tiles).  Same sums with or without it; it only evens out the work per tile."""
-    if not BALANCED_TILES or n_out <= 0:
+    opts = opts or current()
+    if not opts.balanced_tiles or n_out <= 0:
         return None
-    split = _lib.load().agb_spconv_split_hint_opt(n_out, K3, cin, cout, CMP_MODE)
-    _lib.call("agb_spconv_cmp_geometry", n_out, cin, cout, ldx, ldy, split, CMP_MODE, CMP_INTERLEAVE, _GEO)
+    split = _lib.load().agb_spconv_split_hint_opt(n_out, K3, cin, cout, opts.cmp_mode)
+    _lib.call("agb_spconv_cmp_geometry", n_out, cin, cout, ldx, ldy, split, opts.cmp_mode, opts.cmp_interleave, _GEO)
     rpt, ntiles, il = _GEO[1], _GEO[2], _GEO[3]
-    if _GEO[0] == 0 or il == 0:
-        return None
+    if _GEO[0] == 0 or il == 0 or (K3 << il) + 1 > 1024:
+        return None     # another kernel, contiguous tiles, or more pairs per row block than the counting sort has bins
     cache = getattr(nbr, "agb_tiles", None)
     if cache is None:
         cache = nbr.agb_tiles = {}
@@ -79,6 +153,8 @@ def cmp_tile_table(nbr, n_out, K3, cin, cout, ldx, ldy):
                   _lib.stream())
         cache[(rpt, ntiles, il)] = tab
     return tab
+
+
 _lib.declare("agb_dense_split_hint", [_lib.c_int] * 3)
 _lib.declare("agb_dense_bn_chunks", [_lib.c_int] * 3)
 _lib.declare("agb_dense_fwd_bn", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int,
@@ -149,18 +225,20 @@ def _small_cin_pad(cin):
 
 
 # Partial BatchNorm statistics from the epilogue of the forward dense products (agb_dense_fwd_bn); the product's caller
-# moves them onto the tensor it returns (take_bn_hint), norm_ops.batch_norm_act picks them up from there.
-BN_STATS_IN_EPILOGUE = os.environ.get("AGB_BN_EPILOGUE", "1") != "0"   # (host-side tuning knob: measurements with / without)
-_LAST_BN_PART = None
+# moves them onto the tensor it returns (take_bn_hint), norm_ops.batch_norm_act picks them up from there.  The hand-off
+# slot is per thread, holds the output only weakly, and is emptied at the start of every product.
+def _set_last_bn_part(value):
+    _TLS.last_bn_part = value
 
 
 def take_bn_hint(out):
     """Attach the statistics partials of the dense product that just produced `out` (if it left any) to `out`."""
-    global _LAST_BN_PART
-    last, _LAST_BN_PART = _LAST_BN_PART, None
+    last = getattr(_TLS, "last_bn_part", None)
+    _TLS.last_bn_part = None
     if last is not None and isinstance(out, torch.Tensor):
-        part, chunks, y = last
-        if out.data_ptr() == y.data_ptr() and out.shape == y.shape and out.is_contiguous():
+        part, chunks, yref = last
+        y = yref()
+        if y is not None and out.data_ptr() == y.data_ptr() and out.shape == y.shape and out.is_contiguous():
             out.agb_bn_part = (part, chunks, out._version)
     return out
 
@@ -174,10 +252,13 @@ def bn_hint(x, c):
 
 
 def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None, plan=None,
-                       w_kmajor=None, bn_stats=False):
+                       w_kmajor=None, bn_stats=False, opts=None):
     """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout].
     plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
-    w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes."""
+    w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes.
+    opts: KernelOptions of the call (default: the ones in force)."""
+    opts = opts or current()
+    _set_last_bn_part(None)
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
     if n_out == 0:
         return y
@@ -186,7 +267,7 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
         # 900 workgroups of up to 8 offsets x 512 channels: 273 us) split the reduction four ways (186 us)
         split = 4 if ((n_out // 64 + 1) * ((cout + 63) // 64) < 1100 and cin >= 256 and cin % 256 == 0) else 1
     elif nbr is not None:
-        split = _lib.load().agb_spconv_split_hint_opt(n_out, K3, cin, cout, CMP_MODE)
+        split = _lib.load().agb_spconv_split_hint_opt(n_out, K3, cin, cout, opts.cmp_mode)
     else:
         split = _lib.load().agb_dense_split_hint(n_out, cin, cout)
     partial = torch.empty(split, n_out, cout, dtype=torch.float32, device=x.device) if split > 1 else None
@@ -197,17 +278,16 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     if nbr is None and pairs is None:
         pairs = int(n_out)        # dense product: one (in, out) pair per row
     ev = _prof_begin(kind, K3, cin, cout, n_out, plan is not None, split, x.shape[0])
-    prec = _PREC_ID.get(CONV_PRECISION, 0) if (w_kmajor is not None and cin >= 12) else 0
-    global _LAST_BN_PART
+    prec = opts.prec_id if (w_kmajor is not None and cin >= 12) else 0
     bn_chunks = 0
-    if BN_STATS_IN_EPILOGUE and bn_stats and nbr is None and not prec and split == 1:
+    if opts.bn_stats_in_epilogue and bn_stats and nbr is None and not prec and split == 1:
         bn_chunks = _lib.load().agb_dense_bn_chunks(n_out, cin, cout)
     if bn_chunks > 0:
         # forward dense product in training: the BatchNorm that follows takes its statistics from this epilogue
         part = torch.empty(bn_chunks * 3 * cout, dtype=torch.float32, device=x.device)
         _lib.call("agb_dense_fwd_bn", _P(x), x.stride(0), _P(w2d), _P(bias), _P(y), y.stride(0), n_out, cin, cout, _P(part),
                   _lib.stream())
-        _LAST_BN_PART = (part, bn_chunks, y)
+        _set_last_bn_part((part, bn_chunks, weakref.ref(y)))
     elif prec:
         _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip),
                   _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
@@ -215,16 +295,16 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     else:
         # a table pays where it serves several launches: the stride-1 maps (every convolution of a level, forward and
         # data gradient); a strided layer's forward map serves one
-        tiles = (cmp_tile_table(nbr, n_out, K3, cin, cout, x.stride(0), y.stride(0))
+        tiles = (cmp_tile_table(nbr, n_out, K3, cin, cout, x.stride(0), y.stride(0), opts)
                  if (nbr is not None and plan is None and x.shape[0] == n_out and K3 > 1) else None)
         if tiles is not None:
             _lib.call("agb_spconv_fwd_tiles", _P(x), x.stride(0), _P(w2d), _P(nbr), nbr.stride(0), int(kflip), _P(bias), _P(y),
-                      y.stride(0), n_out, K3, cin, cout, split, _P(partial), CMP_MODE, CMP_INTERLEAVE, _P(tiles),
+                      y.stride(0), n_out, K3, cin, cout, split, _P(partial), opts.cmp_mode, opts.cmp_interleave, _P(tiles),
                       tiles.shape[0], tiles.shape[1], _lib.stream())
         else:
             _lib.call("agb_spconv_fwd_opt", _P(x), x.stride(0), _P(w2d), _P(nbr), 0 if nbr is None else nbr.stride(0),
                       int(kflip), _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab),
-                      n_tiles, split, _P(partial), CMP_MODE, CMP_INTERLEAVE, _lib.stream())
+                      n_tiles, split, _P(partial), opts.cmp_mode, opts.cmp_interleave, _lib.stream())
     _prof_end(ev, kind, K3, cin, cout, n_out, pairs, plan is not None, split, x.shape[0])
     return y
 
@@ -252,13 +332,15 @@ class SparseConvFunction(torch.autograd.Function):
                 b = F.pad(b, (0, cout_p - cout))
             b = b.contiguous()
         pairs = getattr(nbr, "agb_pairs", None)
-        wkm = w.transpose(1, 2).contiguous() if (CONV_PRECISION in _PREC_ID and cin_p >= 12) else None
+        opts = ctx.opts = current()
+        wkm = w.transpose(1, 2).contiguous() if (opts.low_precision and cin_p >= 12) else None
         if cin == 3 and cout_p == cout:
             # three input channels (the stem): rows stay 4 floats wide, the weights go in unpadded — the kernel packs
             # 10 offsets x 3 channels per K-chunk instead of 8 x 4
-            y = spconv_forward_raw(x, kernel.contiguous().view(K3 * 3, cout), nbr, 0, b, n_out, K3, 3, cout_p, "fwd", pairs)
+            y = spconv_forward_raw(x, kernel.contiguous().view(K3 * 3, cout), nbr, 0, b, n_out, K3, 3, cout_p, "fwd", pairs,
+                                   opts=opts)
         else:
-            y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs, None, wkm)
+            y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs, None, wkm, opts=opts)
         ctx.pairs = pairs
         ctx.plan = plan
         ctx.save_for_backward(x, w, nbr, nbrT if nbrT is not None else torch.empty(0))
@@ -280,9 +362,10 @@ class SparseConvFunction(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]   # (grad mode is off inside Function.forward)
         nbr = torch.empty(K3, max(n_out, 1), dtype=torch.int32, device=x.device) if need_w else None
         ev = _prof_begin("fwd", K3, 3, cout, n_out)
+        ctx.opts = current()
         _lib.call("agb_spconv_fwd3_grid_lp", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
                   _P(b), _P(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0),
-                  _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
+                  ctx.opts.prec_id, _lib.stream())
         _prof_end(ev, "fwd", K3, 3, cout, n_out, None)
         if ev is not None and nbr is not None:   # profiling only: the kernel-map size, after the closing event
             PROFILE[-1]["pairs"] = (nbr >= 0).sum()
@@ -320,6 +403,7 @@ class SparseConvFunction(torch.autograd.Function):
             return SparseConvFunction._backward_probe(ctx, dy)
         x, w, nbr, nbrT = ctx.saved_tensors
         K3, cin, cout, cin_p, cout_p, n_in, n_out, has_T, has_bias, bias_shape = ctx.dims
+        opts = ctx.opts
         colsum = _colsum_hint(dy)
         dy = dy.contiguous()
         if cout_p != cout:
@@ -327,7 +411,7 @@ class SparseConvFunction(torch.autograd.Function):
         dx = dk = db = dwp = None
         if ctx.needs_input_grad[0]:
             # dX[q] = sum_k dY[nbrT[k][q]] @ W[k]^T : same implicit GEMM with the transposed weights
-            lp = CONV_PRECISION in _PREC_ID and cout_p >= 12
+            lp = opts.low_precision and cout_p >= 12
             # the data gradient multiplies by W[k]^T: its K-major form is the kernel itself ([K3, cin, cout])
             wkm = w.contiguous() if lp else None
             wt2d = None
@@ -340,18 +424,17 @@ class SparseConvFunction(torch.autograd.Function):
             if has_T:
                 plan = ctx.plan if cout_p >= 12 else None
                 dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, plan,
-                                         wkm)
+                                         wkm, opts=opts)
             else:
                 dxp = spconv_forward_raw(dy, wt2d, nbr, 1, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, None,
-                                         wkm)
+                                         wkm, opts=opts)
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
         if ctx.needs_input_grad[1]:
             if dwp is None:
                 dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
             ev = _prof_begin("wgrad", K3, cin_p, cout_p, n_out)
             _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
-                      _P(dwp), n_out, K3, cin_p, cout_p, _PREC_ID.get(CONV_PRECISION, 0) if cin_p >= 12 else 0,
-                      _lib.stream())
+                      _P(dwp), n_out, K3, cin_p, cout_p, opts.prec_id if cin_p >= 12 else 0, _lib.stream())
             _prof_end(ev, "wgrad", K3, cin_p, cout_p, n_out, ctx.pairs)
             dk = dwp if (cin_p == cin and cout_p == cout) else dwp[:, :cin, :cout].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
@@ -365,7 +448,7 @@ class SparseConvFunction(torch.autograd.Function):
 class DenseConvFunction(torch.autograd.Function):
     """1x1 stride-1 convolution (ME's ``use_mm`` case: kernel [Cin, Cout], the coordinate map is the identity):
     Y = X @ W + b on this library's own MFMA kernels — the register-accumulator implicit-GEMM kernels and the weight-gradient
-    kernel run with the identity map (nbr == NULL), in the operand precision of ``CONV_PRECISION``.
+    kernel run with the identity map (nbr == NULL), in the operand precision of the KernelOptions in force.
     Needs Cin >= 12 and Cin, Cout multiples of 4 (the caller falls back to a library matmul otherwise)."""
 
     @staticmethod
@@ -380,11 +463,11 @@ class DenseConvFunction(torch.autograd.Function):
         n = x.shape[0]
         w = kernel.contiguous()
         b = None if bias is None else bias.reshape(-1).contiguous()
-        lp = CONV_PRECISION in _PREC_ID
-        wkm = w.t().contiguous() if lp else None          # K-major [Cout][Cin]
+        opts = ctx.opts = current()
+        wkm = w.t().contiguous() if opts.low_precision else None          # K-major [Cout][Cin]
         # (a forward pass that will be differentiated = training: the BatchNorm behind it wants batch statistics)
         y = spconv_forward_raw(x, w, None, 0, b, n, 1, cin, cout, "fwd1x1", None, None, wkm,
-                               bn_stats=any(ctx.needs_input_grad))
+                               bn_stats=any(ctx.needs_input_grad), opts=opts)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bias_shape = None if bias is None else bias.shape
@@ -398,53 +481,58 @@ class DenseConvFunction(torch.autograd.Function):
         colsum = _colsum_hint(dy)
         dy = dy.contiguous()
         dx = dk = db = None
-        lp = CONV_PRECISION in _PREC_ID
+        opts = ctx.opts
+        lp = opts.low_precision
         if ctx.needs_input_grad[0]:
             if lp:     # the data gradient multiplies by W^T: its K-major form [Cin][Cout] is the kernel itself
-                dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None, w)
+                dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None, w, opts=opts)
             else:
                 wt = torch.empty(cout, cin, dtype=torch.float32, device=w.device)
                 if ctx.needs_input_grad[1]:   # the weight-gradient buffer is cleared by the same launch
                     dk = torch.empty(cin, cout, dtype=torch.float32, device=w.device)
                 _lib.call("agb_spconv_weight_transpose_z", _P(w), _P(wt), _P(dk), 1, cin, cout, _lib.stream())
-                dx = spconv_forward_raw(dy, wt, None, 0, None, n, 1, cout, cin, "dgrad1x1")
+                dx = spconv_forward_raw(dy, wt, None, 0, None, n, 1, cout, cin, "dgrad1x1", opts=opts)
         if ctx.needs_input_grad[1]:
             if dk is None:
                 dk = torch.zeros(cin, cout, dtype=torch.float32, device=w.device)
             ev = _prof_begin("wgrad1x1", 1, cin, cout, n)
             _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), None, 0, _P(dk), n, 1, cin,
-                      cout, _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
+                      cout, opts.prec_id, _lib.stream())
             _prof_end(ev, "wgrad1x1", 1, cin, cout, n, int(n))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(ctx.bias_shape)
         return dx, dk, db
 
 
-def dense_product(x, w, kind="fwd1x1", bn_stats=False):
-    """x [n, cin] @ w [cin, cout] on the identity-map convolution kernels in the operand precision of ``CONV_PRECISION``
-    (no autograd: building block of the fused Functions).  Widths as in ``DenseConvFunction.supported``."""
+def dense_product(x, w, kind="fwd1x1", bn_stats=False, opts=None):
+    """x [n, cin] @ w [cin, cout] on the identity-map convolution kernels in the operand precision of the options in force
+    (no autograd: building block of the fused Functions; a backward pass hands in the options its node was created under).
+    Widths as in ``DenseConvFunction.supported``."""
+    opts = opts or current()
     cin, cout = w.shape
     w = w.contiguous()
-    if CONV_PRECISION in _PREC_ID:
-        return spconv_forward_raw(x, None, None, 0, None, x.shape[0], 1, cin, cout, kind, None, None, w.t().contiguous())
-    return spconv_forward_raw(x, w, None, 0, None, x.shape[0], 1, cin, cout, kind, bn_stats=bn_stats)
+    if opts.low_precision:
+        return spconv_forward_raw(x, None, None, 0, None, x.shape[0], 1, cin, cout, kind, None, None, w.t().contiguous(),
+                                  opts=opts)
+    return spconv_forward_raw(x, w, None, 0, None, x.shape[0], 1, cin, cout, kind, bn_stats=bn_stats, opts=opts)
 
 
-def dense_weight_grad(x, dy):
+def dense_weight_grad(x, dy, opts=None):
     """x^T [cin, n] @ dy [n, cout] (no autograd)."""
+    opts = opts or current()
     n, cin = x.shape
     cout = dy.shape[1]
     dk = torch.zeros(cin, cout, dtype=torch.float32, device=x.device)
     ev = _prof_begin("wgrad1x1", 1, cin, cout, n)
     _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), None, 0, _P(dk), n, 1, cin, cout,
-              _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
+              opts.prec_id, _lib.stream())
     _prof_end(ev, "wgrad1x1", 1, cin, cout, n, int(n))
     return dk
 
 
 class DenseLinearFunction(torch.autograd.Function):
     """y = x @ weight.T + bias with nn.Linear's parameter layout (weight [out, in]) on this library's own MFMA kernels
-    (the identity-map convolution kernels of csrc/spconv.hip), in the operand precision of ``CONV_PRECISION``: the shared
+    (the identity-map convolution kernels of csrc/spconv.hip), in the operand precision of the KernelOptions in force: the shared
     per-point MLP of MinkowskiPointNet (PointNet.py:16-28), KPConv's unary blocks (blocks.py:499-535) and its
     feature x kernel-weight contraction (blocks.py:396-400).  Feature widths are zero-padded to a multiple of 4 (>= 12)."""
 
@@ -460,13 +548,14 @@ class DenseLinearFunction(torch.autograd.Function):
         b = None
         if bias is not None:
             b = (bias if cout_p == cout else F.pad(bias, (0, cout_p - cout))).contiguous()
-        if CONV_PRECISION in _PREC_ID:
-            y = spconv_forward_raw(xp, None, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1", None, None, wp)
+        opts = ctx.opts = current()
+        if opts.low_precision:
+            y = spconv_forward_raw(xp, None, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1", None, None, wp, opts=opts)
         else:
             wt = torch.empty(cin_p, cout_p, dtype=torch.float32, device=x.device)
             _lib.call("agb_spconv_weight_transpose", _P(wp), _P(wt), 1, cout_p, cin_p, _lib.stream())
             y = spconv_forward_raw(xp, wt, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1",
-                                   bn_stats=any(ctx.needs_input_grad) and cout_p == cout)
+                                   bn_stats=any(ctx.needs_input_grad) and cout_p == cout, opts=opts)
         ctx.save_for_backward(xp, wp)
         ctx.dims = (cin, cout, cin_p, cout_p, bias is not None)
         return y if cout_p == cout else y[:, :cout].contiguous()
@@ -480,21 +569,23 @@ class DenseLinearFunction(torch.autograd.Function):
         dy = dy.contiguous()
         dyp = dy if cout_p == cout else F.pad(dy, (0, cout_p - cout)).contiguous()
         dx = dw = db = None
-        lp = CONV_PRECISION in _PREC_ID
+        opts = ctx.opts
+        lp = opts.low_precision
         if ctx.needs_input_grad[0]:
             # dX = dY @ weight: weight [out, in] is the [K, N] operand as stored; its K-major form is the transpose
             if lp:
                 wkm = wp.t().contiguous()
-                dxp = spconv_forward_raw(dyp, None, None, 0, None, n, 1, cout_p, cin_p, "dgrad1x1", None, None, wkm)
+                dxp = spconv_forward_raw(dyp, None, None, 0, None, n, 1, cout_p, cin_p, "dgrad1x1", None, None, wkm,
+                                         opts=opts)
             else:
-                dxp = spconv_forward_raw(dyp, wp, None, 0, None, n, 1, cout_p, cin_p, "dgrad1x1")
+                dxp = spconv_forward_raw(dyp, wp, None, 0, None, n, 1, cout_p, cin_p, "dgrad1x1", opts=opts)
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros(cout_p, cin_p, dtype=torch.float32, device=dy.device)
             ev = _prof_begin("wgrad1x1", 1, cout_p, cin_p, n)
             # dWeight [out, in] = dY^T X: the weight-gradient kernel with the roles of the operands swapped
             _lib.call("agb_spconv_bwd_weight_lp", _P(dyp), dyp.stride(0), _P(xp), xp.stride(0), None, 0, _P(dwp), n, 1,
-                      cout_p, cin_p, _PREC_ID.get(CONV_PRECISION, 0), _lib.stream())
+                      cout_p, cin_p, opts.prec_id, _lib.stream())
             _prof_end(ev, "wgrad1x1", 1, cout_p, cin_p, n, int(n))
             dw = dwp if (cin_p == cin and cout_p == cout) else dwp[:cout, :cin].contiguous()
         if has_bias and ctx.needs_input_grad[2]:

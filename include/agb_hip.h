@@ -139,7 +139,12 @@ int agb_spconv_split_hint_opt(int n_out, int K3, int Cin, int Cout, int cmp_mode
  *   agb_spconv_balance_tiles tile_blocks int32[ntiles][bpt] (bpt = rows per tile >> il; -1 = no block) from the kernel map;
  *                            workspace of agb_spconv_balance_tiles_workspace_bytes bytes.  One table serves every
  *                            stride-1 convolution on that map with that geometry, forward and data gradient (kflip).
- *   agb_spconv_fwd_tiles     agb_spconv_fwd_opt (no class partition) with that table; the geometry is checked. */
+ *                            Needs il in 1..5 and (K3 << il) + 1 <= 1024 (the counting sort's bins): the workspace
+ *                            helper returns 0 and the entry point AGB_EINVAL otherwise (e.g. a 7^3 map with 4-row blocks) —
+ *                            such calls run agb_spconv_fwd_opt with its fixed interleave.
+ *   agb_spconv_fwd_tiles     agb_spconv_fwd_opt (no class partition) with that table; the geometry is checked.  When the
+ *                            shape is one the pair-compacted kernel does not take (agb_spconv_cmp_geometry out[0] == 0)
+ *                            the call runs the kernel agb_spconv_fwd_opt would and the table is not read. */
 int agb_spconv_cmp_geometry(int n_out, int Cin, int Cout, int ldx, int ldy, int ksplit, int cmp_mode,
                             int cmp_interleave_shift, int32_t* out);
 size_t agb_spconv_balance_tiles_workspace_bytes(int n_out, int K3, int il);

@@ -1,0 +1,43 @@
+"""The data-parallel path of bench.py as TWO PROCESSES on the GPU box (one MI355X there, so the ranks share it and the
+gradients travel through gloo — AGB_BENCH_BACKEND=gloo; RCCL needs one GPU per rank and runs only in the driver's
+scaling bench).  What this covers that tests/test_dist_cpu.py cannot: the bucket path fed by the HIP backward, the fused
+AdaBelief reading bucket slices, the side-stream input pipeline, per-rank seeds — under torch.distributed.run, as the
+driver launches it.  Not a measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_dry_run_keeps_ranks_identical():
+    env = dict(os.environ, AGB_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("RANK", None)
+    # a fresh child process (fork + exec of a NEW interpreter, never an exec of this GPU-initialised one)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--reserve-gib", "8"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints ONE JSON line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
+    comm = line["comm"]
+    assert comm["backend"] == "gloo" and comm["world"] == 2 and comm["buckets"] >= 2
+    assert comm["bytes_per_step"] >= 14_000_000 * 4      # SENet14: 14.45 M parameters exchanged every step
+    a, b = comm["param_checksums"]
+    assert a == b and a != 0.0, comm                     # averaged gradients -> bit-identical replicas after 8 steps
+    assert all(v > 0 for v in comm["host_cpu_ms_per_step_p50"])
+    assert line["value"] > 0 and line["roofline"] is not None

@@ -248,16 +248,16 @@ def test_bn_statistics_from_the_product_epilogue(device, n, cin, cout):
         bn = bn.to(device).train()
         w, b = lin.weight.detach().clone().to(device).requires_grad_(True), lin.bias.detach().clone().to(device)
         calls = []
-        orig, flag = _lib.call, sparse_ops.BN_STATS_IN_EPILOGUE
+        orig = _lib.call
         _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
-        sparse_ops.BN_STATS_IN_EPILOGUE = fused
         try:
             xg = x.to(device).requires_grad_(True)
-            z = dense_linear(xg, w, b)
-            y = batch_norm_act(z, bn, "gelu")   # (smooth: a ReLU kink element flipping between the two roundings moves its gradient)
+            with sparse_ops.KernelOptions(bn_stats_in_epilogue=fused):
+                z = dense_linear(xg, w, b)
+                y = batch_norm_act(z, bn, "gelu")   # (smooth: a ReLU kink element flipping between the two roundings moves its gradient)
             y.backward(g.to(device))
         finally:
-            _lib.call, sparse_ops.BN_STATS_IN_EPILOGUE = orig, flag
+            _lib.call = orig
         assert ("agb_bn_stats_fold" in calls) == fused and ("agb_bn_stats_tracked" in calls) == (not fused), calls
         res[fused] = (y.detach(), bn.running_mean.clone(), bn.running_var.clone(), xg.grad.clone(), w.grad.clone())
     for a, b_ in zip(res[True], res[False]):

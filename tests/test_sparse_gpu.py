@@ -153,11 +153,8 @@ def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride,
     """The pair-compacted LDS-accumulating kernel (k_spconv_cmp; picked automatically only for many-row layers) forced
     on the small parity cases: forward and stride-1 data gradient run through it."""
     from dpcr_agb_amd import sparse_ops
-    sparse_ops.CMP_MODE = rows_per_wave
-    try:
+    with sparse_ops.KernelOptions(cmp_mode=rows_per_wave):
         _conv_case(device, cin, cout, K, stride, ts_in)
-    finally:
-        sparse_ops.CMP_MODE = 1
 
 
 @pytest.mark.parametrize("K,negative", [(7, False), (7, True), (3, True), (5, False)])
@@ -573,15 +570,11 @@ def test_conv_low_precision_operands(device, precision, tol, cin, cout, K, strid
     n_in = cm.level(ts_in).n
     x = torch.randn(n_in, cin)
     conv = ME.MinkowskiConvolution(cin, cout, kernel_size=K, stride=stride, bias=True, dimension=3).to(device)
-    old = sparse_ops.CONV_PRECISION
-    sparse_ops.CONV_PRECISION = precision
-    try:
+    with sparse_ops.KernelOptions(precision=precision):
         xg = x.to(device).requires_grad_(True)
         out = conv(ME.SparseTensor(xg, coordinate_map_key=ME.CoordinateMapKey(ts_in), coordinate_manager=cm))
-        g = torch.randn(out.F.shape[0], cout)
-        out.F.backward(g.to(device))
-    finally:
-        sparse_ops.CONV_PRECISION = old
+    g = torch.randn(out.F.shape[0], cout)
+    out.F.backward(g.to(device))      # (outside the scope: the node kept the options it was created under)
     xr = x.double().requires_grad_(True)
     wr = conv.kernel.detach().cpu().double().requires_grad_(True)
     br = conv.bias.detach().cpu().double().requires_grad_(True)
@@ -613,13 +606,10 @@ def test_dense_1x1_conv(device, precision, tol, cin, cout, n):
     assert conv.use_mm and conv.kernel.shape == (cin, cout) and DenseConvFunction.supported(cin, cout)
     x = torch.randn(n, cin)
     g = torch.randn(n, cout)
-    old = sparse_ops.set_conv_precision(precision)
-    try:
+    with sparse_ops.KernelOptions(precision=precision):
         xg = x.to(device).requires_grad_(True)
         out = DenseConvFunction.apply(xg, conv.kernel, conv.bias)
-        out.backward(g.to(device))
-    finally:
-        sparse_ops.set_conv_precision(old)
+    out.backward(g.to(device))
     xr = x.double().requires_grad_(True)
     wr = conv.kernel.detach().cpu().double().requires_grad_(True)
     br = conv.bias.detach().cpu().double().requires_grad_(True)
@@ -668,13 +658,11 @@ def test_senet50_low_precision_matches_oracle(device, precision, out_tol, grad_t
     model, batch = _model_and_batch("SENet50", device, 1500, [0, 1, 2])
     sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
     model.to(device).train()
-    old = sparse_ops.set_conv_precision(precision)
-    try:
-        model.set_input(batch, device)
-        model.forward()
-        model.loss.backward()
-    finally:
-        sparse_ops.set_conv_precision(old)
+    model.set_kernel_options(precision=precision)          # carried by the model: its forward scope and its autograd nodes
+    assert sparse_ops.current().precision == "fp32"        # ... not by the process
+    model.set_input(batch, device)
+    model.forward()
+    model.loss.backward()
     sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v)
           for k, v in sd32.items()}
     coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
@@ -856,8 +844,6 @@ def test_se_block_tail_fused_vs_separate(device, block_name, training, drop):
     for fused in (True, False):
         blk.load_state_dict(state0)
         blk.zero_grad()
-        flag = se_ops.FUSED_TAIL
-        se_ops.FUSED_TAIL = fused
         calls = []
         from dpcr_agb_amd import _lib
         orig = _lib.call
@@ -866,10 +852,11 @@ def test_se_block_tail_fused_vs_separate(device, block_name, training, drop):
         try:
             xf = x0.to(device).requires_grad_(True)
             st = ME.SparseTensor(xf, coordinates=torch.from_numpy(coords).int(), device=device, batch_size=B)
-            y = blk(st).F
+            with sparse_ops.KernelOptions(fused_tail=fused):
+                y = blk(st).F
             y.backward(g.to(device))
         finally:
-            se_ops.FUSED_TAIL, _lib.call = flag, orig
+            _lib.call = orig
         assert ("agb_se_tail_fwd" in calls) == fused and ("agb_add_act_fwd" in calls) == (not fused), calls
         res[fused] = dict(y=y.detach(), dx=xf.grad.clone(), **{"g/" + k: p.grad.clone() for k, p in blk.named_parameters()},
                           **{"s/" + k: v.clone() for k, v in blk.state_dict().items() if "running" in k})
@@ -900,18 +887,14 @@ def test_work_balanced_tiles(device):
         nbr = cm.kernel_map(ts_in, 3, 1)
         x = torch.randn(n, c, device=device)
         w = torch.randn(27 * c, c, device=device) * 0.05
-        old = sparse_ops.BALANCED_TILES
-        try:
-            sparse_ops.BALANCED_TILES = False
+        with sparse_ops.KernelOptions(balanced_tiles=False):
             y0 = sparse_ops.spconv_forward_raw(x, w, nbr, 0, None, n, 27, c, c)
             y0f = sparse_ops.spconv_forward_raw(x, w, nbr, 1, None, n, 27, c, c)
-            sparse_ops.BALANCED_TILES = True
-            if hasattr(nbr, "agb_tiles"):
-                nbr.agb_tiles.clear()
+        if hasattr(nbr, "agb_tiles"):
+            nbr.agb_tiles.clear()
+        with sparse_ops.KernelOptions(balanced_tiles=True):
             y1 = sparse_ops.spconv_forward_raw(x, w, nbr, 0, None, n, 27, c, c)
             y1f = sparse_ops.spconv_forward_raw(x, w, nbr, 1, None, n, 27, c, c)
-        finally:
-            sparse_ops.BALANCED_TILES = old
         tabs = getattr(nbr, "agb_tiles", {})
         assert len(tabs) == 1, (ts_in, list(tabs))            # both calls share one geometry, hence one table
         (rpt, ntiles, il), tab = next(iter(tabs.items()))

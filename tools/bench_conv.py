@@ -2,7 +2,7 @@
 
   python tools/bench_conv.py [--modes 0,64,128] [--reps 20]
 For every (level, Cin, Cout) of the stride-1 3^3 layers it times agb_spconv_fwd_ex per kernel-selection mode
-(sparse_ops.CMP_MODE) and the weight gradient, and prints us/launch and algorithmic TFLOP/s (2*pairs*Cin*Cout)."""
+(sparse_ops.KernelOptions.cmp_mode) and the weight gradient, and prints us/launch and algorithmic TFLOP/s (2*pairs*Cin*Cout)."""
 import argparse
 import os
 import sys
@@ -42,7 +42,7 @@ def main():
         w = torch.randn(27 * cin, cout, device=dev) * 0.05
         ref = None
         for mode, il in [(int(m), int(i)) for m in args.modes.split(",") for i in args.il.split(",")]:
-            sparse_ops.CMP_MODE, sparse_ops.CMP_INTERLEAVE = mode, il
+            sparse_ops.DEFAULTS.cmp_mode, sparse_ops.DEFAULTS.cmp_interleave = mode, il
             y = spconv_forward_raw(x, w, nbr, 0, None, n, 27, cin, cout)
             torch.cuda.synchronize()
             if ref is None:
@@ -79,7 +79,7 @@ def main():
                 us = e0.elapsed_time(e1) / args.reps * 1e3
                 print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} wgrad il {il}: {us:8.1f} us  "
                       f"{2.0 * pairs * cin * cout / us / 1e6:6.1f} TF  (max rel diff vs first {err:.1e})")
-    sparse_ops.CMP_MODE, sparse_ops.CMP_INTERLEAVE = 1, -1
+    sparse_ops.DEFAULTS.cmp_mode, sparse_ops.DEFAULTS.cmp_interleave = 1, -1
 
 
 if __name__ == "__main__":

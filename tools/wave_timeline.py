@@ -27,7 +27,7 @@ def main():
     L = _lib.load()
     if not hasattr(L, "agb_debug_cmp_timeline"):
         raise SystemExit(f"{_lib.LIB_PATH} is not the instrumented build: cd dpcr-agb_amd/csrc && make timeline")
-    sparse_ops.BALANCED_TILES = not args.no_balanced
+    sparse_ops.DEFAULTS.balanced_tiles = not args.no_balanced
     dev = torch.device("cuda", 0)
     b = synthetic.make_sparse_batch(list(range(args.batch)))
     coords = torch.cat([b.batch[:, None].int(), b.coords.int()], 1).to(dev)
