@@ -374,13 +374,14 @@ def main():
     voxels = sum(int(b.coords.shape[0]) for b in pool) / len(pool) / args.batch
     steps_per_epoch = 133  # 4271 train plots / 32
 
-    host_ms, host_cpu_ms = [], []
+    host_ms, host_cpu_ms, main_cpu_ms = [], [], []
 
     def step(i):
-        t_h, c_h = time.perf_counter(), time.process_time()
+        t_h, c_h, m_h = time.perf_counter(), time.process_time(), time.thread_time()
         _step(i)
         host_ms.append((time.perf_counter() - t_h) * 1e3)
         host_cpu_ms.append((time.process_time() - c_h) * 1e3)     # CPU time of ALL threads of this rank
+        main_cpu_ms.append((time.thread_time() - m_h) * 1e3)      # ... of the enqueuing thread alone
 
     def _step(i):
         # software pipeline of the input path: this step's coordinate pyramid was built on a side stream while the
@@ -484,6 +485,8 @@ def main():
         f"{ms1.get('num_alloc_retries', 0) - ms0.get('num_alloc_retries', 0)} retries")
     log(f"device memory: {torch.cuda.memory_allocated() / 2**30:.2f} GiB allocated now, "
         f"{torch.cuda.max_memory_allocated() / 2**30:.2f} GiB peak, {torch.cuda.memory_reserved() / 2**30:.2f} GiB reserved")
+    mc = sorted(main_cpu_ms[-args.steps:])
+    log(f"host CPU time per step: all threads median {hc[len(hc) // 2]:.2f} ms, enqueuing thread {mc[len(mc) // 2]:.2f} ms")
     hm = sorted(host_ms[-args.steps:])
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps; host enqueue time per step: median "
         f"{hm[len(hm) // 2]:.2f} ms, min {hm[0]:.2f} ms (GPU-bound when well below ms_per_step)")
@@ -519,6 +522,7 @@ def main():
             "step_ms_min": round(min(gaps), 3) if gaps else None,
             "device_allocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
             "host_enqueue_ms_p50": round(hm[len(hm) // 2], 3), "host_cpu_ms_per_step_p50": round(hc[len(hc) // 2], 3),
+            "host_main_thread_cpu_ms_p50": round(mc[len(mc) // 2], 3),
             "comm": comm,
             "kernels": summary, "kernels_from": f"{n_instr} fully bracketed warmup step(s), outside the timed region",
         }

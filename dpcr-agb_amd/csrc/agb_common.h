@@ -48,6 +48,12 @@ int agb_dense_stream_launch(const float* X, int ldx, const float* W, const float
 int agb_dense_stream_wgrad_launch(const float* X, int ldx, const float* dY, int ldy, float* dW, int n, int Cin, int Cout,
                                   hipStream_t st);
 
+// dwreg.hip: fp32 weight gradient with both MFMA operands gathered into registers (no LDS staging, no barriers); row chunks
+// folded in a fixed order through `workspace` (NULL: fp32 atomic accumulation)
+size_t agb_dwreg_workspace_bytes(int n_out, int K3, int Cin, int Cout);
+int agb_dwreg_launch(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride, float* dW,
+                     int n_out, int K3, int Cin, int Cout, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 // ---- coordinate key packing -------------------------------------------------
 // [b | z | y | x], 16 bits each, spatial components biased by 32768 so that
 // negative voxel coordinates (ME allows them) order correctly.

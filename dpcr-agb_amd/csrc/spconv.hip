@@ -1722,6 +1722,9 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
 
 // =============================================================== C ABI
 extern "C" {
+int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
+                             float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
                             const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
                             int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream);
@@ -2108,9 +2111,32 @@ int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, in
 // dW must be zero-filled by the caller (it is accumulated into).
 // precision: 0 = fp32 MFMA, 1 = bf16 operands, 2 = split-bf16 x3 (the small-Cin stem path is always fp32).
 // nbr == nullptr (K3 == 1): identity map, dW = X^T dY of a 1x1 stride-1 convolution.
+// True when the call runs the register-operand fp32 kernel (dwreg.hip): fp32, Cin >= 12, not one of the HBM-bound dense
+// shapes the streaming kernel takes.  variant 1 forces the LDS-staged k_spconv_dw_cmp<0> (A/B measurements).
+static bool dw_takes_reg_kernel(const int32_t* nbr, int n_out, int Cin, int Cout, int precision, int variant) {
+    if (precision != 0 || variant == 1 || Cin == 4 || Cin == 8) return false;
+    if (nbr == nullptr && agb_dense_stream_wgrad_ok(n_out, Cin, Cout)) return false;
+    return true;
+}
+
+size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cout, int dense, int precision) {
+    static const int32_t some_map = 0;
+    if (n_out <= 0 || K3 < 1 || Cin < 4 || Cout < 4) return 0;
+    if (!dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0)) return 0;
+    return agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
+}
+
 int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
                              float* dW, int n_out, int K3, int Cin, int Cout, int precision, void* stream) {
+    return agb_spconv_bwd_weight_ws(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, precision, 0, nullptr, 0,
+                                    stream);
+}
+
+int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
+                             float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
+                             size_t workspace_bytes, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_bwd_weight: bad sizes");
+    AGB_CHECK_ARG(variant == 0 || variant == 1, "agb_spconv_bwd_weight_ws: variant %d (0 automatic, 1 LDS-staged)", variant);
     AGB_CHECK_ARG(precision >= 0 && precision <= 2, "agb_spconv_bwd_weight_lp: precision %d (0 fp32, 1 bf16, 2 bf16x3)",
                   precision);
     AGB_CHECK_ARG(nbr != nullptr || K3 == 1, "agb_spconv_bwd_weight: the identity map (nbr == NULL) needs K3 == 1");
@@ -2123,6 +2149,12 @@ int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, 
         int rc = agb_dense_stream_wgrad_launch(X, ldx, dY, ldy, dW, n_out, Cin, Cout, s);
         if (rc) return rc;
         AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (dense, streaming)");
+        return AGB_OK;
+    }
+    if (dw_takes_reg_kernel(nbr, n_out, Cin, Cout, precision, variant)) {
+        int rc = agb_dwreg_launch(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, workspace, workspace_bytes, s);
+        if (rc) return rc;
+        AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (register operands)");
         return AGB_OK;
     }
     int m_tiles, cin_tiles = 1;

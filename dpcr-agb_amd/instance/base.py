@@ -254,3 +254,20 @@ class InstanceBase(torch.nn.Module):
         self._num_epochs = epoch
         self._num_batches += 1
         self._num_samples += batch_size
+        self._pace_host()
+
+    # The host enqueues a step in about half the time the device needs for it and would run ahead until the hardware
+    # queue is full — where the runtime SPINS for a free slot: one core per rank burnt for nothing, and under a CPU quota
+    # shared by eight ranks a reason to be throttled.  Instead the host sleeps on a blocking event (interrupt-driven wait)
+    # until the step issued PACE_DEPTH steps ago is done: the device queue always holds that many whole steps.
+    PACE_DEPTH = 3
+
+    def _pace_host(self):
+        if not torch.cuda.is_available() or self.PACE_DEPTH <= 0:
+            return
+        ring = self.__dict__.setdefault("_pace_ring", [])
+        ev = torch.cuda.Event(blocking=True)
+        ev.record()
+        ring.append(ev)
+        if len(ring) > self.PACE_DEPTH:
+            ring.pop(0).synchronize()

@@ -32,15 +32,19 @@ class KernelOptions:
       balanced_tiles       work-balanced tile tables for that kernel (csrc/tiles.hip)
       bn_stats_in_epilogue forward dense products leave BatchNorm statistics partials (agb_dense_fwd_bn)
       fused_tail           SE / bottleneck block tails as one autograd node (se_ops, backbones)
+      deterministic_wgrad  fp32 weight gradients summed over row chunks in a fixed order through a workspace (csrc/dwreg.hip)
+                           instead of fp32 atomic accumulation
+      dw_variant           0 = automatic, 1 = the LDS-staged weight-gradient kernel of earlier rounds (A/B measurements)
 
     Use: ``model.kernel_options = KernelOptions(precision="bf16")`` (the backbones run their forward pass inside it), or
     ``with KernelOptions(cmp_mode=128): ...`` around direct calls.  Autograd nodes keep the options they were created
     under for their backward pass.  ``DEFAULTS`` (environment-initialised) applies where nothing else is set."""
-    __slots__ = ("precision", "cmp_mode", "cmp_interleave", "balanced_tiles", "bn_stats_in_epilogue", "fused_tail")
+    __slots__ = ("precision", "cmp_mode", "cmp_interleave", "balanced_tiles", "bn_stats_in_epilogue", "fused_tail",
+                 "deterministic_wgrad", "dw_variant")
     PRECISIONS = ("fp32", "bf16", "bf16x3")
 
     def __init__(self, precision=None, cmp_mode=None, cmp_interleave=None, balanced_tiles=None,
-                 bn_stats_in_epilogue=None, fused_tail=None, base=None):
+                 bn_stats_in_epilogue=None, fused_tail=None, deterministic_wgrad=None, dw_variant=None, base=None):
         base = base if base is not None else (current() if "DEFAULTS" in globals() else None)
         pick = lambda v, name, dflt: v if v is not None else (getattr(base, name) if base is not None else dflt)  # noqa: E731
         self.precision = pick(precision, "precision", "fp32")
@@ -51,6 +55,8 @@ class KernelOptions:
         self.balanced_tiles = bool(pick(balanced_tiles, "balanced_tiles", True))
         self.bn_stats_in_epilogue = bool(pick(bn_stats_in_epilogue, "bn_stats_in_epilogue", True))
         self.fused_tail = bool(pick(fused_tail, "fused_tail", True))
+        self.deterministic_wgrad = bool(pick(deterministic_wgrad, "deterministic_wgrad", True))
+        self.dw_variant = int(pick(dw_variant, "dw_variant", 0))
 
     def replace(self, **kw):
         return KernelOptions(base=self, **kw)
@@ -94,7 +100,9 @@ def current():
 
 DEFAULTS = KernelOptions(precision=os.environ.get("AGB_CONV_PRECISION", "fp32"), cmp_mode=1, cmp_interleave=-1,
                          balanced_tiles=os.environ.get("AGB_BALANCED_TILES", "1") != "0",
-                         bn_stats_in_epilogue=os.environ.get("AGB_BN_EPILOGUE", "1") != "0", fused_tail=True)
+                         bn_stats_in_epilogue=os.environ.get("AGB_BN_EPILOGUE", "1") != "0", fused_tail=True,
+                         deterministic_wgrad=os.environ.get("AGB_DETERMINISTIC_WGRAD", "1") != "0",
+                         dw_variant=int(os.environ.get("AGB_DW_VARIANT", "0")))
 
 
 def set_conv_precision(name):
@@ -162,6 +170,10 @@ _lib.declare("agb_dense_fwd_bn", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib
 _lib.declare("agb_spconv_bwd_weight_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
                                           _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                           _lib.c_void_p])
+_lib.declare("agb_spconv_bwd_weight_workspace_bytes", [_lib.c_int] * 6)
+_lib.declare("agb_spconv_bwd_weight_ws", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
+                                          _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
+                                          _lib.c_int, _lib.c_void_p, ctypes.c_size_t, _lib.c_void_p])
 _lib.declare("agb_spconv_fwd_lp", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
                                    _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                    _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
@@ -309,6 +321,16 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     return y
 
 
+def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
+    """dw += gathered(x)^T dy through the C ABI, with the workspace of the deterministic two-level sum (fp32 kernel)."""
+    prec = opts.prec_id if cin >= 12 else 0
+    nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) \
+        if (opts.deterministic_wgrad and opts.dw_variant == 0) else 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    _lib.call("agb_spconv_bwd_weight_ws", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), 0 if nbr is None else nbr.stride(0),
+              _P(dw), n_out, K3, cin, cout, prec, opts.dw_variant, _P(ws), nbytes, _lib.stream())
+
+
 class SparseConvFunction(torch.autograd.Function):
     """Generalized sparse convolution. kernel: [K3, Cin, Cout]; nbr: forward map [K3, N_out];
     nbrT: transposed map [K3, N_in] or None when the k-flipped forward map serves (stride 1, odd kernel)."""
@@ -433,8 +455,7 @@ class SparseConvFunction(torch.autograd.Function):
             if dwp is None:
                 dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
             ev = _prof_begin("wgrad", K3, cin_p, cout_p, n_out)
-            _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
-                      _P(dwp), n_out, K3, cin_p, cout_p, opts.prec_id if cin_p >= 12 else 0, _lib.stream())
+            weight_grad_raw(x, dy, nbr, dwp, n_out, K3, cin_p, cout_p, opts)
             _prof_end(ev, "wgrad", K3, cin_p, cout_p, n_out, ctx.pairs)
             dk = dwp if (cin_p == cin and cout_p == cout) else dwp[:, :cin, :cout].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
@@ -496,8 +517,7 @@ class DenseConvFunction(torch.autograd.Function):
             if dk is None:
                 dk = torch.zeros(cin, cout, dtype=torch.float32, device=w.device)
             ev = _prof_begin("wgrad1x1", 1, cin, cout, n)
-            _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), None, 0, _P(dk), n, 1, cin,
-                      cout, opts.prec_id, _lib.stream())
+            weight_grad_raw(x, dy, None, dk, n, 1, cin, cout, opts)
             _prof_end(ev, "wgrad1x1", 1, cin, cout, n, int(n))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(ctx.bias_shape)
@@ -524,8 +544,7 @@ def dense_weight_grad(x, dy, opts=None):
     cout = dy.shape[1]
     dk = torch.zeros(cin, cout, dtype=torch.float32, device=x.device)
     ev = _prof_begin("wgrad1x1", 1, cin, cout, n)
-    _lib.call("agb_spconv_bwd_weight_lp", _P(x), x.stride(0), _P(dy), dy.stride(0), None, 0, _P(dk), n, 1, cin, cout,
-              opts.prec_id, _lib.stream())
+    weight_grad_raw(x, dy, None, dk, n, 1, cin, cout, opts)
     _prof_end(ev, "wgrad1x1", 1, cin, cout, n, int(n))
     return dk
 
@@ -584,8 +603,7 @@ class DenseLinearFunction(torch.autograd.Function):
             dwp = torch.zeros(cout_p, cin_p, dtype=torch.float32, device=dy.device)
             ev = _prof_begin("wgrad1x1", 1, cout_p, cin_p, n)
             # dWeight [out, in] = dY^T X: the weight-gradient kernel with the roles of the operands swapped
-            _lib.call("agb_spconv_bwd_weight_lp", _P(dyp), dyp.stride(0), _P(xp), xp.stride(0), None, 0, _P(dwp), n, 1,
-                      cout_p, cin_p, opts.prec_id, _lib.stream())
+            weight_grad_raw(dyp, xp, None, dwp, n, 1, cout_p, cin_p, opts)
             _prof_end(ev, "wgrad1x1", 1, cout_p, cin_p, n, int(n))
             dw = dwp if (cin_p == cin and cout_p == cout) else dwp[:cout, :cin].contiguous()
         if has_bias and ctx.needs_input_grad[2]:

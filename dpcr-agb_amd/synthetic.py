@@ -113,12 +113,20 @@ class PlotBatch:
         return torch.cat([counts.new_zeros(1), counts.cumsum(0)])
 
 
+def plot_points(seed: int, density) -> int:
+    """Returns per plot that follow the stand: base + per_tree * n_trees (n_trees = the generator's first draw)."""
+    base, per_tree = density
+    return int(base) + int(per_tree) * int(np.random.default_rng(seed).integers(15, 61))
+
+
 def make_sparse_batch(seeds: List[int], n_points: int = 16000, size: float = 0.0125, extra_feature: bool = False,
-                      perm_seed: Optional[int] = None) -> PlotBatch:
-    """Voxelised batch (test-time transform chain: no augmentation) for the sparse models."""
+                      perm_seed: Optional[int] = None, density=None) -> PlotBatch:
+    """Voxelised batch (test-time transform chain: no augmentation) for the sparse models.
+    density = (base, per_tree): every plot gets base + per_tree * n_trees points instead of n_points (denser stands
+    return more canopy echoes; NFI plots differ in size the same way)."""
     bs, cs, xs, ps, ys = [], [], [], [], []
     for b, seed in enumerate(seeds):
-        pos, x, y = make_plot(seed, n_points, extra_feature)
+        pos, x, y = make_plot(seed, n_points if density is None else plot_points(seed, density), extra_feature)
         prng = np.random.default_rng((seed if perm_seed is None else perm_seed) + 7919)
         perm = prng.permutation(len(pos))
         coords, keep = voxelize_host(pos, perm, size)

@@ -85,6 +85,8 @@ class Coords:
         coords = np.asarray(coords, dtype=np.int64)
         self.levels = {1: coords}
         self.maps = {}
+        self._pairs = {}
+        self.cache_pairs = False
         self.B = int(coords[:, 0].max()) + 1 if batch_size is None else batch_size
 
     def level(self, ts, stride=1):
@@ -100,18 +102,37 @@ class Coords:
             self.maps[key] = torch.from_numpy(kernel_map(self.levels[ts], self.levels[ts_out], K, ts * dilation))
         return self.maps[key]
 
+    def pairs(self, ts, K, stride=1, dilation=1):
+        """Per kernel offset: (output rows, input rows) of the present pairs — the index lists ``conv`` derives from the
+        map, kept so that a Coords object reused across training steps (same batch, next epoch) does not rebuild them."""
+        key = (ts, K, stride, dilation)
+        if key not in self._pairs:
+            nbr = self.map(ts, K, stride, dilation)
+            out = []
+            for k in range(nbr.shape[0]):
+                rows = torch.nonzero(nbr[k] >= 0).squeeze(1)
+                out.append((rows, nbr[k][rows]))
+            self._pairs[key] = out
+        return self._pairs[key]
+
     def batch_index(self, ts):
         return torch.from_numpy(self.levels[ts][:, 0].copy())
 
 
 # --------------------------------------------------------------------------- ops (autograd-friendly)
-def conv(feats, nbr, kernel, bias=None):
-    """out[r] = bias + sum_k feats[nbr[k, r]] @ kernel[k]."""
+def conv(feats, nbr, kernel, bias=None, pairs=None):
+    """out[r] = bias + sum_k feats[nbr[k, r]] @ kernel[k].  pairs (optional): Coords.pairs(...) of the same map — the
+    very index lists computed below, cached."""
     if kernel.dim() == 2:
         kernel = kernel.unsqueeze(0)
     n_out = nbr.shape[1]
     out = feats.new_zeros(n_out, kernel.shape[2])
     for k in range(nbr.shape[0]):
+        if pairs is not None:
+            rows, idx = pairs[k]
+            if len(rows):
+                out = out.index_add(0, rows, feats[idx] @ kernel[k])
+            continue
         m = nbr[k] >= 0
         if m.any():
             rows = torch.nonzero(m).squeeze(1)
@@ -177,7 +198,7 @@ def _conv_module(x, ts, cm, sd, prefix, K, stride):
         out = x @ kernel
         return (out + bias if bias is not None else out), ts
     nbr = cm.map(ts, K, stride)
-    return conv(x, nbr, kernel, bias), ts * stride
+    return conv(x, nbr, kernel, bias, cm.pairs(ts, K, stride) if cm.cache_pairs else None), ts * stride
 
 
 def _block(x, ts, cm, sd, p, stride, act, training, momentum, dp, update):
@@ -211,11 +232,14 @@ def _block(x, ts, cm, sd, p, stride, act, training, momentum, dp, update):
 
 def resnet_forward(sd, coords, feats, layers, strides=(1, 2, 2, 2), activation="gelu", first_stride=1,
                    global_pool_mode="sum", training=True, momentum=0.1, drop_path_prob=0.0, batch_size=None,
-                   update=None):
+                   update=None, cm=None):
     """SENet.py:113-118 with the head of models/instance/minkowski.py:17-29 when ``final.linears.*`` exist.
-    sd: state_dict (torch tensors, any float dtype). Returns [B, n_out]."""
+    sd: state_dict (torch tensors, any float dtype). Returns [B, n_out].
+    cm (optional): a Coords object of these very coordinates kept from an earlier call (a training loop that revisits its
+    batches every epoch): levels, kernel maps and pair lists are reused instead of rebuilt — same arithmetic."""
     act = ACT[activation]
-    cm = Coords(np.asarray(coords), batch_size)
+    if cm is None:
+        cm = Coords(np.asarray(coords), batch_size)
     x, ts = feats, 1
     x, ts = _conv_module(x, ts, cm, sd, "blocks.0.0.conv", 7, first_stride)
     x = act(batch_norm(x, sd, "blocks.0.0.norm", training, momentum, update=update))

@@ -820,7 +820,7 @@ def test_se_block_tail_fused_vs_separate(device, block_name, training, drop):
     import random
     import dpcr_agb_amd.backbones.sparse as SP
     import dpcr_agb_amd.me_compat as ME
-    import dpcr_agb_amd.se_ops as se_ops
+    from dpcr_agb_amd import sparse_ops
     torch.manual_seed(3)
     rng = np.random.default_rng(1)
     B, npts = 5, 700
@@ -916,3 +916,47 @@ def test_work_balanced_tiles(device):
     with pytest.raises(_lib.AgbError):
         _lib.call("agb_spconv_fwd_tiles", x.data_ptr(), c, w.data_ptr(), nbr.data_ptr(), nbr.stride(0), 0, None, y1.data_ptr(), c,
                   n, 27, c, c, 1, None, 1, -1, tab.data_ptr(), tab.shape[0] + 1, tab.shape[1], _lib.stream())
+
+
+@pytest.mark.parametrize("n_plots,npts,cin,cout,K", [(6, 9000, 64, 64, 3), (4, 6000, 128, 36, 3), (3, 5000, 80, 128, 3),
+                                                     (6, 9000, 64, 64, 1), (2, 3000, 512, 256, 1)])
+def test_weight_gradient_register_kernel(device, n_plots, npts, cin, cout, K):
+    """csrc/dwreg.hip (both MFMA operands gathered into registers, row chunks folded in a fixed order) at sizes with
+    several row chunks and ragged last tiles: against the fp64 oracle, bitwise reproducible from run to run, equal to the
+    atomic-accumulation form and to the LDS-staged kernel of earlier rounds within fp32 rounding."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import _lib, sparse_ops
+    rng = np.random.default_rng(cin + cout + K)
+    torch.manual_seed(cin * 3 + cout)
+    coords = random_coords(rng, n_plots, npts, 40)
+    ref = R.Coords(coords, n_plots)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    n = cm.level(1).n
+    nbr = cm.kernel_map(1, K, 1, 1) if K > 1 else None
+    x, dy = torch.randn(n, cin), torch.randn(n, cout)
+    xg, dyg = x.to(device), dy.to(device)
+    K3 = K ** 3
+    nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n, K3, cin, cout, int(nbr is None), 0)
+    assert nbytes >= 2 * K3 * cin * cout * 4 or n < 512         # several row chunks at these sizes
+
+    def run(**kw):
+        dw = torch.zeros(K3, cin, cout, device=device)
+        sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, cin, cout, sparse_ops.KernelOptions(**kw))
+        return dw
+
+    a, b = run(), run()
+    assert torch.equal(a, b)                                     # fixed summation order: bitwise reproducible
+    want = torch.zeros(K3, cin, cout, dtype=torch.float64)
+    if nbr is None:
+        want[0] = x.double().t() @ dy.double()
+    else:
+        for k, (rows, idx) in enumerate(ref.pairs(1, K, 1)):
+            want[k] = x.double()[idx].t() @ dy.double()[rows]
+    assert rel_err(a, want) < 2e-6
+    assert rel_err(run(deterministic_wgrad=False), want) < 2e-6  # same kernel, fp32 atomic accumulation
+    assert rel_err(run(dw_variant=1), want) < 2e-6               # the LDS-staged kernel (kept for A/B measurements)
+    # accumulation contract: dW is added to
+    dw = torch.ones(K3, cin, cout, device=device)
+    sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, cin, cout, sparse_ops.KernelOptions())
+    assert rel_err(dw - 1.0, want) < 1e-4

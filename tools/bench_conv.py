@@ -61,10 +61,11 @@ def main():
         if args.wgrad:
             dy = torch.randn(n, cout, device=dev)
             ref_dw = None
-            for il in [int(i) for i in args.il.split(",")]:
+            # register-operand kernel with the fixed-order fold / with atomic accumulation / the LDS-staged kernel
+            for tag, kw in (("reg+fold", {}), ("reg+atomic", dict(deterministic_wgrad=False)), ("staged", dict(dw_variant=1))):
+                opts = sparse_ops.KernelOptions(**kw)
                 dw = torch.zeros(27, cin, cout, device=dev)
-                _lib.call("agb_spconv_bwd_weight", x.data_ptr(), cin, dy.data_ptr(), cout, nbr.data_ptr(),
-                          nbr.stride(0), dw.data_ptr(), n, 27, cin, cout, _lib.stream())
+                sparse_ops.weight_grad_raw(x, dy, nbr, dw, n, 27, cin, cout, opts)
                 torch.cuda.synchronize()
                 if ref_dw is None:
                     ref_dw = dw.clone()
@@ -72,13 +73,12 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.reps):
-                    _lib.call("agb_spconv_bwd_weight", x.data_ptr(), cin, dy.data_ptr(), cout, nbr.data_ptr(),
-                              nbr.stride(0), dw.data_ptr(), n, 27, cin, cout, _lib.stream())
+                    sparse_ops.weight_grad_raw(x, dy, nbr, dw, n, 27, cin, cout, opts)
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / args.reps * 1e3
-                print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} wgrad il {il}: {us:8.1f} us  "
-                      f"{2.0 * pairs * cin * cout / us / 1e6:6.1f} TF  (max rel diff vs first {err:.1e})")
+                print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} wgrad {tag:10s}: {us:8.1f} us  "
+                      f"{2.0 * pairs * cin * cout / us / 1e6:6.1f} TF  (max rel diff vs first {err:.1e})", flush=True)
     sparse_ops.DEFAULTS.cmp_mode, sparse_ops.DEFAULTS.cmp_interleave = 1, -1
 
 
