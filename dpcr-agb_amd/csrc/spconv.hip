@@ -747,6 +747,162 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 operands FROM bf16 STORAGE: the rows of a bf16 twin of the activations (k_to_bf16 below; a.X reinterpreted,
+// a.ldx in bf16 elements) and K-major bf16 weights Wt16[K3][Cout][Cin] go straight from global memory to LDS — 16-byte
+// pieces of 8 channels, no conversion, half the loads and half the LDS writes of k_spconv_pipe_bf16, which gathers fp32
+// rows and rounds them while staging: that kernel is bound by exactly those staging instructions and by the bytes its
+// gathers pull through the CU's vector-memory path (profiles/r02_v9_senet50_bf16_bench.json: 0.06 of the bf16 MFMA peak;
+// tools/gather_locality_probe.py: not by the gathers' locality).  Cin % 8 == 0.  Same tiling, fp32 accumulate and output.
+template <int TM, bool PERM, int CW = 64>
+__global__ __launch_bounds__(256) void k_spconv_pipe_b16(ConvArgs a) {
+    constexpr int WAVES_M = TM / 32;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int NT = (CW / 32) / WAVES_N;
+    constexpr int BJ = CW / 32;            // 16-byte weight loads per thread per chunk (32 rows per pass)
+    constexpr int AJ = TM / 32;            // 16-byte A gathers per thread per chunk
+    __shared__ __attribute__((aligned(16))) unsigned short As[TM * LLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[CW * LLD];
+    const unsigned short* __restrict__ X16 = reinterpret_cast<const unsigned short*>(a.X);
+    const unsigned short* __restrict__ W16 = reinterpret_cast<const unsigned short*>(a.W);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tile = PERM ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int row0 = tile * TM;
+    const int n0 = blockIdx.y * CW;
+    const int li = lane & 31, lh = lane >> 5;
+    const int t_r = tid >> 3, t_c = (tid & 7) * 8;    // staging: row (+32j), k offset inside the chunk (8 channels)
+    const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
+
+    int noff = K3;
+    const int32_t* offs = nullptr;
+    if (PERM) {
+        int cls = a.tile_cls[tile];
+        if (cls < 0) return;
+        noff = a.cls_tab[cls * (1 + K3)];
+        offs = a.cls_tab + cls * (1 + K3) + 1;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int cpk = (Cin + LBK - 1) / LBK;
+    const int nchunks = noff * cpk;
+    const int ch_beg = (int)((long long)nchunks * blockIdx.z / a.ksplit);
+    const int ch_end = (int)((long long)nchunks * (blockIdx.z + 1) / a.ksplit);
+
+    int grow[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        int r = row0 + t_r + 32 * j;
+        if (PERM) grow[j] = a.perm[r];
+        else grow[j] = r < a.n_out ? r : -1;
+    }
+    int idx_cur[AJ], idx_nxt[AJ];
+    uint4 a_reg[AJ], b_reg[BJ];
+
+    auto offset_of = [&](int ch) {
+        int ko = ch / cpk;
+        return PERM ? offs[ko] : ko;
+    };
+    auto load_idx = [&](int ch, int* dst) {
+        int k = ch < ch_end ? offset_of(ch) : 0;
+        int kn = a.kflip ? (K3 - 1 - k) : k;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            dst[j] = (ch < ch_end && grow[j] >= 0) ? (a.nbr ? a.nbr[(long long)kn * a.nbr_stride + grow[j]] : grow[j]) : -1;
+    };
+    auto load_data = [&](int ch, const int* idx) {
+        int k = offset_of(ch);
+        int c0 = (ch % cpk) * LBK;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            a_reg[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx[j] >= 0 && c0 + t_c < Cin)
+                a_reg[j] = *reinterpret_cast<const uint4*>(X16 + (long long)idx[j] * a.ldx + c0 + t_c);
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            int n = n0 + t_r + 32 * j;
+            b_reg[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (n < Cout && c0 + t_c < Cin)
+                b_reg[j] = *reinterpret_cast<const uint4*>(W16 + ((long long)k * Cout + n) * Cin + c0 + t_c);
+        }
+    };
+
+    if (ch_beg < ch_end) {
+        load_idx(ch_beg, idx_cur);
+        load_idx(ch_beg + 1, idx_nxt);
+        load_data(ch_beg, idx_cur);
+    }
+    for (int ch = ch_beg; ch < ch_end; ++ch) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) *reinterpret_cast<uint4*>(&As[(t_r + 32 * j) * LLD + t_c]) = a_reg[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<uint4*>(&Bs[(t_r + 32 * j) * LLD + t_c]) = b_reg[j];
+        __syncthreads();
+        if (ch + 1 < ch_end) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) idx_cur[j] = idx_nxt[j];
+            load_data(ch + 1, idx_cur);
+            load_idx(ch + 2, idx_nxt);
+        }
+        const int aoff = (wm * 32 + li) * LLD + 8 * lh;
+#pragma unroll
+        for (int s2 = 0; s2 < LBK / 16; ++s2) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[aoff + 16 * s2]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int boff = ((wn * NT + nt) * 32 + li) * LLD + 8 * lh + 16 * s2;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[boff]);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = a.ksplit > 1 ? a.partial + (long long)blockIdx.z * a.n_out * Cout : a.Y;
+    const int ldo = a.ksplit > 1 ? Cout : a.ldy;
+    int rows[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int rt = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        rows[reg] = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
+    }
+    float bvs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + (wn * NT + nt) * 32 + li;
+        bvs[nt] = (a.bias && a.ksplit == 1 && col < Cout) ? a.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = rows[reg];
+        if (row < 0) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + (wn * NT + nt) * 32 + li;
+            if (col < Cout) out[(long long)row * ldo + col] = acc[nt][reg] + bvs[nt];
+        }
+    }
+}
+
+// fp32 [n, C] (row stride ldx) -> bf16 [n, C] (row stride ldy), round to nearest even: the bf16 twin of an activation /
+// gradient / weight matrix.  C % 4 == 0.
+__global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ X, long long ldx, long long n, int C4,
+                                                 unsigned short* __restrict__ Y, long long ldy) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * C4) return;
+    const long long r = t / C4;
+    const int c = (int)(t % C4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(X + r * ldx + c);
+    *reinterpret_cast<uint2*>(Y + r * ldy + c) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+}
+
+// ------------------------------------------------------------------------------------------------
 // PAIR-COMPACTED output-stationary kernel (Cin a multiple of 64).
 // The register-accumulator kernels above multiply zero rows wherever a neighbour is absent (3^3 maps are 50-70 %
 // dense).  Here every WAVE (= workgroup) owns up to R consecutive output rows x 64 output channels whose running sums
@@ -1274,7 +1430,9 @@ __device__ __forceinline__ unsigned pack_bf16_lo(float a, float b) {
     const unsigned h = pack2_bf16(a, b);
     return pack2_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xFFFF0000u));
 }
-template <int PREC>
+// IN16 (PREC 1 only): X and dY are bf16 twins (uint16 rows, ldx / ldy in bf16 elements): 8-byte loads of four channels,
+// no conversion — the two pairs of a dword are interleaved with two bit operations per channel.
+template <int PREC, bool IN16 = false>
 __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ dY, int ldy,
                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
@@ -1362,6 +1520,9 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
 
     constexpr int LJ = DW_KS / 16;
     float4 a_reg[LJ], b_reg[LJ];
+    uint2 a16[IN16 ? LJ : 1], b16[IN16 ? LJ : 1];
+    const unsigned short* X16 = reinterpret_cast<const unsigned short*>(X);
+    const unsigned short* dY16 = reinterpret_cast<const unsigned short*>(dY);
     // loads are unconditional (clamped pair / column) and masked when stored to LDS: under branches every pair's
     // "LDS list read -> global load" chain sat in its own block, four of them back to back before the first MFMA
     const int a_col = min(c0 + t_c, Cin - 4), b_col = min(n0 + t_c, Cout - 4);
@@ -1373,8 +1534,13 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
         for (int j = 0; j < LJ; ++j) {
             const int p = min(pb + pair_of(j), total - 1);
             const int in = p_in[p], out = p_out[p];
-            a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)in * ldx + a_col);
-            b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)out * ldy + b_col);
+            if constexpr (IN16) {
+                a16[j] = *reinterpret_cast<const uint2*>(X16 + (long long)in * ldx + a_col);
+                b16[j] = *reinterpret_cast<const uint2*>(dY16 + (long long)out * ldy + b_col);
+            } else {
+                a_reg[j] = *reinterpret_cast<const float4*>(X + (long long)in * ldx + a_col);
+                b_reg[j] = *reinterpret_cast<const float4*>(dY + (long long)out * ldy + b_col);
+            }
         }
     };
     load_data(0);
@@ -1394,6 +1560,23 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
             unsigned* Bt = reinterpret_cast<unsigned*>(Bs);
 #pragma unroll
             for (int jj = 0; jj < LJ / 2; ++jj) {
+                if constexpr (IN16) {
+                    const bool l0 = pb + pair_of(2 * jj) < total, l1 = pb + pair_of(2 * jj + 1) < total;
+                    const uint2 z = make_uint2(0u, 0u);
+                    const uint2 a0 = (l0 && a_ok) ? a16[2 * jj] : z, a1 = (l1 && a_ok) ? a16[2 * jj + 1] : z;
+                    const uint2 b0 = (l0 && b_ok) ? b16[2 * jj] : z, b1 = (l1 && b_ok) ? b16[2 * jj + 1] : z;
+                    const int pp = t_r + 16 * jj;
+                    const int col = (((pp >> 2) ^ ((t_c >> 2) & 7)) << 2) | (pp & 3);
+                    At[(t_c + 0) * DWT_LD + col] = (a0.x & 0xffffu) | (a1.x << 16);
+                    At[(t_c + 1) * DWT_LD + col] = (a0.x >> 16) | (a1.x & 0xffff0000u);
+                    At[(t_c + 2) * DWT_LD + col] = (a0.y & 0xffffu) | (a1.y << 16);
+                    At[(t_c + 3) * DWT_LD + col] = (a0.y >> 16) | (a1.y & 0xffff0000u);
+                    Bt[(t_c + 0) * DWT_LD + col] = (b0.x & 0xffffu) | (b1.x << 16);
+                    Bt[(t_c + 1) * DWT_LD + col] = (b0.x >> 16) | (b1.x & 0xffff0000u);
+                    Bt[(t_c + 2) * DWT_LD + col] = (b0.y & 0xffffu) | (b1.y << 16);
+                    Bt[(t_c + 3) * DWT_LD + col] = (b0.y >> 16) | (b1.y & 0xffff0000u);
+                    continue;
+                }
                 float av[2][4], bv[2][4];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -2080,6 +2263,55 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
     return AGB_OK;
 }
 
+// bf16 twin of a row matrix (activations, gradients, K-major weights): Y16[r][c] = bf16(X[r][c]), round to nearest even.
+int agb_to_bf16(const float* X, long long ldx, long long n, int C, uint16_t* Y16, long long ldy, void* stream) {
+    AGB_CHECK_ARG(n >= 0 && C >= 4 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0,
+                  "agb_to_bf16: C (%d), ldx, ldy must be multiples of 4", C);
+    if (n == 0) return AGB_OK;
+    AGB_CHECK_ARG(X && Y16, "agb_to_bf16: null pointer");
+    const long long total = n * (C / 4);
+    AGB_CHECK_ARG(agb_cdiv(total, 256) <= 0x7fffffff, "agb_to_bf16: too many elements for one launch");
+    hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, n, C / 4,
+                       Y16, ldy);
+    AGB_CHECK_LAUNCH("agb_to_bf16");
+    return AGB_OK;
+}
+
+// agb_spconv_fwd_lp (precision 1) on bf16 STORAGE: X16 uint16 [n_in][ldx16] and K-major weights Wt16 uint16 [K3][Cout][Cin]
+// are bf16 twins made by agb_to_bf16; fp32 accumulate, bias and output.  Cin % 8 == 0, ldx16 % 8 == 0.
+int agb_spconv_fwd_b16(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const int32_t* nbr, long long nbr_stride,
+                       int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                       float* partial, void* stream) {
+    AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 8 && Cout >= 4 && Cin % 8 == 0 && Cout % 4 == 0 && ldx16 % 8 == 0,
+                  "agb_spconv_fwd_b16: Cin (%d), ldx16 must be multiples of 8, Cout (%d) of 4", Cin, Cout);
+    AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_b16: ksplit needs `partial`");
+    AGB_CHECK_ARG(nbr != nullptr || (K3 == 1 && perm == nullptr), "agb_spconv_fwd_b16: the identity map needs K3 == 1");
+    if (n_out == 0) return AGB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ConvArgs a{reinterpret_cast<const float*>(X16), ldx16, reinterpret_cast<const float*>(Wt16), nbr, nbr_stride, kflip, bias,
+               Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit, partial, 0, -1};
+    dim3 block(256);
+    if (perm) {
+        hipLaunchKernelGGL((k_spconv_pipe_b16<64, true>), dim3(n_tiles, agb_cdiv(Cout, BN), ksplit), block, 0, s, a);
+    } else if (conv_tile_rows(n_out, Cin, Cout) == 128) {
+        const bool wide = Cout >= 128 && (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, 128) * ksplit >= 512;
+        dim3 grid(agb_cdiv(n_out, 128), agb_cdiv(Cout, wide ? 128 : 64), ksplit);
+        if (wide) hipLaunchKernelGGL((k_spconv_pipe_b16<128, false, 128>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_spconv_pipe_b16<128, false>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((k_spconv_pipe_b16<64, false>), dim3(agb_cdiv(n_out, 64), agb_cdiv(Cout, BN), ksplit), block, 0, s,
+                           a);
+    }
+    if (ksplit > 1) {
+        long long total = (long long)n_out * (Cout / 4);
+        hipLaunchKernelGGL(k_split_reduce, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, partial, ksplit, n_out, Cout / 4,
+                           bias, Y, ldy);
+    }
+    AGB_CHECK_LAUNCH("agb_spconv_fwd_b16");
+    return AGB_OK;
+}
+
 int agb_spconv_fwd(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
                    const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, void* stream) {
     return agb_spconv_fwd_ex(X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, nullptr, nullptr,
@@ -2132,13 +2364,33 @@ int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, 
                                     stream);
 }
 
+static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
+                           float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
                              float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
                              size_t workspace_bytes, void* stream) {
+    AGB_CHECK_ARG(precision >= 0 && precision <= 2, "agb_spconv_bwd_weight_ws: precision %d (0 fp32, 1 bf16, 2 bf16x3)",
+                  precision);
+    return bwd_weight_impl(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, precision, variant, workspace,
+                           workspace_bytes, stream);
+}
+
+// bf16 operands from bf16 STORAGE (see agb_spconv_fwd_b16): X16 / dY16 are agb_to_bf16 twins, ld in bf16 elements
+// (multiples of 4); dW fp32, accumulated into.  Cin >= 12.
+int agb_spconv_bwd_weight_b16(const uint16_t* X16, int ldx16, const uint16_t* dY16, int ldy16, const int32_t* nbr,
+                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, void* stream) {
+    AGB_CHECK_ARG(Cin >= 12, "agb_spconv_bwd_weight_b16: Cin %d (>= 12)", Cin);
+    return bwd_weight_impl(reinterpret_cast<const float*>(X16), ldx16, reinterpret_cast<const float*>(dY16), ldy16, nbr,
+                           nbr_stride, dW, n_out, K3, Cin, Cout, 3, 0, nullptr, 0, stream);
+}
+
+static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
+                           float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
+                           size_t workspace_bytes, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_bwd_weight: bad sizes");
     AGB_CHECK_ARG(variant == 0 || variant == 1, "agb_spconv_bwd_weight_ws: variant %d (0 automatic, 1 LDS-staged)", variant);
-    AGB_CHECK_ARG(precision >= 0 && precision <= 2, "agb_spconv_bwd_weight_lp: precision %d (0 fp32, 1 bf16, 2 bf16x3)",
-                  precision);
     AGB_CHECK_ARG(nbr != nullptr || K3 == 1, "agb_spconv_bwd_weight: the identity map (nbr == NULL) needs K3 == 1");
     AGB_CHECK_ARG(nbr != nullptr || (Cin != 4 && Cin != 8), "agb_spconv_bwd_weight: the identity map needs Cin >= 12");
     AGB_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
@@ -2195,7 +2447,10 @@ int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, 
             chunks = agb_cdiv(nblk, bpc);
         }
         dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
-        if (precision == 1)
+        if (precision == 3)       // bf16 operands from bf16 twins (agb_spconv_bwd_weight_b16)
+            hipLaunchKernelGGL((k_spconv_dw_cmp<1, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+        else if (precision == 1)
             hipLaunchKernelGGL(k_spconv_dw_cmp<1>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
         else if (precision == 2)

@@ -35,16 +35,19 @@ class KernelOptions:
       deterministic_wgrad  fp32 weight gradients summed over row chunks in a fixed order through a workspace (csrc/dwreg.hip)
                            instead of fp32 atomic accumulation
       dw_variant           0 = automatic, 1 = the LDS-staged weight-gradient kernel of earlier rounds (A/B measurements)
+      bf16_storage         precision "bf16": convolutions read bf16 twins of their inputs (rows and weights converted once,
+                           gathered as 2-byte channels) instead of converting fp32 rows while staging them
 
     Use: ``model.kernel_options = KernelOptions(precision="bf16")`` (the backbones run their forward pass inside it), or
     ``with KernelOptions(cmp_mode=128): ...`` around direct calls.  Autograd nodes keep the options they were created
     under for their backward pass.  ``DEFAULTS`` (environment-initialised) applies where nothing else is set."""
     __slots__ = ("precision", "cmp_mode", "cmp_interleave", "balanced_tiles", "bn_stats_in_epilogue", "fused_tail",
-                 "deterministic_wgrad", "dw_variant")
+                 "deterministic_wgrad", "dw_variant", "bf16_storage")
     PRECISIONS = ("fp32", "bf16", "bf16x3")
 
     def __init__(self, precision=None, cmp_mode=None, cmp_interleave=None, balanced_tiles=None,
-                 bn_stats_in_epilogue=None, fused_tail=None, deterministic_wgrad=None, dw_variant=None, base=None):
+                 bn_stats_in_epilogue=None, fused_tail=None, deterministic_wgrad=None, dw_variant=None,
+                 bf16_storage=None, base=None):
         base = base if base is not None else (current() if "DEFAULTS" in globals() else None)
         pick = lambda v, name, dflt: v if v is not None else (getattr(base, name) if base is not None else dflt)  # noqa: E731
         self.precision = pick(precision, "precision", "fp32")
@@ -57,6 +60,7 @@ class KernelOptions:
         self.fused_tail = bool(pick(fused_tail, "fused_tail", True))
         self.deterministic_wgrad = bool(pick(deterministic_wgrad, "deterministic_wgrad", True))
         self.dw_variant = int(pick(dw_variant, "dw_variant", 0))
+        self.bf16_storage = bool(pick(bf16_storage, "bf16_storage", True))
 
     def replace(self, **kw):
         return KernelOptions(base=self, **kw)
@@ -102,7 +106,8 @@ DEFAULTS = KernelOptions(precision=os.environ.get("AGB_CONV_PRECISION", "fp32"),
                          balanced_tiles=os.environ.get("AGB_BALANCED_TILES", "1") != "0",
                          bn_stats_in_epilogue=os.environ.get("AGB_BN_EPILOGUE", "1") != "0", fused_tail=True,
                          deterministic_wgrad=os.environ.get("AGB_DETERMINISTIC_WGRAD", "1") != "0",
-                         dw_variant=int(os.environ.get("AGB_DW_VARIANT", "0")))
+                         dw_variant=int(os.environ.get("AGB_DW_VARIANT", "0")),
+                         bf16_storage=os.environ.get("AGB_BF16_STORAGE", "1") != "0")
 
 
 def set_conv_precision(name):
@@ -263,6 +268,33 @@ def bn_hint(x, c):
     return h[0], h[1]
 
 
+_lib.declare("agb_to_bf16", [_lib.c_void_p, _lib.c_ll, _lib.c_ll, _lib.c_int, _lib.c_void_p, _lib.c_ll, _lib.c_void_p])
+_lib.declare("agb_spconv_bwd_weight_b16", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
+                                           _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p])
+_lib.declare("agb_spconv_fwd_b16", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
+                                    _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
+                                    _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
+                                    _lib.c_void_p, _lib.c_void_p])
+
+
+def bf16_twin(t, cache=True):
+    """bf16 copy (round to nearest even, csrc k_to_bf16) of a 2-D fp32 row matrix.  cache: keep it on the tensor (valid while
+    the tensor's version stands) — an activation that feeds several convolutions, forward and weight gradient, is
+    converted once."""
+    if cache:
+        h = getattr(t, "agb_bf16", None)
+        if h is not None and h[1] == t._version and h[0].shape == t.shape:
+            return h[0]
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.AgbError("bf16_twin takes a 2-D row matrix with contiguous rows")
+    n, c = t.shape
+    y = torch.empty(n, c, dtype=torch.bfloat16, device=t.device)
+    _lib.call("agb_to_bf16", _P(t), t.stride(0), n, c, _P(y), y.stride(0), _lib.stream())
+    if cache:
+        t.agb_bf16 = (y, t._version)
+    return y
+
+
 def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None, plan=None,
                        w_kmajor=None, bn_stats=False, opts=None):
     """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout].
@@ -300,6 +332,13 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
         _lib.call("agb_dense_fwd_bn", _P(x), x.stride(0), _P(w2d), _P(bias), _P(y), y.stride(0), n_out, cin, cout, _P(part),
                   _lib.stream())
         _set_last_bn_part((part, bn_chunks, weakref.ref(y)))
+    elif prec == 1 and opts.bf16_storage and cin % 8 == 0 and x.stride(0) % 8 == 0:
+        # bf16 mode on bf16 storage: twins of the rows (cached on the tensor: a block input feeds two convolutions) and of
+        # the K-major weights; the kernel gathers 2-byte channels straight into LDS
+        x16, w16 = bf16_twin(x), bf16_twin(w_kmajor.view(-1, cin), cache=False)
+        _lib.call("agb_spconv_fwd_b16", _P(x16), x16.stride(0), _P(w16), _P(nbr), 0 if nbr is None else nbr.stride(0),
+                  int(kflip), _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
+                  split, _P(partial), _lib.stream())
     elif prec:
         _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip),
                   _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
@@ -324,6 +363,11 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
 def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
     """dw += gathered(x)^T dy through the C ABI, with the workspace of the deterministic two-level sum (fp32 kernel)."""
     prec = opts.prec_id if cin >= 12 else 0
+    if prec == 1 and opts.bf16_storage and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0:
+        x16, dy16 = bf16_twin(x), bf16_twin(dy)     # (dy's twin is shared with the data gradient of the same layer)
+        _lib.call("agb_spconv_bwd_weight_b16", _P(x16), x16.stride(0), _P(dy16), dy16.stride(0), _P(nbr),
+                  0 if nbr is None else nbr.stride(0), _P(dw), n_out, K3, cin, cout, _lib.stream())
+        return
     nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) \
         if (opts.deterministic_wgrad and opts.dw_variant == 0) else 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None

@@ -183,6 +183,17 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
                       const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                       float* partial, int precision, void* stream);
+/* The bf16 mode on bf16 STORAGE (BASELINE config 5: "bf16 with fp32 index kernels"): agb_to_bf16 makes the bf16 twin of a
+ * row matrix (round to nearest even; C, ldx, ldy multiples of 4) — of an activation, of a gradient, of the K-major weights
+ * — and agb_spconv_fwd_b16 is agb_spconv_fwd_lp(precision = 1) reading those twins: X16 uint16 [n_in][ldx16], Wt16 uint16
+ * [K3][Cout][Cin]; 16-byte pieces of 8 channels go from global memory to LDS unconverted (half the bytes through the CU's
+ * vector-memory path, no conversion instructions); fp32 accumulate, bias and output.  Cin, ldx16 multiples of 8.
+ * Same ME convolution as agb_spconv_fwd (SENet.py:185, senet_block.py:99-147 under torch.cuda.amp in the reference). */
+int agb_to_bf16(const float* X, long long ldx, long long n, int C, uint16_t* Y16, long long ldy, void* stream);
+int agb_spconv_fwd_b16(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const int32_t* nbr, long long nbr_stride,
+                       int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                       float* partial, void* stream);
 /* perm int32[n + stride^3*64] (rows grouped by class, -1 padding), tile_cls int32[max_tiles] with
  * max_tiles = n/64 + stride^3 + 1, scratch int32[256].  class = (c/ts_in mod stride) per axis, x fastest. */
 int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, int32_t* perm, int32_t* tile_cls,
@@ -207,6 +218,10 @@ size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cou
 int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, int precision,
                              int variant, void* workspace, size_t workspace_bytes, void* stream);
+/* bf16 operands from bf16 STORAGE (the twins of agb_to_bf16; see agb_spconv_fwd_b16): the weight gradient of the bf16 mode
+ * without the fp32 gathers and conversions; dW fp32, accumulated into.  Cin >= 12; ldx16, ldy16 multiples of 4. */
+int agb_spconv_bwd_weight_b16(const uint16_t* X16, int ldx16, const uint16_t* dY16, int ldy16, const int32_t* nbr,
+                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Pooling / broadcast (replaces ME.MinkowskiMaxPooling SENet.py:53; ME.MinkowskiGlobal{Sum,Avg,Max}Pooling

@@ -960,3 +960,33 @@ def test_weight_gradient_register_kernel(device, n_plots, npts, cin, cout, K):
     dw = torch.ones(K3, cin, cout, device=device)
     sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, cin, cout, sparse_ops.KernelOptions())
     assert rel_err(dw - 1.0, want) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,K,stride", [(64, 64, 3, 1), (64, 128, 3, 2), (128, 72, 1, 1), (256, 64, 3, 1)])
+def test_bf16_storage_equals_bf16_staging(device, cin, cout, K, stride):
+    """The bf16 mode on bf16 twins (agb_to_bf16 + agb_spconv_fwd_b16 / agb_spconv_bwd_weight_b16: 2-byte channels gathered
+    straight into LDS) multiplies exactly the operands the staging-conversion kernels produce (same round-to-nearest-even,
+    same accumulation order): forward, data gradient and weight gradient are bit-identical."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import sparse_ops
+    rng = np.random.default_rng(cin + cout)
+    torch.manual_seed(cin * 7 + cout)
+    coords = random_coords(rng, 3, 2500, 20)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=K, stride=stride, bias=True, dimension=3).to(device)
+    x = torch.randn(cm.level(1).n, cin, device=device)
+    res = {}
+    for storage in (True, False):
+        conv.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        with sparse_ops.KernelOptions(precision="bf16", bf16_storage=storage):
+            out = conv(ME.SparseTensor(xg, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm)).F
+        torch.manual_seed(1)
+        out.backward(torch.randn_like(out))
+        res[storage] = (out.detach().clone(), xg.grad.clone(), conv.kernel.grad.clone())
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    # the twin itself: round to nearest even
+    t = sparse_ops.bf16_twin(x, cache=False)
+    assert torch.equal(t, x.to(torch.bfloat16))
