@@ -40,7 +40,8 @@ static DwrGeo dwr_geometry(int n_out, int K3, int Cin, int Cout) {
     g.cin_tiles = agb_cdiv(Cin, 64);
     g.cout_tiles = agb_cdiv(Cout, 64);
     const long long M = (long long)K3 * g.cin_tiles * g.cout_tiles;
-    long long target = 4096 / M;                  // ~4096 units: two per resident wave slot at two waves per SIMD
+    long long target = 3072 / M;                  // ~3072 units = six per resident workgroup slot (2 per CU); more, smaller
+                                                  // chunks balance better but every unit writes a 16 KB partial tile
     if (target < 1) target = 1;
     long long rows = (n_out + target - 1) / target;
     rows = (rows + 255) / 256 * 256;              // four waves x a multiple of 64 rows

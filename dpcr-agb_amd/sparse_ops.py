@@ -277,6 +277,11 @@ _lib.declare("agb_spconv_fwd_b16", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _l
                                     _lib.c_void_p, _lib.c_void_p])
 
 
+def has_twin(t):
+    h = getattr(t, "agb_bf16", None)
+    return h is not None and h[1] == t._version and h[0].shape == t.shape
+
+
 def bf16_twin(t, cache=True):
     """bf16 copy (round to nearest even, csrc k_to_bf16) of a 2-D fp32 row matrix.  cache: keep it on the tensor (valid while
     the tensor's version stands) — an activation that feeds several convolutions, forward and weight gradient, is
@@ -332,7 +337,9 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
         _lib.call("agb_dense_fwd_bn", _P(x), x.stride(0), _P(w2d), _P(bias), _P(y), y.stride(0), n_out, cin, cout, _P(part),
                   _lib.stream())
         _set_last_bn_part((part, bn_chunks, weakref.ref(y)))
-    elif prec == 1 and opts.bf16_storage and cin % 8 == 0 and x.stride(0) % 8 == 0:
+    elif prec == 1 and opts.bf16_storage and cin % 8 == 0 and x.stride(0) % 8 == 0 and (nbr is not None or has_twin(x)):
+        # (a dense product reads every row once per column tile: converting first only pays when the twin exists already;
+        # a 3^3 gather re-reads every row ~15 times)
         # bf16 mode on bf16 storage: twins of the rows (cached on the tensor: a block input feeds two convolutions) and of
         # the K-major weights; the kernel gathers 2-byte channels straight into LDS
         x16, w16 = bf16_twin(x), bf16_twin(w_kmajor.view(-1, cin), cache=False)
@@ -363,7 +370,7 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
 def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
     """dw += gathered(x)^T dy through the C ABI, with the workspace of the deterministic two-level sum (fp32 kernel)."""
     prec = opts.prec_id if cin >= 12 else 0
-    if prec == 1 and opts.bf16_storage and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0:
+    if prec == 1 and opts.bf16_storage and nbr is not None and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0:
         x16, dy16 = bf16_twin(x), bf16_twin(dy)     # (dy's twin is shared with the data gradient of the same layer)
         _lib.call("agb_spconv_bwd_weight_b16", _P(x16), x16.stride(0), _P(dy16), dy16.stride(0), _P(nbr),
                   0 if nbr is None else nbr.stride(0), _P(dw), n_out, K3, cin, cout, _lib.stream())

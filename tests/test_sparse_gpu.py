@@ -985,8 +985,9 @@ def test_bf16_storage_equals_bf16_staging(device, cin, cout, K, stride):
         torch.manual_seed(1)
         out.backward(torch.randn_like(out))
         res[storage] = (out.detach().clone(), xg.grad.clone(), conv.kernel.grad.clone())
-    for a, b in zip(res[True], res[False]):
-        assert torch.equal(a, b)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    # (the bf16 weight-gradient kernels add their row chunks with fp32 atomics: equal operands, summation order not fixed)
+    assert rel_err(res[True][2], res[False][2]) < 2e-6
     # the twin itself: round to nearest even
     t = sparse_ops.bf16_twin(x, cache=False)
     assert torch.equal(t, x.to(torch.bfloat16))
