@@ -1771,7 +1771,12 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
                                                              const float* __restrict__ dY, int ldy,
                                                              const int32_t* __restrict__ nbr, long long nbr_stride,
                                                              float* __restrict__ dW, int n_out, int K3, int Cout,
-                                                             int rows_per_wg, int chunks, int m_tiles) {
+                                                             int rows_per_wg, int chunks, int m_tiles, int nsub,
+                                                             float* __restrict__ part) {
+    // nsub > 1: the workgroup walks nsub consecutive sub-chunks of rows_per_wg rows with ONE set of accumulators (`chunks`
+    // counts the groups of nsub sub-chunks).  part != NULL: it leaves its 64 x 64 tile in part[chunk] instead of adding it
+    // to dW with fp32 atomics; k_dw_fold_small adds the chunks in ascending order (bitwise reproducible, and a two-level
+    // sum: the 343 x 3 x 64 stem gradient sums 22.7 M cancelling terms behind a BatchNorm).
     constexpr int OPT = 64 / CPAD;   // offsets per M tile
     constexpr int F4 = CPAD / 4;     // float4 per (row, offset)
     __shared__ __attribute__((aligned(16))) float As[BK * 64];  // [r][m]
@@ -1794,10 +1799,16 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
         chunk = blockIdx.x % chunks;
         mt = blockIdx.x / chunks;
     }
-    const int r_begin = chunk * rows_per_wg;
-    const int r_end = min(n_out, r_begin + rows_per_wg);
     const int k0 = mt * OPT;
     const int nk = min(OPT, K3 - k0);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int sub = 0; sub < nsub; ++sub) {
+    const int r_begin = (chunk * nsub + sub) * rows_per_wg;
+    const int r_end = min(n_out, r_begin + rows_per_wg);
+    if (r_begin >= n_out) break;          // (uniform)
+    if (sub > 0) __syncthreads();         // the previous sub-chunk's row list and staging tiles are free
 
     // ---- phase 1: rows with at least one present neighbour among the tile's offsets (order kept).  The neighbour
     // indices of the whole chunk are loaded up front (unconditional, clamped: one exposed latency per workgroup instead
@@ -1833,11 +1844,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
         total += round;
     }
     __syncthreads();
-    if (total == 0) return;
-
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (total == 0) continue;
 
     // software pipeline: the neighbour indices of step i+2 and the gathers of step i+1 are in flight during the MFMAs
     // of step i (index -> gather is a dependent pair of L2 latencies; one step of MFMAs is only ~0.4 us)
@@ -1892,15 +1899,33 @@ __global__ __launch_bounds__(256) void k_spconv_dw_small_cmp(const float* __rest
         }
         __syncthreads();
     }
+    }   // sub-chunks
     const int col = n0 + wc * 32 + li;
     if (col < Cout) {
+        float* dst = part ? part + (long long)chunk * K3 * CPAD * Cout : dW;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             int m = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             long long wrow = (long long)k0 * CPAD + m;
-            if (wrow < (long long)K3 * CPAD) atomicAdd(&dW[wrow * Cout + col], acc[reg]);
+            if (wrow < (long long)K3 * CPAD) {
+                if (part) dst[wrow * Cout + col] = acc[reg];
+                else atomicAdd(&dst[wrow * Cout + col], acc[reg]);
+            }
         }
     }
+}
+
+// dW[e] += sum over chunks (ascending) of part[chunk][e]
+__global__ __launch_bounds__(256) void k_dw_fold_small(const float4* __restrict__ part, int chunks, long long n4,
+                                                       float4* __restrict__ dW) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    float4 s = dW[e];
+    for (int c = 0; c < chunks; ++c) {
+        const float4 v = part[(long long)c * n4 + e];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    dW[e] = s;
 }
 
 // =============================================================== C ABI
@@ -2345,6 +2370,22 @@ int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, in
 // nbr == nullptr (K3 == 1): identity map, dW = X^T dY of a 1x1 stride-1 convolution.
 // True when the call runs the register-operand fp32 kernel (dwreg.hip): fp32, Cin >= 12, not one of the HBM-bound dense
 // shapes the streaming kernel takes.  variant 1 forces the LDS-staged k_spconv_dw_cmp<0> (A/B measurements).
+#define DW_SMALL_NSUB 4     // 1024-row sub-chunks one workgroup of the small-Cin weight gradient accumulates before it stores
+
+// Rows per sub-chunk of the small-Cin (stem) weight gradient: ~4096 workgroups, 256..1024 rows (the kernel is latency-bound
+// (index -> gather): more resident workgroups hide more of it; 512 / 1024 / 2048 rows measured within 5 % of each other on the
+// 7^3 stem, 4096+ clearly slower)
+static int dw_small_rows(int n_out, int K3, int Cin, int Cout) {
+    const long long tiles = (long long)agb_cdiv(K3, 64 / Cin) * agb_cdiv(Cout, 64);
+    long long target_chunks = 4096 / tiles;
+    if (target_chunks < 1) target_chunks = 1;
+    long long rows = (n_out + target_chunks - 1) / target_chunks;
+    if (rows < 256) rows = 256;
+    rows = (rows + 31) / 32 * 32;
+    if (rows > 1024) rows = 1024;
+    return (int)rows;
+}
+
 static bool dw_takes_reg_kernel(const int32_t* nbr, int n_out, int Cin, int Cout, int precision, int variant) {
     if (precision != 0 || variant == 1 || Cin == 4 || Cin == 8) return false;
     if (nbr == nullptr && agb_dense_stream_wgrad_ok(n_out, Cin, Cout)) return false;
@@ -2354,6 +2395,10 @@ static bool dw_takes_reg_kernel(const int32_t* nbr, int n_out, int Cin, int Cout
 size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cout, int dense, int precision) {
     static const int32_t some_map = 0;
     if (n_out <= 0 || K3 < 1 || Cin < 4 || Cout < 4) return 0;
+    if (!dense && (Cin == 4 || Cin == 8)) {      // the small-Cin (stem) kernel: groups of DW_SMALL_NSUB 1024-row chunks
+        const int chunks = agb_cdiv(agb_cdiv(n_out, dw_small_rows(n_out, K3, Cin, Cout)), DW_SMALL_NSUB);
+        return (size_t)chunks * K3 * Cin * Cout * sizeof(float);
+    }
     if (!dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0)) return 0;
     return agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
 }
@@ -2425,19 +2470,38 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
     rows = (rows + 31) / 32 * 32;
     int chunks = agb_cdiv(n_out, rows);
     if (Cin == 4 || Cin == 8) {
-        // 1024-row chunks: the kernel is latency-bound (index -> gather), more resident workgroups hide more of it;
-        // 512 / 1024 / 2048 rows measured within 5 % of each other on the 7^3 stem, 4096+ clearly slower
-        if (rows > 1024) rows = 1024;
+        rows = dw_small_rows(n_out, K3, Cin, Cout);
         chunks = agb_cdiv(n_out, rows);
     }
     dim3 grid((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles), block(256);
-    if (Cin == 4)
-        hipLaunchKernelGGL(k_spconv_dw_small_cmp<4>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
-                           Cout, (int)rows, chunks, m_tiles);
-    else if (Cin == 8)
-        hipLaunchKernelGGL(k_spconv_dw_small_cmp<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
-                           Cout, (int)rows, chunks, m_tiles);
-    else {
+    if (Cin == 4 || Cin == 8) {
+        // with a workspace: groups of DW_SMALL_NSUB sub-chunks per workgroup (one partial tile per group instead of one
+        // atomic accumulation per sub-chunk), folded in a fixed order
+        int nsub = 1;
+        float* part = nullptr;
+        if (workspace != nullptr && variant == 0) {
+            nsub = DW_SMALL_NSUB;
+            chunks = agb_cdiv(chunks, nsub);
+            if ((size_t)chunks * K3 * Cin * Cout * sizeof(float) > workspace_bytes) {
+                agb_set_error("agb_spconv_bwd_weight_ws: workspace of %zu bytes, %zu needed", workspace_bytes,
+                              (size_t)chunks * K3 * Cin * Cout * sizeof(float));
+                return AGB_EINVAL;
+            }
+            if (chunks > 1) part = (float*)workspace;      // (one group: a single writer per element already)
+            grid = dim3((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
+        }
+        if (Cin == 4)
+            hipLaunchKernelGGL(k_spconv_dw_small_cmp<4>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cout, (int)rows, chunks, m_tiles, nsub, part);
+        else
+            hipLaunchKernelGGL(k_spconv_dw_small_cmp<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cout, (int)rows, chunks, m_tiles, nsub, part);
+        if (part) {
+            const long long n4 = (long long)K3 * Cin * Cout / 4;
+            hipLaunchKernelGGL(k_dw_fold_small, dim3((unsigned)agb_cdiv(n4, 256)), dim3(256), 0, s, (const float4*)part, chunks,
+                               n4, (float4*)dW);
+        }
+    } else {
         // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
         if (rows > DW_MAXROWS) rows = DW_MAXROWS;
         chunks = agb_cdiv(n_out, rows);

@@ -460,8 +460,7 @@ class SparseConvFunction(torch.autograd.Function):
                 raise _lib.AgbError("the forward pass ran without gradients enabled: no kernel map was written")
             dwp = torch.zeros(K3, 4, cout, dtype=torch.float32, device=dy.device)
             ev = _prof_begin("wgrad", K3, 4, cout, n_out)
-            _lib.call("agb_spconv_bwd_weight", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), nbr.stride(0),
-                      _P(dwp), n_out, K3, 4, cout, _lib.stream())
+            weight_grad_raw(x, dy, nbr, dwp, n_out, K3, 4, cout, ctx.opts)
             _prof_end(ev, "wgrad", K3, 4, cout, n_out, None)
             if ev is not None:
                 PROFILE[-1]["pairs"] = (nbr >= 0).sum()

@@ -991,3 +991,37 @@ def test_bf16_storage_equals_bf16_staging(device, cin, cout, K, stride):
     # the twin itself: round to nearest even
     t = sparse_ops.bf16_twin(x, cache=False)
     assert torch.equal(t, x.to(torch.bfloat16))
+
+
+def test_stem_weight_gradient_two_level_sum(device):
+    """The small-Cin (7^3 stem) weight gradient with a workspace: groups of sub-chunks leave partial tiles that are folded in
+    ascending order — bitwise reproducible (the atomic form is not), and closer to the exact sum than one fp32 chain."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import _lib, sparse_ops
+    rng = np.random.default_rng(11)
+    torch.manual_seed(11)
+    coords = random_coords(rng, 8, 9000, 36)
+    ref = R.Coords(coords, 8)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    n, K, K3, cout = cm.level(1).n, 7, 343, 64
+    nbr = cm.kernel_map(1, K, 1, 1)
+    x = torch.zeros(n, 4)
+    x[:, :3] = torch.randn(n, 3) + 0.5
+    dy = torch.randn(n, cout)
+    xg, dyg = x.to(device), dy.to(device)
+    assert _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n, K3, 4, cout, 0, 0) >= 2 * K3 * 4 * cout * 4
+
+    def run(**kw):
+        dw = torch.zeros(K3, 4, cout, device=device)
+        sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, 4, cout, sparse_ops.KernelOptions(**kw))
+        return dw
+
+    a, b = run(), run()
+    assert torch.equal(a, b)
+    want = torch.zeros(K3, 4, cout, dtype=torch.float64)
+    for k, (rows, idx) in enumerate(ref.pairs(1, K, 1)):
+        want[k] = x.double()[idx].t() @ dy.double()[rows]
+    err_fold, err_atomic = rel_err(a, want), rel_err(run(deterministic_wgrad=False), want)
+    print(f"stem weight gradient vs fp64: two-level fold {err_fold:.2e}, atomic accumulation {err_atomic:.2e}")
+    assert err_fold < 2e-6 and err_atomic < 5e-6
