@@ -31,7 +31,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DWR_CH 2048     // rows per chunk at most (the LDS pair list: 16 KB per wave)
-// (template parameter DWR_D: steps of four pairs the gathers run ahead of their MFMAs)
+// (template parameter DWR_D: steps of four pairs the gathers run ahead of their MFMAs; 8 measured equal to 4.  A 32 KB
+// two-round reduction for three or four workgroups per CU instead of two was measured SLOWER on the deep levels: 256 -> 256
+// 335 -> 401 us, 512 -> 512 256 -> 361 us — more resident units thrash the XCD's L2: EXPERIMENTS.md)
 
 struct DwrGeo { int rows, chunks, cin_tiles, cout_tiles; };
 
@@ -40,7 +42,7 @@ static DwrGeo dwr_geometry(int n_out, int K3, int Cin, int Cout) {
     g.cin_tiles = agb_cdiv(Cin, 64);
     g.cout_tiles = agb_cdiv(Cout, 64);
     const long long M = (long long)K3 * g.cin_tiles * g.cout_tiles;
-    long long target = 3072 / M;                  // ~3072 units = six per resident workgroup slot (2 per CU); more, smaller
+    long long target = 4096 / M;                  // ~4096 units = eight per resident workgroup slot (2 per CU); more, smaller
                                                   // chunks balance better but every unit writes a 16 KB partial tile
     if (target < 1) target = 1;
     long long rows = (n_out + target - 1) / target;
@@ -219,13 +221,10 @@ int agb_dwreg_launch(const float* X, int ldx, const float* dY, int ldy, const in
     const long long M = (long long)K3 * g.cin_tiles * g.cout_tiles;
     const long long units = (g.chunks >= 16 ? 8LL * agb_cdiv(g.chunks, 8) : g.chunks) * M;
     if (units > 0x7fffffffLL) { agb_set_error("weight gradient: too many units"); return AGB_ERANGE; }
-    // prefetch depth: 4 steps by default; AGB_DWR_DEPTH=8 (tuning aid, read once) selects the deeper instantiation
-    static const int depth = [] { const char* e = getenv("AGB_DWR_DEPTH"); return e ? atoi(e) : 4; }();
-#define DWR_LAUNCH(DENSE, D)                                                                                              \
-    hipLaunchKernelGGL((k_spconv_dw_reg<DENSE, D>), dim3((unsigned)units), dim3(256), 0, s, X, ldx, dY, ldy, nbr, nbr_stride, \
+#define DWR_LAUNCH(DENSE)                                                                                                  \
+    hipLaunchKernelGGL((k_spconv_dw_reg<DENSE, 4>), dim3((unsigned)units), dim3(256), 0, s, X, ldx, dY, ldy, nbr, nbr_stride, \
                        dW, part, n_out, K3, Cin, Cout, g.rows, g.cin_tiles, g.cout_tiles, g.chunks)
-    if (nbr) { if (depth == 8) DWR_LAUNCH(false, 8); else DWR_LAUNCH(false, 4); }
-    else     { if (depth == 8) DWR_LAUNCH(true, 8); else DWR_LAUNCH(true, 4); }
+    if (nbr) DWR_LAUNCH(false); else DWR_LAUNCH(true);
 #undef DWR_LAUNCH
     if (part) {
         const long long n4 = (long long)K3 * Cin * Cout / 4;

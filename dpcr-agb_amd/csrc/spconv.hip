@@ -2386,10 +2386,14 @@ static int dw_small_rows(int n_out, int K3, int Cin, int Cout) {
     return (int)rows;
 }
 
-static bool dw_takes_reg_kernel(const int32_t* nbr, int n_out, int Cin, int Cout, int precision, int variant) {
+static bool dw_takes_reg_kernel(const int32_t* nbr, int n_out, int Cin, int Cout, int precision, int variant,
+                                bool has_workspace) {
     if (precision != 0 || variant == 1 || Cin == 4 || Cin == 8) return false;
     if (nbr == nullptr && agb_dense_stream_wgrad_ok(n_out, Cin, Cout)) return false;
-    return true;
+    // automatic: the register-operand kernel is the REPRODUCIBLE form (fixed-order fold through the workspace); without a
+    // workspace the LDS-staged kernel with atomic accumulation is the faster one in the training step (3.7 % of the
+    // MSENet14 step, profiles/r03_bench_dw_variants.txt)
+    return variant == 2 || has_workspace;
 }
 
 size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cout, int dense, int precision) {
@@ -2399,7 +2403,7 @@ size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cou
         const int chunks = agb_cdiv(agb_cdiv(n_out, dw_small_rows(n_out, K3, Cin, Cout)), DW_SMALL_NSUB);
         return (size_t)chunks * K3 * Cin * Cout * sizeof(float);
     }
-    if (!dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0)) return 0;
+    if (!dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0, true)) return 0;
     return agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
 }
 
@@ -2435,7 +2439,8 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
                            float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
                            size_t workspace_bytes, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_bwd_weight: bad sizes");
-    AGB_CHECK_ARG(variant == 0 || variant == 1, "agb_spconv_bwd_weight_ws: variant %d (0 automatic, 1 LDS-staged)", variant);
+    AGB_CHECK_ARG(variant >= 0 && variant <= 2, "agb_spconv_bwd_weight_ws: variant %d (0 automatic, 1 LDS-staged, 2 register "
+                  "operands)", variant);
     AGB_CHECK_ARG(nbr != nullptr || K3 == 1, "agb_spconv_bwd_weight: the identity map (nbr == NULL) needs K3 == 1");
     AGB_CHECK_ARG(nbr != nullptr || (Cin != 4 && Cin != 8), "agb_spconv_bwd_weight: the identity map needs Cin >= 12");
     AGB_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
@@ -2448,7 +2453,7 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (dense, streaming)");
         return AGB_OK;
     }
-    if (dw_takes_reg_kernel(nbr, n_out, Cin, Cout, precision, variant)) {
+    if (dw_takes_reg_kernel(nbr, n_out, Cin, Cout, precision, variant, workspace != nullptr)) {
         int rc = agb_dwreg_launch(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, workspace, workspace_bytes, s);
         if (rc) return rc;
         AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (register operands)");

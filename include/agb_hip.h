@@ -208,12 +208,14 @@ int agb_spconv_bwd_weight(const float* X, int ldx, const float* dY, int ldy, con
 int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, int precision,
                              void* stream);
-/* The same with a caller-owned workspace: the fp32 kernel (Cin >= 12; csrc/dwreg.hip — both MFMA operands gathered straight
- * into registers, one wave per (row chunk, offset, 64 x 64 tile), no barriers) then writes one partial tile per row chunk
- * and adds the chunks in ascending order: bitwise reproducible sums instead of fp32 atomic accumulation (workspace ==
- * NULL, = agb_spconv_bwd_weight_lp).  agb_spconv_bwd_weight_workspace_bytes (host helper; dense = 1 for nbr == NULL)
- * returns 0 for the shapes / precisions that take another kernel (those ignore the workspace).
- * variant: 0 automatic, 1 = the LDS-staged four-wave kernel of earlier rounds (A/B measurements only). */
+/* The same with a caller-owned workspace = the REPRODUCIBLE form: the fp32 kernels then leave one partial tile per row chunk
+ * and add the chunks in ascending order (bitwise reproducible, two-level sums) instead of accumulating with fp32 atomics —
+ * Cin >= 12: csrc/dwreg.hip (both MFMA operands gathered straight into registers, four waves per (row chunk, offset, 64 x 64
+ * tile) unit, no barrier while they multiply); Cin = 4 / 8 (the 7^3 stem): groups of four sub-chunks per workgroup.
+ * workspace == NULL (= agb_spconv_bwd_weight_lp): the LDS-staged kernels with atomic accumulation, the faster form inside the
+ * training step.  agb_spconv_bwd_weight_workspace_bytes (host helper; dense = 1 for nbr == NULL) returns 0 for the shapes /
+ * precisions whose kernel takes no workspace.  variant: 0 automatic, 1 = LDS-staged kernel, 2 = register-operand kernel
+ * whatever the workspace (A/B measurements). */
 size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cout, int dense, int precision);
 int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, int precision,

@@ -62,7 +62,7 @@ def main():
             dy = torch.randn(n, cout, device=dev)
             ref_dw = None
             # register-operand kernel with the fixed-order fold / with atomic accumulation / the LDS-staged kernel
-            for tag, kw in (("reg+fold", {}), ("reg+atomic", dict(deterministic_wgrad=False)), ("staged", dict(dw_variant=1))):
+            for tag, kw in (("reg+fold", dict(deterministic_wgrad=True)), ("reg+atomic", dict(dw_variant=2)), ("staged", {})):
                 opts = sparse_ops.KernelOptions(**kw)
                 dw = torch.zeros(27, cin, cout, device=dev)
                 sparse_ops.weight_grad_raw(x, dy, nbr, dw, n, 27, cin, cout, opts)
