@@ -208,6 +208,22 @@ def usable_cores():
     return max(1, min(n, 32))
 
 
+def thread_cpu_times():
+    """{tid: (name, user + system CPU seconds)} of every thread of this process (Linux /proc)."""
+    out = {}
+    try:
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            with open(f"/proc/self/task/{tid}/stat") as f:
+                raw = f.read()
+            name = raw[raw.index("(") + 1:raw.rindex(")")]
+            fields = raw[raw.rindex(")") + 2:].split()
+            out[tid] = (name, (int(fields[11]) + int(fields[12])) / tick)
+    except Exception:
+        pass
+    return out
+
+
 def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -431,6 +447,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     prof = []
+    threads0 = thread_cpu_times()
     ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     step_events = []
@@ -485,6 +502,10 @@ def main():
         f"{ms1.get('num_alloc_retries', 0) - ms0.get('num_alloc_retries', 0)} retries")
     log(f"device memory: {torch.cuda.memory_allocated() / 2**30:.2f} GiB allocated now, "
         f"{torch.cuda.max_memory_allocated() / 2**30:.2f} GiB peak, {torch.cuda.memory_reserved() / 2**30:.2f} GiB reserved")
+    threads1 = thread_cpu_times()
+    busy = sorted(((threads1[t][1] - threads0.get(t, (None, 0.0))[1], threads1[t][0], t) for t in threads1), reverse=True)
+    log("CPU time per step by thread over the timed region (ms): " +
+        ", ".join(f"{name}[{tid}] {dt * 1e3 / args.steps:.2f}" for dt, name, tid in busy[:6] if dt > 0))
     mc = sorted(main_cpu_ms[-args.steps:])
     log(f"host CPU time per step: all threads median {hc[len(hc) // 2]:.2f} ms, enqueuing thread {mc[len(mc) // 2]:.2f} ms")
     hm = sorted(host_ms[-args.steps:])
