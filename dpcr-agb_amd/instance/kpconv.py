@@ -65,9 +65,15 @@ class KPConvModel(InstanceBase):
         empty_i = torch.zeros(0, 1, dtype=torch.int32, device=device)
         # Bounding box of the whole batch: ONE host read for the pyramid (barycentres never leave their parent's box, and
         # a cloud rotated about the origin keeps an extent below the box's diagonal), or none when the caller knows it.
+        # The grid-subsampling cells of a randomly oriented cloud are sized from the largest SINGLE-cloud diagonal (a seventh
+        # value of `bounds`; plots at different world positions in one batch would otherwise inflate every cloud's cell
+        # budget to the batch's extent); a caller that hands in six values vouches that the batch diagonal will do.
         if bounds is None:
-            bounds = kp_index.support_bounds(pts, lens)
-        diag = float(np.linalg.norm(np.asarray(bounds[3:]) - np.asarray(bounds[:3]))) * 1.0001 + 1e-6
+            bounds = kp_index.support_bounds(pts, lens, cloud_diag=self.random_grid_orient)
+        if len(bounds) > 6:
+            diag, bounds = float(bounds[6]) * 1.0001 + 1e-6, tuple(bounds[:6])
+        else:
+            diag = float(np.linalg.norm(np.asarray(bounds[3:]) - np.asarray(bounds[:3]))) * 1.0001 + 1e-6
         level = 0
         pool_job = None          # pooled radius search of the previous level: its width is read with this level's counts
         for block in cfg.architecture:

@@ -220,12 +220,17 @@ def neighbors_finish(job, width):
     return out
 
 
-def support_bounds(s, sl):
-    """(min xyz, max xyz) over all clouds: one host read."""
+def support_bounds(s, sl, cloud_diag=False):
+    """(min xyz, max xyz) over all clouds: one host read.  cloud_diag: a seventh value, the largest bounding-box diagonal of
+    a single cloud (what bounds the extent of a cloud rotated about any point, whatever the clouds' world positions)."""
     dev = s.device
     bb = elem_bbox(s, _ptr_tensor(sl, dev), len(sl))
-    lo, hi = read_back(bb[:, :3].min(0).values, bb[:, 3:].max(0).values)
-    return tuple(lo) + tuple(hi)
+    if not cloud_diag:
+        lo, hi = read_back(bb[:, :3].min(0).values, bb[:, 3:].max(0).values)
+        return tuple(lo) + tuple(hi)
+    lo, hi, dg = read_back(bb[:, :3].min(0).values, bb[:, 3:].max(0).values,
+                           (bb[:, 3:] - bb[:, :3]).norm(dim=1).max().reshape(1))
+    return tuple(lo) + tuple(hi) + (dg[0],)
 
 
 def batch_neighbors(queries, supports, q_batches, s_batches, radius, bounds=None):

@@ -156,7 +156,8 @@ def make_point_batch(seeds: List[int], n_points: int = 6144, extra_feature: bool
     # bounding box of the positions, known for free where the batch is assembled (saves the KPConv input pyramid its one
     # bounding-box read-back); slightly widened so that float32 round trips cannot put a point outside
     lo, hi = allp.min(0).astype(np.float64), allp.max(0).astype(np.float64)
-    out.pos_bounds = tuple(lo - 1e-5) + tuple(hi + 1e-5)
+    cloud_diag = max(float(np.linalg.norm(p.max(0).astype(np.float64) - p.min(0).astype(np.float64))) for p in ps)
+    out.pos_bounds = tuple(lo - 1e-5) + tuple(hi + 1e-5) + (cloud_diag + 1e-4,)   # (7th: largest single-plot diagonal)
     return out
 
 

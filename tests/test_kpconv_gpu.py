@@ -241,3 +241,31 @@ def test_kpconv_training_step(device):
         losses.append(float(model.loss.detach()))
     assert all(np.isfinite(losses))
     assert model.get_reg_output().shape == (3, 2)
+
+
+def test_pyramid_of_plots_far_apart(device):
+    """Plots of one batch at different WORLD positions (not centred): the randomly oriented grid subsampling sizes its cells
+    from the largest single-plot diagonal, not from the batch's extent (which made B * cells exceed the grid budget and
+    raised 'sampleDl too small'); the pyramid equals that of the same plots moved together, index for index."""
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import KPConvModel
+    b = synthetic.make_point_batch([21, 22, 23], n_points=1500)
+    lens = np.bincount(b.batch.numpy()).astype(np.int32)
+    ds = synthetic.SyntheticDataset(stat_seeds=range(0, 8))
+    model = KPConvModel(Opt(MODEL_OPTIONS["KPConv"]), "kpconv", ds).to(device).train()
+    np.random.seed(3)
+    from dpcr_agb_amd import kp_index
+    rots = [kp_index.random_grid_rotations(3) for _ in range(4)]
+    pos = torch.round(b.pos * 16384.0) / 16384.0     # 14 fractional bits: the shifts below are exact in fp32
+    near = model.prepare_inputs(pos, b.x, lens, device, rotations=rots)
+    shift = torch.zeros_like(pos)
+    shift[b.batch == 1, 0] = 64.0
+    shift[b.batch == 2, 1] = -128.0
+    far = model.prepare_inputs(pos + shift, b.x, lens, device, rotations=rots)      # (raised before the fix)
+    # level 0: identical differences, identical neighbour matrix; deeper levels: the rotation about the origin rounds the
+    # far plots' barycentres differently in their last bits — same sizes to within a few points
+    assert torch.equal(near["neighbors"][0], far["neighbors"][0])
+    for lvl in range(len(near["points"])):
+        a, c = near["lengths"][lvl].double(), far["lengths"][lvl].double()
+        assert float((a - c).abs().max()) <= 0.02 * float(a.max()) + 2, (lvl, a, c)
