@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void k_kpconv_gather_mm_fwd(const float* __res
                                                               const int32_t* __restrict__ idx, int H, int Ns,
                                                               const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ kp, int K, float inv_ext,
-                                                              float* __restrict__ wf, int N, int Cin, int chunks) {
+                                                              float* __restrict__ wf, int N, int Cin, int chunks,
+                                                              const int32_t* __restrict__ row_ptr) {
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (long long)N * chunks) return;            // (whole waves leave: no barrier in this kernel)
@@ -59,9 +60,12 @@ __global__ __launch_bounds__(256) void k_kpconv_gather_mm_fwd(const float* __res
     kp_f32x4 acc[NC];
 #pragma unroll
     for (int t = 0; t < NC; ++t) acc[t] = kp_f32x4{0.f, 0.f, 0.f, 0.f};
-    const int32_t* row = idx + (long long)n * H;
-    for (int h0 = 0; h0 < H; h0 += 64) {
-        const int myid = h0 + lane < H ? row[h0 + lane] : Ns;
+    // row_ptr != NULL: ragged rows idx[row_ptr[n] .. row_ptr[n + 1]) cut at H entries (the neighbourhood limit); else
+    // the padded matrix idx[n * H + h]
+    const int32_t* row = row_ptr ? idx + row_ptr[n] : idx + (long long)n * H;
+    const int Hn = row_ptr ? min(H, row_ptr[n + 1] - row_ptr[n]) : H;
+    for (int h0 = 0; h0 < Hn; h0 += 64) {
+        const int myid = h0 + lane < Hn ? row[h0 + lane] : Ns;
         const unsigned long long valid = __ballot(myid >= 0 && myid < Ns);
         if (valid == 0ull) break;                          // rows are sorted by distance: the rest is shadow padding
         // two blocks of four neighbours per trip: both blocks' loads are requested before either is used
@@ -110,7 +114,8 @@ __global__ __launch_bounds__(256) void k_kpconv_gather_mm_bwd(const float* __res
                                                               const int32_t* __restrict__ idx, int H, int Ns,
                                                               const float* __restrict__ kp, int K, float inv_ext,
                                                               const float* __restrict__ dwf, float* __restrict__ dx,
-                                                              int ldx, int N, int Cin, int chunks) {
+                                                              int ldx, int N, int Cin, int chunks,
+                                                              const int32_t* __restrict__ row_ptr) {
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (long long)N * chunks) return;
@@ -132,9 +137,12 @@ __global__ __launch_bounds__(256) void k_kpconv_gather_mm_bwd(const float* __res
         }
     }
     const float qx = q[3 * (long long)n], qy = q[3 * (long long)n + 1], qz = q[3 * (long long)n + 2];
-    const int32_t* row = idx + (long long)n * H;
-    for (int h0 = 0; h0 < H; h0 += 64) {
-        const int myid = h0 + lane < H ? row[h0 + lane] : Ns;
+    // row_ptr != NULL: ragged rows idx[row_ptr[n] .. row_ptr[n + 1]) cut at H entries (the neighbourhood limit); else
+    // the padded matrix idx[n * H + h]
+    const int32_t* row = row_ptr ? idx + row_ptr[n] : idx + (long long)n * H;
+    const int Hn = row_ptr ? min(H, row_ptr[n + 1] - row_ptr[n]) : H;
+    for (int h0 = 0; h0 < Hn; h0 += 64) {
+        const int myid = h0 + lane < Hn ? row[h0 + lane] : Ns;
         const unsigned long long valid = __ballot(myid >= 0 && myid < Ns);
         if (valid == 0ull) break;
         const int nblk = (64 - __builtin_clzll(valid) + 15) >> 4;
@@ -172,15 +180,20 @@ __global__ __launch_bounds__(256) void k_kpconv_gather_mm_bwd(const float* __res
 // one-thread-per-element walk over all of it was 2.7 ms of a 32 ms training step).
 __global__ __launch_bounds__(256) void k_kp_maxpool_fwd4(const float* __restrict__ x, int ldx,
                                                          const int32_t* __restrict__ idx, int H, int Ns,
-                                                         float* __restrict__ y, int32_t* __restrict__ arg, int N, int C4) {
+                                                         float* __restrict__ y, int32_t* __restrict__ arg, int N, int C4,
+                                                         const int32_t* __restrict__ row_ptr,
+                                                         const int32_t* __restrict__ width_dev) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = (int)(t / C4), c = (int)(t % C4) * 4;
     if (n >= N) return;
     float best[4] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
     int bi[4] = {-2, -2, -2, -2};
-    const int32_t* row = idx + (long long)n * H;
-    bool shadow = false;
-    for (int h = 0; h < H; ++h) {
+    // ragged rows: a row shorter than the padded matrix would be (min(H, *width_dev) columns: the batch-wide maximum, cut
+    // at the neighbourhood limit) has shadow entries behind it, and the zero shadow row takes part in its max
+    const int32_t* row = row_ptr ? idx + row_ptr[n] : idx + (long long)n * H;
+    const int Hn = row_ptr ? min(H, row_ptr[n + 1] - row_ptr[n]) : H;
+    bool shadow = row_ptr ? Hn < min(H, *width_dev) : false;
+    for (int h = 0; h < Hn; ++h) {
         const int id = row[h];
         if (id >= Ns || id < 0) { shadow = true; break; }      // every later entry is padding too
         const float4 v4 = *reinterpret_cast<const float4*>(x + (long long)id * ldx + c);
@@ -232,7 +245,7 @@ __global__ void k_kp_maxpool_bwd(const float* __restrict__ dy, const int32_t* __
 template <bool BWD>
 static int launch_gather(const float* q, const float* s, const int32_t* idx, int H, int Ns, const float* x, int ldx,
                          const float* kp, int K, float ext, float* wf, const float* dwf, float* dx, int N, int Cin,
-                         hipStream_t st) {
+                         hipStream_t st, const int32_t* row_ptr = nullptr) {
     // one wave per (row, chunk of 16*NC channels)
     const int nc = Cin <= 16 ? 1 : Cin <= 32 ? 2 : 4;
     const int chunks = agb_cdiv(Cin, 16 * nc);
@@ -241,9 +254,9 @@ static int launch_gather(const float* q, const float* s, const int32_t* idx, int
 #define AGB_KP_MM(NC)                                                                                                 \
     do {                                                                                                              \
         if (BWD) hipLaunchKernelGGL((k_kpconv_gather_mm_bwd<NC>), grid, block, 0, st, q, s, idx, H, Ns, kp, K, inv_ext, \
-                                    dwf, dx, ldx, N, Cin, chunks);                                                    \
+                                    dwf, dx, ldx, N, Cin, chunks, row_ptr);                                           \
         else hipLaunchKernelGGL((k_kpconv_gather_mm_fwd<NC>), grid, block, 0, st, q, s, idx, H, Ns, x, ldx, kp, K,    \
-                                inv_ext, wf, N, Cin, chunks);                                                         \
+                                inv_ext, wf, N, Cin, chunks, row_ptr);                                                \
     } while (0)
     if (nc == 1) AGB_KP_MM(1);
     else if (nc == 2) AGB_KP_MM(2);
@@ -284,11 +297,55 @@ int agb_kp_maxpool_fwd(const float* x, int ldx, const int32_t* idx, int H, int N
     if (N == 0) return AGB_OK;
     if (C % 4 == 0 && ldx % 4 == 0)
         hipLaunchKernelGGL(k_kp_maxpool_fwd4, dim3(agb_cdiv((long long)N * (C / 4), 256)), dim3(256), 0,
-                           (hipStream_t)stream, x, ldx, idx, H, Ns, y, argmax, N, C / 4);
+                           (hipStream_t)stream, x, ldx, idx, H, Ns, y, argmax, N, C / 4, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr);
     else
         hipLaunchKernelGGL(k_kp_maxpool_fwd, dim3(agb_cdiv((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, x,
                            ldx, idx, H, Ns, y, argmax, N, C);
     AGB_CHECK_LAUNCH("agb_kp_maxpool_fwd");
+    return AGB_OK;
+}
+
+// The same three passes on RAGGED neighbour rows (row_ptr int32[N + 1], indices int32[total] from agb_ball_query_fill_csr):
+// row n = indices[row_ptr[n] .. row_ptr[n + 1]) cut at `limit` entries (the reference's neighborhood_limits crop of the padded
+// matrix; INT_MAX: none).  max_count_dev (device int32): width of the padded matrix the reference would have built — a row
+// shorter than min(limit, *max_count_dev) has shadow neighbours, whose zero row takes part in the max pool (blocks.py:98-114).
+int agb_kpconv_gather_fwd_csr(const float* q, const float* s, const int32_t* row_ptr, const int32_t* indices, int limit,
+                              int Ns, const float* x, int ldx, const float* kp, int K, float extent, float* wf, int N,
+                              int Cin, void* stream) {
+    AGB_CHECK_ARG(K >= 1 && K <= KP_MAX, "agb_kpconv_gather_fwd_csr: %d kernel points (max %d)", K, KP_MAX);
+    AGB_CHECK_ARG(limit >= 1, "agb_kpconv_gather_fwd_csr: limit %d", limit);
+    if (N == 0) return AGB_OK;
+    AGB_CHECK_ARG(row_ptr != nullptr, "agb_kpconv_gather_fwd_csr: row_ptr required");
+    int rc = launch_gather<false>(q, s, indices, limit, Ns, x, ldx, kp, K, extent, wf, nullptr, nullptr, N, Cin,
+                                  (hipStream_t)stream, row_ptr);
+    if (rc) return rc;
+    AGB_CHECK_LAUNCH("agb_kpconv_gather_fwd_csr");
+    return AGB_OK;
+}
+
+int agb_kpconv_gather_bwd_csr(const float* q, const float* s, const int32_t* row_ptr, const int32_t* indices, int limit,
+                              int Ns, const float* dwf, const float* kp, int K, float extent, float* dx, int ldx, int N,
+                              int Cin, void* stream) {
+    AGB_CHECK_ARG(K >= 1 && K <= KP_MAX, "agb_kpconv_gather_bwd_csr: %d kernel points (max %d)", K, KP_MAX);
+    AGB_CHECK_ARG(limit >= 1, "agb_kpconv_gather_bwd_csr: limit %d", limit);
+    if (N == 0) return AGB_OK;
+    AGB_CHECK_ARG(row_ptr != nullptr, "agb_kpconv_gather_bwd_csr: row_ptr required");
+    int rc = launch_gather<true>(q, s, indices, limit, Ns, nullptr, ldx, kp, K, extent, nullptr, dwf, dx, N, Cin,
+                                 (hipStream_t)stream, row_ptr);
+    if (rc) return rc;
+    AGB_CHECK_LAUNCH("agb_kpconv_gather_bwd_csr");
+    return AGB_OK;
+}
+
+int agb_kp_maxpool_fwd_csr(const float* x, int ldx, const int32_t* row_ptr, const int32_t* indices, int limit,
+                           const int32_t* max_count_dev, int Ns, float* y, int32_t* argmax, int N, int C, void* stream) {
+    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && limit >= 1, "agb_kp_maxpool_fwd_csr: C (%d), ldx multiples of 4", C);
+    if (N == 0) return AGB_OK;
+    AGB_CHECK_ARG(row_ptr && max_count_dev, "agb_kp_maxpool_fwd_csr: row_ptr and max_count_dev required");
+    hipLaunchKernelGGL(k_kp_maxpool_fwd4, dim3(agb_cdiv((long long)N * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, indices, limit, Ns, y, argmax, N, C / 4, row_ptr, max_count_dev);
+    AGB_CHECK_LAUNCH("agb_kp_maxpool_fwd_csr");
     return AGB_OK;
 }
 

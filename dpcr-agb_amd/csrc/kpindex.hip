@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void k_ball_query(const float* __restrict__ qr
                                                     CellGrid g, const int32_t* __restrict__ cell_start,
                                                     const float4* __restrict__ sorted, float r2, int ns,
                                                     int32_t* __restrict__ counts, int32_t* __restrict__ out,
-                                                    int width, int32_t* status) {
+                                                    int width, int32_t* status,
+                                                    const int32_t* __restrict__ row_ptr = nullptr) {
+    // row_ptr != NULL (FILL): ragged output — row q is out[row_ptr[q] .. row_ptr[q + 1]) (the exclusive scan of the count
+    // pass), nothing is padded; NULL: the reference's padded matrix out[q * width + j], shadow index ns behind the row
     __shared__ unsigned long long s_keys[4][FILL ? BQ_CAP : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
@@ -188,9 +191,11 @@ __global__ __launch_bounds__(256) void k_ball_query(const float* __restrict__ qr
         const unsigned long long mykey = lane < count ? s_keys[w][lane] : ~0ull;
         int rank = 0;
         for (int j = 0; j < count; ++j) rank += s_keys[w][j] < mykey ? 1 : 0;
-        int32_t* row = out + (long long)q * width;
+        int32_t* row = row_ptr ? out + row_ptr[q] : out + (long long)q * width;
+        if (row_ptr) width = count;
         if (lane < count && rank < width) row[rank] = (int)(unsigned)(mykey & 0xFFFFFFFFull);
-        for (int j = count + lane; j < width; j += 64) row[j] = ns;
+        if (!row_ptr)
+            for (int j = count + lane; j < width; j += 64) row[j] = ns;
         return;
     }
     // bitonic sort of the hit keys (padded with all-ones) — wave-synchronous on the wave's own LDS slab
@@ -215,8 +220,23 @@ __global__ __launch_bounds__(256) void k_ball_query(const float* __restrict__ qr
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (row_ptr) {
+        int32_t* row = out + row_ptr[q];
+        for (int j = lane; j < count; j += 64) row[j] = (int)(unsigned)(s_keys[w][j] & 0xFFFFFFFFull);
+        return;
+    }
     for (int j = lane; j < width; j += 64)
         out[(long long)q * width + j] = j < count ? (int)(unsigned)(s_keys[w][j] & 0xFFFFFFFFull) : ns;
+}
+
+// ragged -> the reference's padded matrix (for callers of batch_neighbors; the kernels of this library walk the ragged form)
+__global__ void k_csr_to_padded(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ indices, int nq, int width,
+                                int pad, int32_t* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nq * width) return;
+    const int q = (int)(t / width), j = (int)(t % width);
+    const int beg = row_ptr[q], cnt = row_ptr[q + 1] - beg;
+    out[t] = j < cnt ? indices[beg + j] : pad;
 }
 
 // batch element of every row from the element pointer (B is small: linear search per row)
@@ -453,6 +473,48 @@ int agb_ball_query_fill(const float* queries, int nq, const int32_t* q_elem, con
                            cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, out, width, status);
     }
     AGB_CHECK_LAUNCH("agb_ball_query_fill");
+    return AGB_OK;
+}
+
+// Ragged (CSR) form of the radius search — SURVEY.md §8(d): the ball query writes sum(counts) * 4 bytes instead of the padded
+// nq * max_count * 4 (the 16 k-point plots: 20 valid of 265 columns).  Call order: agb_ball_query_count (counts, max_count),
+// agb_ball_query_offsets (row_ptr int32[nq + 1] = exclusive scan of counts, row_ptr[nq] = total; scratch int32[
+// agb_scan_scratch_elems(nq)]), read row_ptr[nq] back, agb_ball_query_fill_csr (indices int32[total]: every row sorted by
+// (d2, index) exactly like the padded rows).  agb_csr_to_padded rebuilds the reference's matrix (pad = ns) for API callers
+// (cpp_neighbors/neighbors.cpp:319-325 pads to the batch-wide maximum).
+int agb_ball_query_offsets(const int32_t* counts, int nq, int32_t* row_ptr, int32_t* scratch, void* stream) {
+    AGB_CHECK_ARG(nq >= 0 && row_ptr != nullptr, "agb_ball_query_offsets: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (nq == 0) { (void)hipMemsetAsync(row_ptr, 0, sizeof(int32_t), s); return AGB_OK; }
+    AGB_CHECK_ARG(counts && scratch, "agb_ball_query_offsets: null pointer");
+    agb_launch_exclusive_scan(counts, nq, row_ptr, scratch, row_ptr + nq, s);
+    AGB_CHECK_LAUNCH("agb_ball_query_offsets");
+    return AGB_OK;
+}
+
+int agb_ball_query_fill_csr(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
+                            const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
+                            const int32_t* row_ptr, int32_t* indices, int32_t* status, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    CellGrid g{origin_cs[0], origin_cs[1], origin_cs[2], 1.0f / origin_cs[3], dims[0], dims[1], dims[2], dims[3]};
+    (void)hipMemsetAsync(status, 0, sizeof(int32_t) * 4, s);
+    if (nq > 0) {
+        AGB_CHECK_ARG(row_ptr && indices, "agb_ball_query_fill_csr: null pointer");
+        float r2 = radius * radius;
+        hipLaunchKernelGGL(k_ball_query<true>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
+                           cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, indices, 0, status, row_ptr);
+    }
+    AGB_CHECK_LAUNCH("agb_ball_query_fill_csr");
+    return AGB_OK;
+}
+
+int agb_csr_to_padded(const int32_t* row_ptr, const int32_t* indices, int nq, int width, int pad, int32_t* out,
+                      void* stream) {
+    AGB_CHECK_ARG(nq >= 0 && width >= 0, "agb_csr_to_padded: bad sizes");
+    if (nq == 0 || width == 0) return AGB_OK;
+    hipLaunchKernelGGL(k_csr_to_padded, dim3((unsigned)agb_cdiv((long long)nq * width, 256)), dim3(256), 0,
+                       (hipStream_t)stream, row_ptr, indices, nq, width, pad, out);
+    AGB_CHECK_LAUNCH("agb_csr_to_padded");
     return AGB_OK;
 }
 

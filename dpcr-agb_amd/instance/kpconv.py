@@ -49,8 +49,14 @@ class KPConvModel(InstanceBase):
     # ------------------------------------------------------------------ input pyramid (kpconv.py:145-264)
     def _crop(self, mat, layer):
         if len(self.neighborhood_limits) > 0:
+            if hasattr(mat, "cropped"):          # ragged rows: the limit travels with them, nothing is copied
+                return mat.cropped(self.neighborhood_limits[layer])
             return mat[:, :self.neighborhood_limits[layer]].contiguous()
         return mat
+
+    # Neighbour lists stay RAGGED inside the pyramid (kp_index.Neighbors; `.padded()` gives the reference's matrix): set to
+    # False for the padded int32 matrices of earlier rounds (A/B measurements)
+    ragged_neighbors = True
 
     def prepare_inputs(self, stacked_points, stacked_features, stack_lengths, device, rotations=None, bounds=None):
         """stacked_points [N,3] / stacked_features [N,F] (numpy or tensors), stack_lengths int[B].
@@ -94,12 +100,16 @@ class KPConvModel(InstanceBase):
                     src = kp_index.rotate_points(pts, lens, rot, False)
                 ext = (diag,) * 3 if self.random_grid_orient else tuple(np.asarray(bounds[3:]) - np.asarray(bounds[:3]))
                 sub_job = kp_index.subsample_begin(src, None, lens, dl, ext)
-            want = ([conv_job.max_count] if conv_job else []) + ([pool_job.max_count] if pool_job else []) + \
+            rag = self.ragged_neighbors
+            sizes = lambda j: [j.max_count, j.row_ptr[-1:]] if rag else [j.max_count]      # noqa: E731
+            finish = (lambda j, g: kp_index.neighbors_finish_csr(j, g.pop(0)[0], g.pop(0)[0])) if rag else \
+                (lambda j, g: kp_index.neighbors_finish(j, g.pop(0)[0]))
+            want = (sizes(conv_job) if conv_job else []) + (sizes(pool_job) if pool_job else []) + \
                 ([sub_job.out_ptr, sub_job.status[:1]] if sub_job else [])
             got = kp_index.read_back(*want) if want else []
-            conv_i = kp_index.neighbors_finish(conv_job, got.pop(0)[0]) if conv_job else empty_i
+            conv_i = finish(conv_job, got) if conv_job else empty_i
             if pool_job is not None:
-                pools[-1] = self._crop(kp_index.neighbors_finish(pool_job, got.pop(0)[0]), len(points) - 1)
+                pools[-1] = self._crop(finish(pool_job, got), len(points) - 1)
                 pool_job = None
             if strided:
                 optr, st = got
@@ -112,10 +122,13 @@ class KPConvModel(InstanceBase):
             else:
                 pool_i, pool_p, pool_b = empty_i, torch.zeros(0, 3, device=device), np.zeros(0, dtype=np.int64)
             points.append(pts)
+            if hasattr(conv_i, "cropped"):
+                conv_i.agb_symmetric = True      # (kept by cropped() only while the limit cuts nothing)
             nb = self._crop(conv_i, len(points) - 1)
             # an uncropped radius search of a point set against itself is symmetric (d2(a, b) is computed from the same
             # differences either way): KPConv layers on it take the scatter-free backward (KPConvSymmetricFunction)
-            nb.agb_symmetric = conv_job is not None and nb.shape[1] == conv_i.shape[1]
+            if not hasattr(nb, "cropped"):
+                nb.agb_symmetric = conv_job is not None and nb.shape[1] == conv_i.shape[1]
             neighbors.append(nb)
             pools.append(pool_i if pool_i is None else self._crop(pool_i, len(points) - 1))
             lengths.append(torch.from_numpy(lens.copy()))
@@ -126,8 +139,12 @@ class KPConvModel(InstanceBase):
             if "global" in block or "upsample" in block:
                 break
         if pool_job is not None:     # (an architecture that ends on a strided block)
-            pools[-1] = self._crop(kp_index.neighbors_finish(pool_job, kp_index.read_back(pool_job.max_count)[0][0]),
-                                   len(points) - 1)
+            if self.ragged_neighbors:
+                got = kp_index.read_back(pool_job.max_count, pool_job.row_ptr[-1:])
+                pools[-1] = self._crop(kp_index.neighbors_finish_csr(pool_job, got[0][0], got[1][0]), len(points) - 1)
+            else:
+                pools[-1] = self._crop(kp_index.neighbors_finish(pool_job, kp_index.read_back(pool_job.max_count)[0][0]),
+                                       len(points) - 1)
         ptr = np.zeros(len(lengths[-1]) + 1, dtype=np.int32)
         np.cumsum(lengths[-1].numpy(), out=ptr[1:])
         return dict(points=points, neighbors=neighbors, pools=pools, lengths=lengths, features=feats,
@@ -164,8 +181,9 @@ class KPConvModel(InstanceBase):
             cur.wait_event(ev)
             for v in inp.values():      # built on the side stream, consumed on the compute stream
                 for t in (v if isinstance(v, (list, tuple)) else [v]):
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        t.record_stream(cur)
+                    for u in (t.tensors() if hasattr(t, "tensors") else [t]):
+                        if isinstance(u, torch.Tensor) and u.is_cuda:
+                            u.record_stream(cur)
             self.input = Opt(inp)
         else:
             self.input = Opt(self._pyramid(data, device))

@@ -29,6 +29,9 @@ _lib.declare("agb_rotate_points", [_V, _V, _V, _I, _I, _V, _V])
 _lib.declare("agb_ball_grid_build", [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V])
 _lib.declare("agb_ball_query_count", [_V, _I, _V, _V, _V, _V, _V, _F, _V, _V, _V])
 _lib.declare("agb_ball_query_fill", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V])
+_lib.declare("agb_ball_query_offsets", [_V, _I, _V, _V, _V])
+_lib.declare("agb_ball_query_fill_csr", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _V, _V, _V, _V])
+_lib.declare("agb_csr_to_padded", [_V, _V, _I, _I, _I, _V, _V])
 _lib.declare("agb_grid_subsample_workspace_bytes", [_I, _I, _I])
 _lib.declare("agb_grid_subsample_ws", [_V, _V, _I, _I, _V, _V, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V])
 
@@ -164,10 +167,61 @@ def read_back(*tensors):
     return out
 
 
+class Neighbors:
+    """The radius neighbours of nq queries as RAGGED rows — what the kernels of this library walk (the
+    ball query writes sum(counts) * 4 bytes instead of the nq x max_count matrix the reference pads to,
+    cpp_neighbors/neighbors.cpp:319-325): ``row_ptr`` int32[nq + 1], ``indices`` int32[total], every row sorted by
+    (distance, index).  ``limit``: the reference's neighborhood_limits crop (rows are cut at that many entries).
+    ``padded()`` builds the reference's int32 [nq, width] matrix (shadow index ``ns`` behind every row) on demand;
+    ``shape`` is that matrix's shape."""
+    __slots__ = ("row_ptr", "indices", "nq", "ns", "max_count", "max_count_dev", "limit", "agb_symmetric", "_padded")
+
+    def __init__(self, row_ptr, indices, nq, ns, max_count, max_count_dev):
+        self.row_ptr, self.indices, self.nq, self.ns = row_ptr, indices, int(nq), int(ns)
+        self.max_count, self.max_count_dev = int(max_count), max_count_dev
+        self.limit, self.agb_symmetric, self._padded = 0x7fffffff, False, None
+
+    @property
+    def width(self):
+        return min(self.max_count, self.limit)
+
+    @property
+    def shape(self):
+        return (self.nq, self.width)
+
+    @property
+    def device(self):
+        return self.row_ptr.device
+
+    def cropped(self, limit):
+        out = Neighbors(self.row_ptr, self.indices, self.nq, self.ns, self.max_count, self.max_count_dev)
+        out.limit, out.agb_symmetric = min(self.limit, int(limit)), self.agb_symmetric and int(limit) >= self.max_count
+        return out
+
+    def padded(self):
+        if self._padded is None:
+            out = torch.empty(self.nq, self.width, dtype=torch.int32, device=self.row_ptr.device)
+            _lib.call("agb_csr_to_padded", _P(self.row_ptr), _P(self.indices), self.nq, self.width, self.ns, _P(out),
+                      _lib.stream())
+            self._padded = out
+        return self._padded
+
+    def tensors(self):
+        return [t for t in (self.row_ptr, self.indices, self.max_count_dev, self._padded) if t is not None]
+
+    def cpu(self):
+        """The padded matrix on the host (what code written against the reference's matrices asks for)."""
+        return self.padded().cpu()
+
+    def numel(self):
+        return self.nq * self.width
+
+
 class NeighborJob:
-    """A radius search whose count pass is enqueued; ``max_count`` (device int32[1]) is the width of the padded matrix."""
+    """A radius search whose count pass is enqueued; ``max_count`` (device int32[1]) is the width of the padded matrix,
+    ``row_ptr`` the exclusive scan of the counts (``row_ptr[nq]`` = total number of neighbours)."""
     __slots__ = ("q", "q_elem", "origin_cs", "dims_c", "cell_start", "sorted_pts", "radius", "ns", "nq", "max_count",
-                 "counts")
+                 "counts", "row_ptr")
 
 
 def neighbors_begin(q, s, ql, sl, radius, bounds):
@@ -202,8 +256,26 @@ def neighbors_begin(q, s, ql, sl, radius, bounds):
     job.max_count = torch.empty(1, dtype=torch.int32, device=dev)
     _lib.call("agb_ball_query_count", _P(q), nq, _P(job.q_elem), job.origin_cs, job.dims_c, _P(job.cell_start),
               _P(job.sorted_pts), radius, _P(job.counts), _P(job.max_count), _lib.stream())
+    job.row_ptr = torch.empty(nq + 1, dtype=torch.int32, device=dev)
+    scan = torch.empty(_lib.scan_scratch_elems(nq), dtype=torch.int32, device=dev)
+    _lib.call("agb_ball_query_offsets", _P(job.counts), nq, _P(job.row_ptr), _P(scan), _lib.stream())
     job.radius, job.ns, job.nq = radius, ns, nq
     return job
+
+
+def neighbors_finish_csr(job, width, total):
+    """Fill pass into ragged rows for a job whose ``max_count`` and ``row_ptr[nq]`` have been read back."""
+    width, total = int(width), int(total)
+    if width == 0:
+        raise RuntimeError("Error")
+    if width > 1024:
+        raise _lib.AgbError("a neighbourhood holds more than 1024 points: beyond the kernel's LDS capacity")
+    dev = job.q.device
+    indices = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    status = torch.empty(4, dtype=torch.int32, device=dev)
+    _lib.call("agb_ball_query_fill_csr", _P(job.q), job.nq, _P(job.q_elem), job.origin_cs, job.dims_c, _P(job.cell_start),
+              _P(job.sorted_pts), job.radius, job.ns, _P(job.row_ptr), _P(indices), _P(status), _lib.stream())
+    return Neighbors(job.row_ptr, indices, job.nq, job.ns, width, job.max_count)
 
 
 def neighbors_finish(job, width):
@@ -248,6 +320,21 @@ def batch_neighbors(queries, supports, q_batches, s_batches, radius, bounds=None
     # the padded matrix the reference returns is as wide as the fullest neighbourhood: one host read
     out = neighbors_finish(job, read_back(job.max_count)[0][0])
     return out if q_is_t else out.cpu().numpy()
+
+
+def batch_neighbors_ragged(queries, supports, q_batches, s_batches, radius, bounds=None):
+    """The same search as ragged rows (``Neighbors``: row_ptr / indices on the device, ``.padded()`` for the matrix)."""
+    q, _ = _to_dev(queries, torch.float32)
+    s, _ = _to_dev(supports, torch.float32)
+    ql, sl = _lengths(q_batches), _lengths(s_batches)
+    _check_shapes(q, s, ql, sl)
+    if q.shape[0] == 0 or s.shape[0] == 0:
+        raise RuntimeError("Error")
+    if bounds is None:
+        bounds = support_bounds(s, sl)
+    job = neighbors_begin(q, s, ql, sl, radius, bounds)
+    width, total = read_back(job.max_count, job.row_ptr[-1:])
+    return neighbors_finish_csr(job, width[0], total[0])
 
 
 def create_3D_rotations(axis, angle):

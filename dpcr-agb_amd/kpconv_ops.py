@@ -11,8 +11,20 @@ _lib.declare("agb_kp_maxpool_fwd", [_V, _I, _V, _I, _I, _V, _V, _I, _I, _V])
 _lib.declare("agb_kp_maxpool_bwd", [_V, _V, _V, _I, _I, _I, _V])
 
 
+_lib.declare("agb_kpconv_gather_fwd_csr", [_V, _V, _V, _V, _I, _I, _V, _I, _V, _I, _F, _V, _I, _I, _V])
+_lib.declare("agb_kpconv_gather_bwd_csr", [_V, _V, _V, _V, _I, _I, _V, _V, _I, _F, _V, _I, _I, _I, _V])
+_lib.declare("agb_kp_maxpool_fwd_csr", [_V, _I, _V, _V, _I, _V, _I, _V, _V, _I, _I, _V])
+
+
+def is_ragged(idx):
+    return hasattr(idx, "row_ptr")
+
+
 def as_index(idx):
-    """Neighbour matrices are int32 on the device; the reference hands int64 (kpconv.py:224-225) — converted once."""
+    """Neighbour matrices are int32 on the device; the reference hands int64 (kpconv.py:224-225) — converted once.  Ragged
+    neighbour rows (kp_index.Neighbors) pass through: the kernels walk them as they are."""
+    if is_ragged(idx):
+        return idx
     if idx.dtype != torch.int32:
         idx = idx.to(torch.int32)
     return idx.contiguous()
@@ -29,18 +41,29 @@ class KPGatherFunction(torch.autograd.Function):
         Ns, cin = x.shape
         K = kernel_points.shape[0]
         wf = _gather(x, q_pts, s_pts, idx, kernel_points, extent)
-        ctx.save_for_backward(q_pts, s_pts, idx, kernel_points)
+        if is_ragged(idx):
+            ctx.ragged = idx
+            ctx.save_for_backward(q_pts, s_pts, kernel_points)
+        else:
+            ctx.ragged = None
+            ctx.save_for_backward(q_pts, s_pts, idx, kernel_points)
         ctx.cfg = (float(extent), Ns, cin)
         return wf
 
     @staticmethod
     def backward(ctx, dwf):
-        q_pts, s_pts, idx, kernel_points = ctx.saved_tensors
         extent, Ns, cin = ctx.cfg
         dwf = dwf.contiguous()
+        dx = torch.zeros(Ns, cin, dtype=torch.float32, device=dwf.device)
+        if ctx.ragged is not None:
+            q_pts, s_pts, kernel_points = ctx.saved_tensors
+            r, K = ctx.ragged, kernel_points.shape[0]
+            _lib.call("agb_kpconv_gather_bwd_csr", _P(q_pts), _P(s_pts), _P(r.row_ptr), _P(r.indices), r.limit, Ns, _P(dwf),
+                      _P(kernel_points), K, extent, _P(dx), dx.stride(0), r.nq, cin, _lib.stream())
+            return dx, None, None, None, None, None
+        q_pts, s_pts, idx, kernel_points = ctx.saved_tensors
         N, H = idx.shape
         K = kernel_points.shape[0]
-        dx = torch.zeros(Ns, cin, dtype=torch.float32, device=dwf.device)
         _lib.call("agb_kpconv_gather_bwd", _P(q_pts), _P(s_pts), _P(idx), H, Ns, _P(dwf), _P(kernel_points), K, extent,
                   _P(dx), dx.stride(0), N, cin, _lib.stream())
         return dx, None, None, None, None, None
@@ -51,6 +74,10 @@ def _gather(x, q_pts, s_pts, idx, kernel_points, extent):
     Ns, cin = x.shape
     K = kernel_points.shape[0]
     wf = torch.empty(N, K, cin, dtype=torch.float32, device=x.device)
+    if is_ragged(idx):
+        _lib.call("agb_kpconv_gather_fwd_csr", _P(q_pts), _P(s_pts), _P(idx.row_ptr), _P(idx.indices), idx.limit, Ns, _P(x),
+                  x.stride(0), _P(kernel_points), K, float(extent), _P(wf), N, cin, _lib.stream())
+        return wf
     _lib.call("agb_kpconv_gather_fwd", _P(q_pts), _P(s_pts), _P(idx), H, Ns, _P(x), x.stride(0), _P(kernel_points), K,
               float(extent), _P(wf), N, cin, _lib.stream())
     return wf
@@ -82,14 +109,22 @@ class KPConvSymmetricFunction(torch.autograd.Function):
         out = dense_product(wf, weights.reshape(K * cin, cout), bn_stats=any(ctx.needs_input_grad), opts=ctx.opts)
         # (by the same symmetry dW[k,c,o] = sum_j x[j,c] wfd[j,k,o] with the mirrored gather of dy, which would let the
         # backward keep x instead of the 15x larger wf; measured 0.1 ms/step slower in the [N,16]^T [N,240] product shape)
-        ctx.save_for_backward(wf, pts, idx, kernel_points, weights)
+        if is_ragged(idx):
+            ctx.ragged = idx
+            ctx.save_for_backward(wf, pts, kernel_points, weights)
+        else:
+            ctx.ragged = None
+            ctx.save_for_backward(wf, pts, idx, kernel_points, weights)
         ctx.extent = float(extent)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         from .sparse_ops import dense_product, dense_weight_grad
-        wf, pts, idx, kernel_points, weights = ctx.saved_tensors
+        if ctx.ragged is not None:
+            (wf, pts, kernel_points, weights), idx = ctx.saved_tensors, ctx.ragged
+        else:
+            wf, pts, idx, kernel_points, weights = ctx.saved_tensors
         K, cin, cout = weights.shape
         dy = dy.contiguous()
         dx = dw = None
@@ -111,7 +146,13 @@ class KPMaxPoolFunction(torch.autograd.Function):
         Ns, c = x.shape
         y = torch.empty(N, c, dtype=torch.float32, device=x.device)
         arg = torch.empty(N, c, dtype=torch.int32, device=x.device)
-        _lib.call("agb_kp_maxpool_fwd", _P(x), x.stride(0), _P(idx), H, Ns, _P(y), _P(arg), N, c, _lib.stream())
+        if is_ragged(idx) and c % 4 == 0 and x.stride(0) % 4 == 0:
+            _lib.call("agb_kp_maxpool_fwd_csr", _P(x), x.stride(0), _P(idx.row_ptr), _P(idx.indices), idx.limit,
+                      _P(idx.max_count_dev), Ns, _P(y), _P(arg), N, c, _lib.stream())
+        else:
+            if is_ragged(idx):
+                idx = idx.padded()
+            _lib.call("agb_kp_maxpool_fwd", _P(x), x.stride(0), _P(idx), H, Ns, _P(y), _P(arg), N, c, _lib.stream())
         ctx.save_for_backward(arg)
         ctx.cfg = (Ns, c)
         return y

@@ -355,6 +355,19 @@ int agb_ball_query_count(const float* queries, int nq, const int32_t* q_elem, co
 int agb_ball_query_fill(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
                         const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
                         int width, int32_t* out, int32_t* status, void* stream);
+/* RAGGED (CSR) radius search — SURVEY.md §8(d): the ball query then writes sum(counts) * 4 bytes instead of the padded
+ * nq * max_count * 4 (16 k-point plots: 20 valid of 265 columns; the reference pads to the batch-wide maximum,
+ * cpp_neighbors/neighbors.cpp:319-325, and gathers the padded matrix, modules/KPConv/blocks.py:304-310,383-386).
+ * Order: agb_ball_query_count -> agb_ball_query_offsets (row_ptr int32[nq + 1] = exclusive scan of counts, row_ptr[nq] =
+ * total; scratch int32[agb_scan_scratch_elems(nq)]) -> read row_ptr[nq] back -> agb_ball_query_fill_csr (indices
+ * int32[total]; every row sorted by (d2, index) exactly like the padded rows).  agb_csr_to_padded rebuilds the reference's
+ * matrix (pad = ns) for callers of batch_neighbors. */
+int agb_ball_query_offsets(const int32_t* counts, int nq, int32_t* row_ptr, int32_t* scratch, void* stream);
+int agb_ball_query_fill_csr(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
+                            const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
+                            const int32_t* row_ptr, int32_t* indices, int32_t* status, void* stream);
+int agb_csr_to_padded(const int32_t* row_ptr, const int32_t* indices, int nq, int width, int pad, int32_t* out,
+                      void* stream);
 /* Grid subsampling (barycentres, optional feature means), canonical order = cell key ascending per cloud.
  * cap = cells reserved per cloud (>= the cloud's NX*NY*NZ; status[0] counts violations).  workspace: one device buffer of
  * agb_grid_subsample_workspace_bytes(n, B, cap) bytes (all internal scratch is carved from it).
@@ -377,6 +390,19 @@ int agb_kpconv_gather_bwd(const float* q, const float* s, const int32_t* idx, in
 int agb_kp_maxpool_fwd(const float* x, int ldx, const int32_t* idx, int H, int Ns, float* y, int32_t* argmax, int N,
                        int C, void* stream);
 int agb_kp_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int ldx, int N, int C, void* stream);
+/* The gather passes and the max-pooled shortcut on RAGGED rows (row_ptr / indices of agb_ball_query_fill_csr): row n =
+ * indices[row_ptr[n] .. row_ptr[n + 1]) cut at `limit` entries (the reference's neighborhood_limits crop of the padded matrix;
+ * INT_MAX: none).  max_count_dev (device int32, from agb_ball_query_count): the width the padded matrix would have — a row
+ * shorter than min(limit, *max_count_dev) has shadow neighbours, whose zero feature row takes part in the max
+ * (blocks.py:98-114).  Same results as the padded entry points. */
+int agb_kpconv_gather_fwd_csr(const float* q, const float* s, const int32_t* row_ptr, const int32_t* indices, int limit,
+                              int Ns, const float* x, int ldx, const float* kp, int K, float extent, float* wf, int N,
+                              int Cin, void* stream);
+int agb_kpconv_gather_bwd_csr(const float* q, const float* s, const int32_t* row_ptr, const int32_t* indices, int limit,
+                              int Ns, const float* dwf, const float* kp, int K, float extent, float* dx, int ldx, int N,
+                              int Cin, void* stream);
+int agb_kp_maxpool_fwd_csr(const float* x, int ldx, const int32_t* row_ptr, const int32_t* indices, int limit,
+                           const int32_t* max_count_dev, int Ns, float* y, int32_t* argmax, int N, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GridSampling3D(size, quantize_coords=True, mode="last") for a batch of clouds

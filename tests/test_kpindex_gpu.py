@@ -118,3 +118,35 @@ def test_error_behaviour(device):
         kp_index.batch_neighbors(pts, pts, [4], [3], 0.1)
     with pytest.raises(RuntimeError):
         kp_index.batch_neighbors(pts[:0], pts, [0], [4], 0.1)
+
+
+@pytest.mark.parametrize("n_points,radius", [(3000, 0.0625), (16000, 0.03125)])
+def test_ragged_neighbours_equal_the_padded_matrix(device, n_points, radius):
+    """The ragged (CSR) radius search the kernels walk since round 3 — rows of exactly count[q] entries, nothing padded —
+    against the padded matrix of the reference's interface: same rows, same order; the KPConv gather (forward, scatter
+    backward), the max-pooled shortcut and the neighbourhood-limit crop give the same results on either form."""
+    from dpcr_agb_amd import kp_index, synthetic
+    from dpcr_agb_amd.kpconv_ops import KPGatherFunction, KPMaxPoolFunction
+    b = synthetic.make_point_batch([31, 32, 33], n_points=n_points)
+    pts = b.pos.to(device)
+    lens = np.bincount(b.batch.numpy()).astype(np.int32)
+    mat = kp_index.batch_neighbors(pts, pts, lens, lens, radius)
+    rag = kp_index.batch_neighbors_ragged(pts, pts, lens, lens, radius)
+    assert rag.shape == tuple(mat.shape) and torch.equal(rag.padded(), mat)
+    counts = (mat < len(pts)).sum(1)
+    assert torch.equal((rag.row_ptr[1:] - rag.row_ptr[:-1]).long(), counts) and int(rag.row_ptr[-1]) == int(counts.sum())
+    print(f"{n_points} pts: padded {mat.numel() * 4 / 1e6:.1f} MB, ragged {(rag.indices.numel() + rag.row_ptr.numel()) * 4 / 1e6:.1f} MB "
+          f"(mean {float(counts.float().mean()):.1f} of {mat.shape[1]} columns)")
+    torch.manual_seed(0)
+    cin, K = 32, 15
+    kp = (torch.rand(K, 3, device=device) - 0.5) * radius
+    res = {}
+    for name, idx in (("padded", mat), ("ragged", rag), ("padded_crop", mat[:, :12].contiguous()), ("ragged_crop", rag.cropped(12))):
+        x = torch.randn(len(pts), cin, device=device, generator=torch.Generator(device=device).manual_seed(1)).requires_grad_(True)
+        wf = KPGatherFunction.apply(x, pts, pts, idx, kp, radius * 0.4)
+        mp = KPMaxPoolFunction.apply(x, idx)
+        (wf.square().sum() + mp.sum()).backward()
+        res[name] = (wf.detach(), mp.detach(), x.grad.clone())
+    for a, c in (("padded", "ragged"), ("padded_crop", "ragged_crop")):
+        assert torch.equal(res[a][0], res[c][0]) and torch.equal(res[a][1], res[c][1])
+        assert float((res[a][2] - res[c][2]).abs().max()) <= 1e-5 * float(res[a][2].abs().max())   # (atomic scatter order)

@@ -57,6 +57,7 @@ def main():
     pyr = model.prepare_inputs(pos, x, lens, dev)
     for lvl, (pts, nb, pl) in enumerate(zip(pyr["points"], pyr["neighbors"], pyr["pools"])):
         for name, m, ns in (("conv", nb, len(pts)), ("pool", pl, len(pts))):
+            m = m.padded() if hasattr(m, "padded") else m
             if m is None or m.numel() == 0 or m.shape[0] == 0:
                 continue
             line = f"level {lvl} {name}: rows {m.shape[0]:7d} width {m.shape[1]:4d}"
