@@ -494,7 +494,8 @@ int agb_ball_query_offsets(const int32_t* counts, int nq, int32_t* row_ptr, int3
 
 int agb_ball_query_fill_csr(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
                             const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
-                            const int32_t* row_ptr, int32_t* indices, int32_t* status, void* stream) {
+                            const int32_t* row_ptr, int32_t* indices, int capacity, int32_t* status, void* stream) {
+    AGB_CHECK_ARG(capacity >= 0, "agb_ball_query_fill_csr: capacity %d", capacity);   // (= row_ptr[nq], read back by the caller)
     hipStream_t s = (hipStream_t)stream;
     CellGrid g{origin_cs[0], origin_cs[1], origin_cs[2], 1.0f / origin_cs[3], dims[0], dims[1], dims[2], dims[3]};
     (void)hipMemsetAsync(status, 0, sizeof(int32_t) * 4, s);

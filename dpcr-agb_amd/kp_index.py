@@ -30,7 +30,7 @@ _lib.declare("agb_ball_grid_build", [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V,
 _lib.declare("agb_ball_query_count", [_V, _I, _V, _V, _V, _V, _V, _F, _V, _V, _V])
 _lib.declare("agb_ball_query_fill", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V])
 _lib.declare("agb_ball_query_offsets", [_V, _I, _V, _V, _V])
-_lib.declare("agb_ball_query_fill_csr", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _V, _V, _V, _V])
+_lib.declare("agb_ball_query_fill_csr", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _V, _V, _I, _V, _V])
 _lib.declare("agb_csr_to_padded", [_V, _V, _I, _I, _I, _V, _V])
 _lib.declare("agb_grid_subsample_workspace_bytes", [_I, _I, _I])
 _lib.declare("agb_grid_subsample_ws", [_V, _V, _I, _I, _V, _V, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V])
@@ -274,7 +274,7 @@ def neighbors_finish_csr(job, width, total):
     indices = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
     status = torch.empty(4, dtype=torch.int32, device=dev)
     _lib.call("agb_ball_query_fill_csr", _P(job.q), job.nq, _P(job.q_elem), job.origin_cs, job.dims_c, _P(job.cell_start),
-              _P(job.sorted_pts), job.radius, job.ns, _P(job.row_ptr), _P(indices), _P(status), _lib.stream())
+              _P(job.sorted_pts), job.radius, job.ns, _P(job.row_ptr), _P(indices), total, _P(status), _lib.stream())
     return Neighbors(job.row_ptr, indices, job.nq, job.ns, width, job.max_count)
 
 

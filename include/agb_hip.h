@@ -360,12 +360,12 @@ int agb_ball_query_fill(const float* queries, int nq, const int32_t* q_elem, con
  * cpp_neighbors/neighbors.cpp:319-325, and gathers the padded matrix, modules/KPConv/blocks.py:304-310,383-386).
  * Order: agb_ball_query_count -> agb_ball_query_offsets (row_ptr int32[nq + 1] = exclusive scan of counts, row_ptr[nq] =
  * total; scratch int32[agb_scan_scratch_elems(nq)]) -> read row_ptr[nq] back -> agb_ball_query_fill_csr (indices
- * int32[total]; every row sorted by (d2, index) exactly like the padded rows).  agb_csr_to_padded rebuilds the reference's
+ * int32[capacity], capacity = that total; every row sorted by (d2, index) exactly like the padded rows).  agb_csr_to_padded rebuilds the reference's
  * matrix (pad = ns) for callers of batch_neighbors. */
 int agb_ball_query_offsets(const int32_t* counts, int nq, int32_t* row_ptr, int32_t* scratch, void* stream);
 int agb_ball_query_fill_csr(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
                             const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
-                            const int32_t* row_ptr, int32_t* indices, int32_t* status, void* stream);
+                            const int32_t* row_ptr, int32_t* indices, int capacity, int32_t* status, void* stream);
 int agb_csr_to_padded(const int32_t* row_ptr, const int32_t* indices, int nq, int width, int pad, int32_t* out,
                       void* stream);
 /* Grid subsampling (barycentres, optional feature means), canonical order = cell key ascending per cloud.

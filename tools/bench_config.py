@@ -94,6 +94,7 @@ def shape_table(groups):
     """Per distinct (rows, Cin, Cout) of the dense products and weight gradients: time, TFLOP/s and GB/s of 3 steps."""
     for name, cost, sig in (("agb_spconv_fwd_opt", conv_call_cost, lambda x: (x[9], (x[10], x[11], x[12]))),
                             ("agb_spconv_bwd_weight_lp", wgrad_call_cost, lambda x: (x[7], (x[8], x[9], x[10]))),
+                            ("agb_spconv_bwd_weight_ws", wgrad_call_cost, lambda x: (x[7], (x[8], x[9], x[10]))),
                             ("agb_bn_stats_tracked", lambda x: (0.0, x[2] * x[3] * 4.0), lambda x: (x[2], (x[3],))),
                             ("agb_bn_act_fwd", lambda x: (0.0, 2.0 * x[2] * x[3] * 4.0), lambda x: (x[2], (x[3],))),
                             ("agb_bn_act_bwd_colsum", lambda x: (0.0, 3.0 * x[4] * x[5] * 4.0), lambda x: (x[4], (x[5],))),
@@ -195,7 +196,7 @@ def run_pointnet(a):
     groups = ct.by_name()
     top_table(groups)
     costs = {"agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_fwd_lp": conv_call_cost,
-             "agb_spconv_bwd_weight_lp": wgrad_call_cost}
+             "agb_spconv_bwd_weight_lp": wgrad_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost}
     dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
     roof = roofline_entry(dom, groups[dom], costs[dom])
     line = dict(metric="training plots/sec (16k-pt NFI plots) MPointNet", value=round(B * a.steps / dt, 2), unit="plots/s",
@@ -221,6 +222,13 @@ def ballquery_cost(args):
     SURVEY.md §8d: Ns*12 (supports) + Nq*12 (queries) + Nq*width*4 (the padded matrix the API returns)."""
     nq, ns, width = args[1], args[8], args[9]
     return 0.0, ns * 16.0 + nq * 12.0 + nq * width * 4.0
+
+
+def ballquery_cost_csr(args):
+    """agb_ball_query_fill_csr(queries, nq, q_elem, origin_cs, dims, cell_start, sorted, radius, ns, row_ptr, indices,
+    capacity, status): SURVEY.md §8d ragged form: Ns*16 (sorted supports) + Nq*12 (queries) + Nq*4 (row_ptr) + sum(counts)*4."""
+    nq, ns, total = args[1], args[8], args[11]
+    return 0.0, ns * 16.0 + nq * 16.0 + total * 4.0
 
 
 def run_kpconv(a):
@@ -265,14 +273,16 @@ def run_kpconv(a):
     top_table(groups, 12)
     if a.shapes:
         shape_table(groups)
-    costs = {"agb_ball_query_fill": ballquery_cost, "agb_spconv_fwd_opt": conv_call_cost,
+    costs = {"agb_ball_query_fill": ballquery_cost, "agb_ball_query_fill_csr": ballquery_cost_csr,
+             "agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost,
              "agb_spconv_bwd_weight_lp": wgrad_call_cost}
     dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
     roof = roofline_entry(dom, groups[dom], costs[dom])
-    index_names = ("agb_ball_query_fill", "agb_ball_query_count", "agb_ball_grid_build", "agb_grid_subsample_ws",
-                   "agb_elem_bbox", "agb_elem_of_row", "agb_rotate_points")
+    index_names = ("agb_ball_query_fill", "agb_ball_query_fill_csr", "agb_ball_query_offsets", "agb_ball_query_count",
+                   "agb_ball_grid_build", "agb_grid_subsample_ws", "agb_elem_bbox", "agb_elem_of_row", "agb_rotate_points")
     index_ms = sum(groups[n]["ms"] for n in index_names if n in groups) / 3
-    bq = roofline_entry("agb_ball_query_fill", groups["agb_ball_query_fill"], ballquery_cost)
+    fill = "agb_ball_query_fill_csr" if "agb_ball_query_fill_csr" in groups else "agb_ball_query_fill"
+    bq = roofline_entry(fill, groups[fill], costs[fill])
     line = dict(metric="training plots/sec KPConv rigid", value=round(B * a.steps / dt, 2), unit="plots/s", n_gpus=1,
                 steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
                 scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
