@@ -409,6 +409,13 @@ def main():
             # step ago) and stages the levels of batch i+2 — the host never waits for a device read-back
             model.prefetch_input(pool[(i + 2) % len(pool)], dev)
 
+    # The side-stream input pipeline is worth 6 % of throughput on one GPU, but a second hardware queue with cross-stream
+    # events keeps one thread of the HIP runtime busy for ~9 ms of CPU per step (10.2 -> 18.3 ms of CPU per step and rank,
+    # profiles/r03_host_cpu.txt).  Where the ranks of a node have fewer than ~2.5 cores each (cgroup quota / world size) that
+    # thread would get the whole process throttled: build the input on the compute stream there.
+    if not args.no_prefetch and usable_cores() / max(world, 1) < 2.5:
+        args.no_prefetch = True
+        log(f"{usable_cores()} usable cores for {world} rank(s): input pipeline on the compute stream (--no-prefetch)")
     # allocator pools grown up front (per stream): no device allocation inside the timed region
     model.reserve_workspace(dev, main_bytes=args.reserve_gib << 30, side_bytes=(args.reserve_gib << 30) // 2)
     if not args.no_prefetch and len(pool) >= 3:
@@ -534,6 +541,7 @@ def main():
                                    f"voxel 0.0125 (0.375x0.375x0.5 m), batch {args.batch}/GPU, F={args.features}, "
                                    f"~{voxels:.0f} voxels/plot, fwd+bwd+AdaBelief incl. coordinate hash/kernel maps",
                        "global_batch": gb, "parallelism": f"dp{world}", "final_loss": round(loss, 5),
+                       "input_pipeline": "compute stream" if args.no_prefetch else "side stream, two batches ahead",
                        "operands": {"fp32": "fp32 MFMA (exact)", "bf16": "bf16 operands, fp32 accumulate; stem, BN, SE, "
                                     "index kernels fp32", "bf16x3": "split-bf16 (3 MFMAs per product), fp32 accumulate"}[
                                         args.precision]},
