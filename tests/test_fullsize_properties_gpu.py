@@ -191,3 +191,37 @@ def test_kpconv_bilinear_form_full_size(kp_full, device, lvl, cin, cout):
     nb.agb_symmetric = True
     for a, b in zip(res["scatter"], res["symmetric"]):
         assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5's single-GPU leg at FULL plot size (MSENet50, 16 000-point plots: the layers take the full-size kernels —
+# pair-compacted / 128-row tiles / bf16 storage twins — that the 1500-point oracle test does not reach).  The fp64 oracle
+# needs minutes per plot here, so the check is HIP against HIP: the exact-fp32 run of the same weights is the reference of
+# the bf16 and split-bf16x3 runs, with the bars of tests/test_sparse_gpu.py::test_senet50_low_precision_matches_oracle.
+def test_senet50_full_size_precisions_agree(device):
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_032))
+    opt = Opt(MODEL_OPTIONS["SENet50"])
+    opt["drop_path"] = 0.0
+    model = MinkowskiBaselineModel(opt, "minkowski", ds).to(device).train()
+    batch = synthetic.make_sparse_batch(list(range(6)), n_points=16000).to(device)
+    runs = {}
+    for prec in ("fp32", "bf16x3", "bf16"):
+        model.set_kernel_options(precision=prec)
+        model.zero_grad()
+        model.set_input(batch, device)
+        model.forward()
+        model.loss.backward()
+        runs[prec] = (model.output.detach().double().cpu(),
+                      torch.cat([p.grad.detach().double().reshape(-1).cpu() for p in model.model.parameters()]))
+    out32, g32 = runs["fp32"]
+    assert torch.isfinite(out32).all() and torch.isfinite(g32).all()
+    for prec, out_tol, cos_tol in (("bf16x3", 1e-4, 1e-6), ("bf16", 3e-2, 2e-2)):
+        out, g = runs[prec]
+        e = float((out - out32).abs().max() / out32.abs().max())
+        one_minus_cos = 1.0 - float(torch.dot(g, g32) / (g.norm() * g32.norm()))
+        print(f"SENet50, 6 x 16000 points, {prec} vs fp32: output {e:.2e}, 1 - cos(gradient) {one_minus_cos:.2e}")
+        assert e < out_tol and one_minus_cos < cos_tol, (prec, e, one_minus_cos)
