@@ -219,7 +219,8 @@ def test_senet50_full_size_precisions_agree(device):
                       torch.cat([p.grad.detach().double().reshape(-1).cpu() for p in model.model.parameters()]))
     out32, g32 = runs["fp32"]
     assert torch.isfinite(out32).all() and torch.isfinite(g32).all()
-    for prec, out_tol, cos_tol in (("bf16x3", 1e-4, 1e-6), ("bf16", 3e-2, 2e-2)):
+    # measured: bf16x3 output 4.6e-5, 1 - cos 1.3e-8; bf16 output 2.8e-2 (8 significant bits through 53 convolutions), 1 - cos 4e-3
+    for prec, out_tol, cos_tol in (("bf16x3", 1e-4, 1e-6), ("bf16", 5e-2, 2e-2)):
         out, g = runs[prec]
         e = float((out - out32).abs().max() / out32.abs().max())
         one_minus_cos = 1.0 - float(torch.dot(g, g32) / (g.norm() * g32.norm()))
