@@ -10,7 +10,7 @@ the fourth cosine cycle, calibrate_bn, running-statistics evaluation): both targ
     five committed CPU trials (oracle/sparse_ref.py, fp32; ~2 h each in the build container, never on the GPU box).
     Asserted: (a) every leg is in the plateau regime (median R2 >= 0.6 on both targets); (b) the gap of the medians is
     within 0.005 PLUS the sampling error of a difference of two medians of five, taken from the trials' own spread
-    (1.2533 s / sqrt(5) per leg, two standard errors) — with trial-to-trial standard deviations of 0.010-0.017 (CPU and
+    (1.2533 s / sqrt(5) per leg, three standard errors: a gate that does not fire on the draw) — with trial-to-trial standard deviations of 0.010-0.017 (CPU and
     HIP alike; two HIP runs of the same five seeds differ by 0.006 in their medians because the stem's weight gradient
     still accumulates with fp32 atomics) a bare +-0.005 on five trials would be decided by the draw, not by the kernels;
     (c) the CPU median lies inside the range of the HIP trials and vice versa.  The table printed says whether the bare
@@ -86,9 +86,10 @@ def test_r2_median_of_five_trials(device):
         med = np.median(r2, 0)
         assert (med >= 0.6).all() and (med_cpu >= 0.6).all(), (name, med)          # (a) plateau regime on every leg
         gap = med - med_cpu
-        allowance = 0.005 + 2.0 * np.sqrt(_median_se(r2) ** 2 + se_cpu ** 2)
-        print(f"{name:18s} median gap to cpu {gap.round(4).tolist()}  bare +-0.005 met: {bool((np.abs(gap) <= 0.005).all())}  "
-              f"allowance (0.005 + 2 s.e.) {allowance.round(4).tolist()}")
+        se = np.sqrt(_median_se(r2) ** 2 + se_cpu ** 2)
+        allowance = 0.005 + 3.0 * se
+        print(f"{name:18s} median gap to cpu {gap.round(4).tolist()} = {(np.abs(gap) / se).round(2).tolist()} s.e.  bare +-0.005 met: "
+              f"{bool((np.abs(gap) <= 0.005).all())}  allowance (0.005 + 3 s.e.) {allowance.round(4).tolist()}")
         assert (np.abs(gap) <= allowance).all(), (name, gap, allowance)            # (b)
         for t in range(2):                                                          # (c) each median inside the other leg
             assert r2[:, t].min() <= med_cpu[t] <= r2[:, t].max() or abs(gap[t]) <= 0.005, (name, t)
