@@ -86,7 +86,7 @@ def main():
         print(f"{name}: {len(d['state_dict'])} state_dict entries, {len(d['modules'])} modules "
               f"(reference classes on me_compat)")
     with open(OUT, "w") as f:
-        json.dump(out, f, indent=0, sort_keys=True)
+        json.dump(out, f, sort_keys=True, separators=(",", ":"))
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
 
