@@ -36,8 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def _ref():
     with open(GOLDEN) as f:
         ref = json.load(f)
-    if "trials" not in ref:      # a fixture of the single-trial protocol of earlier rounds
-        pytest.skip("tests/golden/r2_cpu_leg.json predates the 5-trial protocol: run tests/golden/make_r2_cpu_leg.py")
+    assert "trials" in ref, "tests/golden/r2_cpu_leg.json predates the 5-trial protocol: run tests/golden/make_r2_cpu_leg.py"
     return ref
 
 
