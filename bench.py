@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="operand precision of the convolution MFMAs (fp32 accumulate; BN / SE / index kernels fp32). The "
                          "headline (BASELINE config 4) is fp32; bf16 is BASELINE config 5's mode")
+    ap.add_argument("--bf16-rows", action="store_true",
+                    help="with --precision bf16: store every activation / gradient row matrix of the backbone in bf16 "
+                         "(KernelOptions.bf16_activations; accumulators, statistics, parameters fp32)")
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated batches cycled per rank")
     ap.add_argument("--features", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -372,7 +375,9 @@ def main():
     model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS[args.model]), "minkowski", ds)
     model_sd_cpu = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
     model.to(dev).train()
-    model.set_kernel_options(precision=args.precision)     # carried by the model, not by the process
+    if args.bf16_rows and args.precision != "bf16":
+        raise SystemExit("--bf16-rows needs --precision bf16")
+    model.set_kernel_options(precision=args.precision, bf16_activations=args.bf16_rows)     # carried by the model
     broadcast_parameters(model)
     model.init_train_objects(TRAINING_NFI)
     sync = None
@@ -544,7 +549,8 @@ def main():
                        "input_pipeline": "compute stream" if args.no_prefetch else "side stream, two batches ahead",
                        "operands": {"fp32": "fp32 MFMA (exact)", "bf16": "bf16 operands, fp32 accumulate; stem, BN, SE, "
                                     "index kernels fp32", "bf16x3": "split-bf16 (3 MFMAs per product), fp32 accumulate"}[
-                                        args.precision]},
+                                        args.precision] + ("; activation / gradient rows stored in bf16" if args.bf16_rows
+                                                           else "")},
             "roofline": roof,
             "step_ms_p50": round(sorted(gaps)[len(gaps) // 2], 3) if gaps else None,
             "step_ms_p90": round(sorted(gaps)[int(len(gaps) * 0.9)], 3) if gaps else None,

@@ -66,6 +66,12 @@ _SIGNATURES = {
                            c_float, c_float, c_int, c_float, c_void_p],
 }
 
+# entry points over activation / gradient ROW MATRICES exist twice: fp32 rows (agb_xxx) and bf16 rows (agb_xxx_h), same
+# argument lists (csrc/norm_rows.inc, csrc/pool_rows.inc)
+for _n in ("agb_maxpool_fwd", "agb_maxpool_bwd", "agb_maxpool_fwd_k", "agb_maxpool_bwd_k", "agb_segment_reduce",
+           "agb_segment_broadcast", "agb_segment_scale_add", "agb_segment_max_bwd"):
+    _SIGNATURES[_n + "_h"] = _SIGNATURES[_n]
+
 _lib = None
 
 
@@ -96,13 +102,15 @@ def load():
     return lib
 
 
-def declare(name, argtypes):
-    """Register one more entry point (used by the modules that bind the later-added kernels)."""
-    _SIGNATURES[name] = argtypes
-    if _lib is not None:
-        fn = getattr(_lib, name)
-        fn.argtypes = argtypes
-        fn.restype = c_int
+def declare(name, argtypes, rows=False):
+    """Register one more entry point (used by the modules that bind the later-added kernels).  rows: the entry point has a
+    bf16-row form ``name + "_h"`` with the same argument list."""
+    for nm in ((name, name + "_h") if rows else (name,)):
+        _SIGNATURES[nm] = argtypes
+        if _lib is not None:
+            fn = getattr(_lib, nm)
+            fn.argtypes = argtypes
+            fn.restype = c_int
 
 
 def ptr(t):
@@ -112,7 +120,37 @@ def ptr(t):
     if not t.is_cuda:
         raise AgbError("libagbhip kernels need tensors resident on a HIP device (got a CPU tensor); "
                        "there is no CPU fallback in the product path")
+    if t.dtype == torch.bfloat16:
+        raise AgbError("this entry point takes fp32 rows (got a bf16 row matrix: the bf16-activation mode reaches only the "
+                       "entry points with a _h form; see _lib.rows / _lib.sfx)")
     return t.data_ptr()
+
+
+def ptr16(t):
+    """Device pointer of a bf16 row matrix (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.bfloat16:
+        raise AgbError("expected a device-resident bf16 row matrix")
+    return t.data_ptr()
+
+
+def rows(t):
+    """Device pointer of an activation / gradient row matrix of either storage type (fp32 or bf16); the caller picks the
+    entry point with ``sfx``."""
+    if t is None:
+        return None
+    return ptr16(t) if t.dtype == torch.bfloat16 else ptr(t)
+
+
+def sfx(*ts):
+    """"" when the row matrices are fp32, "_h" when they are bf16 (csrc/*_rows.inc); mixed storage is an error."""
+    kinds = {t.dtype for t in ts if t is not None}
+    if kinds == {torch.bfloat16}:
+        return "_h"
+    if kinds <= {torch.float32}:
+        return ""
+    raise AgbError(f"row matrices of mixed storage types in one call: {sorted(str(k) for k in kinds)}")
 
 
 # torch.cuda.current_stream() builds a Stream object through four Python layers (~9 us): at ~170 launches per training

@@ -82,6 +82,38 @@ __host__ __device__ static inline int agb_floordiv(int a, int d) {
     return (r != 0 && ((r < 0) != (d < 0))) ? q - 1 : q;
 }
 
+// ---- row-matrix storage types -----------------------------------------------------
+// Activation / gradient row matrices [N, C] are fp32, or — the bf16-activation mode of BASELINE config 5 — bf16 (uint16
+// bit patterns, round to nearest even on store; all arithmetic stays fp32).  The HBM-bound kernels of norm.hip / pool.hip
+// are templates over the storage type and move 4 channels per lane either way (16-B / 8-B pieces); entry points of the
+// bf16 form carry the suffix _h.
+typedef unsigned short bf16_t;
+#if defined(__HIPCC__)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ unsigned agb_pack2_bf16(float a, float b) {      // v_cvt_pk_bf16_f32, round to nearest even
+    typedef float agb_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 agb_bf16x2 __attribute__((ext_vector_type(2)));
+    const agb_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, agb_bf16x2));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(agb_pack2_bf16(v.x, v.y), agb_pack2_bf16(v.z, v.w));
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) {
+    const __bf16 h = (__bf16)v;
+    *p = __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((unsigned)*p << 16); }
+#endif
+
 // ---- activations fused into the BatchNorm / pooling kernels ---------------------
 #define ACT_NONE 0
 #define ACT_RELU 1

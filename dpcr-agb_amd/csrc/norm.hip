@@ -33,7 +33,8 @@ static inline int bn_row_lanes(int C) { return C >= 64 ? 16 : 256 / (C >> 2); }
 
 // ---------------------------------------------------------------- statistics
 // grid (chunks, ceil(C/64)); part[chunk][3][C] = (count, mean, M2) of the chunk's rows
-__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ X, int ldx, int n, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const T* __restrict__ X, int ldx, int n, int C,
                                                           int rows_per_chunk, float* __restrict__ part) {
     __shared__ float s_mean[1024];         // [row lane][slab channel]
     __shared__ float s_m2[1024];
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
     if (rl >= L.rl_n) {
     } else if (c < C) {
         for (int r = r_beg + rl; r < r_end; r += L.rl_n) {
-            float4 v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+            float4 v = ld4(X + (long long)r * ldx + c);
             cnt += 1.f;
             float inv = 1.f / cnt;
             float x[4] = {v.x, v.y, v.z, v.w};
@@ -178,10 +179,11 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
 // 16-B loads in flight) — no per-element 64-bit index division, no per-element parameter reloads.
 #define EW_ROWS 128
 #define EW_PER (EW_ROWS / 16)      // rows per thread of the BatchNorm element-wise kernels
-__global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ X, int ldx, int n, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const T* __restrict__ X, int ldx, int n, int C,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    int act, float* __restrict__ Y, int ldy) {
+                                                    int act, T* __restrict__ Y, int ldy) {
     const BnLanes L = bn_lanes(C);
     const int cg = L.cg, rl = L.rl;
     const int c = blockIdx.y * (L.cgs * 4) + cg * 4;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ X,
 #pragma unroll
     for (int j = 0; j < EW_PER; ++j) {
         const int r = r0 + L.rl_n * j;
-        if (r < n) v[j] = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+        if (r < n) v[j] = ld4(X + (long long)r * ldx + c);
     }
 #pragma unroll
     for (int j = 0; j < EW_PER; ++j) {
@@ -206,14 +208,15 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ X,
         o.y = act_fwd((v[j].y - m.y) * s.y * g.y + b.y, act);
         o.z = act_fwd((v[j].z - m.z) * s.z * g.z + b.z, act);
         o.w = act_fwd((v[j].w - m.w) * s.w * g.w + b.w, act);
-        *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = o;
+        st4(Y + (long long)r * ldy + c, o);
     }
 }
 
 // ---------------------------------------------------------------- backward
 // pass 1: per chunk, sum(dz) and sum(dz * xhat) with dz = dy * act'(z), z recomputed from x
-__global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restrict__ X, int ldx,
-                                                            const float* __restrict__ dY, int ldy, int n, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const T* __restrict__ X, int ldx,
+                                                            const T* __restrict__ dY, int ldy, int n, int C,
                                                             int rows_per_chunk, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
@@ -237,8 +240,8 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_partial(const float* __restr
             b[j] = beta ? beta[c + j] : 0.f;
         }
         for (int r = r_beg + rl; r < r_end; r += L.rl_n) {
-            float4 xv = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
-            float4 dv = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+            float4 xv = ld4(X + (long long)r * ldx + c);
+            float4 dv = ld4(dY + (long long)r * ldy + c);
             float x[4] = {xv.x, xv.y, xv.z, xv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -322,13 +325,14 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_fold(const float* __restrict__ 
 }
 
 // pass 2: dx = gamma*rstd*(dz - [training] (dbeta + xhat*dgamma)/n)
-__global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restrict__ X, int ldx,
-                                                          const float* __restrict__ dY, int ldy, int n, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const T* __restrict__ X, int ldx,
+                                                          const T* __restrict__ dY, int ldy, int n, int C,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int act, const float* __restrict__ dbeta,
                                                           const float* __restrict__ dgamma, int training,
-                                                          float* __restrict__ dX, int lddx) {
+                                                          T* __restrict__ dX, int lddx) {
     const BnLanes L = bn_lanes(C);
     const int cg = L.cg, rl = L.rl;
     if (rl >= L.rl_n) return;
@@ -353,8 +357,8 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restric
         for (int j = 0; j < HALF; ++j) {
             const int r = r0 + L.rl_n * (h * HALF + j);
             if (r < n) {
-                xv[j] = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
-                dv[j] = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+                xv[j] = ld4(X + (long long)r * ldx + c);
+                dv[j] = ld4(dY + (long long)r * ldy + c);
             }
         }
 #pragma unroll
@@ -369,17 +373,18 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const float* __restric
                 float dz = d[q] * act_grad(xh * g[q] + b[q], act);
                 o[q] = g[q] * s[q] * (dz - (db[q] + xh * dg[q]) * inv_n);
             }
-            *reinterpret_cast<float4*>(dX + (long long)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+            st4(dX + (long long)r * lddx + c, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
 }
 
 // ---------------------------------------------------------------- residual tail: y = act(a * s[batch] + r)
 // (the drop-path scale s is optional; reference call sites resnet_block.py:70-73, senet_block.py:92-96)
-__global__ __launch_bounds__(256) void k_add_act_fwd(const float* __restrict__ A, int lda, const float* __restrict__ R,
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_act_fwd(const T* __restrict__ A, int lda, const T* __restrict__ R,
                                                      int ldr, const float* __restrict__ scale,
                                                      const int32_t* __restrict__ coords, int n, int C, int act,
-                                                     float* __restrict__ Y, int ldy) {
+                                                     T* __restrict__ Y, int ldy) {
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cg * 4;
     if (c >= C) return;
@@ -391,8 +396,8 @@ __global__ __launch_bounds__(256) void k_add_act_fwd(const float* __restrict__ A
     for (int j = 0; j < NR; ++j) {
         const int r = r0 + 16 * j;
         if (r < n) {
-            av[j] = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
-            bv[j] = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+            av[j] = ld4(A + (long long)r * lda + c);
+            bv[j] = ld4(R + (long long)r * ldr + c);
             sv[j] = scale ? scale[coords[4 * (long long)r]] : 1.f;
         }
     }
@@ -405,16 +410,17 @@ __global__ __launch_bounds__(256) void k_add_act_fwd(const float* __restrict__ A
         o.y = act_fwd(av[j].y * sv[j] + bv[j].y, act);
         o.z = act_fwd(av[j].z * sv[j] + bv[j].z, act);
         o.w = act_fwd(av[j].w * sv[j] + bv[j].w, act);
-        *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = o;
+        st4(Y + (long long)r * ldy + c, o);
     }
 }
 
 // dA = dz * s, dR = dz with dz = dY * act'(a*s + r)
-__global__ __launch_bounds__(256) void k_add_act_bwd(const float* __restrict__ A, int lda, const float* __restrict__ R,
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_act_bwd(const T* __restrict__ A, int lda, const T* __restrict__ R,
                                                      int ldr, const float* __restrict__ scale,
-                                                     const int32_t* __restrict__ coords, const float* __restrict__ dY,
-                                                     int ldy, int n, int C, int act, float* __restrict__ dA,
-                                                     float* __restrict__ dR) {
+                                                     const int32_t* __restrict__ coords, const T* __restrict__ dY,
+                                                     int ldy, int n, int C, int act, T* __restrict__ dA,
+                                                     T* __restrict__ dR) {
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cg * 4;
     if (c >= C) return;
@@ -428,9 +434,9 @@ __global__ __launch_bounds__(256) void k_add_act_bwd(const float* __restrict__ A
         for (int j = 0; j < HALF; ++j) {
             const int r = r0 + 16 * (h * HALF + j);
             if (r < n) {
-                av[j] = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
-                bv[j] = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
-                dv[j] = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+                av[j] = ld4(A + (long long)r * lda + c);
+                bv[j] = ld4(R + (long long)r * ldr + c);
+                dv[j] = ld4(dY + (long long)r * ldy + c);
                 sv[j] = scale ? scale[coords[4 * (long long)r]] : 1.f;
             }
         }
@@ -445,8 +451,8 @@ __global__ __launch_bounds__(256) void k_add_act_bwd(const float* __restrict__ A
             dz.z = dv[j].z * act_grad(av[j].z * s + bv[j].z, act);
             dz.w = dv[j].w * act_grad(av[j].w * s + bv[j].w, act);
             const long long o = (long long)r * C + c;
-            if (dR) *reinterpret_cast<float4*>(dR + o) = dz;
-            if (dA) *reinterpret_cast<float4*>(dA + o) = make_float4(dz.x * s, dz.y * s, dz.z * s, dz.w * s);
+            if (dR) st4(dR + o, dz);
+            if (dA) st4(dA + o, make_float4(dz.x * s, dz.y * s, dz.z * s, dz.w * s));
         }
     }
 }
@@ -494,7 +500,8 @@ __device__ __forceinline__ void plot_chunks_of(const int32_t* __restrict__ ptr, 
 }
 
 // grid (max chunks, slabs): part[chunk][3][C] = (count, mean, M2) of the chunk's rows, as k_bn_stats_partial
-__global__ __launch_bounds__(256) void k_tail_stats(const float* __restrict__ X, int ldx, const int32_t* __restrict__ ptr,
+template <typename T>
+__global__ __launch_bounds__(256) void k_tail_stats(const T* __restrict__ X, int ldx, const int32_t* __restrict__ ptr,
                                                     int B, int C, int R, float* __restrict__ part) {
     __shared__ float s_mean[1024];
     __shared__ float s_m2[1024];
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(256) void k_tail_stats(const float* __restrict__ X,
     float cnt = 0.f;
     if (rl < L.rl_n && c < C) {
         for (int r = pc.r_beg + rl; r < pc.r_end; r += L.rl_n) {
-            const float4 v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + c);
+            const float4 v = ld4(X + (long long)r * ldx + c);
             cnt += 1.f;
             const float inv = 1.f / cnt;
             const float x[4] = {v.x, v.y, v.z, v.w};
@@ -583,9 +590,10 @@ struct TailParams {
 };
 
 // y = act(((z - mean) rstd gamma + beta) * s[plot] * keep[plot] + r)
-__global__ __launch_bounds__(256) void k_tail_fwd(const float* __restrict__ Z, int ldz, const float* __restrict__ R, int ldr,
+template <typename T>
+__global__ __launch_bounds__(256) void k_tail_fwd(const T* __restrict__ Z, int ldz, const T* __restrict__ R, int ldr,
                                                   const int4* __restrict__ coords, TailParams P, int act, int n, int C,
-                                                  float* __restrict__ Y, int ldy) {
+                                                  T* __restrict__ Y, int ldy) {
     const BnLanes L = bn_lanes(C);
     if (L.rl >= L.rl_n) return;
     const int c = min(blockIdx.y * (L.cgs * 4) + L.cg * 4, C - 4);
@@ -603,20 +611,21 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const float* __restrict__ Z, i
         if (r >= n) continue;
         const int b = coords ? coords[r].x : 0;
         const float kf = P.keep ? P.keep[b] : 1.f;
-        const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
-        const float4 r4 = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
+        const float4 z4 = ld4(Z + (long long)r * ldz + c);
+        const float4 r4 = ld4(R + (long long)r * ldr + c);
         const float4 s4 = P.s ? *reinterpret_cast<const float4*>(P.s + (long long)b * C + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float z[4] = {z4.x, z4.y, z4.z, z4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
         float o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = act_fwd(((z[q] - m[q]) * sc[q] + sh[q]) * (ss[q] * kf) + rr[q], act);
-        *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        st4(Y + (long long)r * ldy + c, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
 // chunk partials spart[chunk][2][C] = (sum da, sum da * xhat) over the chunk's rows, da = dy * act'(pre), pre recomputed
-__global__ __launch_bounds__(256) void k_tail_bwd_sums(const float* __restrict__ Z, int ldz, const float* __restrict__ R,
-                                                       int ldr, const float* __restrict__ dY, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void k_tail_bwd_sums(const T* __restrict__ Z, int ldz, const T* __restrict__ R,
+                                                       int ldr, const T* __restrict__ dY, int ldy,
                                                        const int32_t* __restrict__ ptr, int B, TailParams P, int act, int C,
                                                        int RC, float* __restrict__ spart) {
     __shared__ float s_a[1024];
@@ -638,9 +647,9 @@ __global__ __launch_bounds__(256) void k_tail_bwd_sums(const float* __restrict__
             sk[j] = (P.s ? P.s[(long long)pc.b * C + c + j] : 1.f) * kf;
         }
         for (int r = pc.r_beg + rl; r < pc.r_end; r += L.rl_n) {
-            const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
-            const float4 r4 = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
-            const float4 d4 = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+            const float4 z4 = ld4(Z + (long long)r * ldz + c);
+            const float4 r4 = ld4(R + (long long)r * ldr + c);
+            const float4 d4 = ld4(dY + (long long)r * ldy + c);
             const float z[4] = {z4.x, z4.y, z4.z, z4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -729,12 +738,13 @@ __global__ __launch_bounds__(256) void k_tail_bwd_fold(const float* __restrict__
 }
 
 // dz = gamma rstd (dt - [training](dbeta + xhat dgamma) / n),  dt = da s keep + dte[plot];   dr = da
-__global__ __launch_bounds__(256) void k_tail_bwd_apply(const float* __restrict__ Z, int ldz, const float* __restrict__ R,
-                                                        int ldr, const float* __restrict__ dY, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ Z, int ldz, const T* __restrict__ R,
+                                                        int ldr, const T* __restrict__ dY, int ldy,
                                                         const int4* __restrict__ coords, TailParams P,
                                                         const float* __restrict__ dte, const float* __restrict__ dbeta,
                                                         const float* __restrict__ dgamma, int act, int training, int n,
-                                                        int C, float* __restrict__ dZ, int lddz, float* __restrict__ dR,
+                                                        int C, T* __restrict__ dZ, int lddz, T* __restrict__ dR,
                                                         int lddr) {
     const BnLanes L = bn_lanes(C);
     if (L.rl >= L.rl_n) return;
@@ -757,9 +767,9 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const float* __restrict_
         if (r >= n) continue;
         const int b = coords ? coords[r].x : 0;
         const float kf = P.keep ? P.keep[b] : 1.f;
-        const float4 z4 = *reinterpret_cast<const float4*>(Z + (long long)r * ldz + c);
-        const float4 r4 = *reinterpret_cast<const float4*>(R + (long long)r * ldr + c);
-        const float4 d4 = *reinterpret_cast<const float4*>(dY + (long long)r * ldy + c);
+        const float4 z4 = ld4(Z + (long long)r * ldz + c);
+        const float4 r4 = ld4(R + (long long)r * ldr + c);
+        const float4 d4 = ld4(dY + (long long)r * ldy + c);
         const float4 s4 = P.s ? *reinterpret_cast<const float4*>(P.s + (long long)b * C + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 e4 = dte ? *reinterpret_cast<const float4*>(dte + (long long)b * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float z[4] = {z4.x, z4.y, z4.z, z4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w},
@@ -774,8 +784,8 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const float* __restrict_
             oz[q] = g[q] * rs[q] * (dt - (db[q] + xh * dg[q]) * inv_n);
             orr[q] = da;
         }
-        if (dZ) *reinterpret_cast<float4*>(dZ + (long long)r * lddz + c) = make_float4(oz[0], oz[1], oz[2], oz[3]);
-        if (dR) *reinterpret_cast<float4*>(dR + (long long)r * lddr + c) = make_float4(orr[0], orr[1], orr[2], orr[3]);
+        if (dZ) st4(dZ + (long long)r * lddz + c, make_float4(oz[0], oz[1], oz[2], oz[3]));
+        if (dR) st4(dR + (long long)r * lddr + c, make_float4(orr[0], orr[1], orr[2], orr[3]));
     }
 }
 
@@ -798,29 +808,6 @@ static int bn_chunks_for(int n, int C) {
     return want < cap ? want : cap;
 }
 
-// training != 0: batch statistics of X (and running-stat update if the pointers are given); else mean/rstd from the
-// running statistics.  part: float[agb_bn_chunks(n) * 3 * C] scratch.  mean, rstd: float[C] out.
-// num_batches_tracked: the layer's int64 counter (device), incremented by the fold kernel in training mode; or NULL.
-int agb_bn_stats_tracked(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
-                         float* mean, float* rstd, float* running_mean, float* running_var,
-                         long long* num_batches_tracked, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0, "agb_bn_stats: C (%d) and ldx must be multiples of 4", C);
-    hipStream_t s = (hipStream_t)stream;
-    if (!training) {
-        AGB_CHECK_ARG(running_mean && running_var, "agb_bn_stats: eval mode needs running statistics");
-        hipLaunchKernelGGL(k_bn_eval_stats, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, C, eps,
-                           mean, rstd);
-    } else {
-        int chunks = bn_chunks_for(n, C);
-        hipLaunchKernelGGL(k_bn_stats_partial, dim3(chunks, agb_cdiv(C, bn_slab(C))), dim3(256), 0, s, X, ldx, n, C,
-                           rows_per_chunk(n, chunks), part);
-        hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, eps, momentum,
-                           mean, rstd, running_mean, running_var, num_batches_tracked);
-    }
-    AGB_CHECK_LAUNCH("agb_bn_stats");
-    return AGB_OK;
-}
-
 // The second half of agb_bn_stats_tracked on partials produced elsewhere (agb_dense_fwd_bn: the epilogue of the product
 // that wrote X): part float[chunks][3][C] = (count, mean, M2) per chunk and column.
 int agb_bn_stats_fold(const float* part, int chunks, int C, float eps, float momentum, float* mean, float* rstd,
@@ -829,49 +816,6 @@ int agb_bn_stats_fold(const float* part, int chunks, int C, float eps, float mom
     hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, (hipStream_t)stream, part, chunks, C,
                        eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
     AGB_CHECK_LAUNCH("agb_bn_stats_fold");
-    return AGB_OK;
-}
-
-int agb_bn_stats(const float* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
-                 float* mean, float* rstd, float* running_mean, float* running_var, void* stream) {
-    return agb_bn_stats_tracked(X, ldx, n, C, eps, momentum, training, part, mean, rstd, running_mean, running_var,
-                                nullptr, stream);
-}
-
-int agb_bn_act_fwd(const float* X, int ldx, int n, int C, const float* mean, const float* rstd, const float* gamma,
-                   const float* beta, int act, float* Y, int ldy, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_bn_act_fwd: C/ld must be multiples of 4");
-    AGB_CHECK_ARG(act >= 0 && act <= 2, "agb_bn_act_fwd: activation %d", act);
-    if (n == 0) return AGB_OK;
-    hipLaunchKernelGGL(k_bn_act_fwd, dim3(agb_cdiv(n, EW_PER * bn_row_lanes(C)), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
-                       (hipStream_t)stream, X,
-                       ldx, n, C, mean, rstd, gamma, beta, act, Y, ldy);
-    AGB_CHECK_LAUNCH("agb_bn_act_fwd");
-    return AGB_OK;
-}
-
-// part: float[agb_bn_chunks(n) * 2 * C] scratch; dgamma, dbeta: float[C] out (always written); dX: [n, C];
-// colsum (optional, float[C] out): column sums of dX — the bias gradient of the convolution feeding this BatchNorm,
-// produced while dX is written instead of by a separate reduction pass over it.
-int agb_bn_act_bwd_colsum(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
-                          const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
-                          float* dX, int lddx, float* dgamma, float* dbeta, float* colsum, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0,
-                  "agb_bn_act_bwd: C/ld must be multiples of 4");
-    AGB_CHECK_ARG(colsum == nullptr || dX != nullptr, "agb_bn_act_bwd: colsum needs dX");
-    hipStream_t s = (hipStream_t)stream;
-    int chunks = bn_chunks_for(n, C);
-    hipLaunchKernelGGL(k_bn_act_bwd_partial, dim3(chunks, agb_cdiv(C, bn_slab(C))), dim3(256), 0, s, X, ldx, dY, ldy, n,
-                       C,
-                       rows_per_chunk(n, chunks), mean, rstd, gamma, beta, act, part);
-    hipLaunchKernelGGL(k_bn_bwd_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, dbeta, dgamma, colsum,
-                       gamma, rstd, training);
-    if (n > 0 && dX) {
-        hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(agb_cdiv(n, EW_PER * bn_row_lanes(C)), agb_cdiv(C, bn_slab(C))),
-                           dim3(256), 0, s, X, ldx, dY,
-                           ldy, n, C, mean, rstd, gamma, beta, act, dbeta, dgamma, training, dX, lddx);
-    }
-    AGB_CHECK_LAUNCH("agb_bn_act_bwd");
     return AGB_OK;
 }
 
@@ -885,40 +829,11 @@ int agb_bn_bwd_fold(const float* part, int chunks, int C, float* dbeta, float* d
     return AGB_OK;
 }
 
-int agb_bn_act_bwd(const float* X, int ldx, const float* dY, int ldy, int n, int C, const float* mean,
-                   const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
-                   float* dX, int lddx, float* dgamma, float* dbeta, void* stream) {
-    return agb_bn_act_bwd_colsum(X, ldx, dY, ldy, n, C, mean, rstd, gamma, beta, act, training, part, dX, lddx, dgamma,
-                                 dbeta, nullptr, stream);
-}
-
 // ---- squeeze-excite block tail (see k_tail_*).  coords: int4[n] (batch index in .x), ptr: int32[B+1] row offsets.
 static int tail_rows(int n, int C) { return rows_per_chunk(n, bn_chunks_for(n, C)); }
 
 // Plot-aligned row chunks of the tail's reduction kernels (upper bound): sizes `part` (x 3 C floats) and `spart` (x 2 C)
 int agb_se_tail_chunks(int n, int C, int B) { return agb_cdiv(n > 0 ? n : 1, tail_rows(n, C)) + (B > 0 ? B : 0); }
-
-// Statistics of Z for the BatchNorm (as agb_bn_stats_tracked) from plot-aligned chunk partials, which stay in `part`
-// float[agb_se_tail_chunks * 3 * C] for agb_se_tail_pool.
-int agb_se_tail_stats(const float* Z, int ldz, const int32_t* ptr, int n, int C, int B, float eps, float momentum,
-                      int training, float* part, float* mean, float* rstd, float* running_mean, float* running_var,
-                      long long* num_batches_tracked, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && n >= 1 && B >= 1, "agb_se_tail_stats: n %d, C %d, B %d, ld %d", n, C, B, ldz);
-    hipStream_t s = (hipStream_t)stream;
-    const int chunks = agb_se_tail_chunks(n, C, B);
-    hipLaunchKernelGGL(k_tail_stats, dim3(chunks, agb_cdiv(C, bn_slab(C))), dim3(256), 0, s, Z, ldz, ptr, B, C,
-                       tail_rows(n, C), part);
-    if (training) {
-        hipLaunchKernelGGL(k_bn_stats_fold, dim3(agb_cdiv(C, FOLD_CH)), dim3(1024), 0, s, part, chunks, C, eps, momentum,
-                           mean, rstd, running_mean, running_var, num_batches_tracked);
-    } else {
-        AGB_CHECK_ARG(running_mean && running_var, "agb_se_tail_stats: eval mode needs running statistics");
-        hipLaunchKernelGGL(k_bn_eval_stats, dim3(agb_cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, C, eps,
-                           mean, rstd);
-    }
-    AGB_CHECK_LAUNCH("agb_se_tail_stats");
-    return AGB_OK;
-}
 
 // zbar[b, c] = plot mean of z; pooled[b, c] = BatchNorm(zbar): the input of the excitation MLP (agb_se_mlp_fwd)
 int agb_se_tail_pool(const float* part, const int32_t* ptr, int n, int B, int C, const float* mean, const float* rstd,
@@ -926,35 +841,6 @@ int agb_se_tail_pool(const float* part, const int32_t* ptr, int n, int B, int C,
     hipLaunchKernelGGL(k_tail_pool, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, part, ptr, B, C,
                        tail_rows(n, C), mean, rstd, gamma, beta, zbar, pooled);
     AGB_CHECK_LAUNCH("agb_se_tail_pool");
-    return AGB_OK;
-}
-
-// Y = act(BatchNorm(Z) * s[plot] * keep[plot] + R); s float[B, C], keep float[B] or NULL
-int agb_se_tail_fwd(const float* Z, int ldz, const float* R, int ldr, const int32_t* coords, const float* mean,
-                    const float* rstd, const float* gamma, const float* beta, const float* s, const float* keep, int act,
-                    int n, int C, float* Y, int ldy, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0, "agb_se_tail_fwd: C/ld must be multiples of 4");
-    AGB_CHECK_ARG(act >= 0 && act <= 2, "agb_se_tail_fwd: activation %d", act);
-    if (n == 0) return AGB_OK;
-    const TailParams P{mean, rstd, gamma, beta, s, keep};
-    hipLaunchKernelGGL(k_tail_fwd, dim3(agb_cdiv(n, EW_PER * bn_row_lanes(C)), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
-                       (hipStream_t)stream, Z, ldz, R, ldr, (const int4*)coords, P, act, n, C, Y, ldy);
-    AGB_CHECK_LAUNCH("agb_se_tail_fwd");
-    return AGB_OK;
-}
-
-// spart float[agb_se_tail_chunks * 2 * C]: chunk partials of sum da and sum da * xhat
-int agb_se_tail_bwd_sums(const float* Z, int ldz, const float* R, int ldr, const float* dY, int ldy, const int32_t* ptr,
-                         int B, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                         const float* s, const float* keep, int act, int n, int C, float* spart, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0, "agb_se_tail_bwd_sums: C/ld multiples of 4");
-    if (n == 0) return AGB_OK;
-    const TailParams P{mean, rstd, gamma, beta, s, keep};
-    // ptr == NULL: no plots (s and keep must be NULL too): plain row chunks, the kernel's plot count carries n
-    AGB_CHECK_ARG(ptr != nullptr || (s == nullptr && keep == nullptr), "agb_se_tail_bwd_sums: s / keep need ptr");
-    hipLaunchKernelGGL(k_tail_bwd_sums, dim3(agb_se_tail_chunks(n, C, ptr ? B : 0), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
-                       (hipStream_t)stream, Z, ldz, R, ldr, dY, ldy, ptr, ptr ? B : n, P, act, C, tail_rows(n, C), spart);
-    AGB_CHECK_LAUNCH("agb_se_tail_bwd_sums");
     return AGB_OK;
 }
 
@@ -978,45 +864,16 @@ int agb_se_tail_bwd_fold(const float* S2, const float* S3, const float* zbar, co
     return AGB_OK;
 }
 
-// dZ (gradient of the BatchNorm input) and dR (gradient of the residual); either may be NULL
-int agb_se_tail_bwd_apply(const float* Z, int ldz, const float* R, int ldr, const float* dY, int ldy, const int32_t* coords,
-                          const float* mean, const float* rstd, const float* gamma, const float* beta, const float* s,
-                          const float* keep, const float* dte, const float* dbeta, const float* dgamma, int act,
-                          int training, int n, int C, float* dZ, int lddz, float* dR, int lddr, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0 && lddr % 4 == 0,
-                  "agb_se_tail_bwd_apply: C/ld must be multiples of 4");
-    if (n == 0) return AGB_OK;
-    const TailParams P{mean, rstd, gamma, beta, s, keep};
-    hipLaunchKernelGGL(k_tail_bwd_apply, dim3(agb_cdiv(n, EW_PER * bn_row_lanes(C)), agb_cdiv(C, bn_slab(C))), dim3(256), 0,
-                       (hipStream_t)stream, Z, ldz, R, ldr, dY, ldy, (const int4*)coords, P, dte, dbeta, dgamma, act,
-                       training, n, C, dZ, lddz, dR, lddr);
-    AGB_CHECK_LAUNCH("agb_se_tail_bwd_apply");
-    return AGB_OK;
-}
-
-// y = act(A * scale[batch(row)] + R); scale (float[B]) and coords may be NULL (no drop-path)
-int agb_add_act_fwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords, int n,
-                    int C, int act, float* Y, int ldy, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0,
-                  "agb_add_act_fwd: C/ld must be multiples of 4");
-    AGB_CHECK_ARG(scale == nullptr || coords != nullptr, "agb_add_act_fwd: a scale needs the coords (batch column)");
-    if (n == 0) return AGB_OK;
-    hipLaunchKernelGGL(k_add_act_fwd, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, A,
-                       lda, R, ldr, scale, coords, n, C, act, Y, ldy);
-    AGB_CHECK_LAUNCH("agb_add_act_fwd");
-    return AGB_OK;
-}
-
-// dA, dR: contiguous [n, C] (either may be NULL)
-int agb_add_act_bwd(const float* A, int lda, const float* R, int ldr, const float* scale, const int32_t* coords,
-                    const float* dY, int ldy, int n, int C, int act, float* dA, float* dR, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0,
-                  "agb_add_act_bwd: C/ld must be multiples of 4");
-    if (n == 0) return AGB_OK;
-    hipLaunchKernelGGL(k_add_act_bwd, dim3(agb_cdiv(n, EW_ROWS), agb_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, A,
-                       lda, R, ldr, scale, coords, dY, ldy, n, C, act, dA, dR);
-    AGB_CHECK_LAUNCH("agb_add_act_bwd");
-    return AGB_OK;
-}
+// the entry points that take row matrices: once per storage type (float: agb_xxx, bf16: agb_xxx_h)
+#define AGB_T float
+#define AGB_FN(name) name
+#include "norm_rows.inc"
+#undef AGB_T
+#undef AGB_FN
+#define AGB_T bf16_t
+#define AGB_FN(name) name##_h
+#include "norm_rows.inc"
+#undef AGB_T
+#undef AGB_FN
 
 }  // extern "C"

@@ -14,8 +14,9 @@
 // of PB: PB independent index loads, then PB independent row gathers, then the compares (in offset order: ties keep the
 // lowest offset, like the serial loop) — the serial index -> gather -> compare chain per offset ran at 1.3 TB/s.
 #define PB 9
-__global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ X, int ldx, const int32_t* __restrict__ nbr,
-                                                     long long nbr_stride, float* __restrict__ Y, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const T* __restrict__ X, int ldx, const int32_t* __restrict__ nbr,
+                                                     long long nbr_stride, T* __restrict__ Y, int ldy,
                                                      int32_t* __restrict__ arg, int n_out, int K3, int C4) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int r = (int)(t / C4);
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ X
         for (int u = 0; u < PB; ++u) idx[u] = (k0 + u < K3) ? nbr[(long long)(k0 + u) * nbr_stride + r] : -1;
 #pragma unroll
         for (int u = 0; u < PB; ++u)
-            if (idx[u] >= 0) v[u] = *reinterpret_cast<const float4*>(X + (long long)idx[u] * ldx + c);
+            if (idx[u] >= 0) v[u] = ld4(X + (long long)idx[u] * ldx + c);
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
             if (idx[u] < 0) continue;
@@ -44,15 +45,16 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ X
     if (bi.y < 0) best.y = 0.f;
     if (bi.z < 0) best.z = 0.f;
     if (bi.w < 0) best.w = 0.f;
-    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = best;
+    st4(Y + (long long)r * ldy + c, best);
     *reinterpret_cast<int4*>(arg + (long long)r * (C4 * 4) + c) = bi;
 }
 
 // input-stationary gradient: each input row collects from the (at most K3) outputs that could have chosen it; same
 // batching (index loads, then the argmax / gradient rows of the present outputs, then the adds in offset order)
-__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ dY, int ldy, const int32_t* __restrict__ arg,
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const T* __restrict__ dY, int ldy, const int32_t* __restrict__ arg,
                                                      const int32_t* __restrict__ nbrT, long long nbrT_stride,
-                                                     float* __restrict__ dX, int ldx, int n_in, int K3, int C4) {
+                                                     T* __restrict__ dX, int ldx, int n_in, int K3, int C4) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int q = (int)(t / C4);
     int c = (int)(t % C4) * 4;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ d
         for (int u = 0; u < PB; ++u)
             if (o[u] >= 0) {
                 a[u] = *reinterpret_cast<const int4*>(arg + (long long)o[u] * (C4 * 4) + c);
-                d[u] = *reinterpret_cast<const float4*>(dY + (long long)o[u] * ldy + c);
+                d[u] = ld4(dY + (long long)o[u] * ldy + c);
             }
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
@@ -79,15 +81,16 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ d
             if (a[u].w == q) g.w += d[u].w;
         }
     }
-    *reinterpret_cast<float4*>(dX + (long long)q * ldx + c) = g;
+    st4(dX + (long long)q * ldx + c, g);
 }
 
 // The same pair with the winner kept as its OFFSET index (one byte per output element instead of the 4-byte input row):
 // nbrT[k][q] = o  <=>  nbr[k][o] = q, so input row q won channel c of output o iff arg8[o][c] == k.  The gradient pass
 // gathers 4 + 16 bytes per (pair, 4 channels) instead of 16 + 16 (it is bound by those gathers: every output row is read
 // by ~7 input rows), and the forward pass writes a quarter of the argmax bytes.  K3 <= 255.
-__global__ __launch_bounds__(256) void k_maxpool_fwd8(const float* __restrict__ X, int ldx, const int32_t* __restrict__ nbr,
-                                                      long long nbr_stride, float* __restrict__ Y, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool_fwd8(const T* __restrict__ X, int ldx, const int32_t* __restrict__ nbr,
+                                                      long long nbr_stride, T* __restrict__ Y, int ldy,
                                                       uint8_t* __restrict__ arg, int n_out, int K3, int C4) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int r = (int)(t / C4);
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd8(const float* __restrict__ 
         for (int u = 0; u < PB; ++u) idx[u] = (k0 + u < K3) ? nbr[(long long)(k0 + u) * nbr_stride + r] : -1;
 #pragma unroll
         for (int u = 0; u < PB; ++u)
-            if (idx[u] >= 0) v[u] = *reinterpret_cast<const float4*>(X + (long long)idx[u] * ldx + c);
+            if (idx[u] >= 0) v[u] = ld4(X + (long long)idx[u] * ldx + c);
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
             if (idx[u] < 0) continue;
@@ -116,13 +119,14 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd8(const float* __restrict__ 
     if (by == 255) best.y = 0.f;
     if (bz == 255) best.z = 0.f;
     if (bw == 255) best.w = 0.f;
-    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = best;
+    st4(Y + (long long)r * ldy + c, best);
     *reinterpret_cast<uchar4*>(arg + (long long)r * (C4 * 4) + c) = make_uchar4(bx, by, bz, bw);
 }
 
-__global__ __launch_bounds__(256) void k_maxpool_bwd8(const float* __restrict__ dY, int ldy, const uint8_t* __restrict__ arg,
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool_bwd8(const T* __restrict__ dY, int ldy, const uint8_t* __restrict__ arg,
                                                       const int32_t* __restrict__ nbrT, long long nbrT_stride,
-                                                      float* __restrict__ dX, int ldx, int n_in, int K3, int C4) {
+                                                      T* __restrict__ dX, int ldx, int n_in, int K3, int C4) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int q = (int)(t / C4);
     int c = (int)(t % C4) * 4;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd8(const float* __restrict__ 
         for (int u = 0; u < PB; ++u)
             if (o[u] >= 0) {
                 a[u] = *reinterpret_cast<const uchar4*>(arg + (long long)o[u] * (C4 * 4) + c);
-                d[u] = *reinterpret_cast<const float4*>(dY + (long long)o[u] * ldy + c);
+                d[u] = ld4(dY + (long long)o[u] * ldy + c);
             }
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd8(const float* __restrict__ 
             if (a[u].w == k) g.w += d[u].w;
         }
     }
-    *reinterpret_cast<float4*>(dX + (long long)q * ldx + c) = g;
+    st4(dX + (long long)q * ldx + c, g);
 }
 
 // ------------------------------------------------------------ segment reduce
@@ -158,8 +162,9 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd8(const float* __restrict__ 
 // chunks so that long segments (6.8k rows/plot at 64 channels) still fill the chip; chunk partials go to
 // `part` [B*S, C] (and `part_arg`) and a second tiny kernel folds them in a fixed order (deterministic).
 // mode 0 sum, 1 average, 2 max (arg receives the winning row); optional second operand: reduce A*Bm.
-__global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict__ A, int lda,
-                                                        const float* __restrict__ Bm, int ldb,
+template <typename T>
+__global__ __launch_bounds__(256) void k_segment_reduce(const T* __restrict__ A, int lda,
+                                                        const T* __restrict__ Bm, int ldb,
                                                         const int32_t* __restrict__ ptr, int C, int mode, int S,
                                                         float* __restrict__ Y, int32_t* __restrict__ arg) {
     __shared__ float s_val[4][64];
@@ -176,8 +181,8 @@ __global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict_
     int ai = -1;
     if (c < C) {
         for (int r = beg + rl; r < end; r += 4) {
-            float v = A[(long long)r * lda + c];
-            if (Bm) v *= Bm[(long long)r * ldb + c];
+            float v = ld1(A + (long long)r * lda + c);
+            if (Bm) v *= ld1(Bm + (long long)r * ldb + c);
             if (mode == 2) {
                 if (v > acc) { acc = v; ai = r; }
             } else {
@@ -210,8 +215,9 @@ __global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict_
 // folds rows r, r+16, ... of its 4 channels, the 16 lane partials are combined in lane order (fixed order).
 // Used when C, lda (and ldb) are multiples of 4: 4x fewer load instructions than the scalar kernel above
 // (the SE squeeze of 206 k x 64 rows ran at 0.9 TB/s with 4-byte loads).
-__global__ __launch_bounds__(256) void k_segment_reduce4(const float* __restrict__ A, int lda,
-                                                         const float* __restrict__ Bm, int ldb,
+template <typename T>
+__global__ __launch_bounds__(256) void k_segment_reduce4(const T* __restrict__ A, int lda,
+                                                         const T* __restrict__ Bm, int ldb,
                                                          const int32_t* __restrict__ ptr, int C, int mode, int S,
                                                          float* __restrict__ Y, int32_t* __restrict__ arg) {
     __shared__ float s_val[16][64];
@@ -230,9 +236,9 @@ __global__ __launch_bounds__(256) void k_segment_reduce4(const float* __restrict
     for (int j = 0; j < 4; ++j) acc[j] = (mode == 2) ? -FLT_MAX : 0.f;
     if (c < C) {
         for (int r = beg + rl; r < end; r += 16) {
-            float4 v4 = *reinterpret_cast<const float4*>(A + (long long)r * lda + c);
+            float4 v4 = ld4(A + (long long)r * lda + c);
             if (Bm) {
-                float4 m4 = *reinterpret_cast<const float4*>(Bm + (long long)r * ldb + c);
+                float4 m4 = ld4(Bm + (long long)r * ldb + c);
                 v4.x *= m4.x; v4.y *= m4.y; v4.z *= m4.z; v4.w *= m4.w;
             }
             const float v[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -301,9 +307,10 @@ __global__ void k_segment_fold(const float* __restrict__ part, const int32_t* __
 }
 
 // gradient of sum/avg pooling, and the forward of a broadcast: out[r,c] = S[batch(r),c] * scale(b) [* M[r,c]]
+template <typename T>
 __global__ void k_segment_broadcast(const float* __restrict__ S, const int32_t* __restrict__ coords,
-                                    const int32_t* __restrict__ ptr, const float* __restrict__ M, int ldm,
-                                    float* __restrict__ out, int ldo, int n, int C4, int average) {
+                                    const int32_t* __restrict__ ptr, const T* __restrict__ M, int ldm,
+                                    T* __restrict__ out, int ldo, int n, int C4, int average) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int r = (int)(t / C4);
     int c = (int)(t % C4) * 4;
@@ -315,18 +322,19 @@ __global__ void k_segment_broadcast(const float* __restrict__ S, const int32_t* 
         s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
     }
     if (M) {
-        float4 m = *reinterpret_cast<const float4*>(M + (long long)r * ldm + c);
+        float4 m = ld4(M + (long long)r * ldm + c);
         s.x *= m.x; s.y *= m.y; s.z *= m.z; s.w *= m.w;
     }
-    *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = s;
+    st4(out + (long long)r * ldo + c, s);
 }
 
 // out[r,c] = M[r,c] * S[batch(r),c] + T[batch(r),c] / rows(batch(r)): the input gradient of the squeeze-excite layer
 // (product-rule term of the broadcast multiplication + the gradient that reaches the rows through the average pooling)
 // in one pass, instead of two broadcast kernels and an addition
-__global__ void k_segment_scale_add(const float* __restrict__ S, const float* __restrict__ T,
+template <typename T>
+__global__ void k_segment_scale_add(const float* __restrict__ S, const float* __restrict__ Tb,
                                     const int32_t* __restrict__ coords, const int32_t* __restrict__ ptr,
-                                    const float* __restrict__ M, int ldm, float* __restrict__ out, int ldo, int n,
+                                    const T* __restrict__ M, int ldm, T* __restrict__ out, int ldo, int n,
                                     int C4) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int r = (int)(t / C4);
@@ -334,141 +342,38 @@ __global__ void k_segment_scale_add(const float* __restrict__ S, const float* __
     if (r >= n) return;
     int b = coords[4 * (long long)r];
     const float4 s = *reinterpret_cast<const float4*>(S + (long long)b * (C4 * 4) + c);
-    const float4 g = *reinterpret_cast<const float4*>(T + (long long)b * (C4 * 4) + c);
+    const float4 g = *reinterpret_cast<const float4*>(Tb + (long long)b * (C4 * 4) + c);
     const float inv = 1.f / (float)(ptr[b + 1] - ptr[b]);
-    const float4 m = *reinterpret_cast<const float4*>(M + (long long)r * ldm + c);
+    const float4 m = ld4(M + (long long)r * ldm + c);
     float4 o;
     // same operation order as the unfused path: (m * s) + (g * inv)
     o.x = m.x * s.x + g.x * inv; o.y = m.y * s.y + g.y * inv;
     o.z = m.z * s.z + g.z * inv; o.w = m.w * s.w + g.w * inv;
-    *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = o;
+    st4(out + (long long)r * ldo + c, o);
 }
 
 // gradient of global max pooling: dX = 0 except dX[arg[b,c], c] = dY[b,c]
-__global__ void k_segment_max_bwd(const float* __restrict__ dY, const int32_t* __restrict__ arg, float* dX, int ldx,
+template <typename T>
+__global__ void k_segment_max_bwd(const float* __restrict__ dY, const int32_t* __restrict__ arg, T* __restrict__ dX, int ldx,
                                   int B, int C) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * C) return;
     int a = arg[t];
-    if (a >= 0) dX[(long long)a * ldx + (t % C)] = dY[t];
+    if (a >= 0) st1(dX + (long long)a * ldx + (t % C), dY[t]);
 }
 
 // =============================================================== C ABI
 extern "C" {
 
-int agb_maxpool_fwd(const float* X, int ldx, const int32_t* nbr, long long nbr_stride, float* Y, int ldy,
-                    int32_t* argmax, int n_out, int K3, int C, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_maxpool_fwd: C/ld must be multiples of 4");
-    if (n_out == 0) return AGB_OK;
-    long long total = (long long)n_out * (C / 4);
-    hipLaunchKernelGGL(k_maxpool_fwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, nbr,
-                       nbr_stride, Y, ldy, argmax, n_out, K3, C / 4);
-    AGB_CHECK_LAUNCH("agb_maxpool_fwd");
-    return AGB_OK;
-}
-
-int agb_maxpool_bwd(const float* dY, int ldy, const int32_t* argmax, const int32_t* nbrT, long long nbrT_stride,
-                    float* dX, int ldx, int n_in, int K3, int C, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_maxpool_bwd: C/ld must be multiples of 4");
-    if (n_in == 0) return AGB_OK;
-    long long total = (long long)n_in * (C / 4);
-    hipLaunchKernelGGL(k_maxpool_bwd, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dY, ldy, argmax,
-                       nbrT, nbrT_stride, dX, ldx, n_in, K3, C / 4);
-    AGB_CHECK_LAUNCH("agb_maxpool_bwd");
-    return AGB_OK;
-}
-
-// Variant whose argmax is the winning OFFSET index (uint8, 255 = none): argk [n_out, C] bytes.  K3 <= 255.
-int agb_maxpool_fwd_k(const float* X, int ldx, const int32_t* nbr, long long nbr_stride, float* Y, int ldy,
-                      uint8_t* argk, int n_out, int K3, int C, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_maxpool_fwd_k: C/ld must be multiples of 4");
-    AGB_CHECK_ARG(K3 >= 1 && K3 <= 255, "agb_maxpool_fwd_k: K3 %d (1..255)", K3);
-    if (n_out == 0) return AGB_OK;
-    long long total = (long long)n_out * (C / 4);
-    hipLaunchKernelGGL(k_maxpool_fwd8, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, nbr,
-                       nbr_stride, Y, ldy, argk, n_out, K3, C / 4);
-    AGB_CHECK_LAUNCH("agb_maxpool_fwd_k");
-    return AGB_OK;
-}
-
-// nbrT must be the transpose of the map the forward pass used (same offset numbering).
-int agb_maxpool_bwd_k(const float* dY, int ldy, const uint8_t* argk, const int32_t* nbrT, long long nbrT_stride,
-                      float* dX, int ldx, int n_in, int K3, int C, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "agb_maxpool_bwd_k: C/ld must be multiples of 4");
-    AGB_CHECK_ARG(K3 >= 1 && K3 <= 255, "agb_maxpool_bwd_k: K3 %d (1..255)", K3);
-    if (n_in == 0) return AGB_OK;
-    long long total = (long long)n_in * (C / 4);
-    hipLaunchKernelGGL(k_maxpool_bwd8, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dY, ldy, argk,
-                       nbrT, nbrT_stride, dX, ldx, n_in, K3, C / 4);
-    AGB_CHECK_LAUNCH("agb_maxpool_bwd_k");
-    return AGB_OK;
-}
-
-// splits == 1: direct. splits > 1: `part` float[B*splits*C] (and `part_arg` int32[B*splits*C] for max) are
-// caller-provided scratch for the chunk partials.
-int agb_segment_reduce(const float* A, int lda, const float* Bm, int ldb, const int32_t* ptr, int B, int C, int mode,
-                       int splits, float* part, int32_t* part_arg, float* Y, int32_t* argmax, void* stream) {
-    AGB_CHECK_ARG(mode >= 0 && mode <= 2, "agb_segment_reduce: mode %d", mode);
-    AGB_CHECK_ARG(mode != 2 || argmax != nullptr, "agb_segment_reduce: max mode needs an argmax buffer");
-    AGB_CHECK_ARG(splits >= 1 && splits <= 1024, "agb_segment_reduce: splits %d", splits);
-    AGB_CHECK_ARG(splits == 1 || (part != nullptr && (mode != 2 || part_arg != nullptr)),
-                  "agb_segment_reduce: splits > 1 needs scratch buffers");
-    if (B == 0 || C == 0) return AGB_OK;
-    hipStream_t s = (hipStream_t)stream;
-    const bool vec = C % 4 == 0 && lda % 4 == 0 && (Bm == nullptr || ldb % 4 == 0);
-    if (splits == 1) {
-        if (vec)
-            hipLaunchKernelGGL(k_segment_reduce4, dim3(B, agb_cdiv(C, 64), 1), dim3(256), 0, s, A, lda, Bm, ldb, ptr, C,
-                               mode, 1, Y, argmax);
-        else
-            hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64), 1), dim3(256), 0, s, A, lda, Bm, ldb, ptr, C,
-                               mode, 1, Y, argmax);
-    } else {
-        if (vec)
-            hipLaunchKernelGGL(k_segment_reduce4, dim3(B, agb_cdiv(C, 64), splits), dim3(256), 0, s, A, lda, Bm, ldb,
-                               ptr, C, mode, splits, part, part_arg);
-        else
-            hipLaunchKernelGGL(k_segment_reduce, dim3(B, agb_cdiv(C, 64), splits), dim3(256), 0, s, A, lda, Bm, ldb, ptr,
-                           C, mode, splits, part, part_arg);
-        hipLaunchKernelGGL(k_segment_fold, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, s, part, part_arg,
-                           ptr, B, C, mode, splits, Y, argmax);
-    }
-    AGB_CHECK_LAUNCH("agb_segment_reduce");
-    return AGB_OK;
-}
-
-int agb_segment_broadcast(const float* S, const int32_t* coords, const int32_t* ptr, const float* M, int ldm,
-                          float* out, int ldo, int n, int C, int average, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldo % 4 == 0 && (M == nullptr || ldm % 4 == 0),
-                  "agb_segment_broadcast: C/ld must be multiples of 4");
-    if (n == 0) return AGB_OK;
-    long long total = (long long)n * (C / 4);
-    hipLaunchKernelGGL(k_segment_broadcast, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, S, coords,
-                       ptr, M, ldm, out, ldo, n, C / 4, average);
-    AGB_CHECK_LAUNCH("agb_segment_broadcast");
-    return AGB_OK;
-}
-
-// out[r,:] = M[r,:] * S[batch(r),:] + T[batch(r),:] / rows(batch(r));  S, T [B, C]; M, out [n, C]
-int agb_segment_scale_add(const float* S, const float* T, const int32_t* coords, const int32_t* ptr, const float* M,
-                          int ldm, float* out, int ldo, int n, int C, void* stream) {
-    AGB_CHECK_ARG(C % 4 == 0 && ldo % 4 == 0 && ldm % 4 == 0, "agb_segment_scale_add: C/ld must be multiples of 4");
-    AGB_CHECK_ARG(S && T && M, "agb_segment_scale_add: S, T and M are required");
-    if (n == 0) return AGB_OK;
-    long long total = (long long)n * (C / 4);
-    hipLaunchKernelGGL(k_segment_scale_add, dim3(agb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, S, T, coords,
-                       ptr, M, ldm, out, ldo, n, C / 4);
-    AGB_CHECK_LAUNCH("agb_segment_scale_add");
-    return AGB_OK;
-}
-
-// dX must be zero-filled by the caller.
-int agb_segment_max_bwd(const float* dY, const int32_t* argmax, float* dX, int ldx, int B, int C, void* stream) {
-    if (B * C == 0) return AGB_OK;
-    hipLaunchKernelGGL(k_segment_max_bwd, dim3(agb_cdiv((long long)B * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       dY, argmax, dX, ldx, B, C);
-    AGB_CHECK_LAUNCH("agb_segment_max_bwd");
-    return AGB_OK;
-}
+#define AGB_T float
+#define AGB_FN(name) name
+#include "pool_rows.inc"
+#undef AGB_T
+#undef AGB_FN
+#define AGB_T bf16_t
+#define AGB_FN(name) name##_h
+#include "pool_rows.inc"
+#undef AGB_T
+#undef AGB_FN
 
 }  // extern "C"

@@ -753,7 +753,9 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_bf16(ConvArgs a) {
 // rows and rounds them while staging: that kernel is bound by exactly those staging instructions and by the bytes its
 // gathers pull through the CU's vector-memory path (profiles/r02_v9_senet50_bf16_bench.json: 0.06 of the bf16 MFMA peak;
 // tools/gather_locality_probe.py: not by the gathers' locality).  Cin % 8 == 0.  Same tiling, fp32 accumulate and output.
-template <int TM, bool PERM, int CW = 64>
+// Y16: the output rows are bf16 as well (the bf16-activation mode: a.Y reinterpreted, a.ldy in bf16 elements); split
+// partials stay fp32 (k_split_reduce rounds once, at the end).
+template <int TM, bool PERM, int CW = 64, bool Y16 = false>
 __global__ __launch_bounds__(256) void k_spconv_pipe_b16(ConvArgs a) {
     constexpr int WAVES_M = TM / 32;
     constexpr int WAVES_N = 4 / WAVES_M;
@@ -877,6 +879,30 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_b16(ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + (wn * NT + nt) * 32 + li;
         bvs[nt] = (a.bias && a.ksplit == 1 && col < Cout) ? a.bias[col] : 0.f;
+    }
+    if (Y16 && a.ksplit == 1) {
+        // two rows per step: lanes 2j / 2j+1 swap one value each (DPP quad permutation), the even lane then holds columns
+        // (li, li+1) of the first row, the odd lane columns (li-1, li) of the second: one 4-byte store of a bf16 pair per
+        // lane instead of two 2-byte stores (Cout % 4 == 0 and n0, 32 nt even: a pair never straddles the matrix edge)
+        bf16_t* __restrict__ Y16p = reinterpret_cast<bf16_t*>(a.Y);
+        const bool odd = li & 1;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg += 2) {
+            const int row = odd ? rows[reg + 1] : rows[reg];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float mine = odd ? acc[nt][reg + 1] : acc[nt][reg];
+                const float give = odd ? acc[nt][reg] : acc[nt][reg + 1];
+                const float got = __shfl_xor(give, 1);
+                const float bo = __shfl_xor(bvs[nt], 1);
+                const int col = n0 + (wn * NT + nt) * 32 + (li & ~1);
+                if (row >= 0 && col < Cout) {
+                    const unsigned v = odd ? agb_pack2_bf16(got + bo, mine + bvs[nt]) : agb_pack2_bf16(mine + bvs[nt], got + bo);
+                    *reinterpret_cast<unsigned*>(Y16p + (long long)row * a.ldy + col) = v;
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -1168,8 +1194,9 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
 }
 
 // Y[r, :] = bias + sum_s partial[s][r, :]   (fixed order)
+template <typename T = float>
 __global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_out, int C4,
-                               const float* __restrict__ bias, float* __restrict__ Y, int ldy) {
+                               const float* __restrict__ bias, T* __restrict__ Y, int ldy) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int r = (int)(t / C4), c = (int)(t % C4) * 4;
     if (r >= n_out) return;
@@ -1178,7 +1205,7 @@ __global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_o
         float4 v = *reinterpret_cast<const float4*>(partial + ((long long)s * n_out + r) * (C4 * 4) + c);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    *reinterpret_cast<float4*>(Y + (long long)r * ldy + c) = acc;
+    st4(Y + (long long)r * ldy + c, acc);
 }
 
 // WT[k][c][r] = W[k][r][c]: the data gradient multiplies by W[k]^T, and the weights change every step, so this runs
@@ -1651,7 +1678,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
 // as ONE 8-byte write of four bf16 (21 x 3 packed channels needed three 2-byte writes per pair: 550 us; this form: see
 // DESIGN.md section 5).  Same probing, same by-product map, same software pipeline (indices two chunks ahead, rows and
 // weights one chunk ahead) as k_spconv_fwd3<true>.
-template <bool X3>
+template <bool X3, bool Y16 = false>
 __global__ __launch_bounds__(256) void k_spconv_fwd3_lp(const float* __restrict__ X, int ldx,
                                                         const float* __restrict__ W,  // [K3*3, Cout]
                                                         const float* __restrict__ bias, float* __restrict__ Y, int ldy,
@@ -1757,7 +1784,9 @@ __global__ __launch_bounds__(256) void k_spconv_fwd3_lp(const float* __restrict_
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            if (row < n_out) Y[(long long)row * ldy + col] = acc[reg] + bv;
+            if (row >= n_out) continue;
+            if (Y16) st1(reinterpret_cast<bf16_t*>(Y) + (long long)row * ldy + col, acc[reg] + bv);   // (bf16 rows, ldy in bf16)
+            else Y[(long long)row * ldy + col] = acc[reg] + bv;
         }
     }
 }
@@ -2060,7 +2089,7 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
     }
     if (a.ksplit > 1) {
         long long total = (long long)a.n_out * (a.Cout / 4);
-        hipLaunchKernelGGL(k_split_reduce, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, a.partial, a.ksplit, a.n_out,
+        hipLaunchKernelGGL(k_split_reduce<float>, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, a.partial, a.ksplit, a.n_out,
                            a.Cout / 4, a.bias, a.Y, a.ldy);
     }
     return AGB_OK;
@@ -2281,7 +2310,7 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
     }
     if (ksplit > 1) {
         long long total = (long long)n_out * (Cout / 4);
-        hipLaunchKernelGGL(k_split_reduce, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, partial, ksplit, n_out, Cout / 4,
+        hipLaunchKernelGGL(k_split_reduce<float>, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, partial, ksplit, n_out, Cout / 4,
                            bias, Y, ldy);
     }
     AGB_CHECK_LAUNCH("agb_spconv_fwd_lp");
@@ -2304,12 +2333,15 @@ int agb_to_bf16(const float* X, long long ldx, long long n, int C, uint16_t* Y16
 
 // agb_spconv_fwd_lp (precision 1) on bf16 STORAGE: X16 uint16 [n_in][ldx16] and K-major weights Wt16 uint16 [K3][Cout][Cin]
 // are bf16 twins made by agb_to_bf16; fp32 accumulate, bias and output.  Cin % 8 == 0, ldx16 % 8 == 0.
-int agb_spconv_fwd_b16(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const int32_t* nbr, long long nbr_stride,
-                       int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
-                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
-                       float* partial, void* stream) {
+}  // extern "C"
+template <bool Y16>
+static int fwd_b16_impl(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const int32_t* nbr, long long nbr_stride,
+                        int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                        const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                        float* partial, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 8 && Cout >= 4 && Cin % 8 == 0 && Cout % 4 == 0 && ldx16 % 8 == 0,
                   "agb_spconv_fwd_b16: Cin (%d), ldx16 must be multiples of 8, Cout (%d) of 4", Cin, Cout);
+    AGB_CHECK_ARG(!Y16 || ldy % 4 == 0, "agb_spconv_fwd_h: ldy (%d, bf16 elements) must be a multiple of 4", ldy);
     AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_b16: ksplit needs `partial`");
     AGB_CHECK_ARG(nbr != nullptr || (K3 == 1 && perm == nullptr), "agb_spconv_fwd_b16: the identity map needs K3 == 1");
     if (n_out == 0) return AGB_OK;
@@ -2318,23 +2350,46 @@ int agb_spconv_fwd_b16(const uint16_t* X16, int ldx16, const uint16_t* Wt16, con
                Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit, partial, 0, -1};
     dim3 block(256);
     if (perm) {
-        hipLaunchKernelGGL((k_spconv_pipe_b16<64, true>), dim3(n_tiles, agb_cdiv(Cout, BN), ksplit), block, 0, s, a);
+        hipLaunchKernelGGL((k_spconv_pipe_b16<64, true, 64, Y16>), dim3(n_tiles, agb_cdiv(Cout, BN), ksplit), block, 0, s, a);
     } else if (conv_tile_rows(n_out, Cin, Cout) == 128) {
         const bool wide = Cout >= 128 && (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, 128) * ksplit >= 512;
         dim3 grid(agb_cdiv(n_out, 128), agb_cdiv(Cout, wide ? 128 : 64), ksplit);
-        if (wide) hipLaunchKernelGGL((k_spconv_pipe_b16<128, false, 128>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_spconv_pipe_b16<128, false>), grid, block, 0, s, a);
+        if (wide) hipLaunchKernelGGL((k_spconv_pipe_b16<128, false, 128, Y16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_spconv_pipe_b16<128, false, 64, Y16>), grid, block, 0, s, a);
     } else {
-        hipLaunchKernelGGL((k_spconv_pipe_b16<64, false>), dim3(agb_cdiv(n_out, 64), agb_cdiv(Cout, BN), ksplit), block, 0, s,
-                           a);
+        hipLaunchKernelGGL((k_spconv_pipe_b16<64, false, 64, Y16>), dim3(agb_cdiv(n_out, 64), agb_cdiv(Cout, BN), ksplit), block,
+                           0, s, a);
     }
     if (ksplit > 1) {
         long long total = (long long)n_out * (Cout / 4);
-        hipLaunchKernelGGL(k_split_reduce, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, partial, ksplit, n_out, Cout / 4,
-                           bias, Y, ldy);
+        if (Y16)
+            hipLaunchKernelGGL(k_split_reduce<bf16_t>, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, partial, ksplit, n_out,
+                               Cout / 4, bias, reinterpret_cast<bf16_t*>(Y), ldy);
+        else
+            hipLaunchKernelGGL(k_split_reduce<float>, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, partial, ksplit, n_out,
+                               Cout / 4, bias, Y, ldy);
     }
     AGB_CHECK_LAUNCH("agb_spconv_fwd_b16");
     return AGB_OK;
+}
+
+extern "C" {
+int agb_spconv_fwd_b16(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const int32_t* nbr, long long nbr_stride,
+                       int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                       const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                       float* partial, void* stream) {
+    return fwd_b16_impl<false>(X16, ldx16, Wt16, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls,
+                               cls_tab, n_tiles, ksplit, partial, stream);
+}
+
+// The same with bf16 OUTPUT rows (the bf16-activation mode: every row matrix of the network is bf16, accumulation fp32,
+// one rounding when the row leaves the kernel); Y16 uint16 [n_out][ldy16].
+int agb_spconv_fwd_h(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const int32_t* nbr, long long nbr_stride,
+                     int kflip, const float* bias, uint16_t* Y16, int ldy16, int n_out, int K3, int Cin, int Cout,
+                     const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                     float* partial, void* stream) {
+    return fwd_b16_impl<true>(X16, ldx16, Wt16, nbr, nbr_stride, kflip, bias, reinterpret_cast<float*>(Y16), ldy16, n_out, K3,
+                              Cin, Cout, perm, tile_cls, cls_tab, n_tiles, ksplit, partial, stream);
 }
 
 int agb_spconv_fwd(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
@@ -2550,9 +2605,9 @@ int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t*
 }
 
 // precision: 0 fp32 MFMA, 1 bf16 operands (k_spconv_fwd3_lp), 2 split-bf16x3 requested: served by the fp32 kernel
-int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
-                            const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
-                            int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream) {
+static int fwd3_grid_lp_impl(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                             const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                             int32_t* nbr_out, long long nbr_out_stride, int precision, int y16, void* stream) {
     AGB_CHECK_ARG(precision >= 0 && precision <= 2, "agb_spconv_fwd3_grid_lp: precision %d (0 fp32, 1 bf16, 2 bf16x3)",
                   precision);
     AGB_CHECK_ARG(n_out >= 0 && Cout >= 4 && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout, "agb_spconv_fwd3_grid: bad sizes");
@@ -2571,7 +2626,10 @@ int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32
     const dim3 grid3(agb_cdiv(n_out, BM), agb_cdiv(Cout, BN));
     // (split-bf16x3 measured SLOWER than the fp32 kernel here — two LDS planes to stage, three MFMAs: 740 vs 683 us —
     // so precision 2 takes the exact fp32 kernel)
-    if (precision == 1)
+    if (y16)
+        hipLaunchKernelGGL((k_spconv_fwd3_lp<false, true>), grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy,
+                           n_out, K * K * K, Cout, gp);
+    else if (precision == 1)
         hipLaunchKernelGGL(k_spconv_fwd3_lp<false>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy, n_out,
                            K * K * K, Cout, gp);
     else
@@ -2579,6 +2637,22 @@ int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32
                            ldy, n_out, K * K * K, Cout, gp);
     AGB_CHECK_LAUNCH("agb_spconv_fwd3_grid");
     return AGB_OK;
+}
+
+int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                            const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                            int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream) {
+    return fwd3_grid_lp_impl(X, ldx, W, coords, grid, desc, K, bias, Y, ldy, n_out, Cout, nbr_out, nbr_out_stride, precision, 0,
+                             stream);
+}
+
+// bf16 operands and bf16 OUTPUT rows (the bf16-activation mode; the 3-channel input features stay fp32): Y16 uint16
+// [n_out][ldy16]
+int agb_spconv_fwd3_grid_h(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                           const int32_t* desc, int K, const float* bias, uint16_t* Y16, int ldy16, int n_out, int Cout,
+                           int32_t* nbr_out, long long nbr_out_stride, void* stream) {
+    return fwd3_grid_lp_impl(X, ldx, W, coords, grid, desc, K, bias, reinterpret_cast<float*>(Y16), ldy16, n_out, Cout, nbr_out,
+                             nbr_out_stride, 1, 1, stream);
 }
 
 }  // extern "C"

@@ -6,30 +6,31 @@ from . import _lib
 from . import se_ops as _se_ops  # noqa: F401  (declares the agb_se_tail_* entry points used below)
 
 _P = _lib.ptr
+_R, _sfx = _lib.rows, _lib.sfx
 ACT_IDS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
 
 _lib.declare("agb_bn_chunks", [_lib.c_int])
 _lib.declare("agb_bn_stats", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_float, _lib.c_float,
                               _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p,
-                              _lib.c_void_p])
+                              _lib.c_void_p], rows=True)
 _lib.declare("agb_bn_stats_tracked", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_float, _lib.c_float,
                                       _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p,
-                                      _lib.c_void_p, _lib.c_void_p, _lib.c_void_p])
+                                      _lib.c_void_p, _lib.c_void_p, _lib.c_void_p], rows=True)
 _lib.declare("agb_bn_act_fwd", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
-                                _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p])
+                                _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p], rows=True)
 _lib.declare("agb_bn_act_bwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int,
                                 _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
                                 _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
-                                _lib.c_void_p])
+                                _lib.c_void_p], rows=True)
 _lib.declare("agb_bn_act_bwd_colsum", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int,
                                        _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int,
                                        _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_void_p,
-                                       _lib.c_void_p, _lib.c_void_p, _lib.c_void_p])
+                                       _lib.c_void_p, _lib.c_void_p, _lib.c_void_p], rows=True)
 _lib.declare("agb_add_act_fwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
-                                 _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p])
+                                 _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p], rows=True)
 _lib.declare("agb_add_act_bwd", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
                                  _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p,
-                                 _lib.c_void_p, _lib.c_void_p])
+                                 _lib.c_void_p, _lib.c_void_p], rows=True)
 
 
 _lib.declare("agb_bn_stats_fold", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_float, _lib.c_float, _lib.c_void_p,
@@ -46,7 +47,7 @@ def _statistics(x, n, c, eps, momentum, training, running_mean, running_var, cou
                   _P(running_mean), _P(running_var), _P(counter), _lib.stream())
         return stats
     part = torch.empty(bn_chunks(n) * 3 * c, dtype=torch.float32, device=x.device) if training else None
-    _lib.call("agb_bn_stats_tracked", _P(x), x.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
+    _lib.call("agb_bn_stats_tracked" + _sfx(x), _R(x), x.stride(0), n, c, float(eps), float(momentum), int(bool(training)),
               _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter), _lib.stream())
     return stats
 
@@ -70,8 +71,8 @@ class BatchNormActFunction(torch.autograd.Function):
             raise _lib.AgbError("fused batch norm needs a channel count that is a multiple of 4")
         stats = _statistics(x, n, c, eps, momentum, training, running_mean, running_var, counter, hint)
         y = torch.empty_like(x)
-        _lib.call("agb_bn_act_fwd", _P(x), x.stride(0), n, c, _P(stats[0]), _P(stats[1]), _P(gamma), _P(beta),
-                  act_id, _P(y), y.stride(0), _lib.stream())
+        _lib.call("agb_bn_act_fwd" + _sfx(x), _R(x), x.stride(0), n, c, _P(stats[0]), _P(stats[1]), _P(gamma), _P(beta),
+                  act_id, _R(y), y.stride(0), _lib.stream())
         ctx.save_for_backward(x, stats, gamma if gamma is not None else torch.empty(0),
                               beta if beta is not None else torch.empty(0))
         ctx.cfg = (act_id, bool(training), gamma is not None, beta is not None)
@@ -87,8 +88,9 @@ class BatchNormActFunction(torch.autograd.Function):
         part = torch.empty(bn_chunks(n) * 2 * c, dtype=torch.float32, device=dev)
         dgb = torch.empty(3, c, dtype=torch.float32, device=dev)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        _lib.call("agb_bn_act_bwd_colsum", _P(x), x.stride(0), _P(dy), dy.stride(0), n, c, _P(stats[0]), _P(stats[1]),
-                  _P(gamma) if has_g else None, _P(beta) if has_b else None, act_id, int(training), _P(part), _P(dx),
+        _lib.call("agb_bn_act_bwd_colsum" + _sfx(x, dy), _R(x), x.stride(0), _R(dy), dy.stride(0), n, c, _P(stats[0]),
+                  _P(stats[1]),
+                  _P(gamma) if has_g else None, _P(beta) if has_b else None, act_id, int(training), _P(part), _R(dx),
                   0 if dx is None else dx.stride(0), _P(dgb[0]), _P(dgb[1]), _P(dgb[2]) if dx is not None else None,
                   _lib.stream())
         if dx is not None:
@@ -133,8 +135,8 @@ class AddActFunction(torch.autograd.Function):
         if c % 4 != 0:
             raise _lib.AgbError("fused residual tail needs a channel count that is a multiple of 4")
         y = torch.empty_like(a)
-        _lib.call("agb_add_act_fwd", _P(a), a.stride(0), _P(r), r.stride(0), _P(scale),
-                  _P(coords) if scale is not None else None, n, c, act_id, _P(y), y.stride(0), _lib.stream())
+        _lib.call("agb_add_act_fwd" + _sfx(a, r), _R(a), a.stride(0), _R(r), r.stride(0), _P(scale),
+                  _P(coords) if scale is not None else None, n, c, act_id, _R(y), y.stride(0), _lib.stream())
         ctx.save_for_backward(a, r, scale if scale is not None else torch.empty(0), coords)
         ctx.cfg = (act_id, scale is not None)
         return y
@@ -150,8 +152,8 @@ class AddActFunction(torch.autograd.Function):
         # this package writes gradients in place, and autograd only accumulates in place into buffers it owns alone)
         shared = not has_s and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         dr = torch.empty_like(r) if (ctx.needs_input_grad[1] and not shared) else None
-        _lib.call("agb_add_act_bwd", _P(a), a.stride(0), _P(r), r.stride(0), _P(scale) if has_s else None,
-                  _P(coords) if has_s else None, _P(dy), dy.stride(0), n, c, act_id, _P(da), _P(dr), _lib.stream())
+        _lib.call("agb_add_act_bwd" + _sfx(a, r, dy), _R(a), a.stride(0), _R(r), r.stride(0), _P(scale) if has_s else None,
+                  _P(coords) if has_s else None, _R(dy), dy.stride(0), n, c, act_id, _R(da), _R(dr), _lib.stream())
         return da, (da if shared else dr), None, None, None
 
 
@@ -168,8 +170,8 @@ class BatchNormAddActFunction(torch.autograd.Function):
             raise _lib.AgbError("fused batch norm + residual needs a channel count that is a multiple of 4")
         stats = _statistics(z, n, c, eps, momentum, training, running_mean, running_var, counter, hint)
         y = torch.empty_like(z)
-        _lib.call("agb_se_tail_fwd", _P(z), z.stride(0), _P(r), r.stride(0), None, _P(stats[0]), _P(stats[1]), _P(gamma),
-                  _P(beta), None, None, act_id, n, c, _P(y), y.stride(0), _lib.stream())
+        _lib.call("agb_se_tail_fwd" + _sfx(z, r), _R(z), z.stride(0), _R(r), r.stride(0), None, _P(stats[0]), _P(stats[1]),
+                  _P(gamma), _P(beta), None, None, act_id, n, c, _R(y), y.stride(0), _lib.stream())
         none = torch.empty(0)
         ctx.save_for_backward(z, r, stats, gamma if gamma is not None else none, beta if beta is not None else none)
         ctx.cfg = (act_id, bool(training), gamma is not None, beta is not None)
@@ -186,14 +188,15 @@ class BatchNormAddActFunction(torch.autograd.Function):
         chunks = _lib.load().agb_se_tail_chunks(n, c, 0)
         spart = torch.empty(chunks * 2 * c, dtype=torch.float32, device=dev)
         bn = (_P(stats[0]), _P(stats[1]), _P(gamma), _P(beta), None, None)
-        _lib.call("agb_se_tail_bwd_sums", _P(z), z.stride(0), _P(r), r.stride(0), _P(dy), dy.stride(0), None, 0, *bn, act_id,
-                  n, c, _P(spart), _lib.stream())
+        sf = _sfx(z, r, dy)
+        _lib.call("agb_se_tail_bwd_sums" + sf, _R(z), z.stride(0), _R(r), r.stride(0), _R(dy), dy.stride(0), None, 0, *bn,
+                  act_id, n, c, _P(spart), _lib.stream())
         dgb = torch.empty(2, c, dtype=torch.float32, device=dev)
         _lib.call("agb_bn_bwd_fold", _P(spart), chunks, c, _P(dgb[0]), _P(dgb[1]), _lib.stream())
         dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
         dr = torch.empty_like(r) if ctx.needs_input_grad[1] else None
-        _lib.call("agb_se_tail_bwd_apply", _P(z), z.stride(0), _P(r), r.stride(0), _P(dy), dy.stride(0), None, *bn, None,
-                  _P(dgb[0]), _P(dgb[1]), act_id, int(training), n, c, _P(dz), 0 if dz is None else dz.stride(0), _P(dr),
+        _lib.call("agb_se_tail_bwd_apply" + sf, _R(z), z.stride(0), _R(r), r.stride(0), _R(dy), dy.stride(0), None, *bn, None,
+                  _P(dgb[0]), _P(dgb[1]), act_id, int(training), n, c, _R(dz), 0 if dz is None else dz.stride(0), _R(dr),
                   0 if dr is None else dr.stride(0), _lib.stream())
         if dz is not None:
             colsum = torch.zeros(c, dtype=torch.float32, device=dev) if training else \

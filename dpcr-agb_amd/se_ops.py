@@ -6,6 +6,7 @@ import torch
 from . import _lib
 
 _P = _lib.ptr
+_R, _sfx = _lib.rows, _lib.sfx
 _V, _I = _lib.c_void_p, _lib.c_int
 _lib.declare("agb_se_mlp_fwd", [_V, _V, _V, _V, _V, _I, _I, _I, _I, _V, _V, _V])
 _lib.declare("agb_se_mlp_bwd", [_V, _V, _V, _I, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V])
@@ -68,7 +69,7 @@ class SELayerFunction(torch.autograd.Function):
         _lib.call("agb_se_mlp_fwd", _P(p), _P(w1), _P(b1), _P(w2), _P(b2), B, C, H, act_id, _P(h_pre), _P(s),
                   _lib.stream())
         out = torch.empty_like(x)
-        _lib.call("agb_segment_broadcast", _P(s), _P(coords), _P(ptr), _P(x), x.stride(0), _P(out), out.stride(0), n,
+        _lib.call("agb_segment_broadcast" + _sfx(x), _P(s), _P(coords), _P(ptr), _R(x), x.stride(0), _R(out), out.stride(0), n,
                   C, 0, _lib.stream())
         ctx.save_for_backward(x, coords, ptr, p, w1, w2, h_pre, s)
         ctx.cfg = (act_id, b1 is not None, b2 is not None, B)
@@ -94,7 +95,7 @@ class SELayerFunction(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.call("agb_segment_scale_add", _P(s), _P(dp), _P(coords), _P(ptr), _P(dout), dout.stride(0), _P(dx),
+            _lib.call("agb_segment_scale_add" + _sfx(dout), _P(s), _P(dp), _P(coords), _P(ptr), _R(dout), dout.stride(0), _R(dx),
                       dx.stride(0), n, C, _lib.stream())
         return dx, None, None, None, dw1, db1, dw2, db2, None
 
@@ -110,14 +111,14 @@ def se_excite(p, lin1: torch.nn.Linear, act_name: str, lin2: torch.nn.Linear):
 # ---------------------------------------------------------------------------------------------- fused block tail
 _F = _lib.c_float
 _lib.declare("agb_se_tail_chunks", [_I, _I, _I])
-_lib.declare("agb_se_tail_stats", [_V, _I, _V, _I, _I, _I, _F, _F, _I, _V, _V, _V, _V, _V, _V, _V])
+_lib.declare("agb_se_tail_stats", [_V, _I, _V, _I, _I, _I, _F, _F, _I, _V, _V, _V, _V, _V, _V, _V], rows=True)
 _lib.declare("agb_se_tail_pool", [_V, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V])
-_lib.declare("agb_se_tail_fwd", [_V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V, _I, _V])
-_lib.declare("agb_se_tail_bwd_sums", [_V, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V, _V])
+_lib.declare("agb_se_tail_fwd", [_V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V, _I, _V], rows=True)
+_lib.declare("agb_se_tail_bwd_sums", [_V, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V, _V], rows=True)
 _lib.declare("agb_se_tail_bwd_ds", [_V, _V, _I, _V, _V, _V, _I, _I, _V, _V, _V, _V])
 _lib.declare("agb_se_tail_bwd_fold", [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _V, _V, _V, _V])
 _lib.declare("agb_se_tail_bwd_apply", [_V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V,
-                                       _I, _V, _I, _V])
+                                       _I, _V, _I, _V], rows=True)
 # (whether the blocks take this fused tail is sparse_ops.KernelOptions.fused_tail; tests compare both forms)
 
 
@@ -137,7 +138,8 @@ class SEBlockTailFunction(torch.autograd.Function):
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # noqa: E731
         stats = f32(2, C)
         part = f32(_lib.load().agb_se_tail_chunks(n, C, B) * 3 * C)
-        _lib.call("agb_se_tail_stats", _P(z), z.stride(0), _P(ptr), n, C, B, float(eps), float(momentum),
+        sf = _sfx(z, r)
+        _lib.call("agb_se_tail_stats" + sf, _R(z), z.stride(0), _P(ptr), n, C, B, float(eps), float(momentum),
                   int(bool(training)), _P(part), _P(stats[0]), _P(stats[1]), _P(running_mean), _P(running_var), _P(counter),
                   _lib.stream())
         zbar, p, h_pre, s = f32(B, C), f32(B, C), f32(B, H), f32(B, C)
@@ -145,8 +147,8 @@ class SEBlockTailFunction(torch.autograd.Function):
                   _P(p), _lib.stream())
         _lib.call("agb_se_mlp_fwd", _P(p), _P(w1), _P(b1), _P(w2), _P(b2), B, C, H, se_act, _P(h_pre), _P(s), _lib.stream())
         y = torch.empty_like(z)
-        _lib.call("agb_se_tail_fwd", _P(z), z.stride(0), _P(r), r.stride(0), _P(coords), _P(stats[0]), _P(stats[1]),
-                  _P(gamma), _P(beta), _P(s), _P(keep), act_id, n, C, _P(y), y.stride(0), _lib.stream())
+        _lib.call("agb_se_tail_fwd" + sf, _R(z), z.stride(0), _R(r), r.stride(0), _P(coords), _P(stats[0]), _P(stats[1]),
+                  _P(gamma), _P(beta), _P(s), _P(keep), act_id, n, C, _R(y), y.stride(0), _lib.stream())
         none = torch.empty(0)
         ctx.save_for_backward(z, r, stats, zbar, p, h_pre, s, coords, ptr, w1, w2,
                               gamma if gamma is not None else none, beta if beta is not None else none,
@@ -169,7 +171,8 @@ class SEBlockTailFunction(torch.autograd.Function):
         bn = (_P(stats[0]), _P(stats[1]), _P(gamma), _P(beta), _P(s), _P(keep))
         common = (_P(coords),) + bn
         spart = f32(_lib.load().agb_se_tail_chunks(n, C, B) * 2 * C)
-        _lib.call("agb_se_tail_bwd_sums", _P(z), z.stride(0), _P(r), r.stride(0), _P(dy), dy.stride(0), _P(ptr), B, *bn,
+        sf = _sfx(z, r, dy)
+        _lib.call("agb_se_tail_bwd_sums" + sf, _R(z), z.stride(0), _R(r), r.stride(0), _R(dy), dy.stride(0), _P(ptr), B, *bn,
                   act_id, n, C, _P(spart), _lib.stream())
         ds = f32(B, C)
         _lib.call("agb_se_tail_bwd_ds", _P(spart), _P(ptr), n, _P(gamma), _P(beta), _P(keep), B, C, _P(S[0]), _P(S[1]),
@@ -185,8 +188,8 @@ class SEBlockTailFunction(torch.autograd.Function):
                   _P(stats[1]), B, C, _P(dte), _P(dgb[0]), _P(dgb[1]), _lib.stream())
         dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
         dr = torch.empty_like(r) if ctx.needs_input_grad[1] else None
-        _lib.call("agb_se_tail_bwd_apply", _P(z), z.stride(0), _P(r), r.stride(0), _P(dy), dy.stride(0), *common, _P(dte),
-                  _P(dgb[0]), _P(dgb[1]), act_id, int(training), n, C, _P(dz), 0 if dz is None else dz.stride(0), _P(dr),
+        _lib.call("agb_se_tail_bwd_apply" + sf, _R(z), z.stride(0), _R(r), r.stride(0), _R(dy), dy.stride(0), *common, _P(dte),
+                  _P(dgb[0]), _P(dgb[1]), act_id, int(training), n, C, _R(dz), 0 if dz is None else dz.stride(0), _R(dr),
                   0 if dr is None else dr.stride(0), _lib.stream())
         if dz is not None:
             # column sums of dz = the bias gradient of the convolution that produced z: 0 with batch statistics (the

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from . import _lib
 
 _P = _lib.ptr
+_P16 = _lib.ptr16
 
 class KernelOptions:
     """Operand precision and kernel-choice knobs of ONE model (or one call) — carried by the model / its modules, not by
@@ -38,17 +39,22 @@ class KernelOptions:
       dw_variant           0 = automatic, 1 = LDS-staged weight-gradient kernel, 2 = register-operand kernel (A/B measurements)
       bf16_storage         precision "bf16": convolutions read bf16 twins of their inputs (rows and weights converted once,
                            gathered as 2-byte channels) instead of converting fp32 rows while staging them
+      bf16_activations     precision "bf16" on the sparse backbones: every activation / gradient ROW MATRIX of the network is
+                           stored in bf16 (the stem convolution writes bf16 rows, every later kernel follows the storage type
+                           of its input: csrc/*_rows.inc, agb_spconv_fwd_h); accumulators, BatchNorm / SE statistics,
+                           per-plot matrices, parameters and their gradients stay fp32.  Halves the HBM traffic of the
+                           element-wise passes that dominate MSENet50 (BASELINE config 5).  Default off.
 
     Use: ``model.kernel_options = KernelOptions(precision="bf16")`` (the backbones run their forward pass inside it), or
     ``with KernelOptions(cmp_mode=128): ...`` around direct calls.  Autograd nodes keep the options they were created
     under for their backward pass.  ``DEFAULTS`` (environment-initialised) applies where nothing else is set."""
     __slots__ = ("precision", "cmp_mode", "cmp_interleave", "balanced_tiles", "bn_stats_in_epilogue", "fused_tail",
-                 "deterministic_wgrad", "dw_variant", "bf16_storage")
+                 "deterministic_wgrad", "dw_variant", "bf16_storage", "bf16_activations")
     PRECISIONS = ("fp32", "bf16", "bf16x3")
 
     def __init__(self, precision=None, cmp_mode=None, cmp_interleave=None, balanced_tiles=None,
                  bn_stats_in_epilogue=None, fused_tail=None, deterministic_wgrad=None, dw_variant=None,
-                 bf16_storage=None, base=None):
+                 bf16_storage=None, bf16_activations=None, base=None):
         base = base if base is not None else (current() if "DEFAULTS" in globals() else None)
         pick = lambda v, name, dflt: v if v is not None else (getattr(base, name) if base is not None else dflt)  # noqa: E731
         self.precision = pick(precision, "precision", "fp32")
@@ -62,6 +68,7 @@ class KernelOptions:
         self.deterministic_wgrad = bool(pick(deterministic_wgrad, "deterministic_wgrad", False))
         self.dw_variant = int(pick(dw_variant, "dw_variant", 0))
         self.bf16_storage = bool(pick(bf16_storage, "bf16_storage", True))
+        self.bf16_activations = bool(pick(bf16_activations, "bf16_activations", False))
 
     def replace(self, **kw):
         return KernelOptions(base=self, **kw)
@@ -73,6 +80,11 @@ class KernelOptions:
     @property
     def low_precision(self):
         return self.precision in _PREC_ID
+
+    @property
+    def rows_bf16(self):
+        """True when the backbone's row matrices are to be stored in bf16 (bf16 operands AND bf16_activations)."""
+        return self.bf16_activations and self.precision == "bf16"
 
     def __enter__(self):
         _scope().append(self)
@@ -276,9 +288,18 @@ _lib.declare("agb_spconv_fwd_b16", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _l
                                     _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                     _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
                                     _lib.c_void_p, _lib.c_void_p])
+_lib.declare("agb_spconv_fwd_h", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
+                                    _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
+                                    _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
+                                    _lib.c_void_p, _lib.c_void_p])
+_lib.declare("agb_spconv_fwd3_grid_h", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p,
+                                        _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int,
+                                        _lib.c_void_p, _lib.c_ll, _lib.c_void_p])
 
 
 def has_twin(t):
+    if t.dtype == torch.bfloat16:
+        return True
     h = getattr(t, "agb_bf16", None)
     return h is not None and h[1] == t._version and h[0].shape == t.shape
 
@@ -287,6 +308,8 @@ def bf16_twin(t, cache=True):
     """bf16 copy (round to nearest even, csrc k_to_bf16) of a 2-D fp32 row matrix.  cache: keep it on the tensor (valid while
     the tensor's version stands) — an activation that feeds several convolutions, forward and weight gradient, is
     converted once."""
+    if t.dtype == torch.bfloat16:      # bf16 storage: the row matrix is its own twin
+        return t
     if cache:
         h = getattr(t, "agb_bf16", None)
         if h is not None and h[1] == t._version and h[0].shape == t.shape:
@@ -295,21 +318,35 @@ def bf16_twin(t, cache=True):
         raise _lib.AgbError("bf16_twin takes a 2-D row matrix with contiguous rows")
     n, c = t.shape
     y = torch.empty(n, c, dtype=torch.bfloat16, device=t.device)
-    _lib.call("agb_to_bf16", _P(t), t.stride(0), n, c, _P(y), y.stride(0), _lib.stream())
+    _lib.call("agb_to_bf16", _P(t), t.stride(0), n, c, _P16(y), y.stride(0), _lib.stream())
     if cache:
         t.agb_bf16 = (y, t._version)
     return y
 
 
 def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None, plan=None,
-                       w_kmajor=None, bn_stats=False, opts=None):
+                       w_kmajor=None, bn_stats=False, opts=None, out_bf16=None):
     """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout].
     plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
     w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes.
-    opts: KernelOptions of the call (default: the ones in force)."""
+    opts: KernelOptions of the call (default: the ones in force).
+    out_bf16: storage type of the output rows (default: that of x).  bf16 rows (in or out) take the bf16 operand mode:
+    w_kmajor is required."""
     opts = opts or current()
     _set_last_bn_part(None)
-    y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+    x_bf16 = x.dtype == torch.bfloat16
+    if out_bf16 is None:
+        out_bf16 = x_bf16
+    if x_bf16 or out_bf16:
+        if w_kmajor is None or opts.prec_id != 1:
+            raise _lib.AgbError("bf16 row matrices need the bf16 operand mode (KernelOptions precision='bf16') and K-major "
+                                "weights")
+        if cin % 8 != 0 or x.stride(0) % 8 != 0 or cout % 4 != 0:
+            # widths the bf16-storage kernel does not take (none in MSENet14/50): fp32 rows through the staging kernel
+            y = spconv_forward_raw(x.float() if x_bf16 else x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind, pairs, plan,
+                                   w_kmajor, bn_stats, opts, out_bf16=False)
+            return y.to(torch.bfloat16) if out_bf16 else y
+    y = torch.empty(n_out, cout, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     if n_out == 0:
         return y
     if plan is not None:
@@ -338,15 +375,16 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
         _lib.call("agb_dense_fwd_bn", _P(x), x.stride(0), _P(w2d), _P(bias), _P(y), y.stride(0), n_out, cin, cout, _P(part),
                   _lib.stream())
         _set_last_bn_part((part, bn_chunks, weakref.ref(y)))
-    elif prec == 1 and opts.bf16_storage and cin % 8 == 0 and x.stride(0) % 8 == 0 and (nbr is not None or has_twin(x)):
+    elif prec == 1 and (x_bf16 or out_bf16 or (opts.bf16_storage and cin % 8 == 0 and x.stride(0) % 8 == 0
+                                               and (nbr is not None or has_twin(x)))):
         # (a dense product reads every row once per column tile: converting first only pays when the twin exists already;
         # a 3^3 gather re-reads every row ~15 times)
         # bf16 mode on bf16 storage: twins of the rows (cached on the tensor: a block input feeds two convolutions) and of
         # the K-major weights; the kernel gathers 2-byte channels straight into LDS
         x16, w16 = bf16_twin(x), bf16_twin(w_kmajor.view(-1, cin), cache=False)
-        _lib.call("agb_spconv_fwd_b16", _P(x16), x16.stride(0), _P(w16), _P(nbr), 0 if nbr is None else nbr.stride(0),
-                  int(kflip), _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
-                  split, _P(partial), _lib.stream())
+        _lib.call("agb_spconv_fwd_h" if out_bf16 else "agb_spconv_fwd_b16", _P16(x16), x16.stride(0), _P16(w16), _P(nbr),
+                  0 if nbr is None else nbr.stride(0), int(kflip), _P(bias), _lib.rows(y), y.stride(0), n_out, K3, cin, cout,
+                  _P(perm), _P(tile_cls), _P(cls_tab), n_tiles, split, _P(partial), _lib.stream())
     elif prec:
         _lib.call("agb_spconv_fwd_lp", _P(x), x.stride(0), _P(w_kmajor), _P(nbr), 0 if nbr is None else nbr.stride(0), int(kflip),
                   _P(bias), _P(y), y.stride(0), n_out, K3, cin, cout, _P(perm), _P(tile_cls), _P(cls_tab), n_tiles,
@@ -371,11 +409,17 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
 def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
     """dw += gathered(x)^T dy through the C ABI, with the workspace of the deterministic two-level sum (fp32 kernel)."""
     prec = opts.prec_id if cin >= 12 else 0
-    if prec == 1 and opts.bf16_storage and nbr is not None and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0:
+    rows16 = x.dtype == torch.bfloat16 or dy.dtype == torch.bfloat16
+    if rows16 and prec != 1:
+        # (the stem: fp32 3-channel features against a bf16 gradient; a handful of rows x 64 columns converted back)
+        x, dy, rows16 = x.float(), dy.float(), False
+    if prec == 1 and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0 and (rows16 or (opts.bf16_storage and nbr is not None)):
         x16, dy16 = bf16_twin(x), bf16_twin(dy)     # (dy's twin is shared with the data gradient of the same layer)
-        _lib.call("agb_spconv_bwd_weight_b16", _P(x16), x16.stride(0), _P(dy16), dy16.stride(0), _P(nbr),
+        _lib.call("agb_spconv_bwd_weight_b16", _P16(x16), x16.stride(0), _P16(dy16), dy16.stride(0), _P(nbr),
                   0 if nbr is None else nbr.stride(0), _P(dw), n_out, K3, cin, cout, _lib.stream())
         return
+    if rows16:
+        x, dy = x.float(), dy.float()
     nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) \
         if (opts.deterministic_wgrad and opts.dw_variant != 1) else 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
@@ -414,7 +458,12 @@ class SparseConvFunction(torch.autograd.Function):
             y = spconv_forward_raw(x, kernel.contiguous().view(K3 * 3, cout), nbr, 0, b, n_out, K3, 3, cout_p, "fwd", pairs,
                                    opts=opts)
         else:
-            y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs, None, wkm, opts=opts)
+            if x.dtype == torch.bfloat16 and wkm is None:     # (bf16 rows into a layer the bf16 kernels do not take)
+                x = x.float()
+            y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs, None, wkm, opts=opts,
+                                   out_bf16=True if (opts.rows_bf16 and wkm is not None) else None)
+        if opts.rows_bf16 and y.dtype != torch.bfloat16:
+            y = y.to(torch.bfloat16)          # (a narrow first layer on the fp32 kernels: the rows leave in the model's storage)
         ctx.pairs = pairs
         ctx.plan = plan
         ctx.save_for_backward(x, w, nbr, nbrT if nbrT is not None else torch.empty(0))
@@ -432,14 +481,19 @@ class SparseConvFunction(torch.autograd.Function):
             raise _lib.AgbError("the grid-probing path takes 3 input channels and a multiple of 4 output channels")
         x = F.pad(feats, (0, 1)).contiguous()
         b = None if bias is None else bias.reshape(-1).contiguous()
-        y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+        ctx.opts = current()
+        rows16 = ctx.opts.rows_bf16
+        y = torch.empty(n_out, cout, dtype=torch.bfloat16 if rows16 else torch.float32, device=x.device)
         need_w = ctx.needs_input_grad[1]   # (grad mode is off inside Function.forward)
         nbr = torch.empty(K3, max(n_out, 1), dtype=torch.int32, device=x.device) if need_w else None
         ev = _prof_begin("fwd", K3, 3, cout, n_out)
-        ctx.opts = current()
-        _lib.call("agb_spconv_fwd3_grid_lp", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
-                  _P(b), _P(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0),
-                  ctx.opts.prec_id, _lib.stream())
+        if rows16:
+            _lib.call("agb_spconv_fwd3_grid_h", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
+                      _P(b), _P16(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0), _lib.stream())
+        else:
+            _lib.call("agb_spconv_fwd3_grid_lp", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
+                      _P(b), _P(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0),
+                      ctx.opts.prec_id, _lib.stream())
         _prof_end(ev, "fwd", K3, 3, cout, n_out, None)
         if ev is not None and nbr is not None:   # profiling only: the kernel-map size, after the closing event
             PROFILE[-1]["pairs"] = (nbr >= 0).sum()
@@ -467,7 +521,8 @@ class SparseConvFunction(torch.autograd.Function):
                 PROFILE[-1]["pairs"] = (nbr >= 0).sum()
             dk = dwp[:, :3, :].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
-            db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(bias_shape)
+            db = (colsum if (colsum is not None and colsum.numel() == cout)
+                  else dy.sum(0, dtype=torch.float32)).reshape(bias_shape)
         return None, dk, db, None, None, None, None, None, None
 
     @staticmethod
@@ -481,6 +536,9 @@ class SparseConvFunction(torch.autograd.Function):
         dy = dy.contiguous()
         if cout_p != cout:
             dy = F.pad(dy, (0, cout_p - cout)).contiguous()
+        x_bf16 = x.dtype == torch.bfloat16
+        if dy.dtype == torch.bfloat16 and not (opts.prec_id == 1 and cout_p >= 12 and cout_p % 8 == 0):
+            dy = dy.float()                     # (bf16 rows on a layer the bf16 kernels do not take)
         dx = dk = db = dwp = None
         if ctx.needs_input_grad[0]:
             # dX[q] = sum_k dY[nbrT[k][q]] @ W[k]^T : same implicit GEMM with the transposed weights
@@ -497,11 +555,13 @@ class SparseConvFunction(torch.autograd.Function):
             if has_T:
                 plan = ctx.plan if cout_p >= 12 else None
                 dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, plan,
-                                         wkm, opts=opts)
+                                         wkm, opts=opts, out_bf16=x_bf16 if dy.dtype == torch.bfloat16 else None)
             else:
                 dxp = spconv_forward_raw(dy, wt2d, nbr, 1, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, None,
-                                         wkm, opts=opts)
+                                         wkm, opts=opts, out_bf16=x_bf16 if dy.dtype == torch.bfloat16 else None)
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
+            if dx.dtype != x.dtype:
+                dx = dx.to(x.dtype)
         if ctx.needs_input_grad[1]:
             if dwp is None:
                 dwp = torch.zeros(K3, cin_p, cout_p, dtype=torch.float32, device=dy.device)
@@ -513,7 +573,7 @@ class SparseConvFunction(torch.autograd.Function):
             if colsum is not None and colsum.numel() == cout and cout_p == cout:
                 db = colsum.reshape(bias_shape)
             else:
-                db = dy[:, :cout].sum(0).reshape(bias_shape)
+                db = dy[:, :cout].sum(0, dtype=torch.float32).reshape(bias_shape)
         return dx, dk, db, None, None, None, None, None, None
 
 
@@ -538,8 +598,13 @@ class DenseConvFunction(torch.autograd.Function):
         opts = ctx.opts = current()
         wkm = w.t().contiguous() if opts.low_precision else None          # K-major [Cout][Cin]
         # (a forward pass that will be differentiated = training: the BatchNorm behind it wants batch statistics)
+        if x.dtype == torch.bfloat16 and (wkm is None or opts.prec_id != 1):
+            x = x.float()
         y = spconv_forward_raw(x, w, None, 0, b, n, 1, cin, cout, "fwd1x1", None, None, wkm,
-                               bn_stats=any(ctx.needs_input_grad), opts=opts)
+                               bn_stats=any(ctx.needs_input_grad), opts=opts,
+                               out_bf16=True if (opts.rows_bf16 and wkm is not None) else None)
+        if opts.rows_bf16 and y.dtype != torch.bfloat16:
+            y = y.to(torch.bfloat16)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bias_shape = None if bias is None else bias.shape
@@ -555,9 +620,12 @@ class DenseConvFunction(torch.autograd.Function):
         dx = dk = db = None
         opts = ctx.opts
         lp = opts.low_precision
+        if dy.dtype == torch.bfloat16 and (opts.prec_id != 1 or cout % 8 != 0):
+            dy = dy.float()
         if ctx.needs_input_grad[0]:
             if lp:     # the data gradient multiplies by W^T: its K-major form [Cin][Cout] is the kernel itself
-                dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None, w, opts=opts)
+                dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None, w, opts=opts,
+                                        out_bf16=(x.dtype == torch.bfloat16) if dy.dtype == torch.bfloat16 else None)
             else:
                 wt = torch.empty(cout, cin, dtype=torch.float32, device=w.device)
                 if ctx.needs_input_grad[1]:   # the weight-gradient buffer is cleared by the same launch
@@ -571,7 +639,10 @@ class DenseConvFunction(torch.autograd.Function):
             weight_grad_raw(x, dy, None, dk, n, 1, cin, cout, opts)
             _prof_end(ev, "wgrad1x1", 1, cin, cout, n, int(n))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = (colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)).reshape(ctx.bias_shape)
+            db = (colsum if (colsum is not None and colsum.numel() == cout)
+                  else dy.sum(0, dtype=torch.float32)).reshape(ctx.bias_shape)
+        if dx is not None and dx.dtype != x.dtype:
+            dx = dx.to(x.dtype)
         return dx, dk, db
 
 
@@ -680,11 +751,11 @@ class MaxPoolFunction(torch.autograd.Function):
         x = _pad_cols(feats, 4)
         cp = x.shape[1]
         K3 = nbr.shape[0]
-        y = torch.empty(n_out, cp, dtype=torch.float32, device=x.device)
+        y = torch.empty(n_out, cp, dtype=x.dtype, device=x.device)
         small = K3 <= 255
         arg = torch.empty(n_out, cp, dtype=torch.uint8 if small else torch.int32, device=x.device)
-        _lib.call("agb_maxpool_fwd_k" if small else "agb_maxpool_fwd", _P(x), x.stride(0), _P(nbr), nbr.stride(0), _P(y),
-                  y.stride(0), _P(arg), n_out, K3, cp, _lib.stream())
+        _lib.call(("agb_maxpool_fwd_k" if small else "agb_maxpool_fwd") + _lib.sfx(x), _lib.rows(x), x.stride(0), _P(nbr),
+                  nbr.stride(0), _lib.rows(y), y.stride(0), _P(arg), n_out, K3, cp, _lib.stream())
         ctx.save_for_backward(arg, nbrT)
         ctx.dims = (c, cp, n_in, K3, small)
         return y if cp == c else y[:, :c].contiguous()
@@ -694,9 +765,9 @@ class MaxPoolFunction(torch.autograd.Function):
         arg, nbrT = ctx.saved_tensors
         c, cp, n_in, K3, small = ctx.dims
         dy = _pad_cols(dy, 4)
-        dx = torch.empty(n_in, cp, dtype=torch.float32, device=dy.device)
-        _lib.call("agb_maxpool_bwd_k" if small else "agb_maxpool_bwd", _P(dy), dy.stride(0), _P(arg), _P(nbrT),
-                  nbrT.stride(0), _P(dx), dx.stride(0), n_in, K3, cp, _lib.stream())
+        dx = torch.empty(n_in, cp, dtype=dy.dtype, device=dy.device)
+        _lib.call(("agb_maxpool_bwd_k" if small else "agb_maxpool_bwd") + _lib.sfx(dy), _lib.rows(dy), dy.stride(0), _P(arg),
+                  _P(nbrT), nbrT.stride(0), _lib.rows(dx), dx.stride(0), n_in, K3, cp, _lib.stream())
         return (dx if cp == c else dx[:, :c].contiguous()), None, None, None, None
 
 
@@ -714,8 +785,8 @@ def segment_reduce(a, bm, ptr, B, mode_id):
     if splits > 1:
         part = torch.empty(B * splits, c, dtype=torch.float32, device=a.device)
         part_arg = torch.empty(B * splits, c, dtype=torch.int32, device=a.device) if mode_id == 2 else None
-    _lib.call("agb_segment_reduce", _P(a), a.stride(0), _P(bm), 0 if bm is None else bm.stride(0), _P(ptr), B, c,
-              mode_id, splits, _P(part), _P(part_arg), _P(y), _P(arg), _lib.stream())
+    _lib.call("agb_segment_reduce" + _lib.sfx(a, bm), _lib.rows(a), a.stride(0), _lib.rows(bm), 0 if bm is None else bm.stride(0),
+              _P(ptr), B, c, mode_id, splits, _P(part), _P(part_arg), _P(y), _P(arg), _lib.stream())
     return y, arg
 
 
@@ -730,6 +801,7 @@ class GlobalPoolFunction(torch.autograd.Function):
         y, arg = segment_reduce(x, None, ptr, B, m)
         ctx.save_for_backward(coords, ptr, arg if arg is not None else torch.empty(0))
         ctx.dims = (n, c, B, m)
+        ctx.rows_dtype = x.dtype
         return y
 
     @staticmethod
@@ -738,13 +810,13 @@ class GlobalPoolFunction(torch.autograd.Function):
         n, c, B, m = ctx.dims
         dy = dy.contiguous()
         if m == 2:
-            dx = torch.zeros(n, c, dtype=torch.float32, device=dy.device)
-            _lib.call("agb_segment_max_bwd", _P(dy), _P(arg), _P(dx), dx.stride(0), B, c, _lib.stream())
+            dx = torch.zeros(n, c, dtype=ctx.rows_dtype, device=dy.device)
+            _lib.call("agb_segment_max_bwd" + _lib.sfx(dx), _P(dy), _P(arg), _lib.rows(dx), dx.stride(0), B, c, _lib.stream())
             return dx, None, None, None, None
         if c % 4 != 0:
             raise _lib.AgbError("global sum/avg pooling gradient needs a channel count that is a multiple of 4")
-        dx = torch.empty(n, c, dtype=torch.float32, device=dy.device)
-        _lib.call("agb_segment_broadcast", _P(dy), _P(coords), _P(ptr), None, 0, _P(dx), dx.stride(0), n, c,
+        dx = torch.empty(n, c, dtype=ctx.rows_dtype, device=dy.device)
+        _lib.call("agb_segment_broadcast" + _lib.sfx(dx), _P(dy), _P(coords), _P(ptr), None, 0, _lib.rows(dx), dx.stride(0), n, c,
                   1 if m == 1 else 0, _lib.stream())
         return dx, None, None, None, None
 
@@ -760,8 +832,8 @@ class BroadcastMulFunction(torch.autograd.Function):
         if c % 4 != 0:
             raise _lib.AgbError("broadcast multiplication needs a channel count that is a multiple of 4")
         out = torch.empty_like(x)
-        _lib.call("agb_segment_broadcast", _P(s), _P(coords), _P(ptr), _P(x), x.stride(0), _P(out), out.stride(0), n,
-                  c, 0, _lib.stream())
+        _lib.call("agb_segment_broadcast" + _lib.sfx(x), _P(s), _P(coords), _P(ptr), _lib.rows(x), x.stride(0), _lib.rows(out),
+                  out.stride(0), n, c, 0, _lib.stream())
         ctx.save_for_backward(x, s, coords, ptr)
         return out
 
@@ -774,8 +846,8 @@ class BroadcastMulFunction(torch.autograd.Function):
         dx = ds = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.call("agb_segment_broadcast", _P(s), _P(coords), _P(ptr), _P(dout), dout.stride(0), _P(dx),
-                      dx.stride(0), n, c, 0, _lib.stream())
+            _lib.call("agb_segment_broadcast" + _lib.sfx(dout), _P(s), _P(coords), _P(ptr), _lib.rows(dout), dout.stride(0),
+                      _lib.rows(dx), dx.stride(0), n, c, 0, _lib.stream())
         if ctx.needs_input_grad[1]:
             ds, _ = segment_reduce(dout, x, ptr, B, 0)
         return dx, ds, None, None

@@ -194,6 +194,21 @@ int agb_spconv_fwd_b16(const uint16_t* X16, int ldx16, const uint16_t* Wt16, con
                        int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
                        const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                        float* partial, void* stream);
+/* bf16 ROW STORAGE (KernelOptions.bf16_activations; BASELINE config 5): every activation / gradient row matrix [N, C] of
+ * the sparse backbone is uint16 bf16 (round to nearest even when a row leaves a kernel; accumulators, statistics, per-plot
+ * [B, C] matrices, parameters and their gradients stay fp32).  agb_spconv_fwd_h = agb_spconv_fwd_b16 with bf16 output rows
+ * Y16 uint16 [n_out][ldy16] (ldy16 % 4 == 0); agb_spconv_fwd3_grid_h = the grid-probing 3-channel stem with bf16 operands
+ * writing bf16 rows.  The weight gradient of this mode is agb_spconv_bwd_weight_b16 on the rows themselves.
+ * Every entry point below that takes row matrices has a twin with the suffix _h and the same argument list where
+ * `float*` row-matrix arguments are `uint16_t*` (leading dimensions in elements): same arithmetic in fp32, 8-byte instead
+ * of 16-byte pieces (csrc/norm_rows.inc, csrc/pool_rows.inc). */
+int agb_spconv_fwd_h(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const int32_t* nbr, long long nbr_stride,
+                     int kflip, const float* bias, uint16_t* Y16, int ldy16, int n_out, int K3, int Cin, int Cout,
+                     const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                     float* partial, void* stream);
+int agb_spconv_fwd3_grid_h(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                           const int32_t* desc, int K, const float* bias, uint16_t* Y16, int ldy16, int n_out, int Cout,
+                           int32_t* nbr_out, long long nbr_out_stride, void* stream);
 /* perm int32[n + stride^3*64] (rows grouped by class, -1 padding), tile_cls int32[max_tiles] with
  * max_tiles = n/64 + stride^3 + 1, scratch int32[256].  class = (c/ts_in mod stride) per axis, x fastest. */
 int agb_parity_partition(const int32_t* coords, int n, int ts_in, int stride, int32_t* perm, int32_t* tile_cls,
@@ -517,6 +532,60 @@ int agb_pointnet_mlp_fwd(const float* x, int ldx, int n, int cin_pad, const floa
                          const float* W2, const float* const* bn2, int c2, const float* W3, const float* const* bn3,
                          int c3, int act, float eps, float momentum, int training, const int32_t* ptr, int B, int mode,
                          void* workspace, float* pooled, int32_t* argmax, void* stream);
+
+/* ---- bf16-row twins (see agb_spconv_fwd_h): BatchNorm / residual / SE-tail kernels (norm.hip) and pooling / broadcast
+ * kernels (pool.hip) on uint16 bf16 row matrices; per-plot matrices, statistics, partials and argmax buffers as in the fp32
+ * forms.  Reference call sites: those of the fp32 entry points. */
+int agb_bn_stats_tracked_h(const uint16_t* X, int ldx, int n, int C, float eps, float momentum, int training,
+                           float* part, float* mean, float* rstd, float* running_mean, float* running_var,
+                           long long* num_batches_tracked, void* stream);
+int agb_bn_stats_h(const uint16_t* X, int ldx, int n, int C, float eps, float momentum, int training, float* part,
+                   float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
+int agb_bn_act_fwd_h(const uint16_t* X, int ldx, int n, int C, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int act, uint16_t* Y, int ldy, void* stream);
+int agb_bn_act_bwd_colsum_h(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, int n, int C, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, int act, int training,
+                            float* part, uint16_t* dX, int lddx, float* dgamma, float* dbeta, float* colsum,
+                            void* stream);
+int agb_bn_act_bwd_h(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, int n, int C, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int act, int training, float* part,
+                     uint16_t* dX, int lddx, float* dgamma, float* dbeta, void* stream);
+int agb_se_tail_stats_h(const uint16_t* Z, int ldz, const int32_t* ptr, int n, int C, int B, float eps,
+                        float momentum, int training, float* part, float* mean, float* rstd, float* running_mean,
+                        float* running_var, long long* num_batches_tracked, void* stream);
+int agb_se_tail_fwd_h(const uint16_t* Z, int ldz, const uint16_t* R, int ldr, const int32_t* coords,
+                      const float* mean, const float* rstd, const float* gamma, const float* beta, const float* s,
+                      const float* keep, int act, int n, int C, uint16_t* Y, int ldy, void* stream);
+int agb_se_tail_bwd_sums_h(const uint16_t* Z, int ldz, const uint16_t* R, int ldr, const uint16_t* dY, int ldy,
+                           const int32_t* ptr, int B, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, const float* s, const float* keep, int act, int n, int C, float* spart,
+                           void* stream);
+int agb_se_tail_bwd_apply_h(const uint16_t* Z, int ldz, const uint16_t* R, int ldr, const uint16_t* dY, int ldy,
+                            const int32_t* coords, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, const float* s, const float* keep, const float* dte,
+                            const float* dbeta, const float* dgamma, int act, int training, int n, int C,
+                            uint16_t* dZ, int lddz, uint16_t* dR, int lddr, void* stream);
+int agb_add_act_fwd_h(const uint16_t* A, int lda, const uint16_t* R, int ldr, const float* scale,
+                      const int32_t* coords, int n, int C, int act, uint16_t* Y, int ldy, void* stream);
+int agb_add_act_bwd_h(const uint16_t* A, int lda, const uint16_t* R, int ldr, const float* scale,
+                      const int32_t* coords, const uint16_t* dY, int ldy, int n, int C, int act, uint16_t* dA,
+                      uint16_t* dR, void* stream);
+int agb_maxpool_fwd_h(const uint16_t* X, int ldx, const int32_t* nbr, long long nbr_stride, uint16_t* Y, int ldy,
+                      int32_t* argmax /* [n_out, C] */, int n_out, int K3, int C, void* stream);
+int agb_maxpool_bwd_h(const uint16_t* dY, int ldy, const int32_t* argmax, const int32_t* nbrT, long long nbrT_stride,
+                      uint16_t* dX, int ldx, int n_in, int K3, int C, void* stream);
+int agb_maxpool_fwd_k_h(const uint16_t* X, int ldx, const int32_t* nbr, long long nbr_stride, uint16_t* Y, int ldy,
+                        uint8_t* argk, int n_out, int K3, int C, void* stream);
+int agb_maxpool_bwd_k_h(const uint16_t* dY, int ldy, const uint8_t* argk, const int32_t* nbrT, long long nbrT_stride,
+                        uint16_t* dX, int ldx, int n_in, int K3, int C, void* stream);
+int agb_segment_reduce_h(const uint16_t* A, int lda, const uint16_t* Bm, int ldb, const int32_t* ptr, int B, int C,
+                         int mode, int splits, float* part, int32_t* part_arg, float* Y, int32_t* argmax,
+                         void* stream);
+int agb_segment_broadcast_h(const float* S, const int32_t* coords, const int32_t* ptr, const uint16_t* M, int ldm,
+                            uint16_t* out, int ldo, int n, int C, int average, void* stream);
+int agb_segment_scale_add_h(const float* S, const float* T, const int32_t* coords, const int32_t* ptr,
+                            const uint16_t* M, int ldm, uint16_t* out, int ldo, int n, int C, void* stream);
+int agb_segment_max_bwd_h(const float* dY, const int32_t* argmax, uint16_t* dX, int ldx, int B, int C, void* stream);
 
 #ifdef __cplusplus
 }

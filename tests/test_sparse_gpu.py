@@ -1025,3 +1025,221 @@ def test_stem_weight_gradient_two_level_sum(device):
     err_fold, err_atomic = rel_err(a, want), rel_err(run(), want)
     print(f"stem weight gradient vs fp64: two-level fold {err_fold:.2e}, atomic accumulation {err_atomic:.2e}")
     assert err_fold < 2e-6 and err_atomic < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ bf16 ROW STORAGE
+# KernelOptions(precision="bf16", bf16_activations=True): every activation / gradient row matrix of the sparse backbone is
+# stored in bf16 (csrc/norm_rows.inc, pool_rows.inc, agb_spconv_fwd_h).  The arithmetic of every kernel is the fp32
+# arithmetic of its fp32-row form (same instruction sequence after the load, same reduction trees): on bf16-representable
+# inputs the bf16-row result is the fp32-row result rounded once (round to nearest even) — asserted BITWISE below.
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _same_after_rounding(got16, want32, what):
+    assert got16.dtype == torch.bfloat16 and want32.dtype == torch.float32, what
+    assert torch.equal(got16, want32.to(torch.bfloat16)), (what, float((got16.float() - want32).abs().max()))
+
+
+@pytest.mark.parametrize("c,act", [(64, "gelu"), (256, "relu"), (32, None), (16, "gelu")])
+def test_bf16_rows_batchnorm_act(device, c, act):
+    from dpcr_agb_amd import norm_ops
+    torch.manual_seed(c)
+    n = 20_011
+    bn = {}
+    res = {}
+    x16 = _bf(torch.randn(n, c, device=device) * 1.7 + 0.3)
+    dy16 = _bf(torch.randn(n, c, device=device))
+    for rows in ("bf16", "fp32"):
+        m = torch.nn.BatchNorm1d(c).to(device).train()
+        torch.manual_seed(3)
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(c, device=device) + 0.5)
+            m.bias.copy_(torch.rand(c, device=device) - 0.5)
+        x = (x16 if rows == "bf16" else x16.float()).clone().requires_grad_(True)
+        y = norm_ops.batch_norm_act(x, m, act)
+        y.backward(dy16 if rows == "bf16" else dy16.float())
+        res[rows] = (y.detach(), x.grad, m.weight.grad.clone(), m.bias.grad.clone(), m.running_mean.clone(),
+                     m.running_var.clone())
+        bn[rows] = m
+    _same_after_rounding(res["bf16"][0], res["fp32"][0], "y")
+    _same_after_rounding(res["bf16"][1], res["fp32"][1], "dx")
+    for i, what in ((2, "dgamma"), (3, "dbeta"), (4, "running_mean"), (5, "running_var")):
+        assert torch.equal(res["bf16"][i], res["fp32"][i]), what       # fp32 either way: identical sums
+    # eval mode (running statistics)
+    for m in bn.values():
+        m.eval()
+    _same_after_rounding(norm_ops.batch_norm_act(x16, bn["bf16"], act), norm_ops.batch_norm_act(x16.float(), bn["fp32"], act),
+                         "eval y")
+
+
+def test_bf16_rows_residual_and_se_tail(device):
+    """AddActFunction, BatchNormAddActFunction and the fused SE block tail on bf16 rows = their fp32-row results rounded."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import norm_ops, se_ops
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    coords = random_coords(rng, 4, 3000, 24)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    n, B, C = cm.level(1).n, 4, 128
+    lvl_coords, ptr = cm.level(1).coords, cm.batch_ptr(1)
+    z16, r16, dy16 = (_bf(torch.randn(n, C, device=device)) for _ in range(3))
+    keep = torch.tensor([1.25, 0.0, 1.25, 1.25], device=device)
+    lin1, lin2 = torch.nn.Linear(C, C // 16).to(device), torch.nn.Linear(C // 16, C).to(device)
+    out = {}
+    for rows in ("bf16", "fp32"):
+        cast = (lambda t: t.clone()) if rows == "bf16" else (lambda t: t.float())
+        got = []
+        # residual tail with a drop-path scale
+        a, r = cast(z16).requires_grad_(True), cast(r16).requires_grad_(True)
+        y = norm_ops.AddActFunction.apply(a, r, keep, lvl_coords, norm_ops.ACT_IDS["gelu"])
+        y.backward(cast(dy16))
+        got += [y.detach(), a.grad, r.grad]
+        # BatchNorm + residual (KPConv block tail form)
+        bn = torch.nn.BatchNorm1d(C).to(device).train()
+        a, r = cast(z16).requires_grad_(True), cast(r16).requires_grad_(True)
+        y = norm_ops.batch_norm_add_act(a, r, bn, "relu")
+        y.backward(cast(dy16))
+        got += [y.detach(), a.grad, r.grad, bn.weight.grad.clone(), bn.bias.grad.clone()]
+        # fused SE block tail
+        bn = torch.nn.BatchNorm1d(C).to(device).train()
+        lin1.zero_grad(), lin2.zero_grad()
+        a, r = cast(z16).requires_grad_(True), cast(r16).requires_grad_(True)
+        y = se_ops.se_block_tail(a, r, bn, lvl_coords, ptr, B, lin1, "gelu", lin2, keep, "gelu")
+        y.backward(cast(dy16))
+        got += [y.detach(), a.grad, r.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), lin1.weight.grad.clone(),
+                lin2.weight.grad.clone(), bn.running_var.clone()]
+        out[rows] = got
+    for i, (g, w) in enumerate(zip(out["bf16"], out["fp32"])):
+        if g.dtype == torch.bfloat16:
+            _same_after_rounding(g, w, f"tensor {i}")
+        else:
+            assert torch.equal(g, w), i
+
+
+def test_bf16_rows_pooling(device):
+    """Max pooling over a kernel map, global pooling (sum / avg / max) and the broadcast multiplication on bf16 rows."""
+    import dpcr_agb_amd.me_compat as ME
+    rng = np.random.default_rng(6)
+    torch.manual_seed(6)
+    coords = random_coords(rng, 3, 2500, 20)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    n, C = cm.level(1).n, 64
+    x16 = _bf(torch.randn(n, C, device=device))
+    res = {}
+    for rows in ("bf16", "fp32"):
+        got = []
+        x = (x16 if rows == "bf16" else x16.float()).clone().requires_grad_(True)
+        sx = ME.SparseTensor(x, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm)
+        y = ME.MinkowskiMaxPooling(kernel_size=3, stride=2, dimension=3)(sx)
+        torch.manual_seed(1)
+        dy = _bf(torch.randn(y.F.shape, device=device))
+        y.F.backward(dy if rows == "bf16" else dy.float())
+        got += [y.F.detach(), x.grad.clone()]
+        for pool in (ME.MinkowskiGlobalSumPooling(), ME.MinkowskiGlobalAvgPooling(), ME.MinkowskiGlobalMaxPooling()):
+            x.grad = None
+            p = pool(sx).F
+            assert p.dtype == torch.float32
+            p.backward(torch.arange(p.numel(), device=device, dtype=torch.float32).view_as(p) / 100.0)
+            got += [p.detach(), x.grad.clone()]
+        res[rows] = got
+    for i, (g, w) in enumerate(zip(res["bf16"], res["fp32"])):
+        if g.dtype == torch.bfloat16:
+            _same_after_rounding(g, w, f"tensor {i}")
+        else:
+            assert torch.equal(g, w), i
+
+
+@pytest.mark.parametrize("cin,cout,K,stride", [(64, 64, 3, 1), (64, 128, 3, 2), (128, 512, 1, 1), (256, 64, 1, 1),
+                                               (512, 512, 3, 1)])
+def test_bf16_rows_convolution(device, cin, cout, K, stride):
+    """agb_spconv_fwd_h (bf16 rows in AND out) against agb_spconv_fwd_b16 (fp32 output) on the same bf16 operands: forward and
+    data gradient are the fp32 results rounded once (also through the split-reduction path of the few-row wide layers);
+    the weight gradient reads the same bf16 rows."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import sparse_ops
+    rng = np.random.default_rng(cin + cout)
+    torch.manual_seed(cin * 7 + cout)
+    coords = random_coords(rng, 3, 2500 if cin < 512 else 900, 20)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=K, stride=stride, bias=True, dimension=3).to(device)
+    x16 = _bf(torch.randn(cm.level(1).n, cin, device=device))
+    res = {}
+    for rows in ("bf16", "fp32"):
+        conv.zero_grad()
+        xg = (x16 if rows == "bf16" else x16.float()).clone().requires_grad_(True)
+        with sparse_ops.KernelOptions(precision="bf16", bf16_activations=(rows == "bf16")):
+            out = conv(ME.SparseTensor(xg, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm)).F
+        torch.manual_seed(1)
+        dy = _bf(torch.randn(out.shape, device=device))
+        out.backward(dy if rows == "bf16" else dy.float())
+        res[rows] = (out.detach().clone(), xg.grad.clone(), conv.kernel.grad.clone(), conv.bias.grad.clone())
+    _same_after_rounding(res["bf16"][0], res["fp32"][0], "y")
+    _same_after_rounding(res["bf16"][1], res["fp32"][1], "dx")
+    assert rel_err(res["bf16"][2], res["fp32"][2]) < 2e-6          # (fp32 atomics: same operands, order not fixed)
+    assert rel_err(res["bf16"][3], res["fp32"][3]) < 1e-5
+
+
+def test_bf16_rows_senet50_training_step(device):
+    """MSENet50 with bf16 row storage end to end: every row matrix the backbone hands on is bf16, the regression output
+    stays within the bf16 bar of the fp64 oracle, the gradient points where the fp32-row bf16 mode's does, and a few
+    AdaBelief steps reduce the loss."""
+    from dpcr_agb_amd import sparse_ops
+    from dpcr_agb_amd.config import TRAINING_NFI
+    model, batch = _model_and_batch("SENet50", device, 1500, [0, 1, 2])
+    sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    model.to(device).train()
+    grads = {}
+    for rows in (False, True):
+        model.model.load_state_dict(sd32)
+        model.set_kernel_options(precision="bf16", bf16_activations=rows)
+        model.zero_grad(set_to_none=True)
+        model.set_input(batch, device)
+        seen = []
+        hooks = [m.register_forward_hook(lambda mod, i, o: seen.append(o.F.dtype) if hasattr(o, "F") else None)
+                 for m in model.model.blocks]
+        model.forward()
+        for h in hooks:
+            h.remove()
+        assert all(d == (torch.bfloat16 if rows else torch.float32) for d in seen) and len(seen) == 5
+        assert model.output.dtype == torch.float32
+        model.loss.backward()
+        grads[rows] = (model.output.detach().clone(),
+                       torch.cat([p.grad.detach().double().reshape(-1) for p in model.model.parameters()]))
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}
+    coords = torch.cat([batch.batch[:, None], batch.coords.long()], 1).numpy()
+    with torch.no_grad():
+        want = R.resnet_forward(sd, coords, batch.x.double(), (3, 4, 6, 3), batch_size=len(batch))
+    e16, e32 = rel_err(grads[True][0], want), rel_err(grads[False][0], want)
+    ga, gb = grads[True][1], grads[False][1]
+    cos = float(torch.dot(ga, gb) / (ga.norm() * gb.norm()))
+    print(f"SENet50 bf16 rows: output rel err {e16:.3e} (fp32 rows, bf16 operands: {e32:.3e}); cos(gradient, fp32-row "
+          f"gradient) {cos:.5f}")
+    assert e16 < 6e-2, e16
+    assert cos > 0.97, cos
+    # a few optimiser steps on the one batch (a tenth of the recipe's learning rate: three plots are no batch of 32), next to
+    # the same steps with fp32 rows: same trajectory, loss going down
+    import copy
+    tr = copy.deepcopy(TRAINING_NFI)
+    tr.optim.base_lr = tr.optim.optimizer.params.lr = 5e-4
+    traj = {}
+    for rows in (False, True):
+        model.model.load_state_dict(sd32)
+        model.set_kernel_options(precision="bf16", bf16_activations=rows)
+        model.init_train_objects(tr)
+        random.seed(5)
+        losses = []
+        for it in range(8):
+            model.set_input(batch, device)
+            model.optimize_parameters(0, len(batch), 100)
+            losses.append(float(model.loss.detach()))
+        traj[rows] = losses
+        print(f"bf16 operands, {'bf16' if rows else 'fp32'} rows, losses:", [round(v, 4) for v in losses])
+    # (AdaBelief's first step moves every weight by about the learning rate whatever its gradient: the loss jumps, in both
+    # storage modes alike, and falls from there)
+    assert all(np.isfinite(traj[True])) and traj[True][-1] < 0.5 * traj[True][1]
+    for a, b in zip(traj[True][:4], traj[False][:4]):
+        assert abs(a - b) < 0.15 * max(1.0, abs(b)), (traj[True], traj[False])
