@@ -2523,7 +2523,13 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
     }
     int n_tiles = agb_cdiv(Cout, 64);
     // aim for ~4096 workgroups; at least 256 rows per workgroup (multiple of 32)
-    long long target_chunks = 4096 / ((long long)m_tiles * n_tiles);
+    // (dense products with bf16 operands: the MFMA work of a workgroup is small against the 64 x 64 atomic adds it ends
+    // with — 4096 workgroups put 13 M atomics on the 256 x 1024 gradient of a 14 k-row layer: 71 us, 512 workgroups: 34 us;
+    // 211 k x 64 x 256: 120 -> 41 us.  The 3^3 maps sit at the 2048-row cap of the pair list either way.)
+    static const int target_wgs_env = getenv("AGB_DW_TARGET") ? atoi(getenv("AGB_DW_TARGET")) : 0;   // (tuning aid)
+    int target_wgs = (nbr == nullptr && (precision == 1 || precision == 3)) ? 512 : 4096;
+    if (target_wgs_env > 0 && nbr == nullptr) target_wgs = target_wgs_env;
+    long long target_chunks = target_wgs / ((long long)m_tiles * n_tiles);
     if (target_chunks < 1) target_chunks = 1;
     long long rows = (n_out + target_chunks - 1) / target_chunks;
     if (rows < 256) rows = 256;

@@ -62,9 +62,13 @@ def main():
             dy = torch.randn(n, cout, device=dev)
             ref_dw = None
             # register-operand kernel with the fixed-order fold / with atomic accumulation / the LDS-staged kernel
-            for tag, kw in (("reg+fold", dict(deterministic_wgrad=True)), ("reg+atomic", dict(dw_variant=2)), ("staged", {})):
+            x16, dy16 = x.to(torch.bfloat16), dy.to(torch.bfloat16)
+            for tag, kw in (("reg+fold", dict(deterministic_wgrad=True)), ("reg+atomic", dict(dw_variant=2)), ("staged", {}),
+                            ("bf16 rows", dict(precision="bf16"))):
                 opts = sparse_ops.KernelOptions(**kw)
                 dw = torch.zeros(27, cin, cout, device=dev)
+                if tag == "bf16 rows":
+                    x, dy = x16, dy16
                 sparse_ops.weight_grad_raw(x, dy, nbr, dw, n, 27, cin, cout, opts)
                 torch.cuda.synchronize()
                 if ref_dw is None:
