@@ -6,8 +6,8 @@ Protocol = the reference's own: every R2 it publishes is the MEDIAN OF 5 TRIALS 
 schedule are those of tests/golden/make_r2_cpu_leg.py (MSENet14, reference recipe, 256 / 128 plots, 150 epochs = the end of
 the fourth cosine cycle, calibrate_bn, running-statistics evaluation): both targets plateau at R2 ~ 0.77.
 
-  * test_r2_median_of_five_trials: the five seeds on the HIP path in fp32 AND in bf16 (config 5's operand mode) against the
-    five committed CPU trials (oracle/sparse_ref.py, fp32; ~2 h each in the build container, never on the GPU box).
+  * test_r2_median_of_five_trials: the five seeds on the HIP path in fp32, in bf16 (config 5's operand mode) AND in bf16 with
+    bf16 row storage (KernelOptions.bf16_activations, "bf16rows") against the five committed CPU trials (oracle/sparse_ref.py, fp32; ~2 h each in the build container, never on the GPU box).
     Asserted: (a) every leg is in the plateau regime (median R2 >= 0.6 on both targets); (b) the gap of the medians is
     within 0.005 PLUS the sampling error of a difference of two medians of five, taken from the trials' own spread
     (1.2533 s / sqrt(5) per leg, three standard errors: a gate that does not fire on the draw) — with trial-to-trial standard deviations of 0.014-0.021 (CPU and
@@ -74,7 +74,7 @@ def test_r2_median_of_five_trials(device):
     cpu = np.array(ref["r2_rs"])
     data = acceptance_data(cfg, device)
     rows = [("cpu fp32 (oracle)", cpu)]
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "bf16rows"):
         r2 = np.array([acceptance_gpu_trial(cfg, t, device, prec, data)["final"]["r2_rs"] for t in range(cfg["trials"])])
         rows.append((f"hip {prec}", r2))
     print()

@@ -47,7 +47,9 @@ def acceptance_gpu_trial(cfg, trial, dev, precision="fp32", data=None, log=None,
     train, val, train_h, val_mean = data if data is not None else acceptance_data(cfg, dev)
     model = gen.build_model(cfg, train_h, trial).to(dev)
     # fixed-order weight-gradient sums: the fp32 leg is bitwise reproducible from run to run (the test's outcome is not a draw)
-    model.set_kernel_options(precision=precision, deterministic_wgrad=True)
+    # ("bf16rows": bf16 operands AND bf16 row storage, KernelOptions.bf16_activations — BASELINE config 5's fastest mode)
+    rows16 = precision == "bf16rows"
+    model.set_kernel_options(precision="bf16" if rows16 else precision, bf16_activations=rows16, deterministic_wgrad=True)
     model.init_train_objects(TRAINING_NFI)
     nb = len(train)
     random.seed(gen.trial_seeds(trial)["drop_seed"])
