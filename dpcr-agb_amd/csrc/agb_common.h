@@ -105,6 +105,19 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = make_uint2(agb_pack2_bf16(v.x, v.y), agb_pack2_bf16(v.z, v.w));
 }
+// value of the neighbouring lane (lane ^ 1) through a DPP quad permutation [1, 0, 3, 2]: a VALU move, no LDS traffic
+__device__ __forceinline__ float agb_lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+// One bf16 pair per lane from two accumulator registers that hold rows r (v0) and r + 1 (v1) of column `lane`: the even
+// lane of a pair returns row r, columns (lane, lane + 1), the odd lane row r + 1, columns (lane - 1, lane) — one 4-byte
+// store each instead of two 2-byte stores.  (Written with the select on the PACKED words: a select between the two
+// accumulator registers themselves is folded into a dynamically indexed vector read, ~16 compare/select pairs each.)
+__device__ __forceinline__ unsigned agb_bf16_pair_rows(float v0, float v1, bool odd) {
+    const float n0 = agb_lane_xor1(v0), n1 = agb_lane_xor1(v1);
+    const unsigned even_w = agb_pack2_bf16(v0, n0), odd_w = agb_pack2_bf16(n1, v1);
+    return odd ? odd_w : even_w;
+}
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_t* p, float v) {
     const __bf16 h = (__bf16)v;

@@ -886,20 +886,25 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_b16(ConvArgs a) {
         // lane instead of two 2-byte stores (Cout % 4 == 0 and n0, 32 nt even: a pair never straddles the matrix edge)
         bf16_t* __restrict__ Y16p = reinterpret_cast<bf16_t*>(a.Y);
         const bool odd = li & 1;
+        int prow[8];
 #pragma unroll
-        for (int reg = 0; reg < 16; reg += 2) {
-            const int row = odd ? rows[reg + 1] : rows[reg];
+        for (int h2 = 0; h2 < 8; ++h2) {
+            const int reg = 2 * h2;
+            const int rt = row0 + wm * 32 + (reg & 3) + (int)odd + 8 * (reg >> 2) + 4 * lh;
+            prow[h2] = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
+        }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float mine = odd ? acc[nt][reg + 1] : acc[nt][reg];
-                const float give = odd ? acc[nt][reg] : acc[nt][reg + 1];
-                const float got = __shfl_xor(give, 1);
-                const float bo = __shfl_xor(bvs[nt], 1);
-                const int col = n0 + (wn * NT + nt) * 32 + (li & ~1);
-                if (row >= 0 && col < Cout) {
-                    const unsigned v = odd ? agb_pack2_bf16(got + bo, mine + bvs[nt]) : agb_pack2_bf16(mine + bvs[nt], got + bo);
-                    *reinterpret_cast<unsigned*>(Y16p + (long long)row * a.ldy + col) = v;
-                }
+        for (int h2 = 0; h2 < 8; ++h2) {
+            const int row = prow[h2];
+            unsigned w[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                w[nt] = agb_bf16_pair_rows(acc[nt][2 * h2] + bvs[nt], acc[nt][2 * h2 + 1] + bvs[nt], odd);
+            if (row >= 0) {
+                bf16_t* yrow = Y16p + (long long)row * a.ldy + n0 + wn * NT * 32 + (li & ~1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)     // (Cout % 4 == 0, the pair's first column even: both inside or both outside)
+                    if (n0 + (wn * NT + nt) * 32 + (li & ~1) < Cout) *reinterpret_cast<unsigned*>(yrow + nt * 32) = w[nt];
             }
         }
         return;
