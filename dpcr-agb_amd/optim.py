@@ -178,3 +178,6 @@ class AdaBelief(Optimizer):
         _lib.call("agb_adabelief_step", _lib.ptr(descs), _lib.ptr(cache["ct"]), _lib.ptr(cache["ci"]),
                   cache["n"], decay, beta1, beta2, 1 - beta1, 1 - beta2, eps, stepv, inv_sqrt_bc2, mode, clip,
                   _lib.stream())
+        # (the parameters were rewritten through raw pointers: torch's version counters did not move)
+        from .sparse_ops import bump_weight_epoch
+        bump_weight_epoch()

@@ -297,6 +297,36 @@ _lib.declare("agb_spconv_fwd3_grid_h", [_lib.c_void_p, _lib.c_int, _lib.c_void_p
                                         _lib.c_void_p, _lib.c_ll, _lib.c_void_p])
 
 
+_lib.declare("agb_weight_twins_bf16", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
+                                       _lib.c_void_p])
+
+
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Parameters were rewritten through raw device pointers (the fused optimiser step: torch's version counters do not
+    see it): cached bf16 forms of the weights are stale."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def weight_twins(kernel):
+    """(W16 [K3, cin, cout], Wt16 [K3, cout, cin]) bf16 operand forms of a convolution kernel [K3, cin, cout] (or [cin, cout]),
+    one launch, cached on the parameter until its next update (version counter for torch's in-place writes, the weight
+    epoch for the fused optimiser): the forward pass takes Wt16, the data gradient W16."""
+    key = (kernel._version, _WEIGHT_EPOCH[0])
+    h = getattr(kernel, "agb_twins", None)
+    if h is not None and h[0] == key:
+        return h[1], h[2]
+    w = kernel.detach().contiguous()
+    K3, cin, cout = (1,) + tuple(w.shape) if w.dim() == 2 else tuple(w.shape)
+    w16 = torch.empty(K3, cin, cout, dtype=torch.bfloat16, device=w.device)
+    wt16 = torch.empty(K3, cout, cin, dtype=torch.bfloat16, device=w.device)
+    _lib.call("agb_weight_twins_bf16", _P(w), K3, cin, cout, _P16(w16), _P16(wt16), _lib.stream())
+    kernel.agb_twins = (key, w16, wt16)
+    return w16, wt16
+
+
 def has_twin(t):
     if t.dtype == torch.bfloat16:
         return True
@@ -325,24 +355,26 @@ def bf16_twin(t, cache=True):
 
 
 def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd", pairs=None, plan=None,
-                       w_kmajor=None, bn_stats=False, opts=None, out_bf16=None):
+                       w_kmajor=None, bn_stats=False, opts=None, out_bf16=None, w16=None):
     """Y = bias + sum_k X[nbr[k]] @ W[k].  x: [N_in, cin] (cin % 4 == 0), w2d: [K3*cin, cout].
     plan: optional (perm, tile_cls, cls_tab, max_tiles) class partition of the output rows (strided data grad).
     w_kmajor: the same weights as [K3, cout, cin] (k contiguous), needed by the bf16 / bf16x3 operand modes.
     opts: KernelOptions of the call (default: the ones in force).
     out_bf16: storage type of the output rows (default: that of x).  bf16 rows (in or out) take the bf16 operand mode:
-    w_kmajor is required."""
+    w_kmajor is required — or w16, its bf16 form [K3, cout, cin] (weight_twins), which then is what the kernel reads."""
     opts = opts or current()
     _set_last_bn_part(None)
     x_bf16 = x.dtype == torch.bfloat16
     if out_bf16 is None:
         out_bf16 = x_bf16
     if x_bf16 or out_bf16:
-        if w_kmajor is None or opts.prec_id != 1:
+        if (w_kmajor is None and w16 is None) or opts.prec_id != 1:
             raise _lib.AgbError("bf16 row matrices need the bf16 operand mode (KernelOptions precision='bf16') and K-major "
                                 "weights")
         if cin % 8 != 0 or x.stride(0) % 8 != 0 or cout % 4 != 0:
             # widths the bf16-storage kernel does not take (none in MSENet14/50): fp32 rows through the staging kernel
+            if w_kmajor is None:
+                w_kmajor = w16.float()
             y = spconv_forward_raw(x.float() if x_bf16 else x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind, pairs, plan,
                                    w_kmajor, bn_stats, opts, out_bf16=False)
             return y.to(torch.bfloat16) if out_bf16 else y
@@ -365,7 +397,7 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
     if nbr is None and pairs is None:
         pairs = int(n_out)        # dense product: one (in, out) pair per row
     ev = _prof_begin(kind, K3, cin, cout, n_out, plan is not None, split, x.shape[0])
-    prec = opts.prec_id if (w_kmajor is not None and cin >= 12) else 0
+    prec = opts.prec_id if ((w_kmajor is not None or w16 is not None) and cin >= 12) else 0
     bn_chunks = 0
     if opts.bn_stats_in_epilogue and bn_stats and nbr is None and not prec and split == 1:
         bn_chunks = _lib.load().agb_dense_bn_chunks(n_out, cin, cout)
@@ -381,7 +413,9 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
         # a 3^3 gather re-reads every row ~15 times)
         # bf16 mode on bf16 storage: twins of the rows (cached on the tensor: a block input feeds two convolutions) and of
         # the K-major weights; the kernel gathers 2-byte channels straight into LDS
-        x16, w16 = bf16_twin(x), bf16_twin(w_kmajor.view(-1, cin), cache=False)
+        x16 = bf16_twin(x)
+        if w16 is None:
+            w16 = bf16_twin(w_kmajor.view(-1, cin), cache=False)
         _lib.call("agb_spconv_fwd_h" if out_bf16 else "agb_spconv_fwd_b16", _P16(x16), x16.stride(0), _P16(w16), _P(nbr),
                   0 if nbr is None else nbr.stride(0), int(kflip), _P(bias), _lib.rows(y), y.stride(0), n_out, K3, cin, cout,
                   _P(perm), _P(tile_cls), _P(cls_tab), n_tiles, split, _P(partial), _lib.stream())
@@ -427,6 +461,15 @@ def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
               _P(dw), n_out, K3, cin, cout, prec, opts.dw_variant, _P(ws), nbytes, _lib.stream())
 
 
+def _twins_for(kernel, rows, opts, cin, cout, cin_p, cout_p):
+    """weight_twins(kernel) when the call runs on bf16 rows (`rows`: its input row matrix) with unpadded widths the bf16-storage
+    kernels take; else None (the per-call conversions)."""
+    if (rows.dtype != torch.bfloat16 or opts.prec_id != 1 or cin_p != cin or cout_p != cout or cin % 8 != 0 or cout % 8 != 0
+            or cin < 12 or cout < 12 or not kernel.is_contiguous()):
+        return None
+    return weight_twins(kernel)
+
+
 class SparseConvFunction(torch.autograd.Function):
     """Generalized sparse convolution. kernel: [K3, Cin, Cout]; nbr: forward map [K3, N_out];
     nbrT: transposed map [K3, N_in] or None when the k-flipped forward map serves (stride 1, odd kernel)."""
@@ -451,17 +494,21 @@ class SparseConvFunction(torch.autograd.Function):
             b = b.contiguous()
         pairs = getattr(nbr, "agb_pairs", None)
         opts = ctx.opts = current()
-        wkm = w.transpose(1, 2).contiguous() if (opts.low_precision and cin_p >= 12) else None
+        lp = opts.low_precision and cin_p >= 12
         if cin == 3 and cout_p == cout:
             # three input channels (the stem): rows stay 4 floats wide, the weights go in unpadded — the kernel packs
             # 10 offsets x 3 channels per K-chunk instead of 8 x 4
             y = spconv_forward_raw(x, kernel.contiguous().view(K3 * 3, cout), nbr, 0, b, n_out, K3, 3, cout_p, "fwd", pairs,
                                    opts=opts)
         else:
-            if x.dtype == torch.bfloat16 and wkm is None:     # (bf16 rows into a layer the bf16 kernels do not take)
+            if x.dtype == torch.bfloat16 and not lp:     # (bf16 rows into a layer the bf16 kernels do not take)
                 x = x.float()
+            # bf16 rows: both bf16 operand forms of the weights come from one launch per layer and step (weight_twins);
+            # else the K-major fp32 kernel [K3, cout, cin] for the staging-conversion kernels
+            tw = _twins_for(kernel, x, opts, cin, cout, cin_p, cout_p) if lp else None
+            wkm = w.transpose(1, 2).contiguous() if (lp and not tw) else None
             y = spconv_forward_raw(x, w2d, nbr, 0, b, n_out, K3, cin_p, cout_p, "fwd", pairs, None, wkm, opts=opts,
-                                   out_bf16=True if (opts.rows_bf16 and wkm is not None) else None)
+                                   w16=tw[1] if tw else None, out_bf16=True if (opts.rows_bf16 and lp) else None)
         if opts.rows_bf16 and y.dtype != torch.bfloat16:
             y = y.to(torch.bfloat16)          # (a narrow first layer on the fp32 kernels: the rows leave in the model's storage)
         ctx.pairs = pairs
@@ -544,7 +591,8 @@ class SparseConvFunction(torch.autograd.Function):
             # dX[q] = sum_k dY[nbrT[k][q]] @ W[k]^T : same implicit GEMM with the transposed weights
             lp = opts.low_precision and cout_p >= 12
             # the data gradient multiplies by W[k]^T: its K-major form is the kernel itself ([K3, cin, cout])
-            wkm = w.contiguous() if lp else None
+            tw = _twins_for(w, dy, opts, cin, cout, cin_p, cout_p) if lp else None
+            wkm = w.contiguous() if (lp and not tw) else None
             wt2d = None
             if not lp:
                 w = w.contiguous()
@@ -555,10 +603,12 @@ class SparseConvFunction(torch.autograd.Function):
             if has_T:
                 plan = ctx.plan if cout_p >= 12 else None
                 dxp = spconv_forward_raw(dy, wt2d, nbrT, 0, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, plan,
-                                         wkm, opts=opts, out_bf16=x_bf16 if dy.dtype == torch.bfloat16 else None)
+                                         wkm, opts=opts, out_bf16=x_bf16 if dy.dtype == torch.bfloat16 else None,
+                                         w16=tw[0] if tw else None)
             else:
                 dxp = spconv_forward_raw(dy, wt2d, nbr, 1, None, n_in, K3, cout_p, cin_p, "dgrad", ctx.pairs, None,
-                                         wkm, opts=opts, out_bf16=x_bf16 if dy.dtype == torch.bfloat16 else None)
+                                         wkm, opts=opts, out_bf16=x_bf16 if dy.dtype == torch.bfloat16 else None,
+                                         w16=tw[0] if tw else None)
             dx = dxp if cin_p == cin else dxp[:, :cin].contiguous()
             if dx.dtype != x.dtype:
                 dx = dx.to(x.dtype)
@@ -596,13 +646,15 @@ class DenseConvFunction(torch.autograd.Function):
         w = kernel.contiguous()
         b = None if bias is None else bias.reshape(-1).contiguous()
         opts = ctx.opts = current()
-        wkm = w.t().contiguous() if opts.low_precision else None          # K-major [Cout][Cin]
-        # (a forward pass that will be differentiated = training: the BatchNorm behind it wants batch statistics)
-        if x.dtype == torch.bfloat16 and (wkm is None or opts.prec_id != 1):
+        lp = opts.low_precision
+        if x.dtype == torch.bfloat16 and opts.prec_id != 1:
             x = x.float()
+        tw = _twins_for(kernel, x, opts, cin, cout, cin, cout) if lp else None
+        wkm = w.t().contiguous() if (lp and not tw) else None          # K-major [Cout][Cin]
+        # (a forward pass that will be differentiated = training: the BatchNorm behind it wants batch statistics)
         y = spconv_forward_raw(x, w, None, 0, b, n, 1, cin, cout, "fwd1x1", None, None, wkm,
-                               bn_stats=any(ctx.needs_input_grad), opts=opts,
-                               out_bf16=True if (opts.rows_bf16 and wkm is not None) else None)
+                               bn_stats=any(ctx.needs_input_grad), opts=opts, w16=tw[1] if tw else None,
+                               out_bf16=True if (opts.rows_bf16 and lp) else None)
         if opts.rows_bf16 and y.dtype != torch.bfloat16:
             y = y.to(torch.bfloat16)
         ctx.save_for_backward(x, w)
@@ -624,7 +676,9 @@ class DenseConvFunction(torch.autograd.Function):
             dy = dy.float()
         if ctx.needs_input_grad[0]:
             if lp:     # the data gradient multiplies by W^T: its K-major form [Cin][Cout] is the kernel itself
-                dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None, w, opts=opts,
+                tw = _twins_for(w, dy, opts, cin, cout, cin, cout)
+                dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None, None if tw else w,
+                                        opts=opts, w16=tw[0] if tw else None,
                                         out_bf16=(x.dtype == torch.bfloat16) if dy.dtype == torch.bfloat16 else None)
             else:
                 wt = torch.empty(cout, cin, dtype=torch.float32, device=w.device)

@@ -1243,3 +1243,31 @@ def test_bf16_rows_senet50_training_step(device):
     assert all(np.isfinite(traj[True])) and traj[True][-1] < 0.5 * traj[True][1]
     for a, b in zip(traj[True][:4], traj[False][:4]):
         assert abs(a - b) < 0.15 * max(1.0, abs(b)), (traj[True], traj[False])
+
+
+def test_weight_twins_one_launch_and_cache(device):
+    """agb_weight_twins_bf16: W16 = bf16(W), Wt16 = bf16(W^T per offset), both from one launch; cached on the parameter and
+    invalidated by torch's version counter AND by the fused optimiser step (which writes through raw pointers)."""
+    from dpcr_agb_amd import sparse_ops
+    from dpcr_agb_amd.optim import AdaBelief
+    torch.manual_seed(2)
+    for shape in [(27, 64, 128), (1, 256, 72), (136, 40)]:
+        w = torch.nn.Parameter(torch.randn(*shape, device=device))
+        w16, wt16 = sparse_ops.weight_twins(w)
+        w3 = w.detach().view((1,) + shape if len(shape) == 2 else shape)
+        assert torch.equal(w16, w3.to(torch.bfloat16)) and torch.equal(wt16, w3.transpose(1, 2).contiguous().to(torch.bfloat16))
+        assert sparse_ops.weight_twins(w)[0] is w16                       # cached
+        with torch.no_grad():
+            w.mul_(2.0)                                                   # torch in-place write: version counter
+        assert torch.equal(sparse_ops.weight_twins(w)[0], (2.0 * w3 / 2.0).to(torch.bfloat16))
+        assert sparse_ops.weight_twins(w)[0] is not w16
+    # fused optimiser step: parameters move without torch noticing
+    w = torch.nn.Parameter(torch.randn(27, 64, 64, device=device))
+    opt = AdaBelief([w], lr=0.05, weight_decay=1e-2)
+    before = sparse_ops.weight_twins(w)[0].clone()
+    w.grad = torch.randn_like(w)
+    version = w._version
+    opt.step()
+    after = sparse_ops.weight_twins(w)[0]
+    assert torch.equal(after, w.detach().to(torch.bfloat16)) and not torch.equal(after, before)
+    print("parameter version before / after the fused step:", version, w._version)
