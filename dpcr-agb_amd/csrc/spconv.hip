@@ -1493,7 +1493,18 @@ __device__ __forceinline__ unsigned pack_bf16_lo(float a, float b) {
 }
 // IN16 (PREC 1 only): X and dY are bf16 twins (uint16 rows, ldx / ldy in bf16 elements): 8-byte loads of four channels,
 // no conversion — the two pairs of a dword are interleaved with two bit operations per channel.
-template <int PREC, bool IN16 = false>
+// TR16 (with IN16): the bf16 rows are staged AS THEY ARE — image [pair][64 channels] of 128-byte rows, one ds_write_b128 per
+// 16-byte piece, 16-byte chunk index XORed with 4 * ((pair >> 1) & 1) — and the transposition the MFMA wants (8 consecutive
+// pairs per lane) is done by the LDS hardware: two ds_read_b64_tr_b16 per operand and MFMA (each 16-lane group reads a block
+// of 4 pairs x 16 channels and receives it column-major; conflict-free with that XOR by the bank rule of
+// MI355X_MICROARCH.md section LDS).  Four 16-byte loads and four LDS writes per thread and 64-pair step instead of eight
+// 8-byte loads, sixteen 4-byte writes and the bit interleave.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(const unsigned short* p) {
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+template <int PREC, bool IN16 = false, bool TR16 = false>
 __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ dY, int ldy,
                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
@@ -1582,6 +1593,11 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     constexpr int LJ = DW_KS / 16;
     float4 a_reg[LJ], b_reg[LJ];
     uint2 a16[IN16 ? LJ : 1], b16[IN16 ? LJ : 1];
+    uint4 a8_0, a8_1, b8_0, b8_1;                             // TR16: pair (tid >> 3) + 32 j, channels 8 (tid & 7) ..
+    // (four named registers, not arrays: as arrays captured by the load lambda they were left in scratch memory)
+    const int t8_p = tid >> 3, t8_c = (tid & 7) * 8;
+    const int a8_col = min(c0 + t8_c, Cin - 8), b8_col = min(n0 + t8_c, Cout - 8);
+    const bool a8_ok = c0 + t8_c < Cin, b8_ok = n0 + t8_c < Cout;
     const unsigned short* X16 = reinterpret_cast<const unsigned short*>(X);
     const unsigned short* dY16 = reinterpret_cast<const unsigned short*>(dY);
     // loads are unconditional (clamped pair / column) and masked when stored to LDS: under branches every pair's
@@ -1591,6 +1607,15 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     // pair (inside the 64-pair step) of register j: fp32 rows t_r + 16 j; bf16: the two pairs of pair-pair t_r + 16 (j >> 1)
     auto pair_of = [&](int j) { return PREC == 0 ? t_r + 16 * j : 2 * (t_r + 16 * (j >> 1)) + (j & 1); };
     auto load_data = [&](int pb) {
+        if constexpr (TR16) {
+            const int p0 = min(pb + t8_p, total - 1), p1 = min(pb + t8_p + 32, total - 1);
+            const int i0 = p_in[p0], o0 = p_out[p0], i1 = p_in[p1], o1 = p_out[p1];
+            a8_0 = *reinterpret_cast<const uint4*>(X16 + (long long)i0 * ldx + a8_col);
+            b8_0 = *reinterpret_cast<const uint4*>(dY16 + (long long)o0 * ldy + b8_col);
+            a8_1 = *reinterpret_cast<const uint4*>(X16 + (long long)i1 * ldx + a8_col);
+            b8_1 = *reinterpret_cast<const uint4*>(dY16 + (long long)o1 * ldy + b8_col);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < LJ; ++j) {
             const int p = min(pb + pair_of(j), total - 1);
@@ -1616,6 +1641,21 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
                 *reinterpret_cast<float4*>(&As[(t_r + 16 * j) * 64 + t_c]) = av;
                 *reinterpret_cast<float4*>(&Bs[(t_r + 16 * j) * 64 + t_c]) = bv;
             }
+        } else if constexpr (TR16) {
+            unsigned short* A16 = reinterpret_cast<unsigned short*>(As);
+            unsigned short* B16 = reinterpret_cast<unsigned short*>(Bs);
+            // (component-wise masks: a ternary between two uint4 STRUCTS is compiled as a select between two stack slots)
+            auto masked = [](uint4 v, bool keep) {
+                const unsigned m = keep ? 0xFFFFFFFFu : 0u;
+                return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+            };
+            const bool live0 = pb + t8_p < total, live1 = pb + t8_p + 32 < total;
+            // (pairs p and p + 32 have the same swizzle: ((p >> 1) & 1) is bit 1 of the pair)
+            const int off = t8_p * 64 + (((t8_c >> 3) ^ (((t8_p >> 1) & 1) << 2)) << 3);
+            *reinterpret_cast<uint4*>(&A16[off]) = masked(a8_0, live0 && a8_ok);
+            *reinterpret_cast<uint4*>(&B16[off]) = masked(b8_0, live0 && b8_ok);
+            *reinterpret_cast<uint4*>(&A16[off + 32 * 64]) = masked(a8_1, live1 && a8_ok);
+            *reinterpret_cast<uint4*>(&B16[off + 32 * 64]) = masked(b8_1, live1 && b8_ok);
         } else {
             unsigned* At = reinterpret_cast<unsigned*>(As);
             unsigned* Bt = reinterpret_cast<unsigned*>(Bs);
@@ -1670,6 +1710,27 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
                 float av = ap[(2 * s2 + lh) * 64];
                 float bv = bp[(2 * s2 + lh) * 64];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+        } else if constexpr (TR16) {
+            // 16-lane group g = lane >> 4 reads the block of pairs 16 s + 8 (g >> 1) + {0..3} (second read: + 4) x channels
+            // 32 w + 16 (g & 1) + {0..15}: lane 4 q + p of the group supplies the address of pair q, channels 4 p .. 4 p + 3, and
+            // receives channel (lane & 15) of the four pairs = A[m = lane & 31][8 h + 0..3] of the MFMA operand
+            const unsigned short* A16 = reinterpret_cast<const unsigned short*>(As);
+            const unsigned short* B16 = reinterpret_cast<const unsigned short*>(Bs);
+            const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+            const int prow = 8 * (g >> 1) + q;                       // (+ 16 s, + 4 for the second read)
+            const int acol = wr * 32 + 16 * (g & 1) + 4 * pp, bcol = wc * 32 + 16 * (g & 1) + 4 * pp;
+#pragma unroll
+            for (int s2 = 0; s2 < DW_KS / 16; ++s2) {
+                const int r0 = 16 * s2 + prow, r1 = r0 + 4;
+                const int x0 = ((r0 >> 1) & 1) << 2, x1 = ((r1 >> 1) & 1) << 2;
+                const uint2 a0 = lds_read_tr16(&A16[r0 * 64 + ((((acol >> 3) ^ x0) << 3) | (acol & 7))]);
+                const uint2 a1 = lds_read_tr16(&A16[r1 * 64 + ((((acol >> 3) ^ x1) << 3) | (acol & 7))]);
+                const uint2 b0 = lds_read_tr16(&B16[r0 * 64 + ((((bcol >> 3) ^ x0) << 3) | (bcol & 7))]);
+                const uint2 b1 = lds_read_tr16(&B16[r1 * 64 + ((((bcol >> 3) ^ x1) << 3) | (bcol & 7))]);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
             }
         } else {
             // lane (r = lane & 31, h = lane >> 5) holds A[m = r][pair 16 s + 8 h + j] and B[same pairs][n = r], j = 0..7:
@@ -2623,7 +2684,12 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
             chunks = agb_cdiv(nblk, bpc);
         }
         dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
-        if (precision == 3)       // bf16 operands from bf16 twins (agb_spconv_bwd_weight_b16)
+        static const bool no_tr = getenv("AGB_DW_NO_TR16") != nullptr;       // (A/B measurements)
+        if (precision == 3 && !no_tr && Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0)
+            // bf16 twins, rows staged as they are and transposed by the LDS reads (ds_read_b64_tr_b16)
+            hipLaunchKernelGGL((k_spconv_dw_cmp<1, true, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out,
+                               K3, Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+        else if (precision == 3)       // bf16 operands from bf16 twins (agb_spconv_bwd_weight_b16)
             hipLaunchKernelGGL((k_spconv_dw_cmp<1, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
         else if (precision == 1)
