@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--wgrad", action="store_true")
+    ap.add_argument("--b16", action="store_true", help="also time the forward pass on bf16 rows (agb_spconv_fwd_h)")
     ap.add_argument("--il", default="-1", help="interleave block shifts to sweep for the pair-compacted kernel, e.g. 0,2,3 (-1: by level size, the library default)")
     args = ap.parse_args()
     from dpcr_agb_amd import _lib, sparse_ops, synthetic
@@ -58,6 +59,21 @@ def main():
             print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} rows {n:7d} density {pairs / (27 * n):.2f} mode {mode:3d} il {il}: "
                   f"{us:8.1f} us  {2.0 * pairs * cin * cout / us / 1e6:6.1f} TF  (max rel diff vs first mode {err:.1e})",
                   flush=True)
+        if args.b16:
+            x16 = x.to(torch.bfloat16)
+            wkm = w.view(27, cin, cout).transpose(1, 2).contiguous()
+            opts = sparse_ops.KernelOptions(precision="bf16")
+            spconv_forward_raw(x16, None, nbr, 0, None, n, 27, cin, cout, w_kmajor=wkm, opts=opts)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                spconv_forward_raw(x16, None, nbr, 0, None, n, 27, cin, cout, w_kmajor=wkm, opts=opts)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / args.reps * 1e3
+            print(f"ts{ts_in:2d} {cin:4d}->{cout:4d} fwd bf16 rows (incl. the weight conversion launch): {us:8.1f} us  "
+                  f"{2.0 * pairs * cin * cout / us / 1e6:6.1f} TF", flush=True)
         if args.wgrad:
             dy = torch.randn(n, cout, device=dev)
             ref_dw = None
