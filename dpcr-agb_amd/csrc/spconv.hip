@@ -2459,8 +2459,7 @@ static int fwd_b16_impl(const uint16_t* X16, int ldx16, const uint16_t* Wt16, co
     if (perm) {
         hipLaunchKernelGGL((k_spconv_pipe_b16<64, true, 64, Y16>), dim3(n_tiles, agb_cdiv(Cout, BN), ksplit), block, 0, s, a);
     } else if (conv_tile_rows(n_out, Cin, Cout) == 128) {
-        static const int wide_min = getenv("AGB_WIDE_MIN") ? atoi(getenv("AGB_WIDE_MIN")) : 512;      // (tuning aid)
-        const bool wide = Cout >= 128 && (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, 128) * ksplit >= wide_min;
+        const bool wide = Cout >= 128 && (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, 128) * ksplit >= 512;
         dim3 grid(agb_cdiv(n_out, 128), agb_cdiv(Cout, wide ? 128 : 64), ksplit);
         if (wide) hipLaunchKernelGGL((k_spconv_pipe_b16<128, false, 128, Y16>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_spconv_pipe_b16<128, false, 64, Y16>), grid, block, 0, s, a);
