@@ -21,13 +21,15 @@ def _free_port():
 
 
 @pytest.mark.gpu
-def test_two_rank_bench_dry_run_keeps_ranks_identical():
+@pytest.mark.parametrize("mode", [[], ["--precision", "bf16", "--bf16-rows"]], ids=["fp32", "bf16rows"])
+def test_two_rank_bench_dry_run_keeps_ranks_identical(mode):
+    """mode bf16rows: BASELINE config 5's operand / storage mode (bf16 rows; gradients, buckets and optimiser state fp32)."""
     env = dict(os.environ, AGB_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     env.pop("RANK", None)
     # a fresh child process (fork + exec of a NEW interpreter, never an exec of this GPU-initialised one)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--no-cpu-baseline", "--reserve-gib", "8"]
+           "--no-cpu-baseline", "--reserve-gib", "8"] + mode
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
