@@ -14,7 +14,6 @@
 // kernel offsets, gathering the 64 neighbour rows of each offset into LDS (coalesced 16-B row pieces).
 // Results are run-to-run deterministic for fwd/data-grad.
 #include "agb_common.h"
-#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -2633,9 +2632,7 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
     // (dense products with bf16 operands: the MFMA work of a workgroup is small against the 64 x 64 atomic adds it ends
     // with — 4096 workgroups put 13 M atomics on the 256 x 1024 gradient of a 14 k-row layer: 71 us, 512 workgroups: 34 us;
     // 211 k x 64 x 256: 120 -> 41 us.  The 3^3 maps sit at the 2048-row cap of the pair list either way.)
-    static const int target_wgs_env = getenv("AGB_DW_TARGET") ? atoi(getenv("AGB_DW_TARGET")) : 0;   // (tuning aid)
-    int target_wgs = (nbr == nullptr && (precision == 1 || precision == 3)) ? 512 : 4096;
-    if (target_wgs_env > 0 && nbr == nullptr) target_wgs = target_wgs_env;
+    const int target_wgs = (nbr == nullptr && (precision == 1 || precision == 3)) ? 512 : 4096;
     long long target_chunks = target_wgs / ((long long)m_tiles * n_tiles);
     if (target_chunks < 1) target_chunks = 1;
     long long rows = (n_out + target_chunks - 1) / target_chunks;
@@ -2684,8 +2681,7 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
             chunks = agb_cdiv(nblk, bpc);
         }
         dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
-        static const bool no_tr = getenv("AGB_DW_NO_TR16") != nullptr;       // (A/B measurements)
-        if (precision == 3 && !no_tr && Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0)
+        if (precision == 3 && Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0)
             // bf16 twins, rows staged as they are and transposed by the LDS reads (ds_read_b64_tr_b16)
             hipLaunchKernelGGL((k_spconv_dw_cmp<1, true, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out,
                                K3, Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
