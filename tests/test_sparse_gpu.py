@@ -1271,3 +1271,15 @@ def test_weight_twins_one_launch_and_cache(device):
     after = sparse_ops.weight_twins(w)[0]
     assert torch.equal(after, w.detach().to(torch.bfloat16)) and not torch.equal(after, before)
     print("parameter version before / after the fused step:", version, w._version)
+
+
+def test_bf16_rows_refuse_kernels_without_a_bf16_form(device):
+    """A row kernel that exists for fp32 rows only (LayerNorm here) refuses bf16 rows loudly instead of reading them as
+    floats."""
+    from dpcr_agb_amd import _lib, norm_ops
+    x16 = torch.randn(100, 64, device=device).to(torch.bfloat16)
+    ln = torch.nn.LayerNorm(64).to(device)
+    with pytest.raises(_lib.AgbError, match="fp32 rows"):
+        norm_ops.layer_norm(x16, ln)
+    with pytest.raises(_lib.AgbError, match="mixed storage"):
+        _lib.sfx(x16, x16.float())
