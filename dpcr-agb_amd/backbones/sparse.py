@@ -98,6 +98,8 @@ class MinkowskiLayerNorm(nn.Module):
 
     def forward(self, input):
         from ..norm_ops import layer_norm
+        if input.F.dtype == torch.bfloat16:     # bf16 row storage: csrc/layernorm.hip takes fp32 rows
+            return input._like(layer_norm(input.F.float(), self.ln).to(torch.bfloat16))
         return input._like(layer_norm(input.F, self.ln))
 
 

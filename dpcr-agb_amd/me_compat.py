@@ -306,6 +306,11 @@ class MinkowskiInstanceNorm(nn.Module):
         self._bmul = MinkowskiBroadcastMultiplication()
 
     def forward(self, input: SparseTensor) -> SparseTensor:
+        if input.F.dtype == torch.bfloat16:
+            # bf16 row storage (KernelOptions.bf16_activations): this composite normalisation computes on fp32 rows and hands
+            # bf16 rows on (the fused BatchNorm kernels are the ones with a bf16-row form)
+            out = self.forward(input._like(input.F.float()))
+            return out._like(out.F.to(torch.bfloat16))
         ones = input._like(torch.ones_like(input.F))
         mean = self._bmul(ones, self._avg(input))
         centred = input - mean

@@ -1283,3 +1283,31 @@ def test_bf16_rows_refuse_kernels_without_a_bf16_form(device):
         norm_ops.layer_norm(x16, ln)
     with pytest.raises(_lib.AgbError, match="mixed storage"):
         _lib.sfx(x16, x16.float())
+
+
+@pytest.mark.parametrize("norm_type,activation", [("ln", "gelu"), ("in", "relu")])
+def test_bf16_rows_other_normalisations(device, norm_type, activation):
+    """Backbone variants whose normalisation has no bf16-row kernel (LayerNorm, InstanceNorm: computed on fp32 rows, handed on
+    as bf16 rows) train under bf16 row storage too: output and gradient close to the same model on fp32 rows."""
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_032))
+    opt = Opt(MODEL_OPTIONS["SENet14"])
+    opt["drop_path"], opt["norm_type"], opt["activation"] = 0.0, norm_type, activation
+    model = MinkowskiBaselineModel(opt, "minkowski", ds).to(device).train()
+    batch = synthetic.make_sparse_batch([0, 1, 2], n_points=1500)
+    res = {}
+    for rows in (False, True):
+        model.set_kernel_options(precision="bf16", bf16_activations=rows)
+        model.zero_grad(set_to_none=True)
+        model.set_input(batch, device)
+        model.forward()
+        model.loss.backward()
+        res[rows] = (model.output.detach().clone(),
+                     torch.cat([p.grad.detach().double().reshape(-1) for p in model.model.parameters()]))
+    e = rel_err(res[True][0], res[False][0])
+    cos = float(torch.dot(res[True][1], res[False][1]) / (res[True][1].norm() * res[False][1].norm()))
+    print(f"SENet14 norm_type={norm_type}: bf16 rows vs fp32 rows (bf16 operands): output rel diff {e:.3e}, cos(gradients) {cos:.5f}")
+    assert e < 5e-2 and cos > 0.97
