@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="build each batch's coordinate plan inside set_input")
     ap.add_argument("--cpu-plots", type=int, default=1)
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the BASELINE configs 2, 3 and 5 (single-GPU leg) that the default N = 1 headline run measures "
+                         "afterwards as fresh child processes and reports under `other_configs`")
     ap.add_argument("--reserve-gib", type=int, default=16, help="allocator pool reserved up front on the compute stream "
                     "(half of it again on the input pipeline's side stream); 0 = grow on demand")
     return ap.parse_args()
@@ -70,42 +73,17 @@ def conv_cost(rec, pairs):
 
 
 def kernel_of(rec):
-    """Name of the HIP kernel a recorded launch ran (mirrors the dispatch rules of csrc/spconv.hip)."""
-    small = rec["cin"] in (4, 8)
-    lp = PRECISION != "fp32" and rec["cin"] >= 12
-    dense = rec["kind"].endswith("1x1")
-    if rec["kind"].startswith("wgrad"):
-        if small:
-            return f"k_spconv_dw_small_cmp<{rec['cin']}>"
-        return f"k_spconv_dw_cmp<{ {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[PRECISION] }>" + (" (dense)" if dense else "")
-    if rec["cin"] == 3:
-        return "k_spconv_fwd3"   # (<true>: the grid-probing instantiation, when the level is in grid mode)
-    if small:
-        return f"k_spconv_fwd<{rec['cin']}>"
-    col_tiles = -(-rec["cout"] // 64)
-    tall = -(-rec["rows"] // 128) * col_tiles >= 1024 or (rec["cin"] >= 256 and rec["rows"] >= 1024)
-    if lp:
-        x3 = "true" if PRECISION == "bf16x3" else "false"
-        if rec.get("perm"):
-            return f"k_spconv_pipe_bf16<64, true, {x3}>"
-        split = rec.get("split", 1)
-        wide = tall and rec["cout"] >= 128 and -(-rec["rows"] // 128) * -(-rec["cout"] // 128) * split >= 512
-        return f"k_spconv_pipe_bf16<{128 if tall else 64}, false, {x3}{', 128' if wide else ''}>" + \
-            (" (dense)" if dense else "")
-    if rec.get("perm"):
-        return "k_spconv_pipe<64, true>"
-    split = rec.get("split", 1)
-    if not dense and rec["cin"] % 64 == 0 and (rec["cin"] // 64) % split == 0 and \
-            -(-rec["rows"] // 128) * col_tiles * split >= 384:
-        return "k_spconv_cmp<128>"
-    return f"k_spconv_pipe<{128 if tall else 64}, false>" + (" (dense)" if dense else "")
+    """Name of the HIP kernel a recorded launch ran: what the library itself noted when it launched it (agb_last_kernel,
+    csrc/agb_common.h AGB_LAUNCH) — the names rocprof shows — with " (dense)" appended for identity-map products."""
+    name = rec.get("kernel") or "unknown"
+    return name + (" (dense)" if rec["kind"].endswith("1x1") else "")
 
 
 def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, file it was read from) from the newest committed PMC pass
     (tools/collect_pmc.sh <tag> -> profiles/<tag>_pmc_traffic.json; separate --pmc runs of this same command, corrected as
     MI355X_MICROARCH.md prescribes) — counters cannot be collected from inside a running benchmark — or (None, None)."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", f"{tag}_pmc_traffic.json")
         try:
             data = json.load(open(os.path.join(ROOT, rel)))["kernels"]
@@ -198,9 +176,10 @@ def kernel_summary(groups):
                     tflops=round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)) for k, v in groups.items()}
 
 
-def usable_cores():
-    """Host cores this process may really use: affinity mask, cgroup CPU quota, capped at 32 (oversubscribing a
-    quota-limited container with one OpenMP thread per visible core makes the CPU leg arbitrarily slow)."""
+def usable_cores(cap=32):
+    """Host cores this process may really use: affinity mask, cgroup CPU quota, capped at `cap` (32 for the CPU legs:
+    oversubscribing a quota-limited container with one OpenMP thread per visible core makes them arbitrarily slow;
+    cap=None: the uncapped count, what the per-rank host budget is decided on)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -208,7 +187,7 @@ def usable_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    return max(1, min(n, 32))
+    return max(1, n if cap is None else min(n, cap))
 
 
 def thread_cpu_times():
@@ -338,6 +317,48 @@ def cpu_baseline_kpconv_index(batch, B, points):
                        f"number next to it is the WHOLE training step")
 
 
+OTHER_CONFIGS = (
+    ("config2", "PointNet fp32 on 1xMI355X, synthetic 16k-pt plots, batch=64",
+     [os.path.join("tools", "bench_config.py"), "pointnet", "--steps", "20", "--warmup", "5"]),
+    ("config3", "KPConv rigid, 1xMI355X, 16k-pt plots batch=32",
+     [os.path.join("tools", "bench_config.py"), "kpconv", "--points", "16000", "--steps", "20", "--warmup", "5"]),
+    ("config5_single_gpu_leg", "MSENet50 biomass+wood-volume, bf16 with fp32 index kernels (one rank's share: batch 32)",
+     ["bench.py", "--model", "SENet50", "--precision", "bf16", "--bf16-rows", "--steps", "30", "--warmup", "8",
+      "--no-other-configs", "--no-cpu-baseline"]),
+)
+
+
+def run_other_configs(timeout_s=150):
+    """BASELINE configs 2, 3 and the single-GPU leg of config 5 under the same clock as the headline: each as a FRESH CHILD
+    PROCESS (subprocess: a new interpreter with its own HIP context; never an exec of this GPU-initialised process), bounded
+    in time; a failure is recorded as a string.  The headline metric / value / config are not touched by these."""
+    import subprocess
+    out = {}
+    for key, name, argv in OTHER_CONFIGS:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable] + argv, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[key] = dict(baseline_config=name, error=f"rc {r.returncode}: " + (r.stderr or r.stdout)[-400:])
+                continue
+            d = json.loads(lines[-1])
+            out[key] = dict(baseline_config=name, metric=d["metric"], value=d["value"], unit=d["unit"],
+                            ms_per_step=d["ms_per_step"], steps=d["steps"], warmup=d["warmup"], dtype=d["dtype"],
+                            workload=d["config"]["workload"], roofline=d.get("roofline"),
+                            cpu_baseline=d.get("cpu_baseline"), wall_s=round(time.perf_counter() - t0, 1),
+                            command="python " + " ".join(argv))
+            for extra in ("ball_query_roofline", "index_path_ms_per_step", "step_ms_p50"):
+                if extra in d:
+                    out[key][extra] = d[extra]
+        except subprocess.TimeoutExpired:
+            out[key] = dict(baseline_config=name, error=f"timeout after {timeout_s} s")
+        except Exception as e:      # noqa: BLE001 — a failed side measurement must not lose the headline line
+            out[key] = dict(baseline_config=name, error=f"{type(e).__name__}: {e}")
+        log(f"other config {key}: " + (f"{out[key]['value']} {out[key]['unit']}" if "value" in out[key] else out[key]["error"]))
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -418,9 +439,12 @@ def main():
     # events keeps one thread of the HIP runtime busy for ~9 ms of CPU per step (10.2 -> 18.3 ms of CPU per step and rank,
     # profiles/r03_host_cpu.txt).  Where the ranks of a node have fewer than ~2.5 cores each (cgroup quota / world size) that
     # thread would get the whole process throttled: build the input on the compute stream there.
-    if not args.no_prefetch and usable_cores() / max(world, 1) < 2.5:
+    # (the node's uncapped core count over the ranks of THIS node: LOCAL_WORLD_SIZE under torch.distributed.run)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world) or world)
+    if not args.no_prefetch and usable_cores(None) / max(local_world, 1) < 2.5:
         args.no_prefetch = True
-        log(f"{usable_cores()} usable cores for {world} rank(s): input pipeline on the compute stream (--no-prefetch)")
+        log(f"{usable_cores(None)} usable cores for {local_world} rank(s) on this node: input pipeline on the compute stream "
+            f"(--no-prefetch)")
     # allocator pools grown up front (per stream): no device allocation inside the timed region
     model.reserve_workspace(dev, main_bytes=args.reserve_gib << 30, side_bytes=(args.reserve_gib << 30) // 2)
     if not args.no_prefetch and len(pool) >= 3:
@@ -564,6 +588,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             stats = (model.reg_center_targets.cpu(), model.reg_scale_targets.cpu(), model.reg_weights.cpu())
             line["cpu_baseline"] = cpu_baseline(args, model_sd_cpu, stats, tuple(model.model.LAYERS))
+        if world == 1 and not args.no_other_configs and args.model == "SENet14" and args.precision == "fp32":
+            # (the headline run only; this process's cached pools go back to the device first: 288 GB, but the children
+            # reserve 12-24 GiB each)
+            torch.cuda.empty_cache()
+            line["other_configs"] = run_other_configs()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

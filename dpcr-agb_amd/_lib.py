@@ -92,6 +92,8 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.agb_last_error.restype = ctypes.c_char_p
     lib.agb_last_error.argtypes = []
+    lib.agb_last_kernel.restype = ctypes.c_char_p
+    lib.agb_last_kernel.argtypes = []
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is None:
@@ -177,6 +179,11 @@ def call(name, *args):
     if rc != 0:
         raise AgbError(f"{name} failed ({rc}): {load().agb_last_error().decode()}")
     return rc
+
+
+def last_kernel():
+    """Name of the compute kernel the last convolution / dense-product / weight-gradient call of this thread launched."""
+    return load().agb_last_kernel().decode()
 
 
 def size_call(name, *args):

@@ -370,6 +370,7 @@ class ResNetBase(nn.Module):
         return specs
 
     kernel_options = None      # sparse_ops.KernelOptions of this model (None: the ones in force / the defaults)
+    supports_bf16_rows = True  # KernelOptions.bf16_activations: every row kernel of this backbone has a bf16-row form
 
     def forward(self, x):
         with model_scope(self):

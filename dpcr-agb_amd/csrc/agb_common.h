@@ -20,6 +20,16 @@
 
 extern "C" const char* agb_last_error(void);
 void agb_set_error(const char* fmt, ...);
+// Diagnostic (thread-local, like the error string): the compute kernel the last convolution / dense-product / weight-
+// gradient entry point of this thread launched — bench tools name the kernel of a timed launch with it instead of
+// mirroring the dispatch rules.  A leading '(' of a parenthesised template name is skipped.
+extern "C" const char* agb_last_kernel(void);
+void agb_note_kernel(const char* name);
+#define AGB_LAUNCH(kern, ...)            \
+    do {                                 \
+        agb_note_kernel(#kern);          \
+        hipLaunchKernelGGL(kern, __VA_ARGS__); \
+    } while (0)
 
 #define AGB_CHECK_ARG(cond, ...)                 \
     do {                                         \

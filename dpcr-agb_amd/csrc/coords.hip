@@ -10,11 +10,22 @@
 // HBM-bound integer work: every kernel is one thread per row (or per row x offset),
 // rows fastest so that table writes and coordinate reads coalesce.
 #include "agb_common.h"
+#include <string.h>
 #include <limits.h>
 #include <stdarg.h>
 
 static thread_local char g_err[512] = "";
 extern "C" const char* agb_last_error(void) { return g_err; }
+static thread_local char g_kernel[128] = "";
+extern "C" const char* agb_last_kernel(void) { return g_kernel; }
+void agb_note_kernel(const char* name) {
+    // "(k_spconv_pipe<128, false>)" -> "k_spconv_pipe<128, false>"
+    size_t n = strlen(name);
+    if (n >= 2 && name[0] == '(' && name[n - 1] == ')') { ++name; n -= 2; }
+    if (n >= sizeof(g_kernel)) n = sizeof(g_kernel) - 1;
+    memcpy(g_kernel, name, n);
+    g_kernel[n] = 0;
+}
 void agb_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -13,6 +13,7 @@
 // workgroup, rows padded by 4 floats so the four k of a step fall on different banks.  fp32 exact products, like every
 // fp32 kernel of this library.
 #include "agb_common.h"
+#include <stdio.h>
 
 typedef float ds_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -210,6 +211,9 @@ static int launch_stream(const float* X, int ldx, const float* W, const float* b
     const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;   // 8-wave workgroups
     int grid = 256 * per_cu;
     if (grid > agb_cdiv(items, 8)) grid = agb_cdiv(items, 8);
+    char nm[64];
+    snprintf(nm, sizeof nm, "k_dense_stream<%d, %s>", NTB, NT_LOADS ? "true" : "false");
+    agb_note_kernel(nm);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, ldx, W, bias, Y, ldy, n, Cin, Cout, items);
     return AGB_OK;
 }
@@ -233,7 +237,7 @@ int agb_dense_stream_wgrad_launch(const float* X, int ldx, const float* dY, int 
     const int blocks16 = agb_cdiv(n, 16);
     int grid = 512;
     if (grid > agb_cdiv(blocks16, 2)) grid = agb_cdiv(blocks16, 2);
-    hipLaunchKernelGGL(k_dense_stream_wgrad, dim3(grid), dim3(512), 0, st, X, ldx, dY, ldy, dW, Cout, 1, n, Cin, Cout,
+    AGB_LAUNCH(k_dense_stream_wgrad, dim3(grid), dim3(512), 0, st, X, ldx, dY, ldy, dW, Cout, 1, n, Cin, Cout,
                        blocks16);
     return AGB_OK;
 }

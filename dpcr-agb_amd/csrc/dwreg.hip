@@ -222,7 +222,7 @@ int agb_dwreg_launch(const float* X, int ldx, const float* dY, int ldy, const in
     const long long units = (g.chunks >= 16 ? 8LL * agb_cdiv(g.chunks, 8) : g.chunks) * M;
     if (units > 0x7fffffffLL) { agb_set_error("weight gradient: too many units"); return AGB_ERANGE; }
 #define DWR_LAUNCH(DENSE)                                                                                                  \
-    hipLaunchKernelGGL((k_spconv_dw_reg<DENSE, 4>), dim3((unsigned)units), dim3(256), 0, s, X, ldx, dY, ldy, nbr, nbr_stride, \
+    AGB_LAUNCH((k_spconv_dw_reg<DENSE, 4>), dim3((unsigned)units), dim3(256), 0, s, X, ldx, dY, ldy, nbr, nbr_stride, \
                        dW, part, n_out, K3, Cin, Cout, g.rows, g.cin_tiles, g.cout_tiles, g.chunks)
     if (nbr) DWR_LAUNCH(false); else DWR_LAUNCH(true);
 #undef DWR_LAUNCH

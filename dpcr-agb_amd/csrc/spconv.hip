@@ -1509,9 +1509,12 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
                                                        float* __restrict__ dW, int n_out, int K3, int Cin, int Cout,
                                                        int rows_per_wg, int cin_tiles, int chunks, int m_tiles,
-                                                       int il_shift) {
+                                                       int il_shift, float* __restrict__ part) {
     // il_shift > 0: a row chunk is made of 2^il_shift-row blocks taken `chunks` blocks apart (see k_spconv_cmp: evens
     // out the pair count per workgroup where the density varies by region)
+    // part != nullptr (the REPRODUCIBLE form, any operand precision): the workgroup's tile goes to part[chunk] with plain
+    // stores — one writer per element — and k_dw_fold_small adds the chunks in ascending order; nullptr: fp32 atomic adds
+    // on dW, whose arrival order differs from run to run.
     constexpr int NP = PREC == 2 ? 2 : 1;
     // fp32: As [pair][m], Bs [pair][n];  bf16: At [m][pair/2] / Bt [n][pair/2] (transposed, swizzled), hi (and lo) planes
     __shared__ __attribute__((aligned(16))) float As[PREC == 0 ? DW_KS * 64 : NP * 64 * DWT_LD];
@@ -1583,11 +1586,23 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
         total += round;
     }
     __syncthreads();
-    if (total == 0) return;
-
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (total == 0) {
+        if (part == nullptr) return;
+        // (the fold reads every chunk's tile: an empty chunk still writes its zeros)
+        const int colz = n0 + wc * 32 + li;
+        if (colz < Cout) {
+            float* dst = part + (long long)chunk * K3 * Cin * Cout;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (c0 + m < Cin) dst[((long long)k * Cin + c0 + m) * Cout + colz] = 0.f;
+            }
+        }
+        return;
+    }
 
     constexpr int LJ = DW_KS / 16;
     float4 a_reg[LJ], b_reg[LJ];
@@ -1756,10 +1771,14 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     }
     const int col = n0 + wc * 32 + li;
     if (col < Cout) {
+        float* dst = part ? part + (long long)chunk * K3 * Cin * Cout : dW;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             int m = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            if (c0 + m < Cin) atomicAdd(&dW[((long long)k * Cin + c0 + m) * Cout + col], acc[reg]);
+            if (c0 + m < Cin) {
+                float* e = &dst[((long long)k * Cin + c0 + m) * Cout + col];
+                if (part) *e = acc[reg]; else atomicAdd(e, acc[reg]);
+            }
         }
     }
 }
@@ -2141,7 +2160,7 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             agb_set_error("agb_spconv_fwd_ex: the packed 3-channel path takes neither a class partition nor a split");
             return AGB_EUNSUPPORTED;
         }
-        hipLaunchKernelGGL(k_spconv_fwd3<false>, dim3(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN)), block, 0, s, a.X, a.ldx,
+        AGB_LAUNCH(k_spconv_fwd3<false>, dim3(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN)), block, 0, s, a.X, a.ldx,
                            a.W, a.nbr, a.nbr_stride, a.kflip, a.bias, a.Y, a.ldy, a.n_out, a.K3, a.Cout, GridProbe{});
         return AGB_OK;
     }
@@ -2151,34 +2170,34 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             return AGB_EUNSUPPORTED;
         }
         dim3 grid(n_tiles_perm, agb_cdiv(a.Cout, BN), a.ksplit);
-        hipLaunchKernelGGL((k_spconv_pipe<64, true>), grid, block, 0, s, a);
+        AGB_LAUNCH((k_spconv_pipe<64, true>), grid, block, 0, s, a);
     } else if (small) {
         dim3 grid(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN));
         if (a.Cin == 4)
-            hipLaunchKernelGGL(k_spconv_fwd<4>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
+            AGB_LAUNCH(k_spconv_fwd<4>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
                                a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
         else
-            hipLaunchKernelGGL(k_spconv_fwd<8>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
+            AGB_LAUNCH(k_spconv_fwd<8>, grid, block, 0, s, a.X, a.ldx, a.W, a.nbr, a.nbr_stride, a.kflip, a.bias,
                                a.Y, a.ldy, a.n_out, a.K3, a.Cin, a.Cout);
     } else if (a.nbr != nullptr && cmp_rows(a) > 0) {   // (a dense product has no absent pairs to skip)
         int R, rpt, ntiles, nct, il;
         cmp_geometry(a, &R, &rpt, &ntiles, &nct, &il);
         dim3 grid(8 * agb_cdiv(ntiles, 8) * nct * a.ksplit), blk(64);
-        if (R == 128) hipLaunchKernelGGL((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
-        else hipLaunchKernelGGL((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
+        if (R == 128) AGB_LAUNCH((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
+        else AGB_LAUNCH((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
     } else if (conv_tile_rows(a.n_out, a.Cin, a.Cout) == 128) {
         // 128-row tiles: the W tile is reused by twice as many rows (layers with many rows, or W-heavy layers);
         // 128-column tiles on top where the layer is wide and still fills the chip (the A tile — re-read from L2 once
         // per column tile — serves twice the columns: the dense products are bound by that traffic)
         const bool wide = a.Cout >= 128 && (long long)agb_cdiv(a.n_out, 128) * agb_cdiv(a.Cout, 128) * a.ksplit >= 512;
         if (wide)
-            hipLaunchKernelGGL((k_spconv_pipe<128, false, 128>),
+            AGB_LAUNCH((k_spconv_pipe<128, false, 128>),
                                dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, 128), a.ksplit), block, 0, s, a);
         else
-            hipLaunchKernelGGL((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
+            AGB_LAUNCH((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
                                block, 0, s, a);
     } else {
-        hipLaunchKernelGGL((k_spconv_pipe<64, false>), dim3(agb_cdiv(a.n_out, 64), agb_cdiv(a.Cout, BN), a.ksplit),
+        AGB_LAUNCH((k_spconv_pipe<64, false>), dim3(agb_cdiv(a.n_out, 64), agb_cdiv(a.Cout, BN), a.ksplit),
                            block, 0, s, a);
     }
     if (a.ksplit > 1) {
@@ -2397,22 +2416,22 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
     const bool x3 = precision == 2;
     if (perm) {
         dim3 grid(n_tiles, agb_cdiv(Cout, BN), ksplit);
-        if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<64, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_spconv_pipe_bf16<64, true, false>), grid, block, 0, s, a);
+        if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<64, true, true>), grid, block, 0, s, a);
+        else AGB_LAUNCH((k_spconv_pipe_bf16<64, true, false>), grid, block, 0, s, a);
     } else if (conv_tile_rows(n_out, Cin, Cout) == 128) {
         // 128-column tiles when the layer is wide enough and still fills the chip: the gathered and converted A tile
         // (the VALU / L2 cost of this kernel) serves twice the columns
         const bool wide = Cout >= 128 && (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, 128) * ksplit >= 512;
         dim3 grid(agb_cdiv(n_out, 128), agb_cdiv(Cout, wide ? 128 : 64), ksplit);
         if (wide) {
-            if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, true, 128>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, false, 128>), grid, block, 0, s, a);
-        } else if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_spconv_pipe_bf16<128, false, false>), grid, block, 0, s, a);
+            if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<128, false, true, 128>), grid, block, 0, s, a);
+            else AGB_LAUNCH((k_spconv_pipe_bf16<128, false, false, 128>), grid, block, 0, s, a);
+        } else if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<128, false, true>), grid, block, 0, s, a);
+        else AGB_LAUNCH((k_spconv_pipe_bf16<128, false, false>), grid, block, 0, s, a);
     } else {
         dim3 grid(agb_cdiv(n_out, 64), agb_cdiv(Cout, BN), ksplit);
-        if (x3) hipLaunchKernelGGL((k_spconv_pipe_bf16<64, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_spconv_pipe_bf16<64, false, false>), grid, block, 0, s, a);
+        if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<64, false, true>), grid, block, 0, s, a);
+        else AGB_LAUNCH((k_spconv_pipe_bf16<64, false, false>), grid, block, 0, s, a);
     }
     if (ksplit > 1) {
         long long total = (long long)n_out * (Cout / 4);
@@ -2457,14 +2476,18 @@ static int fwd_b16_impl(const uint16_t* X16, int ldx16, const uint16_t* Wt16, co
     dim3 block(256);
     if (perm) {
         hipLaunchKernelGGL((k_spconv_pipe_b16<64, true, 64, Y16>), dim3(n_tiles, agb_cdiv(Cout, BN), ksplit), block, 0, s, a);
+        agb_note_kernel(Y16 ? "k_spconv_pipe_b16<64, true, 64, true>" : "k_spconv_pipe_b16<64, true, 64, false>");
     } else if (conv_tile_rows(n_out, Cin, Cout) == 128) {
         const bool wide = Cout >= 128 && (long long)agb_cdiv(n_out, 128) * agb_cdiv(Cout, 128) * ksplit >= 512;
         dim3 grid(agb_cdiv(n_out, 128), agb_cdiv(Cout, wide ? 128 : 64), ksplit);
         if (wide) hipLaunchKernelGGL((k_spconv_pipe_b16<128, false, 128, Y16>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_spconv_pipe_b16<128, false, 64, Y16>), grid, block, 0, s, a);
+        agb_note_kernel(wide ? (Y16 ? "k_spconv_pipe_b16<128, false, 128, true>" : "k_spconv_pipe_b16<128, false, 128, false>")
+                             : (Y16 ? "k_spconv_pipe_b16<128, false, 64, true>" : "k_spconv_pipe_b16<128, false, 64, false>"));
     } else {
         hipLaunchKernelGGL((k_spconv_pipe_b16<64, false, 64, Y16>), dim3(agb_cdiv(n_out, 64), agb_cdiv(Cout, BN), ksplit), block,
                            0, s, a);
+        agb_note_kernel(Y16 ? "k_spconv_pipe_b16<64, false, 64, true>" : "k_spconv_pipe_b16<64, false, 64, false>");
     }
     if (ksplit > 1) {
         long long total = (long long)n_out * (Cout / 4);
@@ -2550,13 +2573,47 @@ static int dw_small_rows(int n_out, int K3, int Cin, int Cout) {
 static bool dw_takes_reg_kernel(const int32_t* nbr, int n_out, int Cin, int Cout, int precision, int variant,
                                 bool has_workspace) {
     if (precision != 0 || variant == 1 || Cin == 4 || Cin == 8) return false;
-    if (nbr == nullptr && agb_dense_stream_wgrad_ok(n_out, Cin, Cout)) return false;
+    // (the HBM-bound dense shapes of the streaming kernel end in cross-workgroup fp32 atomics: a caller that brings a
+    // workspace asked for the reproducible sum and gets the register-operand kernel's fixed-order fold instead)
+    if (nbr == nullptr && agb_dense_stream_wgrad_ok(n_out, Cin, Cout) && !has_workspace) return false;
     // automatic: the register-operand kernel is the REPRODUCIBLE form (fixed-order fold through the workspace); without a
     // workspace the LDS-staged kernel with atomic accumulation is the faster one in the training step (3.7 % of the
     // MSENet14 step, profiles/r03_bench_dw_variants.txt)
     return variant == 2 || has_workspace;
 }
 
+// Row chunks of the LDS-staged pair-compacted kernel k_spconv_dw_cmp (Cin >= 12; every operand precision).
+// precision 3 = bf16 operands read from bf16 storage (agb_spconv_bwd_weight_b16).
+struct DwCmpGeo { int rows, chunks, il, m_tiles, cin_tiles, n_tiles; };
+static DwCmpGeo dw_cmp_geometry(int n_out, int K3, int Cin, int Cout, bool dense, int precision) {
+    DwCmpGeo g;
+    g.cin_tiles = agb_cdiv(Cin, 64);
+    g.m_tiles = K3 * g.cin_tiles;
+    g.n_tiles = agb_cdiv(Cout, 64);
+    // aim for ~4096 workgroups; at least 256 rows per workgroup (multiple of 32)
+    // (dense products with bf16 operands: the MFMA work of a workgroup is small against the 64 x 64 tile it ends with —
+    // 4096 workgroups put 13 M atomics on the 256 x 1024 gradient of a 14 k-row layer: 71 us, 512 workgroups: 34 us;
+    // 211 k x 64 x 256: 120 -> 41 us.  The 3^3 maps sit at the 2048-row cap of the pair list either way.)
+    const int target_wgs = (dense && (precision == 1 || precision == 3)) ? 512 : 4096;
+    long long target_chunks = target_wgs / ((long long)g.m_tiles * g.n_tiles);
+    if (target_chunks < 1) target_chunks = 1;
+    long long rows = (n_out + target_chunks - 1) / target_chunks;
+    if (rows < 256) rows = 256;
+    rows = (rows + 31) / 32 * 32;
+    if (rows > DW_MAXROWS) rows = DW_MAXROWS;     // (the LDS pair list)
+    g.rows = (int)rows;
+    g.chunks = agb_cdiv(n_out, g.rows);
+    g.il = g.chunks >= 16 ? cmp_interleave(n_out, -1) : 0;
+    if (g.il > 0) {
+        const int nblk = agb_cdiv(n_out, 1 << g.il), bpc = g.rows >> g.il;
+        g.chunks = agb_cdiv(nblk, bpc);
+    }
+    return g;
+}
+
+// Bytes of the workspace that makes the weight gradient of this shape a fixed-order (bitwise reproducible) sum, in EVERY
+// operand precision (0 fp32, 1 bf16, 2 bf16x3; the bf16-storage entry point agb_spconv_bwd_weight_b16_ws asks with 1) and for
+// the dense shapes (dense != 0: the identity map).  0 only for empty products.
 size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cout, int dense, int precision) {
     static const int32_t some_map = 0;
     if (n_out <= 0 || K3 < 1 || Cin < 4 || Cout < 4) return 0;
@@ -2564,8 +2621,10 @@ size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cou
         const int chunks = agb_cdiv(agb_cdiv(n_out, dw_small_rows(n_out, K3, Cin, Cout)), DW_SMALL_NSUB);
         return (size_t)chunks * K3 * Cin * Cout * sizeof(float);
     }
-    if (!dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0, true)) return 0;
-    return agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
+    if (dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0, true))
+        return agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
+    const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, dense != 0, precision);
+    return (size_t)g.chunks * K3 * Cin * Cout * sizeof(float);
 }
 
 int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
@@ -2596,6 +2655,17 @@ int agb_spconv_bwd_weight_b16(const uint16_t* X16, int ldx16, const uint16_t* dY
                            nbr_stride, dW, n_out, K3, Cin, Cout, 3, 0, nullptr, 0, stream);
 }
 
+// The same with a caller-owned workspace of agb_spconv_bwd_weight_workspace_bytes(n_out, K3, Cin, Cout, nbr == NULL, 1)
+// bytes: row chunks leave partial tiles and are folded in ascending order — the bf16 weight gradient bitwise reproducible
+// from run to run (workspace == NULL: fp32 atomic accumulation, as agb_spconv_bwd_weight_b16).
+int agb_spconv_bwd_weight_b16_ws(const uint16_t* X16, int ldx16, const uint16_t* dY16, int ldy16, const int32_t* nbr,
+                                 long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    AGB_CHECK_ARG(Cin >= 12, "agb_spconv_bwd_weight_b16_ws: Cin %d (>= 12)", Cin);
+    return bwd_weight_impl(reinterpret_cast<const float*>(X16), ldx16, reinterpret_cast<const float*>(dY16), ldy16, nbr,
+                           nbr_stride, dW, n_out, K3, Cin, Cout, 3, 0, workspace, workspace_bytes, stream);
+}
+
 static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
                            float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
                            size_t workspace_bytes, void* stream) {
@@ -2608,7 +2678,7 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
                   "agb_spconv_bwd_weight: Cin (%d), Cout (%d), ldx, ldy must be multiples of 4", Cin, Cout);
     if (n_out == 0) return AGB_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (nbr == nullptr && precision == 0 && agb_dense_stream_wgrad_ok(n_out, Cin, Cout)) {
+    if (nbr == nullptr && precision == 0 && workspace == nullptr && agb_dense_stream_wgrad_ok(n_out, Cin, Cout)) {
         int rc = agb_dense_stream_wgrad_launch(X, ldx, dY, ldy, dW, n_out, Cin, Cout, s);
         if (rc) return rc;
         AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (dense, streaming)");
@@ -2620,31 +2690,11 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (register operands)");
         return AGB_OK;
     }
-    int m_tiles, cin_tiles = 1;
     if (Cin == 4 || Cin == 8) {
-        m_tiles = agb_cdiv(K3, 64 / Cin);
-    } else {
-        cin_tiles = agb_cdiv(Cin, 64);
-        m_tiles = K3 * cin_tiles;
-    }
-    int n_tiles = agb_cdiv(Cout, 64);
-    // aim for ~4096 workgroups; at least 256 rows per workgroup (multiple of 32)
-    // (dense products with bf16 operands: the MFMA work of a workgroup is small against the 64 x 64 atomic adds it ends
-    // with — 4096 workgroups put 13 M atomics on the 256 x 1024 gradient of a 14 k-row layer: 71 us, 512 workgroups: 34 us;
-    // 211 k x 64 x 256: 120 -> 41 us.  The 3^3 maps sit at the 2048-row cap of the pair list either way.)
-    const int target_wgs = (nbr == nullptr && (precision == 1 || precision == 3)) ? 512 : 4096;
-    long long target_chunks = target_wgs / ((long long)m_tiles * n_tiles);
-    if (target_chunks < 1) target_chunks = 1;
-    long long rows = (n_out + target_chunks - 1) / target_chunks;
-    if (rows < 256) rows = 256;
-    rows = (rows + 31) / 32 * 32;
-    int chunks = agb_cdiv(n_out, rows);
-    if (Cin == 4 || Cin == 8) {
-        rows = dw_small_rows(n_out, K3, Cin, Cout);
-        chunks = agb_cdiv(n_out, rows);
-    }
-    dim3 grid((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles), block(256);
-    if (Cin == 4 || Cin == 8) {
+        const int m_tiles = agb_cdiv(K3, 64 / Cin), n_tiles = agb_cdiv(Cout, 64);
+        const int rows = dw_small_rows(n_out, K3, Cin, Cout);
+        int chunks = agb_cdiv(n_out, rows);
+        dim3 grid((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles), block(256);
         // with a workspace: groups of DW_SMALL_NSUB sub-chunks per workgroup (one partial tile per group instead of one
         // atomic accumulation per sub-chunk), folded in a fixed order
         int nsub = 1;
@@ -2661,10 +2711,10 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
             grid = dim3((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
         }
         if (Cin == 4)
-            hipLaunchKernelGGL(k_spconv_dw_small_cmp<4>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH(k_spconv_dw_small_cmp<4>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cout, (int)rows, chunks, m_tiles, nsub, part);
         else
-            hipLaunchKernelGGL(k_spconv_dw_small_cmp<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH(k_spconv_dw_small_cmp<8>, grid, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cout, (int)rows, chunks, m_tiles, nsub, part);
         if (part) {
             const long long n4 = (long long)K3 * Cin * Cout / 4;
@@ -2673,30 +2723,40 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         }
     } else {
         // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
-        if (rows > DW_MAXROWS) rows = DW_MAXROWS;
-        chunks = agb_cdiv(n_out, rows);
-        int il = chunks >= 16 ? cmp_interleave(n_out, -1) : 0;
-        if (il > 0) {
-            const int nblk = agb_cdiv(n_out, 1 << il), bpc = (int)rows >> il;
-            chunks = agb_cdiv(nblk, bpc);
+        const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, nbr == nullptr, precision);
+        const int rows = g.rows, chunks = g.chunks, il = g.il, m_tiles = g.m_tiles, cin_tiles = g.cin_tiles;
+        const dim3 block(256);
+        float* part = nullptr;
+        if (workspace != nullptr) {
+            const size_t need = (size_t)chunks * K3 * Cin * Cout * sizeof(float);
+            if (need > workspace_bytes) {
+                agb_set_error("agb_spconv_bwd_weight_ws: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+                return AGB_EINVAL;
+            }
+            if (chunks > 1) part = (float*)workspace;      // (one chunk: a single writer per element already)
         }
-        dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, n_tiles);
+        dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, g.n_tiles);
         if (precision == 3 && Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0)
             // bf16 twins, rows staged as they are and transposed by the LDS reads (ds_read_b64_tr_b16)
-            hipLaunchKernelGGL((k_spconv_dw_cmp<1, true, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out,
-                               K3, Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+            AGB_LAUNCH((k_spconv_dw_cmp<1, true, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out,
+                               K3, Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 3)       // bf16 operands from bf16 twins (agb_spconv_bwd_weight_b16)
-            hipLaunchKernelGGL((k_spconv_dw_cmp<1, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
-                               Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+            AGB_LAUNCH((k_spconv_dw_cmp<1, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 1)
-            hipLaunchKernelGGL(k_spconv_dw_cmp<1>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
-                               Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+            AGB_LAUNCH(k_spconv_dw_cmp<1>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 2)
-            hipLaunchKernelGGL(k_spconv_dw_cmp<2>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
-                               Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+            AGB_LAUNCH(k_spconv_dw_cmp<2>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else
-            hipLaunchKernelGGL(k_spconv_dw_cmp<0>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
-                               Cin, Cout, (int)rows, cin_tiles, chunks, m_tiles, il);
+            AGB_LAUNCH(k_spconv_dw_cmp<0>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+                               Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
+        if (part) {
+            const long long n4 = (long long)K3 * Cin * Cout / 4;
+            hipLaunchKernelGGL(k_dw_fold_small, dim3((unsigned)agb_cdiv(n4, 256)), dim3(256), 0, s, (const float4*)part, chunks,
+                               n4, (float4*)dW);
+        }
     }
     AGB_CHECK_LAUNCH("agb_spconv_bwd_weight");
     return AGB_OK;
@@ -2741,13 +2801,13 @@ static int fwd3_grid_lp_impl(const float* X, int ldx, const float* W, const int3
     // (split-bf16x3 measured SLOWER than the fp32 kernel here — two LDS planes to stage, three MFMAs: 740 vs 683 us —
     // so precision 2 takes the exact fp32 kernel)
     if (y16)
-        hipLaunchKernelGGL((k_spconv_fwd3_lp<false, true>), grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy,
+        AGB_LAUNCH((k_spconv_fwd3_lp<false, true>), grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy,
                            n_out, K * K * K, Cout, gp);
     else if (precision == 1)
-        hipLaunchKernelGGL(k_spconv_fwd3_lp<false>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy, n_out,
+        AGB_LAUNCH(k_spconv_fwd3_lp<false>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy, n_out,
                            K * K * K, Cout, gp);
     else
-        hipLaunchKernelGGL(k_spconv_fwd3<true>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, nullptr, 0LL, 0, bias, Y,
+        AGB_LAUNCH(k_spconv_fwd3<true>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, nullptr, 0LL, 0, bias, Y,
                            ldy, n_out, K * K * K, Cout, gp);
     AGB_CHECK_LAUNCH("agb_spconv_fwd3_grid");
     return AGB_OK;

@@ -115,6 +115,10 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=No
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=process_group)
+    # (a write through .data does not move the parameter's version counter: the cached bf16 operand forms of the
+    # convolution weights — sparse_ops.weight_twins — are stale now)
+    from .sparse_ops import bump_weight_epoch
+    bump_weight_epoch()
 
 
 def shard_seeds(global_batch: int, rank: int, world: int, step: int, base: int = 0) -> List[int]:

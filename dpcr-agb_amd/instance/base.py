@@ -91,7 +91,13 @@ class InstanceBase(torch.nn.Module):
         ``precision="bf16"``): carried by its backbone, applied to its forward pass and kept by its autograd nodes."""
         from ..sparse_ops import KernelOptions
         base = getattr(self.model, "kernel_options", None)
-        self.model.kernel_options = KernelOptions(base=base, **kw) if base is not None else KernelOptions(**kw)
+        opts = KernelOptions(base=base, **kw) if base is not None else KernelOptions(**kw)
+        if opts.bf16_activations and not getattr(self.model, "supports_bf16_rows", False):
+            # (bf16 ROW storage exists for the sparse ResNet / SENet backbones only: KPConv's gather / max-pool kernels and
+            # the PointNet pooling take fp32 rows and would fail mid-network)
+            raise ValueError(f"bf16_activations is implemented for the sparse ResNet/SENet backbones, not for "
+                             f"{type(self.model).__name__}")
+        self.model.kernel_options = opts
         return self.model.kernel_options
 
     # ----------------------------------------------------------- contract

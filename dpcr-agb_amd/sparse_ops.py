@@ -33,9 +33,11 @@ class KernelOptions:
       balanced_tiles       work-balanced tile tables for that kernel (csrc/tiles.hip)
       bn_stats_in_epilogue forward dense products leave BatchNorm statistics partials (agb_dense_fwd_bn)
       fused_tail           SE / bottleneck block tails as one autograd node (se_ops, backbones)
-      deterministic_wgrad  fp32 weight gradients summed over row chunks in a fixed order through a workspace (csrc/dwreg.hip,
-                           the stem's grouped sub-chunks): bitwise reproducible training, 3.7 % slower MSENet14 step than
-                           the default (LDS-staged kernels, fp32 atomic accumulation)
+      deterministic_wgrad  weight gradients summed over row chunks in a fixed order through a workspace — in EVERY operand
+                           precision and for every shape that reaches sparse_ops.weight_grad_raw (fp32: csrc/dwreg.hip and the
+                           stem's grouped sub-chunks, the HBM-bound dense shapes included; bf16 / bf16x3: partial tiles of
+                           k_spconv_dw_cmp folded in ascending order): bitwise reproducible training, 3.7 % slower MSENet14
+                           fp32 step than the default (LDS-staged kernels, fp32 atomic accumulation)
       dw_variant           0 = automatic, 1 = LDS-staged weight-gradient kernel, 2 = register-operand kernel (A/B measurements)
       bf16_storage         precision "bf16": convolutions read bf16 twins of their inputs (rows and weights converted once,
                            gathered as 2-byte channels) instead of converting fp32 rows while staging them
@@ -223,7 +225,7 @@ def _prof_end(ev0, kind, K3, cin, cout, rows, pairs, perm=False, split=1, rows_i
     ev1 = torch.cuda.Event(enable_timing=True)
     ev1.record()
     PROFILE.append(dict(kind=kind, K3=K3, cin=cin, cout=cout, rows=rows, pairs=pairs, start=ev0, end=ev1, perm=perm,
-                        split=split, rows_in=rows_in))
+                        split=split, rows_in=rows_in, kernel=_lib.last_kernel()))
 
 
 def _colsum_hint(dy):
@@ -284,6 +286,9 @@ def bn_hint(x, c):
 _lib.declare("agb_to_bf16", [_lib.c_void_p, _lib.c_ll, _lib.c_ll, _lib.c_int, _lib.c_void_p, _lib.c_ll, _lib.c_void_p])
 _lib.declare("agb_spconv_bwd_weight_b16", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
                                            _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p])
+_lib.declare("agb_spconv_bwd_weight_b16_ws", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_ll,
+                                              _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p,
+                                              ctypes.c_size_t, _lib.c_void_p])
 _lib.declare("agb_spconv_fwd_b16", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
                                     _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
                                     _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
@@ -441,21 +446,25 @@ def spconv_forward_raw(x, w2d, nbr, kflip, bias, n_out, K3, cin, cout, kind="fwd
 
 
 def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
-    """dw += gathered(x)^T dy through the C ABI, with the workspace of the deterministic two-level sum (fp32 kernel)."""
+    """dw += gathered(x)^T dy through the C ABI.  KernelOptions.deterministic_wgrad: with the workspace of the fixed-order
+    two-level sum — honoured in every operand precision (fp32, bf16 on twins or bf16 rows, bf16x3) and for every shape,
+    the HBM-bound dense ones included (they leave the streaming kernel and its cross-workgroup atomics)."""
     prec = opts.prec_id if cin >= 12 else 0
     rows16 = x.dtype == torch.bfloat16 or dy.dtype == torch.bfloat16
     if rows16 and prec != 1:
         # (the stem: fp32 3-channel features against a bf16 gradient; a handful of rows x 64 columns converted back)
         x, dy, rows16 = x.float(), dy.float(), False
+    det = opts.deterministic_wgrad and opts.dw_variant != 1
     if prec == 1 and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0 and (rows16 or (opts.bf16_storage and nbr is not None)):
         x16, dy16 = bf16_twin(x), bf16_twin(dy)     # (dy's twin is shared with the data gradient of the same layer)
-        _lib.call("agb_spconv_bwd_weight_b16", _P16(x16), x16.stride(0), _P16(dy16), dy16.stride(0), _P(nbr),
-                  0 if nbr is None else nbr.stride(0), _P(dw), n_out, K3, cin, cout, _lib.stream())
+        nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), 1) if det else 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+        _lib.call("agb_spconv_bwd_weight_b16_ws", _P16(x16), x16.stride(0), _P16(dy16), dy16.stride(0), _P(nbr),
+                  0 if nbr is None else nbr.stride(0), _P(dw), n_out, K3, cin, cout, _P(ws), nbytes, _lib.stream())
         return
     if rows16:
         x, dy = x.float(), dy.float()
-    nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) \
-        if (opts.deterministic_wgrad and opts.dw_variant != 1) else 0
+    nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) if det else 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     _lib.call("agb_spconv_bwd_weight_ws", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), 0 if nbr is None else nbr.stride(0),
               _P(dw), n_out, K3, cin, cout, prec, opts.dw_variant, _P(ws), nbytes, _lib.stream())

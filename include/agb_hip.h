@@ -30,6 +30,10 @@ extern "C" {
 #define AGB_EUNSUPPORTED (-4)
 
 const char* agb_last_error(void);
+/* Diagnostic: name of the compute kernel the last convolution / dense-product / weight-gradient entry point of the calling
+ * thread launched (e.g. "k_spconv_cmp<128>", "k_spconv_pipe_b16<128, false, 64, true>", "k_dense_stream<2, false>"): the
+ * bench tools label a timed launch with what actually ran (rocprof shows the same names) instead of mirroring dispatch rules. */
+const char* agb_last_kernel(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Sparse-voxel coordinates (replaces ME's coordinate manager behind
@@ -231,9 +235,11 @@ int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, 
  * Cin >= 12: csrc/dwreg.hip (both MFMA operands gathered straight into registers, four waves per (row chunk, offset, 64 x 64
  * tile) unit, no barrier while they multiply); Cin = 4 / 8 (the 7^3 stem): groups of four sub-chunks per workgroup.
  * workspace == NULL (= agb_spconv_bwd_weight_lp): the LDS-staged kernels with atomic accumulation, the faster form inside the
- * training step.  agb_spconv_bwd_weight_workspace_bytes (host helper; dense = 1 for nbr == NULL) returns 0 for the shapes /
- * precisions whose kernel takes no workspace.  variant: 0 automatic, 1 = LDS-staged kernel, 2 = register-operand kernel
- * whatever the workspace (A/B measurements). */
+ * training step.  Since round 4 the workspace form covers EVERY operand precision and shape: bf16 / bf16x3 operands (the
+ * LDS-staged kernel writes one partial tile per row chunk, folded in ascending order) and the HBM-bound dense shapes (which
+ * take the register-operand kernel instead of the streaming kernel's cross-workgroup atomics).
+ * agb_spconv_bwd_weight_workspace_bytes (host helper; dense = 1 for nbr == NULL) returns 0 only for empty products.
+ * variant: 0 automatic, 1 = LDS-staged kernel, 2 = register-operand kernel whatever the workspace (A/B measurements). */
 size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cout, int dense, int precision);
 int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, int precision,
@@ -242,6 +248,12 @@ int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, 
  * without the fp32 gathers and conversions; dW fp32, accumulated into.  Cin >= 12; ldx16, ldy16 multiples of 4. */
 int agb_spconv_bwd_weight_b16(const uint16_t* X16, int ldx16, const uint16_t* dY16, int ldy16, const int32_t* nbr,
                               long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, void* stream);
+/* The same with a caller-owned workspace of agb_spconv_bwd_weight_workspace_bytes(n_out, K3, Cin, Cout, nbr == NULL, 1)
+ * bytes: the bf16 weight gradient as a fixed-order two-level sum — bitwise reproducible training in the bf16 modes
+ * (the reference's eval.py:12-21 seeds everything to be repeatable; ME's atomics are not).  workspace == NULL: as above. */
+int agb_spconv_bwd_weight_b16_ws(const uint16_t* X16, int ldx16, const uint16_t* dY16, int ldy16, const int32_t* nbr,
+                                 long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Pooling / broadcast (replaces ME.MinkowskiMaxPooling SENet.py:53; ME.MinkowskiGlobal{Sum,Avg,Max}Pooling

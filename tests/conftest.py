@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Kernel parity first, statistics last: the driver runs `pytest -x`, so a statistical (training-outcome) test must
+    never sit in front of a kernel parity file.  Every item of the R2 acceptance file goes to the end of the run, whatever
+    the file is called and however the files sort; the multi-process dry run just before it."""
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        if "r2_acceptance" in name:
+            return 2
+        if name == "test_dist_gpu.py":
+            return 1
+        return 0
+    items.sort(key=rank)        # (stable: the collection order inside a rank stays)
+
+
 @pytest.fixture(scope="session")
 def device():
     import torch

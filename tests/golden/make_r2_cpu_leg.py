@@ -5,7 +5,7 @@ Protocol = the reference's own (README.md:24-56: every published R2 is the MEDIA
 that differ only in their seeds (initial weights, batch order, drop-path draws), the reference recipe (AdaBelief lr 0.005 /
 wd 1e-2, clip 100, cosine warm restarts T_0 = 10, T_mult = 2 stepped per batch, smooth-L1 on standardised targets, drop-path
 0.01), run on ``oracle/sparse_ref.py`` in fp32 on the CPU; validation metrics as metrics/instance_tracker.py:85-87 and
-meters/r2meter.py:15-26 define them.  tests/test_r2_acceptance.py runs the same five seeds on the HIP path and compares
+meters/r2meter.py:15-26 define them.  tests/test_zz_r2_acceptance.py runs the same five seeds on the HIP path and compares
 medians.
 
 The set (found with tools/r2_explore.py on the GPU, profiles/r03_r2_explore*.log): 256 training / 128 validation plots whose

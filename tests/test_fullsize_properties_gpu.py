@@ -130,7 +130,7 @@ def kp_full(device):
     np.random.seed(11)
     ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_016))
     model = KPConvModel(Opt(MODEL_OPTIONS["KPConv"]), "kpconv", ds).to(device)
-    b = synthetic.make_point_batch(list(range(8)), n_points=16000)
+    b = synthetic.make_point_batch(list(range(32)), n_points=16000)      # BASELINE config 3's batch: 32 plots
     lens = np.bincount(b.batch.numpy()).astype(np.int64)
     return model, model.prepare_inputs(b.pos, b.x, lens, device), lens
 
@@ -226,3 +226,184 @@ def test_senet50_full_size_precisions_agree(device):
         one_minus_cos = 1.0 - float(torch.dot(g, g32) / (g.norm() * g32.norm()))
         print(f"SENet50, 6 x 16000 points, {prec} vs fp32: output {e:.2e}, 1 - cos(gradient) {one_minus_cos:.2e}")
         assert e < out_tol and one_minus_cos < cos_tol, (prec, e, one_minus_cos)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 2 AT ITS WORKLOAD: MinkowskiPointNet, B = 64 plots x 16 000 points (~870 k voxel rows; the 1024-wide
+# pre-activation is 3.6 GB).  The oracle's PointNet (oracle/sparse_ref.py:pointnet_forward, PointNet.py:9-49) is plain torch
+# and device-agnostic: evaluated in fp64 ON THE DEVICE by torch's own kernels it is the checker at full size — forward,
+# loss and every parameter gradient — where the CPU would need minutes.
+@pytest.fixture(scope="module")
+def pn_full(device):
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_064))
+    model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS["MPointNet"]), "minkowski", ds)
+    batch = synthetic.make_sparse_batch(list(range(64)), n_points=16000)
+    sd32 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    return model.to(device), batch, sd32
+
+
+def test_config2_mpointnet_full_size_vs_oracle_on_device(pn_full, device):
+    from oracle import sparse_ref as R
+    model, batch, sd32 = pn_full
+    model.train()
+    model.zero_grad(set_to_none=True)
+    model.set_input(batch, device)
+    model.forward()
+    model.loss.backward()
+    n = batch.coords.shape[0]
+    assert 64 * 12_000 < n < 64 * 16_000
+    sd = {k: (v.to(device).double().requires_grad_("running" not in k) if v.is_floating_point() else v.to(device))
+          for k, v in sd32.items()}
+    feats = torch.cat([batch.pos, batch.x], 1).to(device).double()
+    upd = {}
+    out = R.pointnet_forward(sd, batch.batch.to(device), feats, 64, update=upd)
+    loss = R.reg_loss(out, batch.y_reg.to(device).double(), model.reg_center_targets.double(),
+                      model.reg_scale_targets.double(), model.reg_weights.double())
+    loss.backward()
+    e_out = float((model.output.detach().double() - out.detach()).abs().max() / out.detach().abs().max())
+    e_loss = abs(float(model.loss.detach()) - float(loss.detach())) / max(1.0, abs(float(loss.detach())))
+    gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.model.named_parameters())
+    worst = ("", 0.0)
+    for k, p in model.model.named_parameters():
+        denom = max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
+        e = float((p.grad.detach().double() - sd[k].grad).abs().max()) / denom
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 3e-4, (k, e)      # the bar of test_mpointnet_matches_oracle (fp32 floor of this network: 1.1e-4)
+    # the BatchNorm of the 1024-wide activation: running statistics after one training-mode pass = the oracle's two-pass fp64
+    for key in ("blocks.7.bn.running_mean", "blocks.7.bn.running_var", "blocks.1.bn.running_var"):
+        got = dict(model.model.state_dict())[key].double()
+        assert float((got - upd[key].double()).abs().max() / upd[key].double().abs().max()) < 1e-5, key
+    print(f"MPointNet, 64 x 16000 points ({n} rows): output {e_out:.2e}, loss {e_loss:.2e}, worst gradient {worst[0]} {worst[1]:.2e}")
+    assert e_out < 1e-4 and e_loss < 1e-5
+
+
+def test_config2_pool_identities_and_inference_path_full_size(pn_full, device):
+    """Per-plot pooling of the fused BatchNorm + GELU + pool kernel at 870 k x 1024: sum == avg x rows, max >= avg, the
+    single-call inference path (agb_pointnet_mlp_fwd) == the layer-by-layer path on running statistics; the shared MLP's
+    widest product (128 -> 1024) is linear and <y, g> = <x, dx> = <W, dW>."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import norm_ops, sparse_ops
+    model, batch, _ = pn_full
+    net = model.model
+    coords = torch.cat([batch.batch[:, None].int(), batch.coords.int()], 1)
+    feats = torch.cat([batch.pos, batch.x], 1)
+    st = ME.SparseTensor(feats, coordinates=coords, device=device, batch_size=64, bounds=batch.coord_bounds)
+    cm, ts = st.coordinate_manager, st._ts
+    ptr, lvl = cm.batch_ptr(ts), cm.level(ts)
+    n = lvl.n
+    counts = (ptr[1:] - ptr[:-1]).float().unsqueeze(1)
+    torch.manual_seed(1)
+    z = torch.randn(n, 1024, device=device)
+    bn = torch.nn.BatchNorm1d(1024).to(device).train()
+    pooled = {m: norm_ops.batch_norm_act_pool(z, bn, "gelu", lvl.coords, ptr, 64, m).detach() for m in ("sum", "avg", "max")}
+    assert float((pooled["sum"] - pooled["avg"] * counts).abs().max() / pooled["sum"].abs().max()) < 1e-5
+    assert bool((pooled["max"] >= pooled["avg"] - 1e-6).all())
+    # against torch on the device (fp64 two-pass statistics, plot by plot)
+    zd = z.double()
+    mean, var = zd.mean(0), zd.var(0, unbiased=False)
+    want = torch.stack([torch.nn.functional.gelu((zd[int(ptr[b]):int(ptr[b + 1])] - mean) / torch.sqrt(var + bn.eps)).sum(0)
+                        for b in range(64)])
+    assert float((pooled["sum"].double() - want).abs().max() / want.abs().max()) < 1e-5
+    del zd, z
+    # inference: one library call for the whole shared MLP vs the layer-by-layer modules, running statistics
+    net.eval()
+    with torch.no_grad():
+        one_call = net._embed(st).F
+    with torch.enable_grad():                                   # (grad mode keeps _embed on the layer-by-layer path)
+        layered = net._embed(st).F.detach()
+    assert float((one_call - layered).abs().max() / layered.abs().max()) < 1e-4
+    net.train()
+    # widest shared product
+    lin = net.blocks[6].linear
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x1, x2 = (torch.randn(n, 128, generator=g).to(device) for _ in range(2))
+    w = lin.weight.detach().clone().requires_grad_(True)
+    x = x1.clone().requires_grad_(True)
+    y = sparse_ops.dense_linear(x, w)
+    gy = torch.randn(n, 1024, device=device)
+    y.backward(gy)
+    with torch.no_grad():
+        y12, y2 = sparse_ops.dense_linear(0.5 * x1 - 2.0 * x2, w), sparse_ops.dense_linear(x2, w)
+    assert float((y12 - (0.5 * y.detach() - 2.0 * y2)).abs().max()) < 1e-4 * float(y.detach().abs().max())
+    form_y = float((y.detach().double() * gy.double()).sum())
+    form_x = float((x1.double() * x.grad.double()).sum())
+    form_w = float((w.detach().double() * w.grad.double()).sum())
+    scale = float((y.detach().double().abs() * gy.double().abs()).sum())
+    assert abs(form_y - form_x) < 1e-5 * scale and abs(form_y - form_w) < 1e-5 * scale, (form_y, form_x, form_w)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5's single-GPU leg IN THE MODE THE BENCH LINE RUNS: MSENet50, bf16 operands AND bf16 row storage
+# (KernelOptions.bf16_activations), one rank's share B = 32 plots x 16 000 points.
+def test_config5_senet50_bf16_rows_full_size(device):
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import sparse_ops, synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_032))
+    opt = Opt(MODEL_OPTIONS["SENet50"])
+    opt["drop_path"] = 0.0
+    model = MinkowskiBaselineModel(opt, "minkowski", ds).to(device).train()
+    sd0 = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    batch = synthetic.make_sparse_batch(list(range(32)), n_points=16000).to(device)
+    convs = [m for m in model.model.modules() if isinstance(m, ME.MinkowskiConvolution)]
+    pick = {"3^3 stride 1": next(m for m in convs if m.kernel_size == 3 and m.stride == 1 and m.in_channels >= 64),
+            "3^3 stride 2": next(m for m in convs if m.kernel_size == 3 and m.stride == 2),
+            "1x1 wide": next(m for m in convs if m.kernel_size == 1 and m.out_channels >= 256),
+            "max pool": next(m for m in model.model.modules() if isinstance(m, ME.MinkowskiMaxPooling))}
+    runs, taps = {}, {}
+    for rows in (True, False):
+        model.model.load_state_dict(sd0)
+        model.set_kernel_options(precision="bf16", bf16_activations=rows, deterministic_wgrad=True)
+        model.zero_grad(set_to_none=True)
+        hooks = []
+        if rows:
+            for name, mod in pick.items():
+                hooks.append(mod.register_forward_hook(
+                    lambda m, i, o, name=name: taps.__setitem__(name, (i[0], o.F.detach()))))
+        model.set_input(batch, device)
+        model.forward()
+        for h in hooks:
+            h.remove()
+        model.loss.backward()
+        runs[rows] = (model.output.detach().double(), float(model.loss.detach()),
+                      torch.cat([p.grad.detach().double().reshape(-1) for p in model.model.parameters()]))
+    out16, loss16, g16 = runs[True]
+    out32, loss32, g32 = runs[False]
+    assert torch.isfinite(out16).all() and torch.isfinite(g16).all() and np.isfinite(loss16)
+    # mid-network tensors: the bf16-row kernel's output IS its fp32-row form's output rounded once (bitwise), on the very
+    # rows the full-size network handed it
+    for name, (inp, got) in taps.items():
+        assert inp.F.dtype == torch.bfloat16 and got.dtype == torch.bfloat16, name
+        x32 = ME.SparseTensor(inp.F.float(), coordinate_map_key=inp.coordinate_map_key,
+                              coordinate_manager=inp.coordinate_manager)
+        with torch.no_grad(), sparse_ops.KernelOptions(precision="bf16", bf16_activations=False):
+            want = pick[name](x32).F
+        assert want.dtype == torch.float32 and want.shape == got.shape
+        assert torch.equal(got, want.to(torch.bfloat16)), (name, float((got.float() - want).abs().max()))
+        print(f"{name}: {tuple(got.shape)} bf16 rows == fp32 rows rounded once")
+    e = float((out16 - out32).abs().max() / out32.abs().max())
+    cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
+    print(f"MSENet50, 32 x 16000 points, bf16 operands: bf16 rows vs fp32 rows: output {e:.2e}, loss {loss16:.5f} / {loss32:.5f}, "
+          f"cos(gradient) {cos:.5f}")
+    assert e < 6e-2 and cos > 0.97
+    # a full training step (pyramid + forward + backward + clip + AdaBelief) in the bench line's mode: finite, parameters move,
+    # and — fixed-order weight-gradient sums — the step is bitwise repeatable
+    sums = []
+    for _ in range(2):
+        model.model.load_state_dict(sd0)
+        model.set_kernel_options(precision="bf16", bf16_activations=True, deterministic_wgrad=True)
+        model.init_train_objects(TRAINING_NFI)
+        model.set_input(batch, device)
+        model.optimize_parameters(epoch=0, batch_size=32, num_batches=133)
+        torch.cuda.synchronize()
+        assert np.isfinite(float(model.loss.detach()))
+        sums.append([p.detach().clone() for p in model.model.parameters()])
+    moved = sum(float((a - sd0[k].to(device)).abs().sum()) for (k, _), a in zip(model.model.named_parameters(), sums[0]))
+    assert moved > 0
+    assert all(torch.equal(a, b) for a, b in zip(*sums))

@@ -1027,6 +1027,77 @@ def test_stem_weight_gradient_two_level_sum(device):
     assert err_fold < 2e-6 and err_atomic < 5e-6
 
 
+@pytest.mark.parametrize("precision,rows16", [("bf16", False), ("bf16", True), ("bf16x3", False)])
+@pytest.mark.parametrize("n_plots,npts,cin,cout,K", [(6, 9000, 64, 64, 3), (4, 6000, 128, 40, 3), (6, 9000, 64, 256, 1),
+                                                     (2, 3000, 512, 256, 1)])
+def test_low_precision_weight_gradient_reproducible(device, precision, rows16, n_plots, npts, cin, cout, K):
+    """KernelOptions.deterministic_wgrad in the bf16 / bf16x3 operand modes (round 4): k_spconv_dw_cmp<PREC> leaves one partial
+    tile per row chunk, k_dw_fold_small adds them in ascending order — bitwise reproducible from run to run (the atomic form
+    is not), same sums as the atomic form within fp32 rounding, against the fp64 product of the bf16-rounded operands;
+    empty row chunks (an offset with no pair in a chunk) still contribute their zeros; dW is accumulated into."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import _lib, sparse_ops
+    rng = np.random.default_rng(cin + cout + K)
+    torch.manual_seed(cin * 3 + cout)
+    coords = random_coords(rng, n_plots, npts, 40)
+    ref = R.Coords(coords, n_plots)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    n = cm.level(1).n
+    nbr = cm.kernel_map(1, K, 1, 1) if K > 1 else None
+    x, dy = torch.randn(n, cin), torch.randn(n, cout)
+    if rows16:
+        xg, dyg = x.to(device).to(torch.bfloat16), dy.to(device).to(torch.bfloat16)
+    else:
+        xg, dyg = x.to(device), dy.to(device)
+    K3 = K ** 3
+    nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n, K3, cin, cout, int(nbr is None), 1)
+    assert nbytes >= K3 * cin * cout * 4
+
+    def run(**kw):
+        dw = torch.zeros(K3, cin, cout, device=device)
+        sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, cin, cout, sparse_ops.KernelOptions(precision=precision, **kw))
+        return dw
+
+    a, b = run(deterministic_wgrad=True), run(deterministic_wgrad=True)
+    assert torch.equal(a, b)
+    xr, dyr = (x.bfloat16().double(), dy.bfloat16().double()) if precision == "bf16" else (x.double(), dy.double())
+    want = torch.zeros(K3, cin, cout, dtype=torch.float64)
+    if nbr is None:
+        want[0] = xr.t() @ dyr
+    else:
+        for k, (rows, idx) in enumerate(ref.pairs(1, K, 1)):
+            want[k] = xr[idx].t() @ dyr[rows]
+    tol = 2e-6 if precision == "bf16" else 2e-5          # (bf16x3 drops the lo x lo term: 2^-16 relative per product)
+    assert rel_err(a, want) < tol, rel_err(a, want)
+    assert rel_err(run(), want) < tol                                # the default: atomic accumulation, same operands
+    dw = torch.ones(K3, cin, cout, device=device)
+    sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, cin, cout,
+                               sparse_ops.KernelOptions(precision=precision, deterministic_wgrad=True))
+    assert rel_err(dw - 1.0, want) < 1e-4
+
+
+def test_dense_stream_shape_takes_reproducible_kernel_with_workspace(device):
+    """The HBM-bound dense shapes (n >= 16384, wide Cin, narrow Cout: KPConv's K*Cin x Cout products) sum across workgroups
+    with fp32 atomics in k_dense_stream_wgrad; with deterministic_wgrad they take the register-operand kernel and its
+    fixed-order fold instead: bitwise reproducible, same sums."""
+    from dpcr_agb_amd import _lib, sparse_ops
+    torch.manual_seed(5)
+    n, cin, cout = 40000, 240, 32
+    assert _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n, 1, cin, cout, 1, 0) >= 2 * cin * cout * 4
+    x, dy = torch.randn(n, cin, device=device), torch.randn(n, cout, device=device)
+
+    def run(**kw):
+        dw = torch.zeros(1, cin, cout, device=device)
+        sparse_ops.weight_grad_raw(x, dy, None, dw, n, 1, cin, cout, sparse_ops.KernelOptions(**kw))
+        return dw
+
+    a, b = run(deterministic_wgrad=True), run(deterministic_wgrad=True)
+    assert torch.equal(a, b)
+    want = (x.double().t() @ dy.double())[None]
+    assert rel_err(a, want.cpu()) < 2e-6 and rel_err(run(), want.cpu()) < 2e-6
+
+
 # ------------------------------------------------------------------------------------------------ bf16 ROW STORAGE
 # KernelOptions(precision="bf16", bf16_activations=True): every activation / gradient row matrix of the sparse backbone is
 # stored in bf16 (csrc/norm_rows.inc, pool_rows.inc, agb_spconv_fwd_h).  The arithmetic of every kernel is the fp32

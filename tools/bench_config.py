@@ -41,6 +41,12 @@ def usable_cores():
     return max(1, min(n, 32))
 
 
+# entry points whose launch notes its compute kernel (agb_last_kernel): the roofline entry names that kernel
+KERNEL_NOTED = ("agb_spconv_fwd_opt", "agb_spconv_fwd_lp", "agb_spconv_fwd_tiles", "agb_spconv_fwd_b16", "agb_spconv_fwd_h",
+                "agb_spconv_bwd_weight_lp", "agb_spconv_bwd_weight_ws", "agb_spconv_bwd_weight_b16_ws", "agb_dense_fwd_bn")
+KERNEL_OF_ENTRY = {"agb_ball_query_fill": "k_ball_query<true>", "agb_ball_query_fill_csr": "k_ball_query<true> (ragged rows)"}
+
+
 class CallTimer:
     """Brackets every library call (dpcr_agb_amd._lib.call) with HIP events on torch's current stream while active."""
 
@@ -54,7 +60,8 @@ class CallTimer:
             e0.record()
             rc = self._orig(name, *args)
             e1.record()
-            self.records.append((name, args, e0, e1))
+            kern = self._lib.last_kernel() if name in KERNEL_NOTED else None
+            self.records.append((name, args, e0, e1, kern))
             return rc
         self._lib.call = timed
         import dpcr_agb_amd.sparse_ops as so, dpcr_agb_amd.norm_ops as no, dpcr_agb_amd.kpconv_ops as ko  # noqa: E401
@@ -68,12 +75,14 @@ class CallTimer:
     def by_name(self):
         torch.cuda.synchronize()
         out = {}
-        for name, args, e0, e1 in self.records:
-            g = out.setdefault(name, dict(ms=0.0, n=0, calls=[]))
+        for name, args, e0, e1, kern in self.records:
+            g = out.setdefault(name, dict(ms=0.0, n=0, calls=[], kernels={}))
             ms = e0.elapsed_time(e1)
             g["ms"] += ms
             g["n"] += 1
             g["calls"].append((args, ms))
+            if kern:
+                g["kernels"][kern] = g["kernels"].get(kern, 0.0) + ms
         return out
 
 
@@ -128,8 +137,12 @@ def roofline_entry(name, g, cost):
     else:
         ach = byts / secs / 1e9
         r = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
-    r.update(traffic=None, kernel=name, launches=g["n"], avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2),
-             alg_bytes_per_launch=round(byts / g["n"]), alg_flops_per_launch=round(flops / g["n"]))
+    # the kernel(s) behind the entry point, by device time (the library notes what it launches: agb_last_kernel)
+    kernels = {k: round(ms / g["ms"], 3) for k, ms in sorted(g.get("kernels", {}).items(), key=lambda kv: -kv[1])}
+    kernel = next(iter(kernels), KERNEL_OF_ENTRY.get(name, name))
+    r.update(traffic=None, kernel=kernel, entry_point=name, kernels_time_share=kernels or None, launches=g["n"],
+             avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2), alg_bytes_per_launch=round(byts / g["n"]),
+             alg_flops_per_launch=round(flops / g["n"]))
     return r
 
 

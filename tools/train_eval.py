@@ -37,7 +37,7 @@ def acceptance_data(cfg, dev):
     return [b.to(dev) for b in train_h], [b.to(dev) for b in val_h], train_h, val_mean
 
 
-def acceptance_gpu_trial(cfg, trial, dev, precision="fp32", data=None, log=None, keep=None):
+def acceptance_gpu_trial(cfg, trial, dev, precision="fp32", data=None, log=None, keep=None, deterministic=True):
     """Trial `trial` of the schedule of tests/golden/make_r2_cpu_leg.py (same initial weights, batch order, drop-path draws,
     recipe, calibrate_bn passes, running-statistics evaluation) on the HIP path, in the given operand precision.
     Returns dict(history, final) with the reference's metric definitions."""
@@ -46,10 +46,12 @@ def acceptance_gpu_trial(cfg, trial, dev, precision="fp32", data=None, log=None,
     from dpcr_agb_amd.config import TRAINING_NFI
     train, val, train_h, val_mean = data if data is not None else acceptance_data(cfg, dev)
     model = gen.build_model(cfg, train_h, trial).to(dev)
-    # fixed-order weight-gradient sums: the fp32 leg is bitwise reproducible from run to run (the test's outcome is not a draw)
+    # fixed-order weight-gradient sums (every operand precision since round 4): a trial is bitwise reproducible from run to
+    # run and from box to box — the test's outcome is not a draw.  deterministic=False: the default atomic kernels.
     # ("bf16rows": bf16 operands AND bf16 row storage, KernelOptions.bf16_activations — BASELINE config 5's fastest mode)
     rows16 = precision == "bf16rows"
-    model.set_kernel_options(precision="bf16" if rows16 else precision, bf16_activations=rows16, deterministic_wgrad=True)
+    model.set_kernel_options(precision="bf16" if rows16 else precision, bf16_activations=rows16,
+                             deterministic_wgrad=bool(deterministic))
     model.init_train_objects(TRAINING_NFI)
     nb = len(train)
     random.seed(gen.trial_seeds(trial)["drop_seed"])
