@@ -1,0 +1,93 @@
+"""Micro-benchmark of the two 7^3 stem kernels (3 -> 64 channels, SENet.py:47-53) on level 0 of a real synthetic batch
+(B = 32 x 16 000 points, ~411 k voxels): the grid-probing forward with and without its by-product kernel map, and the
+small-Cin weight gradient (atomic / fixed-order fold).  Prints us per launch, useful and issued FLOPs.
+
+  python tools/bench_stem.py [--reps 20] [--batch 32]
+(tuning aid; tools/collect_stem_pmc.sh runs it under rocprofv3 --pmc)"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--variants", default="", help="comma list of extra stem variants the library knows (see csrc/stem.hip)")
+    a = ap.parse_args()
+    from dpcr_agb_amd import _lib, sparse_ops, synthetic
+    from dpcr_agb_amd.coords import CoordinateManager
+    _P = _lib.ptr
+    dev = torch.device("cuda", 0)
+    b = synthetic.make_sparse_batch(list(range(a.batch)))
+    coords = torch.cat([b.batch[:, None].int(), b.coords.int()], 1).to(dev)
+    cm = CoordinateManager(coords, device=dev, batch_size=a.batch, bounds=b.coord_bounds)
+    K, K3, cout = 7, 343, 64
+    lvl_coords, grid, desc = cm.grid_probe(1, K, 1, 1)
+    n = cm.level(1).n
+    torch.manual_seed(0)
+    x = torch.zeros(n, 4, device=dev)
+    x[:, :3] = b.x.to(dev)[:n] if b.x.shape[0] == n else torch.randn(n, 3, device=dev)
+    w = torch.randn(K3, 3, cout, device=dev) * 0.05
+    bias = torch.randn(cout, device=dev)
+    y = torch.empty(n, cout, device=dev)
+    nbr = torch.empty(K3, n, dtype=torch.int32, device=dev)
+
+    def fwd(with_map):
+        _lib.call("agb_spconv_fwd3_grid_lp", _P(x), 4, _P(w), _P(lvl_coords), _P(grid), desc, K, _P(bias), _P(y), cout, n, cout,
+                  _P(nbr) if with_map else None, n if with_map else 0, 0, _lib.stream())
+
+    us_map, us_nomap = timed(lambda: fwd(True), a.reps), timed(lambda: fwd(False), a.reps)
+    pairs = int((nbr >= 0).sum())
+    useful = 2.0 * pairs * 3 * cout
+    issued_fwd = 2.0 * n * 35 * 32 * cout          # 35 K-chunks of 32 (10 offsets x 3 channels + 2 zero rows)
+    print(f"level 0: {n} rows, {pairs} pairs ({pairs / n:.1f} per row, map density {pairs / (K3 * n):.3f}); useful "
+          f"{useful / 1e9:.2f} GFLOP, issued by the dense-over-offsets forward {issued_fwd / 1e9:.1f} GFLOP "
+          f"({issued_fwd / useful:.1f}x)")
+    print(f"stem forward, grid probing, WITH the kernel map as by-product ({K3 * n * 4 / 1e6:.0f} MB written): {us_map:8.1f} us  "
+          f"{useful / us_map / 1e6:6.1f} TF useful  {issued_fwd / us_map / 1e6:6.1f} TF issued")
+    print(f"stem forward, grid probing, WITHOUT the map:                                   {us_nomap:8.1f} us  "
+          f"{useful / us_nomap / 1e6:6.1f} TF useful  {issued_fwd / us_nomap / 1e6:6.1f} TF issued")
+    dy = torch.randn(n, cout, device=dev)
+    for tag, kw in (("atomic", {}), ("fixed-order fold", dict(deterministic_wgrad=True))):
+        opts = sparse_ops.KernelOptions(**kw)
+        dw = torch.zeros(K3, 4, cout, device=dev)
+        us = timed(lambda: sparse_ops.weight_grad_raw(x, dy, nbr, dw, n, K3, 4, cout, opts), a.reps)
+        issued = 2.0 * n * K3 * 4 * cout
+        print(f"stem weight gradient ({tag}): {us:8.1f} us  {useful / us / 1e6:6.1f} TF useful  (dense over offsets would issue "
+              f"{issued / 1e9:.1f} GFLOP)")
+    for v in [s for s in a.variants.split(",") if s]:
+        name = f"agb_stem_fwd_{v}"
+        if not hasattr(_lib.load(), name):
+            print(f"variant {v}: the library has no {name}")
+            continue
+        y2 = torch.empty(n, cout, device=dev)
+        V, I = _lib.c_void_p, _lib.c_int
+        _lib.declare(name, [V, I, V, V, V, V, I, V, V, I, I, I, V, _lib.c_ll, V])
+        run = lambda: _lib.call(name, _P(x), 4, _P(w), _P(lvl_coords), _P(grid), desc, K, _P(bias), _P(y2), cout, n, cout,  # noqa: E731
+                                None, 0, _lib.stream())
+        us = timed(run, a.reps)
+        fwd(False)
+        err = float((y2 - y).abs().max() / y.abs().max())
+        print(f"stem forward variant {v}: {us:8.1f} us  {useful / us / 1e6:6.1f} TF useful  (max rel diff vs the product kernel "
+              f"{err:.1e})")
+
+
+if __name__ == "__main__":
+    main()
