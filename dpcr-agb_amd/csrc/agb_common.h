@@ -64,6 +64,12 @@ size_t agb_dwreg_workspace_bytes(int n_out, int K3, int Cin, int Cout);
 int agb_dwreg_launch(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride, float* dW,
                      int n_out, int K3, int Cin, int Cout, void* workspace, size_t workspace_bytes, hipStream_t st);
 
+// stem.hip: pair-sparse weight gradient of the 3-channel stem (one 4x4x1 MFMA per pair, fixed-order fold)
+bool agb_stem_dw_ok(int n_out, int K3, int Cin, int Cout, int ldx, int ldy);
+size_t agb_stem_dw_workspace_bytes(int n_out, int K3);
+int agb_stem_dw_launch(const float* X, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride, float* dW, int n_out,
+                       int K3, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 // ---- coordinate key packing -------------------------------------------------
 // [b | z | y | x], 16 bits each, spatial components biased by 32768 so that
 // negative voxel coordinates (ME allows them) order correctly.

@@ -2619,7 +2619,13 @@ size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cou
     if (n_out <= 0 || K3 < 1 || Cin < 4 || Cout < 4) return 0;
     if (!dense && (Cin == 4 || Cin == 8)) {      // the small-Cin (stem) kernel: groups of DW_SMALL_NSUB 1024-row chunks
         const int chunks = agb_cdiv(agb_cdiv(n_out, dw_small_rows(n_out, K3, Cin, Cout)), DW_SMALL_NSUB);
-        return (size_t)chunks * K3 * Cin * Cout * sizeof(float);
+        size_t bytes = (size_t)chunks * K3 * Cin * Cout * sizeof(float);
+        // (the pair-sparse stem kernel of stem.hip, taken when the rows are 4 floats wide: its row partitions)
+        if (agb_stem_dw_ok(n_out, K3, Cin, Cout, 4, Cout)) {
+            const size_t b2 = agb_stem_dw_workspace_bytes(n_out, K3);
+            if (b2 > bytes) bytes = b2;
+        }
+        return bytes;
     }
     if (dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0, true))
         return agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
@@ -2688,6 +2694,13 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         int rc = agb_dwreg_launch(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, workspace, workspace_bytes, s);
         if (rc) return rc;
         AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (register operands)");
+        return AGB_OK;
+    }
+    if (workspace != nullptr && variant == 0 && nbr != nullptr && agb_stem_dw_ok(n_out, K3, Cin, Cout, ldx, ldy)) {
+        // the 3-channel stem with a workspace: pair-sparse, one 4x4x1 MFMA per pair (csrc/stem.hip)
+        int rc = agb_stem_dw_launch(X, dY, ldy, nbr, nbr_stride, dW, n_out, K3, workspace, workspace_bytes, s);
+        if (rc) return rc;
+        AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (stem, pair-sparse)");
         return AGB_OK;
     }
     if (Cin == 4 || Cin == 8) {

@@ -302,6 +302,9 @@ _lib.declare("agb_spconv_fwd3_grid_h", [_lib.c_void_p, _lib.c_int, _lib.c_void_p
                                         _lib.c_void_p, _lib.c_ll, _lib.c_void_p])
 
 
+_lib.declare("agb_stem_fwd_pairs", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p,
+                                    _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int,
+                                    _lib.c_void_p, _lib.c_ll, _lib.c_void_p])
 _lib.declare("agb_weight_twins_bf16", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
                                        _lib.c_void_p])
 
@@ -464,7 +467,13 @@ def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
         return
     if rows16:
         x, dy = x.float(), dy.float()
-    nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) if det else 0
+    # the 3-channel stem (rows 4 floats wide, 64 output channels) always brings a workspace: with one the library takes its
+    # pair-sparse kernel (csrc/stem.hip: one 4x4x1 MFMA per pair, partial tiles folded in a fixed order) — faster than the
+    # dense-over-offsets kernel AND reproducible
+    stem = (cin == 4 and cout == 64 and nbr is not None and x.stride(0) == 4 and opts.dw_variant == 0
+            and x.dtype == torch.float32 and dy.dtype == torch.float32)
+    nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) \
+        if (det or stem) else 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     _lib.call("agb_spconv_bwd_weight_ws", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), 0 if nbr is None else nbr.stride(0),
               _P(dw), n_out, K3, cin, cout, prec, opts.dw_variant, _P(ws), nbytes, _lib.stream())

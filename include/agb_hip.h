@@ -171,6 +171,11 @@ int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t*
 int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
                             const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
                             int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream);
+/* The pair-sparse form of the same 3-channel stem (csrc/stem.hip; SENet.py:47-53): one wave per 64 output rows, the grid
+ * probed per (row, offset), v_mfma_f32_4x4x1 on groups of four rows that have the offset.  Cout == 64, ldx == 4, fp32. */
+int agb_stem_fwd_pairs(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                       const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                       int32_t* nbr_out, long long nbr_out_stride, void* stream);
 /* WT [K3][C][R] = per-offset transpose of W [K3][R][C] (R, C multiples of 4): the operand of the data gradient
  * dX = sum_k dY[nbrT[k]] @ W[k]^T, rebuilt once per layer per step (ME does the same inside its backward GEMMs with
  * a transposed-operand flag: MinkowskiEngine/src/convolution_kernel.cu ConvolutionBackwardKernelGPU). */

@@ -197,6 +197,57 @@ def test_stem_conv_probes_dense_grid(device, K, negative):
     assert rel_err(res["probe"][1], wr.grad) < RTOL
 
 
+@pytest.mark.parametrize("K,negative,n_per", [(7, False, 2500), (7, True, 2500), (3, True, 2500), (5, False, 700), (7, False, 37)])
+def test_stem_pair_sparse_kernels(device, K, negative, n_per):
+    """csrc/stem.hip directly: the pair-sparse forward (lane = row, grid probes, v_mfma_f32_4x4x1 on four-row groups that have
+    the offset) against the oracle and against the map kernel's map; the pair-sparse weight gradient (one 4x4x1 MFMA per
+    pair, row partitions folded in a fixed order) against the fp64 sum, bitwise reproducible; ragged last tile / chunk."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import _lib, sparse_ops
+    rng = np.random.default_rng(50 + K + n_per)
+    torch.manual_seed(50 + K)
+    coords = random_coords(rng, 3, n_per, 18, negative=negative)
+    ref = R.Coords(coords, 3)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    lvl_coords, grid, desc = cm.grid_probe(1, K, 1, 1)
+    n, K3 = cm.level(1).n, K ** 3
+    x = torch.zeros(n, 4)
+    x[:, :3] = torch.randn(n, 3)
+    w = torch.randn(K3, 3, 64) * 0.1
+    b = torch.randn(64)
+    xg, wg, bg = x.to(device), w.to(device), b.to(device)
+    for with_map in (True, False):
+        y = torch.full((n, 64), float("nan"), device=device)
+        nbr = torch.full((K3, n), -7, dtype=torch.int32, device=device) if with_map else None
+        _lib.call("agb_stem_fwd_pairs", _lib.ptr(xg), 4, _lib.ptr(wg), _lib.ptr(lvl_coords), _lib.ptr(grid), desc, K, _lib.ptr(bg),
+                  _lib.ptr(y), 64, n, 64, _lib.ptr(nbr), n if with_map else 0, _lib.stream())
+        want = R.conv(x[:, :3].double(), ref.map(1, K, 1), w.double(), b.double().view(1, -1))
+        assert rel_err(y, want) < 2e-6, (with_map, rel_err(y, want))
+        if with_map:
+            assert torch.equal(nbr, cm.kernel_map(1, K, 1)[:, :n])
+    # weight gradient on the map
+    nbr = cm.kernel_map(1, K, 1)
+    dy = torch.randn(n, 64)
+    dyg = dy.to(device)
+
+    def run():
+        dw = torch.zeros(K3, 4, 64, device=device)
+        sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, 4, 64, sparse_ops.KernelOptions())
+        return dw
+
+    a, a2 = run(), run()
+    assert _lib.last_kernel() == "k_stem_dw_pairs"
+    assert torch.equal(a, a2)
+    want = torch.zeros(K3, 4, 64, dtype=torch.float64)
+    for k, (rows, idx) in enumerate(ref.pairs(1, K, 1)):
+        want[k] = x.double()[idx].t() @ dy.double()[rows]
+    assert rel_err(a, want) < 2e-6, rel_err(a, want)
+    dw = torch.ones(K3, 4, 64, device=device)             # accumulation contract: dW is added to
+    sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, 4, 64, sparse_ops.KernelOptions())
+    assert rel_err(dw - 1.0, want) < 1e-4
+
+
 @pytest.mark.parametrize("shift", [3, 4])
 def test_conv_pair_compacted_interleaved_tiles(device, shift):
     """Interleaved tiles (row blocks taken from regions ntiles blocks apart) only change which wave sums a row: the

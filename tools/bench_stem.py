@@ -65,28 +65,36 @@ def main():
     print(f"stem forward, grid probing, WITHOUT the map:                                   {us_nomap:8.1f} us  "
           f"{useful / us_nomap / 1e6:6.1f} TF useful  {issued_fwd / us_nomap / 1e6:6.1f} TF issued")
     dy = torch.randn(n, cout, device=dev)
-    for tag, kw in (("atomic", {}), ("fixed-order fold", dict(deterministic_wgrad=True))):
+    ref_dw = None
+    for tag, kw in (("dense over offsets, atomic", dict(dw_variant=1)), ("pair-sparse 4x4x1 MFMA + fold (default)", {}),
+                    ("the same under deterministic_wgrad", dict(deterministic_wgrad=True))):
         opts = sparse_ops.KernelOptions(**kw)
         dw = torch.zeros(K3, 4, cout, device=dev)
         us = timed(lambda: sparse_ops.weight_grad_raw(x, dy, nbr, dw, n, K3, 4, cout, opts), a.reps)
-        issued = 2.0 * n * K3 * 4 * cout
-        print(f"stem weight gradient ({tag}): {us:8.1f} us  {useful / us / 1e6:6.1f} TF useful  (dense over offsets would issue "
-              f"{issued / 1e9:.1f} GFLOP)")
+        dw.zero_()
+        sparse_ops.weight_grad_raw(x, dy, nbr, dw, n, K3, 4, cout, opts)
+        ref_dw = dw.clone() if ref_dw is None else ref_dw
+        err = float((dw - ref_dw).abs().max() / ref_dw.abs().max())
+        print(f"stem weight gradient ({tag}): {us:8.1f} us  {useful / us / 1e6:6.1f} TF useful  (max rel diff vs the first "
+              f"{err:.1e})")
     for v in [s for s in a.variants.split(",") if s]:
-        name = f"agb_stem_fwd_{v}"
+        name = f"agb_stem_fwd_{v.split(':')[0]}"
+        with_map = v.endswith(":map")
         if not hasattr(_lib.load(), name):
             print(f"variant {v}: the library has no {name}")
             continue
         y2 = torch.empty(n, cout, device=dev)
         V, I = _lib.c_void_p, _lib.c_int
         _lib.declare(name, [V, I, V, V, V, V, I, V, V, I, I, I, V, _lib.c_ll, V])
+        nbr2 = torch.empty(K3, n, dtype=torch.int32, device=dev) if with_map else None
         run = lambda: _lib.call(name, _P(x), 4, _P(w), _P(lvl_coords), _P(grid), desc, K, _P(bias), _P(y2), cout, n, cout,  # noqa: E731
-                                None, 0, _lib.stream())
+                                _P(nbr2), n if with_map else 0, _lib.stream())
         us = timed(run, a.reps)
         fwd(False)
         err = float((y2 - y).abs().max() / y.abs().max())
-        print(f"stem forward variant {v}: {us:8.1f} us  {useful / us / 1e6:6.1f} TF useful  (max rel diff vs the product kernel "
-              f"{err:.1e})")
+        same_map = bool(torch.equal(nbr2, nbr)) if with_map else None
+        print(f"stem forward variant {v}: {us:8.1f} us  {useful / us / 1e6:6.1f} TF useful  (max rel diff vs the dense kernel "
+              f"{err:.1e}; kernel map identical: {same_map})")
 
 
 if __name__ == "__main__":
