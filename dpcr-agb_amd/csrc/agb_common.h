@@ -68,7 +68,13 @@ int agb_dwreg_launch(const float* X, int ldx, const float* dY, int ldy, const in
 bool agb_stem_dw_ok(int n_out, int K3, int Cin, int Cout, int ldx, int ldy);
 size_t agb_stem_dw_workspace_bytes(int n_out, int K3);
 int agb_stem_dw_launch(const float* X, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride, float* dW, int n_out,
-                       int K3, void* workspace, size_t workspace_bytes, hipStream_t st);
+                       int K3, void* workspace, size_t workspace_bytes, hipStream_t st, const int32_t* coords = nullptr,
+                       const int32_t* grid = nullptr, const int32_t* desc = nullptr, int K = 0);
+
+bool agb_stem_fwd_ok(int n_out, int K, int Cout, int ldx);
+int agb_stem_fwd_launch(const float* X, const float* W, const float* bias, float* Y, int ldy, int n_out, int K,
+                        const int32_t* coords, const int32_t* grid, const int32_t* desc, int32_t* nbr_out,
+                        long long nbr_out_stride, hipStream_t st);
 
 // ---- coordinate key packing -------------------------------------------------
 // [b | z | y | x], 16 bits each, spatial components biased by 32768 so that
@@ -148,19 +154,39 @@ __device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((
 #define ACT_RELU 1
 #define ACT_GELU 2
 
+// GELU = z * Phi(z) with Phi through the five-term rational-exponential erfc of Abramowitz & Stegun 7.1.26 (absolute error of
+// erf <= 1.5e-7, i.e. <= 7.5e-8 on Phi: three orders below the 1e-4 parity bar, below bf16 resolution by five) instead of
+// libm's erff: value + derivative take 24 VALU instructions instead of 46 (the exponential is shared with the density term
+// of the derivative).  The element-wise kernels of the bf16-row mode move 2 + 2 bytes per element: at 5 TB/s that is 1.25 T
+// elements/s, and erff alone put them at the VALU roof (they ran at 3.4-3.9 TB/s where the fp32-row forms reach 5.3,
+// profiles/r03_pmc_senet50_rows.txt).
+//   q = 0.5 erfc(|z| / sqrt 2) in (0, 0.5];  Phi(z) = 1 - q (z >= 0), q (z < 0);  *e2 = exp(-z^2 / 2)
+__device__ __forceinline__ float agb_phi(float z, float* e2) {
+    const float ax = fabsf(z) * 0.70710678118654752440f;
+    const float e = __expf(-0.5f * z * z);                      // (v_exp_f32, 2 ulp)
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.f));
+    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    p = __builtin_fmaf(t, p, 1.421413741f);
+    p = __builtin_fmaf(t, p, -0.284496736f);
+    p = __builtin_fmaf(t, p, 0.254829592f);
+    const float q = 0.5f * (p * t) * e;
+    *e2 = e;
+    return z >= 0.f ? 1.f - q : q;
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
     if (act == ACT_RELU) return z > 0.f ? z : 0.f;
-    if (act == ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+    if (act == ACT_GELU) { float e2; return z * agb_phi(z, &e2); }
     return z;
 }
-// value and derivative at once (the GELU pair shares its erf)
+// value and derivative at once (the GELU pair shares its exponential)
 __device__ __forceinline__ void act_fwd_grad(float z, int act, float* val, float* grad) {
     if (act == ACT_RELU) { *val = z > 0.f ? z : 0.f; *grad = z > 0.f ? 1.f : 0.f; return; }
     if (act == ACT_GELU) {
-        const float e = erff(z * 0.70710678118654752440f);
-        const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);   // (v_exp_f32: 2 ulp, the sums take 1e-7)
-        *val = 0.5f * z * (1.f + e);                  // (the expressions of act_fwd / act_grad: same rounding)
-        *grad = 0.5f * (1.f + e) + z * pdf;
+        float e2;
+        const float cdf = agb_phi(z, &e2);
+        *val = z * cdf;                               // (the expressions of act_fwd / act_grad: same rounding)
+        *grad = cdf + z * (0.39894228040143267794f * e2);
         return;
     }
     *val = z; *grad = 1.f;
@@ -168,9 +194,9 @@ __device__ __forceinline__ void act_fwd_grad(float z, int act, float* val, float
 __device__ __forceinline__ float act_grad(float z, int act) {
     if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
     if (act == ACT_GELU) {
-        float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
-        float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);   // (v_exp_f32, 2 ulp)
-        return cdf + z * pdf;
+        float e2;
+        const float cdf = agb_phi(z, &e2);
+        return cdf + z * (0.39894228040143267794f * e2);
     }
     return 1.f;
 }

@@ -2794,7 +2794,8 @@ int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t*
 // precision: 0 fp32 MFMA, 1 bf16 operands (k_spconv_fwd3_lp), 2 split-bf16x3 requested: served by the fp32 kernel
 static int fwd3_grid_lp_impl(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
                              const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
-                             int32_t* nbr_out, long long nbr_out_stride, int precision, int y16, void* stream) {
+                             int32_t* nbr_out, long long nbr_out_stride, int precision, int y16, void* stream,
+                             int dense_form = 0) {
     AGB_CHECK_ARG(precision >= 0 && precision <= 2, "agb_spconv_fwd3_grid_lp: precision %d (0 fp32, 1 bf16, 2 bf16x3)",
                   precision);
     AGB_CHECK_ARG(n_out >= 0 && Cout >= 4 && Cout % 4 == 0 && ldx % 4 == 0 && ldy >= Cout, "agb_spconv_fwd3_grid: bad sizes");
@@ -2810,6 +2811,15 @@ static int fwd3_grid_lp_impl(const float* X, int ldx, const float* W, const int3
     gp.coords = (const int4*)coords; gp.grid = grid;
     gp.ox = desc[0]; gp.oy = desc[1]; gp.oz = desc[2]; gp.X = desc[3]; gp.Y = desc[4]; gp.Z = desc[5];
     gp.ts = desc[6]; gp.K = K; gp.nbr_out = nbr_out; gp.nbr_out_stride = nbr_out_stride;
+    if (!y16 && precision != 1 && dense_form == 0 && agb_stem_fwd_ok(n_out, K, Cout, ldx)) {
+        // fp32 operands, 64 output channels: the pair-sparse kernel of csrc/stem.hip (lane = row, 4x4x1 MFMA on the four-row
+        // groups that have the offset): 23 GFLOP issued instead of 57 for the 9 useful
+        int rc = agb_stem_fwd_launch(X, W, bias, Y, ldy, n_out, K, coords, grid, desc, nbr_out, nbr_out_stride,
+                                     (hipStream_t)stream);
+        if (rc) return rc;
+        AGB_CHECK_LAUNCH("agb_spconv_fwd3_grid (pair-sparse)");
+        return AGB_OK;
+    }
     const dim3 grid3(agb_cdiv(n_out, BM), agb_cdiv(Cout, BN));
     // (split-bf16x3 measured SLOWER than the fp32 kernel here — two LDS planes to stage, three MFMAs: 740 vs 683 us —
     // so precision 2 takes the exact fp32 kernel)
@@ -2831,6 +2841,16 @@ int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32
                             int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream) {
     return fwd3_grid_lp_impl(X, ldx, W, coords, grid, desc, K, bias, Y, ldy, n_out, Cout, nbr_out, nbr_out_stride, precision, 0,
                              stream);
+}
+
+// The dense-over-offsets fp32 form of the same stem (k_spconv_fwd3<true>: what agb_spconv_fwd3_grid ran until round 4 and
+// still runs for Cout != 64), kept callable for A/B measurements (tools/bench_stem.py) and as the second implementation the
+// parity tests compare the pair-sparse kernel with.
+int agb_spconv_fwd3_grid_dense(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                               const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                               int32_t* nbr_out, long long nbr_out_stride, void* stream) {
+    return fwd3_grid_lp_impl(X, ldx, W, coords, grid, desc, K, bias, Y, ldy, n_out, Cout, nbr_out, nbr_out_stride, 0, 0, stream,
+                             1);
 }
 
 // bf16 operands and bf16 OUTPUT rows (the bf16-activation mode; the 3-channel input features stay fp32): Y16 uint16

@@ -26,6 +26,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SDW_OPW 11       // offsets a wave owns (accumulators: 4 VGPRs each)
 #define SDW_WAVES 16
 
+// cell of a row in the level's dense lookup grid int32[B][Z][Y][X] (origin (ox, oy, oz), tensor stride ts), as csrc/spconv.hip
+// GridProbe: the neighbour of row r at kernel offset (ix, iy, iz) is grid[cell(r) + ((iz - h) Y + (iy - h)) X + (ix - h)],
+// INT_MAX = none (the grid carries a halo of >= K/2 empty cells)
+struct StemGrid {
+    const int4* coords;
+    const int32_t* grid;
+    int ox, oy, oz, X, Y, Z, ts, K;
+};
+__device__ __forceinline__ int stem_cell(const StemGrid& g, int row) {
+    const int4 c = g.coords[row];
+    return ((c.x * g.Z + (c.w - g.oz) / g.ts) * g.Y + (c.z - g.oy) / g.ts) * g.X + (c.y - g.ox) / g.ts;
+}
+__device__ __forceinline__ int stem_delta(const StemGrid& g, int k) {
+    const int h = g.K >> 1, ix = k % g.K, iy = (k / g.K) % g.K, iz = k / (g.K * g.K);
+    return ((iz - h) * g.Y + (iy - h)) * g.X + (ix - h);
+}
+
 struct StemDwGeo { int nq, nchunks, nparts; };
 
 static StemDwGeo stem_dw_geometry(int n_out, int K3) {
@@ -48,15 +65,17 @@ size_t agb_stem_dw_workspace_bytes(int n_out, int K3) {
     return (size_t)g.nparts * K3 * 4 * 64 * sizeof(float);
 }
 
+// PROBE: the neighbours come from the level's dense grid (the probes of the forward kernel) instead of a kernel map: the
+// 343 x N int32 map of the stem (578 MB at B = 32) is then neither written by the forward pass nor read here.
+template <bool PROBE>
 __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict__ X, const float* __restrict__ dY, int ldy,
                                                         const int32_t* __restrict__ nbr, long long nbr_stride,
                                                         float* __restrict__ part, int n_out, int K3, int nq, int nchunks,
-                                                        int nparts) {
+                                                        int nparts, StemGrid sg) {
     __shared__ __attribute__((aligned(16))) float s_dy[2][SDW_R * 64];
-    __shared__ unsigned s_list[SDW_WAVES][SDW_R];
+    __shared__ unsigned s_list[SDW_WAVES][2][SDW_R];     // two pair lists per wave: the current step's and the next one's
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = blockIdx.x % nq, rp = blockIdx.x / nq;
-    unsigned* list = s_list[w];
 
     f32x4 acc[SDW_OPW];
 #pragma unroll
@@ -83,73 +102,153 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
         *reinterpret_cast<float4*>(dst_ + 12) = stg3;                                              \
     } while (0)
 
+    // ---- software pipeline over the STEPS (chunk, owned offset j) of this wave: while step s multiplies, the neighbour
+    // indices of step s + 2 are in flight, step s + 1 is compacted into the other pair list and its first gather is issued.
+    // (A step's own chain index load -> compaction -> list read -> gather is two memory latencies; without the pipeline
+    // every step of ~40 pairs exposed them: 562 us for the B = 32 stem, tools/bench_stem.py)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int g4 = lane >> 2, c4 = lane & 3;
+    // step descriptor: (chunk, j) -> neighbour indices of this lane's four rows of the chunk
+#define SDW_CELLS(CH, C0, C1, C2, C3)                                                                               \
+    do {                                                                                                            \
+        C0 = C1 = C2 = C3 = 0;                                                                                       \
+        if (PROBE && (CH) < nchunks) {                                                                               \
+            C0 = stem_cell(sg, min((CH) * SDW_R + lane, n_out - 1));                                                 \
+            C1 = stem_cell(sg, min((CH) * SDW_R + 64 + lane, n_out - 1));                                            \
+            C2 = stem_cell(sg, min((CH) * SDW_R + 128 + lane, n_out - 1));                                           \
+            C3 = stem_cell(sg, min((CH) * SDW_R + 192 + lane, n_out - 1));                                           \
+        }                                                                                                            \
+    } while (0)
+#define SDW_LOAD_IDX(CH, J, C0, C1, C2, C3, I0, I1, I2, I3)                                                         \
+    do {                                                                                                            \
+        const int k_ = ((J) * SDW_WAVES + w) * nq + q;                                                               \
+        const int r0_ = (CH) * SDW_R;                                                                                \
+        I0 = I1 = I2 = I3 = -1;                                                                                      \
+        if (k_ < K3 && (CH) < nchunks) {                                                                             \
+            if (PROBE) {                                                                                             \
+                const int dk_ = stem_delta(sg, k_);                                                                  \
+                const int a0_ = sg.grid[(C0) + dk_];                                                                 \
+                const int a1_ = sg.grid[(C1) + dk_];                                                                 \
+                const int a2_ = sg.grid[(C2) + dk_];                                                                 \
+                const int a3_ = sg.grid[(C3) + dk_];                                                                 \
+                I0 = (a0_ == INT_MAX || r0_ + lane >= n_out) ? -1 : a0_;                                             \
+                I1 = (a1_ == INT_MAX || r0_ + 64 + lane >= n_out) ? -1 : a1_;                                        \
+                I2 = (a2_ == INT_MAX || r0_ + 128 + lane >= n_out) ? -1 : a2_;                                       \
+                I3 = (a3_ == INT_MAX || r0_ + 192 + lane >= n_out) ? -1 : a3_;                                       \
+            } else {                                                                                                 \
+                const int32_t* col_ = nbr + (long long)k_ * nbr_stride + r0_;                                        \
+                if (r0_ + lane < n_out) I0 = col_[lane];                                                             \
+                if (r0_ + 64 + lane < n_out) I1 = col_[64 + lane];                                                   \
+                if (r0_ + 128 + lane < n_out) I2 = col_[128 + lane];                                                 \
+                if (r0_ + 192 + lane < n_out) I3 = col_[192 + lane];                                                 \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
+    // ordered compaction of a step's present pairs into LIST: entry = (input row << 8) | local output row; the slots up to
+    // the next multiple of 16 are padded with entries of pair 0 (their A operand is zeroed when they are multiplied)
+#define SDW_COMPACT1(LIST, TOTAL, IDX, S)                                                                           \
+    do {                                                                                                            \
+        const bool p_ = (IDX) >= 0;                                                                                  \
+        const unsigned long long bal_ = __ballot(p_);                                                                \
+        if (p_) (LIST)[(TOTAL) + __popcll(bal_ & lt)] = ((unsigned)(IDX) << 8) | (unsigned)(64 * (S) + lane);        \
+        (TOTAL) += __popcll(bal_);                                                                                   \
+    } while (0)
+#define SDW_COMPACT(LIST, TOTAL, I0, I1, I2, I3)                                                                    \
+    do {                                                                                                            \
+        (TOTAL) = 0;                                                                                                 \
+        SDW_COMPACT1(LIST, TOTAL, I0, 0); SDW_COMPACT1(LIST, TOTAL, I1, 1);                                          \
+        SDW_COMPACT1(LIST, TOTAL, I2, 2); SDW_COMPACT1(LIST, TOTAL, I3, 3);                                          \
+        if (lane < 16 && (TOTAL) + lane < SDW_R) (LIST)[(TOTAL) + lane] = 0u;                                        \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST); /* wave-private list, in-order LDS: a compiler fence is enough */  \
+    } while (0)
+
     int chunk = rp;
     if (chunk < nchunks) {
         SDW_LOAD_CHUNK(chunk);
         SDW_STORE_CHUNK(0);
     }
     __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    // prologue: step 0 compacted and its first gather issued, indices of step 1 in flight
+    unsigned* lcur = s_list[w][0];
+    unsigned* lnxt = s_list[w][1];
+    int n0, n1, n2, n3;               // neighbour indices of the step after the current one
+    int total_cur;
+    unsigned e_first;
+    float a_first;
+    // PROBE: the grid cells of this lane's four rows, of the current chunk (cc*) and of the wave's next chunk (cn*)
+    int cc0, cc1, cc2, cc3, cn0, cn1, cn2, cn3;
+    SDW_CELLS(chunk, cc0, cc1, cc2, cc3);
+    SDW_CELLS(chunk + nparts, cn0, cn1, cn2, cn3);
+    {
+        int t0, t1, t2, t3;
+        SDW_LOAD_IDX(chunk, 0, cc0, cc1, cc2, cc3, t0, t1, t2, t3);
+        static_assert(SDW_OPW >= 3, "the step pipeline looks two offsets ahead inside one chunk");
+        SDW_LOAD_IDX(chunk, 1, cc0, cc1, cc2, cc3, n0, n1, n2, n3);
+        SDW_COMPACT(lcur, total_cur, t0, t1, t2, t3);
+        e_first = lcur[g4];
+        a_first = X[(long long)(e_first >> 8) * 4 + c4];
+    }
     for (int it = 0; chunk < nchunks; ++it, chunk += nparts) {
         const int buf = it & 1;
         const bool more = chunk + nparts < nchunks;
         if (more) SDW_LOAD_CHUNK(chunk + nparts);                  // in flight while this chunk multiplies
         const float* dyb = s_dy[buf];
-        const int r0 = chunk * SDW_R;
 #pragma unroll
         for (int j = 0; j < SDW_OPW; ++j) {
-            const int k = (j * SDW_WAVES + w) * nq + q;
-            if (k >= K3) continue;                                 // (wave-uniform)
-            // ---- the pairs of offset k in this chunk, in row order: list entry = (input row << 8) | local output row
-            const int32_t* col = nbr + (long long)k * nbr_stride + r0;
-            const int i0 = (r0 + lane < n_out) ? col[lane] : -1;
-            const int i1 = (r0 + 64 + lane < n_out) ? col[64 + lane] : -1;
-            const int i2 = (r0 + 128 + lane < n_out) ? col[128 + lane] : -1;
-            const int i3 = (r0 + 192 + lane < n_out) ? col[192 + lane] : -1;
-            int total = 0;
-#define SDW_COMPACT(IDX, S)                                                                                  \
-    do {                                                                                                     \
-        const bool p_ = (IDX) >= 0;                                                                          \
-        const unsigned long long bal_ = __ballot(p_);                                                        \
-        if (p_) list[total + __popcll(bal_ & lt)] = ((unsigned)(IDX) << 8) | (unsigned)(64 * (S) + lane);    \
-        total += __popcll(bal_);                                                                             \
-    } while (0)
-            SDW_COMPACT(i0, 0); SDW_COMPACT(i1, 1); SDW_COMPACT(i2, 2); SDW_COMPACT(i3, 3);
-#undef SDW_COMPACT
-            if (total == 0) continue;
-            // pad the last group of 16 with entries of pair 0 (their A operand is zeroed below)
-            if (lane < 16 && total + lane < SDW_R) list[total + lane] = 0u;
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);               // wave-private list, in-order LDS: a compiler fence is enough
-            const int ngroups = (total + 15) >> 4;
-            const int g4 = lane >> 2, c4 = lane & 3;
-            unsigned e = list[g4];
-            float a = X[(long long)(e >> 8) * 4 + c4];
-            for (int g = 0; g < ngroups; ++g) {
-                const unsigned e_cur = e;
-                float a_cur = (16 * g + g4 < total) ? a : 0.f;
-                if (g + 1 < ngroups) {                              // next group's entries and gathered x in flight
-                    e = list[16 * (g + 1) + g4];
-                    a = X[(long long)(e >> 8) * 4 + c4];
-                }
+            // (1) indices of step s + 2
+            int f0, f1, f2, f3;
+            if (j + 2 >= SDW_OPW) SDW_LOAD_IDX(chunk + nparts, (j + 2) % SDW_OPW, cn0, cn1, cn2, cn3, f0, f1, f2, f3);
+            else SDW_LOAD_IDX(chunk, j + 2, cc0, cc1, cc2, cc3, f0, f1, f2, f3);
+            // (2) step s + 1: compaction into the other list, first group's entries and gather
+            int total_nxt;
+            SDW_COMPACT(lnxt, total_nxt, n0, n1, n2, n3);
+            const unsigned e_nf = lnxt[g4];
+            const float a_nf = X[(long long)(e_nf >> 8) * 4 + c4];
+            // (3) step s: one 4x4x1 MFMA per pair
+            if (total_cur > 0) {
+                const int ngroups = (total_cur + 15) >> 4;
+                unsigned e = e_first;
+                float a = a_first;
                 f32x4 d = acc[j];
+                for (int g = 0; g < ngroups; ++g) {
+                    const unsigned e_cur = e;
+                    const float a_cur = (16 * g + g4 < total_cur) ? a : 0.f;
+                    if (g + 1 < ngroups) {                          // next group's entries and gathered x in flight
+                        e = lcur[16 * (g + 1) + g4];
+                        a = X[(long long)(e >> 8) * 4 + c4];
+                    }
 #pragma unroll
-                for (int p = 0; p < 16; ++p) {
-                    const int n = __builtin_amdgcn_readlane((int)e_cur, 4 * p) & 255;
-                    const float b = dyb[n * 64 + lane];
-                    // block p of `a_cur` (lanes 4p .. 4p+3: x[m_p][0..3]) is the A operand of all 16 blocks
-                    switch (p) {
+                    for (int p = 0; p < 16; ++p) {
+                        const int n = __builtin_amdgcn_readlane((int)e_cur, 4 * p) & 255;
+                        const float b = dyb[n * 64 + lane];
+                        // block p of `a_cur` (lanes 4p .. 4p+3: x[m_p][0..3]) is the A operand of all 16 blocks
+                        switch (p) {
 #define SDW_CASE(P) case P: d = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur, b, d, 4, P, 0); break;
-                        SDW_CASE(0) SDW_CASE(1) SDW_CASE(2) SDW_CASE(3) SDW_CASE(4) SDW_CASE(5) SDW_CASE(6) SDW_CASE(7)
-                        SDW_CASE(8) SDW_CASE(9) SDW_CASE(10) SDW_CASE(11) SDW_CASE(12) SDW_CASE(13) SDW_CASE(14) SDW_CASE(15)
+                            SDW_CASE(0) SDW_CASE(1) SDW_CASE(2) SDW_CASE(3) SDW_CASE(4) SDW_CASE(5) SDW_CASE(6) SDW_CASE(7)
+                            SDW_CASE(8) SDW_CASE(9) SDW_CASE(10) SDW_CASE(11) SDW_CASE(12) SDW_CASE(13) SDW_CASE(14)
+                            SDW_CASE(15)
 #undef SDW_CASE
+                        }
                     }
                 }
                 acc[j] = d;
             }
+            // (4) rotate: s + 1 becomes the current step
+            {
+                unsigned* t = lcur; lcur = lnxt; lnxt = t;
+            }
+            total_cur = total_nxt; e_first = e_nf; a_first = a_nf;
+            n0 = f0; n1 = f1; n2 = f2; n3 = f3;
         }
         if (more) SDW_STORE_CHUNK(buf ^ 1);
+        cc0 = cn0; cc1 = cn1; cc2 = cn2; cc3 = cn3;
+        SDW_CELLS(chunk + 2 * nparts, cn0, cn1, cn2, cn3);
         __syncthreads();
     }
+#undef SDW_CELLS
+#undef SDW_LOAD_IDX
+#undef SDW_COMPACT
+#undef SDW_COMPACT1
     // ---- partial tiles: part[rp][k][c][o], register i of lane o = dW[k][c = i][o]
     float* dst = part + (long long)rp * K3 * 256;
 #pragma unroll
@@ -174,17 +273,28 @@ __global__ __launch_bounds__(256) void k_stem_dw_fold(const float4* __restrict__
     dW[e] = s;
 }
 
-// dW [K3][4][64] += gathered(X)^T dY through `workspace` (agb_stem_dw_workspace_bytes): X rows 4 floats wide (channel 3 = 0)
+// dW [K3][4][64] += gathered(X)^T dY through `workspace` (agb_stem_dw_workspace_bytes): X rows 4 floats wide (channel 3 = 0).
+// Neighbours from the kernel map `nbr`, or (nbr == NULL) probed in the level's dense grid (coords, grid, desc, K).
 int agb_stem_dw_launch(const float* X, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride, float* dW, int n_out,
-                       int K3, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                       int K3, void* workspace, size_t workspace_bytes, hipStream_t s, const int32_t* coords,
+                       const int32_t* grid, const int32_t* desc, int K) {
     const StemDwGeo g = stem_dw_geometry(n_out, K3);
     const size_t need = (size_t)g.nparts * K3 * 256 * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) {
         agb_set_error("stem weight gradient: workspace of %zu bytes, %zu needed", workspace_bytes, need);
         return AGB_EINVAL;
     }
-    AGB_LAUNCH(k_stem_dw_pairs, dim3(g.nparts * g.nq), dim3(1024), 0, s, X, dY, ldy, nbr, nbr_stride, (float*)workspace, n_out,
-               K3, g.nq, g.nchunks, g.nparts);
+    StemGrid sg{};
+    if (nbr == nullptr) {
+        sg.coords = (const int4*)coords; sg.grid = grid;
+        sg.ox = desc[0]; sg.oy = desc[1]; sg.oz = desc[2]; sg.X = desc[3]; sg.Y = desc[4]; sg.Z = desc[5]; sg.ts = desc[6];
+        sg.K = K;
+        AGB_LAUNCH((k_stem_dw_pairs<true>), dim3(g.nparts * g.nq), dim3(1024), 0, s, X, dY, ldy, nbr, nbr_stride,
+                   (float*)workspace, n_out, K3, g.nq, g.nchunks, g.nparts, sg);
+    } else {
+        AGB_LAUNCH((k_stem_dw_pairs<false>), dim3(g.nparts * g.nq), dim3(1024), 0, s, X, dY, ldy, nbr, nbr_stride,
+                   (float*)workspace, n_out, K3, g.nq, g.nchunks, g.nparts, sg);
+    }
     const long long n4 = (long long)K3 * 64;
     hipLaunchKernelGGL(k_stem_dw_fold, dim3((unsigned)agb_cdiv(n4, 256)), dim3(256), 0, s, (const float4*)workspace, g.nparts,
                        n4, (float4*)dW);
@@ -210,6 +320,11 @@ __device__ __forceinline__ int stem_probe_base(const int4 c, int ox, int oy, int
     return ((c.x * Z + (c.w - oz) / ts) * Y + (c.z - oy) / ts) * X + (c.y - ox) / ts;
 }
 
+// W is staged through LDS in blocks of SFW_WB offsets (12 KB, double-buffered; the four waves of a workgroup share it, one
+// barrier per block): three ds_read_b32 per offset and wave instead of three global loads.  Probes run four offsets ahead,
+// gathers two (rotating registers, the offset loop unrolled by four): with one offset of look-ahead an iteration took one
+// memory latency (1640 cycles against ~300 of instruction issue, 548 us for the B = 32 stem).
+#define SFW_WB 16
 template <bool WRITE_MAP>
 __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Yo, int ldy,
@@ -217,15 +332,35 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
                                                         const int32_t* __restrict__ grid, int ox, int oy, int oz, int GX, int GY,
                                                         int GZ, int ts, int K, int32_t* __restrict__ nbr_out,
                                                         long long nbr_out_stride) {
-    __shared__ int s_delta[SFW_DELTA_MAX];
+    __shared__ int s_delta[SFW_DELTA_MAX + 8];
+    __shared__ __attribute__((aligned(16))) float s_w[2][SFW_WB * 192];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int k = tid; k < K3; k += 256) {
-        const int h = K >> 1, ix = k % K, iy = (k / K) % K, iz = k / (K * K);
+    for (int k = tid; k < SFW_DELTA_MAX + 8; k += 256) {
+        const int kc = min(k, K3 - 1);
+        const int h = K >> 1, ix = kc % K, iy = (kc / K) % K, iz = kc / (K * K);
         s_delta[k] = ((iz - h) * GY + (iy - h)) * GX + (ix - h);
     }
+    // W block staging: thread t moves three float4 of the block's 3072 floats
+    const long long wtotal = (long long)K3 * 192;
+    float4 wst0, wst1, wst2;
+#define SFW_LOAD_W(B)                                                                              \
+    do {                                                                                           \
+        const long long o_ = (long long)(B) * (SFW_WB * 192) + 4 * tid;                            \
+        wst0 = *reinterpret_cast<const float4*>(W + min(o_, wtotal - 4));                          \
+        wst1 = *reinterpret_cast<const float4*>(W + min(o_ + 1024, wtotal - 4));                   \
+        wst2 = *reinterpret_cast<const float4*>(W + min(o_ + 2048, wtotal - 4));                   \
+    } while (0)
+#define SFW_STORE_W(BUF)                                                                           \
+    do {                                                                                           \
+        *reinterpret_cast<float4*>(&s_w[BUF][4 * tid]) = wst0;                                     \
+        *reinterpret_cast<float4*>(&s_w[BUF][4 * tid + 1024]) = wst1;                              \
+        *reinterpret_cast<float4*>(&s_w[BUF][4 * tid + 2048]) = wst2;                              \
+    } while (0)
+    SFW_LOAD_W(0);
+    SFW_STORE_W(0);
     __syncthreads();
     const int r0 = (blockIdx.x * 4 + w) * 64;
-    if (r0 >= n_out) return;
+    const bool wave_ok = r0 < n_out;                 // (idle waves of the last workgroup still stage W and meet the barriers)
     const int row = r0 + lane;
     const bool row_ok = row < n_out;
     const int base = stem_probe_base(coords[min(row, n_out - 1)], ox, oy, oz, GX, GY, GZ, ts);
@@ -235,56 +370,76 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = (f32x4){bv, bv, bv, bv};
 
-    // software pipeline over the offsets: cell value of k + 2, feature row of k + 1, weights of k + 1
-    int cell_n2, cell_n1;
-    float4 x_n1;
-    float w0_n1, w1_n1, w2_n1;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    cell_n1 = grid[base + s_delta[0]];
-    cell_n2 = grid[base + s_delta[min(1, K3 - 1)]];
-    {
-        const bool pr = row_ok && cell_n1 != INT_MAX;
-        x_n1 = *reinterpret_cast<const float4*>(X + (long long)(pr ? cell_n1 : 0) * 4);
-        w0_n1 = W[lane]; w1_n1 = W[64 + lane]; w2_n1 = W[128 + lane];
+    // rotating registers: cells of offsets k .. k + 3 (c0 = offset k when k % 4 == 0), feature rows of k and k + 1
+    int c0 = grid[base + s_delta[0]], c1 = grid[base + s_delta[1]], c2 = grid[base + s_delta[2]],
+        c3 = grid[base + s_delta[3]];
+    float xa0, xa1, xa2, xb0, xb1, xb2;
+#define SFW_GATHER(CELL, X0, X1, X2)                                                               \
+    do {                                                                                           \
+        const float* xr_ = X + (long long)((row_ok && (CELL) != INT_MAX) ? (CELL) : 0) * 4;         \
+        X0 = xr_[0]; X1 = xr_[1]; X2 = xr_[2];                                                      \
+    } while (0)
+    SFW_GATHER(c0, xa0, xa1, xa2);
+    SFW_GATHER(c1, xb0, xb1, xb2);
+    const int nblocks = (K3 + SFW_WB - 1) / SFW_WB;
+    // one offset: CELL = its cell value; (X0, X1, X2) = its gathered feature row; afterwards CELL receives the probe of
+    // offset k + 4 and (X0, X1, X2) the gather of offset k + 2, whose cell value is CELL2
+#define SFW_STEP(KK, CELL, CELL2, X0, X1, X2)                                                       \
+    do {                                                                                           \
+        const int k_ = kb * SFW_WB + (KK);                                                          \
+        const int cell_ = CELL;                                                                     \
+        const bool present_ = row_ok && cell_ != INT_MAX && k_ < K3;                                \
+        const float w0_ = wb[(KK) * 192 + lane], w1_ = wb[(KK) * 192 + 64 + lane],                  \
+                    w2_ = wb[(KK) * 192 + 128 + lane];                                              \
+        CELL = grid[base + s_delta[k_ + 4]];                                                        \
+        if (WRITE_MAP) {                                                                            \
+            if (row_ok && k_ < K3) nbr_out[(long long)k_ * nbr_out_stride + row] = present_ ? cell_ : -1; \
+        }                                                                                           \
+        const float x0_ = present_ ? X0 : 0.f, x1_ = present_ ? X1 : 0.f, x2_ = present_ ? X2 : 0.f; \
+        const unsigned long long mask_ = __ballot(present_);                                        \
+        if (mask_ != 0ull) {                                                                        \
+            SFW_GROUPS(mask_, x0_, x1_, x2_, w0_, w1_, w2_);                                        \
+        }                                                                                           \
+        SFW_GATHER(CELL2, X0, X1, X2);                                                              \
+    } while (0)
+#define SFW_GROUP(P, M, A0, A1, A2, B0, B1, B2)                                                     \
+    if (((M) >> (4 * (P))) & 0xFull) {                                                              \
+        acc[P] = __builtin_amdgcn_mfma_f32_4x4x1f32(A0, B0, acc[P], 4, P, 0);                       \
+        acc[P] = __builtin_amdgcn_mfma_f32_4x4x1f32(A1, B1, acc[P], 4, P, 0);                       \
+        acc[P] = __builtin_amdgcn_mfma_f32_4x4x1f32(A2, B2, acc[P], 4, P, 0);                       \
     }
-    for (int k = 0; k < K3; ++k) {
-        const int cell = cell_n1;
-        const bool present = row_ok && cell != INT_MAX;
-        float4 x = x_n1;
-        if (!present) x = zero4;
-        const float w0 = w0_n1, w1 = w1_n1, w2 = w2_n1;
-        // next offset's gather and weights, the probe after it
-        cell_n1 = cell_n2;
-        {
-            const int kn = min(k + 1, K3 - 1);
-            const bool pn = row_ok && cell_n1 != INT_MAX;
-            x_n1 = *reinterpret_cast<const float4*>(X + (long long)(pn ? cell_n1 : 0) * 4);
-            const float* wn = W + (long long)kn * 192;
-            w0_n1 = wn[lane]; w1_n1 = wn[64 + lane]; w2_n1 = wn[128 + lane];
-            cell_n2 = grid[base + s_delta[min(k + 2, K3 - 1)]];
-        }
-        if (WRITE_MAP) {
-            if (row_ok) nbr_out[(long long)k * nbr_out_stride + row] = present ? cell : -1;
-        }
-        const unsigned long long mask = __ballot(present);
-        if (mask == 0ull) continue;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            if ((mask >> (4 * p)) & 0xFull) {
-                switch (p) {
-#define SFW_CASE(P)                                                              \
-    case P:                                                                      \
-        acc[P] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, w0, acc[P], 4, P, 0);  \
-        acc[P] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, w1, acc[P], 4, P, 0);  \
-        acc[P] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, w2, acc[P], 4, P, 0);  \
-        break;
-                    SFW_CASE(0) SFW_CASE(1) SFW_CASE(2) SFW_CASE(3) SFW_CASE(4) SFW_CASE(5) SFW_CASE(6) SFW_CASE(7)
-                    SFW_CASE(8) SFW_CASE(9) SFW_CASE(10) SFW_CASE(11) SFW_CASE(12) SFW_CASE(13) SFW_CASE(14) SFW_CASE(15)
-#undef SFW_CASE
-                }
+#define SFW_GROUPS(M, A0, A1, A2, B0, B1, B2)                                                       \
+    SFW_GROUP(0, M, A0, A1, A2, B0, B1, B2) SFW_GROUP(1, M, A0, A1, A2, B0, B1, B2)                 \
+    SFW_GROUP(2, M, A0, A1, A2, B0, B1, B2) SFW_GROUP(3, M, A0, A1, A2, B0, B1, B2)                 \
+    SFW_GROUP(4, M, A0, A1, A2, B0, B1, B2) SFW_GROUP(5, M, A0, A1, A2, B0, B1, B2)                 \
+    SFW_GROUP(6, M, A0, A1, A2, B0, B1, B2) SFW_GROUP(7, M, A0, A1, A2, B0, B1, B2)                 \
+    SFW_GROUP(8, M, A0, A1, A2, B0, B1, B2) SFW_GROUP(9, M, A0, A1, A2, B0, B1, B2)                 \
+    SFW_GROUP(10, M, A0, A1, A2, B0, B1, B2) SFW_GROUP(11, M, A0, A1, A2, B0, B1, B2)               \
+    SFW_GROUP(12, M, A0, A1, A2, B0, B1, B2) SFW_GROUP(13, M, A0, A1, A2, B0, B1, B2)               \
+    SFW_GROUP(14, M, A0, A1, A2, B0, B1, B2) SFW_GROUP(15, M, A0, A1, A2, B0, B1, B2)
+    for (int kb = 0; kb < nblocks; ++kb) {
+        const bool more = kb + 1 < nblocks;
+        if (more) SFW_LOAD_W(kb + 1);
+        const float* wb = s_w[kb & 1];
+        if (wave_ok) {
+#pragma unroll 1
+            for (int k4 = 0; k4 < SFW_WB; k4 += 4) {
+                SFW_STEP(k4 + 0, c0, c2, xa0, xa1, xa2);
+                SFW_STEP(k4 + 1, c1, c3, xb0, xb1, xb2);
+                SFW_STEP(k4 + 2, c2, c0, xa0, xa1, xa2);
+                SFW_STEP(k4 + 3, c3, c1, xb0, xb1, xb2);
             }
         }
+        if (more) SFW_STORE_W((kb + 1) & 1);
+        __syncthreads();
     }
+#undef SFW_STEP
+#undef SFW_GROUPS
+#undef SFW_GROUP
+#undef SFW_GATHER
+#undef SFW_LOAD_W
+#undef SFW_STORE_W
+    if (!wave_ok) return;
     // register i of lane o in acc[p] = y[r0 + 4p + i][o]
 #pragma unroll
     for (int p = 0; p < 16; ++p)
@@ -329,6 +484,27 @@ int agb_stem_fwd_pairs(const float* X, int ldx, const float* W, const int32_t* c
     int rc = agb_stem_fwd_launch(X, W, bias, Y, ldy, n_out, K, coords, grid, desc, nbr_out, nbr_out_stride, (hipStream_t)stream);
     if (rc) return rc;
     AGB_CHECK_LAUNCH("agb_stem_fwd_pairs");
+    return AGB_OK;
+}
+
+// Weight gradient of the same stem with the neighbours probed in the level's dense grid (no kernel map): dW [K^3][4][Cout]
+// fp32, accumulated into; workspace of agb_stem_bwd_weight_grid_workspace_bytes(n_out, K) bytes (row partitions folded in a
+// fixed order: bitwise reproducible).
+size_t agb_stem_bwd_weight_grid_workspace_bytes(int n_out, int K) { return agb_stem_dw_workspace_bytes(n_out, K * K * K); }
+int agb_stem_bwd_weight_grid(const float* X, int ldx, const float* dY, int ldy, const int32_t* coords, const int32_t* grid,
+                             const int32_t* desc, int K, float* dW, int n_out, int Cout, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    AGB_CHECK_ARG(coords && grid && desc, "agb_stem_bwd_weight_grid: coords, grid and desc are required");
+    AGB_CHECK_ARG(K >= 1 && K <= 9 && (K & 1), "agb_stem_bwd_weight_grid: kernel size %d (odd, <= 9)", K);
+    AGB_CHECK_ARG(n_out >= 0, "agb_stem_bwd_weight_grid: n_out %d", n_out);
+    if (n_out == 0) return AGB_OK;
+    AGB_CHECK_ARG(agb_stem_dw_ok(n_out, K * K * K, 4, Cout, ldx, ldy), "agb_stem_bwd_weight_grid: takes 64 output channels and "
+                  "4-float input rows (Cout %d, ldx %d, ldy %d)", Cout, ldx, ldy);
+    AGB_CHECK_ARG(((desc[7] >> 16) & 0xff) >= K / 2, "agb_stem_bwd_weight_grid: the grid's halo is narrower than K/2");
+    int rc = agb_stem_dw_launch(X, dY, ldy, nullptr, 0, dW, n_out, K * K * K, workspace, workspace_bytes, (hipStream_t)stream,
+                                coords, grid, desc, K);
+    if (rc) return rc;
+    AGB_CHECK_LAUNCH("agb_stem_bwd_weight_grid");
     return AGB_OK;
 }
 }  // extern "C"

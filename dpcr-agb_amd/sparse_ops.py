@@ -305,6 +305,10 @@ _lib.declare("agb_spconv_fwd3_grid_h", [_lib.c_void_p, _lib.c_int, _lib.c_void_p
 _lib.declare("agb_stem_fwd_pairs", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p,
                                     _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int,
                                     _lib.c_void_p, _lib.c_ll, _lib.c_void_p])
+_V_, _I_ = _lib.c_void_p, _lib.c_int
+_lib.declare("agb_spconv_fwd3_grid_dense", [_V_, _I_, _V_, _V_, _V_, _V_, _I_, _V_, _V_, _I_, _I_, _I_, _V_, _lib.c_ll, _V_])
+_lib.declare("agb_stem_bwd_weight_grid_workspace_bytes", [_I_, _I_])
+_lib.declare("agb_stem_bwd_weight_grid", [_V_, _I_, _V_, _I_, _V_, _V_, _V_, _I_, _V_, _I_, _I_, _V_, ctypes.c_size_t, _V_])
 _lib.declare("agb_weight_twins_bf16", [_lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
                                        _lib.c_void_p])
 
@@ -479,6 +483,18 @@ def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
               _P(dw), n_out, K3, cin, cout, prec, opts.dw_variant, _P(ws), nbytes, _lib.stream())
 
 
+def _probe_pair_count(coords, grid, desc, K, n_out):
+    """Profiling only: number of (row, offset) pairs of a K^3 stride-1 map on a grid-mode level (device int64 scalar), from
+    a scratch kernel map (the product path no longer writes one for the 64-channel stem)."""
+    nbr = torch.empty(K ** 3, max(n_out, 1), dtype=torch.int32, device=coords.device)
+    y = torch.empty(n_out, 64, dtype=torch.float32, device=coords.device)
+    x = torch.zeros(n_out, 4, dtype=torch.float32, device=coords.device)
+    w = torch.zeros(K ** 3, 3, 64, dtype=torch.float32, device=coords.device)
+    _lib.call("agb_stem_fwd_pairs", _P(x), 4, _P(w), _P(coords), _P(grid), desc, K, None, _P(y), 64, n_out, 64, _P(nbr),
+              nbr.stride(0), _lib.stream())
+    return (nbr >= 0).sum()
+
+
 def _twins_for(kernel, rows, opts, cin, cout, cin_p, cout_p):
     """weight_twins(kernel) when the call runs on bf16 rows (`rows`: its input row matrix) with unpadded widths the bf16-storage
     kernels take; else None (the per-call conversions)."""
@@ -550,7 +566,10 @@ class SparseConvFunction(torch.autograd.Function):
         rows16 = ctx.opts.rows_bf16
         y = torch.empty(n_out, cout, dtype=torch.bfloat16 if rows16 else torch.float32, device=x.device)
         need_w = ctx.needs_input_grad[1]   # (grad mode is off inside Function.forward)
-        nbr = torch.empty(K3, max(n_out, 1), dtype=torch.int32, device=x.device) if need_w else None
+        # 64 output channels: the weight gradient probes the grid itself (csrc/stem.hip, agb_stem_bwd_weight_grid) — the
+        # K^3 x N kernel map (578 MB for the 7^3 stem at B = 32) is neither written here nor read there
+        grid_wgrad = cout == 64 and x.dtype == torch.float32 and ctx.opts.dw_variant == 0
+        nbr = (torch.empty(K3, max(n_out, 1), dtype=torch.int32, device=x.device) if (need_w and not grid_wgrad) else None)
         ev = _prof_begin("fwd", K3, 3, cout, n_out)
         if rows16:
             _lib.call("agb_spconv_fwd3_grid_h", _P(x), x.stride(0), _P(kernel.contiguous()), _P(coords), _P(grid), desc, K,
@@ -560,10 +579,11 @@ class SparseConvFunction(torch.autograd.Function):
                       _P(b), _P(y), y.stride(0), n_out, cout, _P(nbr), 0 if nbr is None else nbr.stride(0),
                       ctx.opts.prec_id, _lib.stream())
         _prof_end(ev, "fwd", K3, 3, cout, n_out, None)
-        if ev is not None and nbr is not None:   # profiling only: the kernel-map size, after the closing event
-            PROFILE[-1]["pairs"] = (nbr >= 0).sum()
+        if ev is not None:   # profiling only: the kernel-map size, after the closing event
+            PROFILE[-1]["pairs"] = (nbr >= 0).sum() if nbr is not None else _probe_pair_count(coords, grid, desc, K, n_out)
         ctx.pairs = None
         ctx.probe = True
+        ctx.probe_args = (coords, grid, desc, K) if (need_w and grid_wgrad) else None
         ctx.save_for_backward(x, nbr if nbr is not None else torch.empty(0))
         ctx.dims = (K3, cout, n_out, bias is not None, None if bias is None else bias.shape)
         return y
@@ -576,14 +596,24 @@ class SparseConvFunction(torch.autograd.Function):
         dy = dy.contiguous()
         dk = db = None
         if ctx.needs_input_grad[1]:
-            if nbr.numel() == 0:
+            probe_args = getattr(ctx, "probe_args", None)
+            if nbr.numel() == 0 and probe_args is None:
                 raise _lib.AgbError("the forward pass ran without gradients enabled: no kernel map was written")
             dwp = torch.zeros(K3, 4, cout, dtype=torch.float32, device=dy.device)
             ev = _prof_begin("wgrad", K3, 4, cout, n_out)
-            weight_grad_raw(x, dy, nbr, dwp, n_out, K3, 4, cout, ctx.opts)
+            if probe_args is not None:
+                coords, grid, desc, K = probe_args
+                dyf = dy if dy.dtype == torch.float32 else dy.float()     # (bf16 rows: 64 columns converted back)
+                nbytes = _lib.size_call("agb_stem_bwd_weight_grid_workspace_bytes", n_out, K)
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dy.device)
+                _lib.call("agb_stem_bwd_weight_grid", _P(x), x.stride(0), _P(dyf), dyf.stride(0), _P(coords), _P(grid), desc, K,
+                          _P(dwp), n_out, cout, _P(ws), nbytes, _lib.stream())
+            else:
+                weight_grad_raw(x, dy, nbr, dwp, n_out, K3, 4, cout, ctx.opts)
             _prof_end(ev, "wgrad", K3, 4, cout, n_out, None)
             if ev is not None:
-                PROFILE[-1]["pairs"] = (nbr >= 0).sum()
+                PROFILE[-1]["pairs"] = ((nbr >= 0).sum() if probe_args is None
+                                        else _probe_pair_count(probe_args[0], probe_args[1], probe_args[2], probe_args[3], n_out))
             dk = dwp[:, :3, :].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             db = (colsum if (colsum is not None and colsum.numel() == cout)

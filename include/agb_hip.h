@@ -171,11 +171,24 @@ int agb_spconv_fwd3_grid(const float* X, int ldx, const float* W, const int32_t*
 int agb_spconv_fwd3_grid_lp(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
                             const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
                             int32_t* nbr_out, long long nbr_out_stride, int precision, void* stream);
+/* The dense-over-offsets fp32 form of the stem (what agb_spconv_fwd3_grid ran until round 4; still taken for Cout != 64):
+ * exported for A/B measurements and as the second implementation the parity tests compare with. */
+int agb_spconv_fwd3_grid_dense(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
+                               const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
+                               int32_t* nbr_out, long long nbr_out_stride, void* stream);
 /* The pair-sparse form of the same 3-channel stem (csrc/stem.hip; SENet.py:47-53): one wave per 64 output rows, the grid
  * probed per (row, offset), v_mfma_f32_4x4x1 on groups of four rows that have the offset.  Cout == 64, ldx == 4, fp32. */
 int agb_stem_fwd_pairs(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
                        const int32_t* desc, int K, const float* bias, float* Y, int ldy, int n_out, int Cout,
                        int32_t* nbr_out, long long nbr_out_stride, void* stream);
+/* Its weight gradient dW[k][c][o] += x[nbr(n, k)][c] dY[n][o] with the neighbours probed in the same grid — the stem's
+ * 343 x N kernel map (578 MB at B = 32) is neither written nor read: one v_mfma_f32_4x4x1 per pair, dY staged in LDS per
+ * 256-row chunk, row partitions folded in a fixed order through the caller's workspace (bitwise reproducible).
+ * dW fp32 [K^3][4][Cout] (channel 3 of X is zero padding). */
+size_t agb_stem_bwd_weight_grid_workspace_bytes(int n_out, int K);
+int agb_stem_bwd_weight_grid(const float* X, int ldx, const float* dY, int ldy, const int32_t* coords, const int32_t* grid,
+                             const int32_t* desc, int K, float* dW, int n_out, int Cout, void* workspace,
+                             size_t workspace_bytes, void* stream);
 /* WT [K3][C][R] = per-offset transpose of W [K3][R][C] (R, C multiples of 4): the operand of the data gradient
  * dX = sum_k dY[nbrT[k]] @ W[k]^T, rebuilt once per layer per step (ME does the same inside its backward GEMMs with
  * a transposed-operand flag: MinkowskiEngine/src/convolution_kernel.cu ConvolutionBackwardKernelGPU). */

@@ -49,9 +49,9 @@ def main():
     y = torch.empty(n, cout, device=dev)
     nbr = torch.empty(K3, n, dtype=torch.int32, device=dev)
 
-    def fwd(with_map):
-        _lib.call("agb_spconv_fwd3_grid_lp", _P(x), 4, _P(w), _P(lvl_coords), _P(grid), desc, K, _P(bias), _P(y), cout, n, cout,
-                  _P(nbr) if with_map else None, n if with_map else 0, 0, _lib.stream())
+    def fwd(with_map):       # the dense-over-offsets form (what agb_spconv_fwd3_grid ran until round 4)
+        _lib.call("agb_spconv_fwd3_grid_dense", _P(x), 4, _P(w), _P(lvl_coords), _P(grid), desc, K, _P(bias), _P(y), cout, n, cout,
+                  _P(nbr) if with_map else None, n if with_map else 0, _lib.stream())
 
     us_map, us_nomap = timed(lambda: fwd(True), a.reps), timed(lambda: fwd(False), a.reps)
     pairs = int((nbr >= 0).sum())
@@ -60,9 +60,9 @@ def main():
     print(f"level 0: {n} rows, {pairs} pairs ({pairs / n:.1f} per row, map density {pairs / (K3 * n):.3f}); useful "
           f"{useful / 1e9:.2f} GFLOP, issued by the dense-over-offsets forward {issued_fwd / 1e9:.1f} GFLOP "
           f"({issued_fwd / useful:.1f}x)")
-    print(f"stem forward, grid probing, WITH the kernel map as by-product ({K3 * n * 4 / 1e6:.0f} MB written): {us_map:8.1f} us  "
+    print(f"stem forward, dense over offsets, grid probing, WITH the kernel map as by-product ({K3 * n * 4 / 1e6:.0f} MB written): {us_map:8.1f} us  "
           f"{useful / us_map / 1e6:6.1f} TF useful  {issued_fwd / us_map / 1e6:6.1f} TF issued")
-    print(f"stem forward, grid probing, WITHOUT the map:                                   {us_nomap:8.1f} us  "
+    print(f"stem forward, dense over offsets, grid probing, WITHOUT the map:               {us_nomap:8.1f} us  "
           f"{useful / us_nomap / 1e6:6.1f} TF useful  {issued_fwd / us_nomap / 1e6:6.1f} TF issued")
     dy = torch.randn(n, cout, device=dev)
     ref_dw = None
@@ -77,6 +77,16 @@ def main():
         err = float((dw - ref_dw).abs().max() / ref_dw.abs().max())
         print(f"stem weight gradient ({tag}): {us:8.1f} us  {useful / us / 1e6:6.1f} TF useful  (max rel diff vs the first "
               f"{err:.1e})")
+    nbytes = _lib.size_call("agb_stem_bwd_weight_grid_workspace_bytes", n, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dw = torch.zeros(K3, 4, cout, device=dev)
+    run_g = lambda: _lib.call("agb_stem_bwd_weight_grid", _P(x), 4, _P(dy), cout, _P(lvl_coords), _P(grid), desc, K, _P(dw), n,  # noqa: E731
+                              cout, _P(ws), nbytes, _lib.stream())
+    us = timed(run_g, a.reps)
+    dw.zero_()
+    run_g()
+    print(f"stem weight gradient (pair-sparse, neighbours PROBED in the grid: no kernel map): {us:8.1f} us  "
+          f"{useful / us / 1e6:6.1f} TF useful  (max rel diff vs the first {float((dw - ref_dw).abs().max() / ref_dw.abs().max()):.1e})")
     for v in [s for s in a.variants.split(",") if s]:
         name = f"agb_stem_fwd_{v.split(':')[0]}"
         with_map = v.endswith(":map")
