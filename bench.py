@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--features", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="build each batch's coordinate plan inside set_input")
+    ap.add_argument("--force-prefetch", action="store_true", help="keep the side-stream input pipeline even where the ranks "
+                    "of this node have fewer than 2.5 usable cores each (tools/host_budget.py measures both forms)")
     ap.add_argument("--cpu-plots", type=int, default=1)
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the BASELINE configs 2, 3 and 5 (single-GPU leg) that the default N = 1 headline run measures "
@@ -441,7 +443,7 @@ def main():
     # thread would get the whole process throttled: build the input on the compute stream there.
     # (the node's uncapped core count over the ranks of THIS node: LOCAL_WORLD_SIZE under torch.distributed.run)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world) or world)
-    if not args.no_prefetch and usable_cores(None) / max(local_world, 1) < 2.5:
+    if not args.no_prefetch and not args.force_prefetch and usable_cores(None) / max(local_world, 1) < 2.5:
         args.no_prefetch = True
         log(f"{usable_cores(None)} usable cores for {local_world} rank(s) on this node: input pipeline on the compute stream "
             f"(--no-prefetch)")

@@ -19,6 +19,7 @@
 //   offsets k = (16 j + w) nq + q, j < 11, and keeps their accumulators in registers over all of its chunks: no atomics, one
 //   partial tile per (row partition, offset), folded in ascending order (k_stem_dw_fold) — bitwise reproducible.
 #include "agb_common.h"
+#include <math.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -44,6 +45,51 @@ __device__ __forceinline__ int stem_delta(const StemGrid& g, int k) {
 }
 
 struct StemDwGeo { int nq, nchunks, nparts; };
+
+// Which (wave, class) column owns which kernel offset, and as which of its SDW_OPW accumulators: e[k] = (column << 4) | j.
+// The pair count of an offset falls with its distance from the centre (measured on the synthetic NFI plots: the centre
+// offset is present for EVERY row = 6.9 x the mean, its face neighbours 1.7 x, the corners of the 7^3 cube 0.55 x), and a
+// row chunk ends at a workgroup barrier: with k = (16 j + w) nq + q the wave that owned the centre carried 48 % more pairs
+// than the mean.  The host deals the offsets longest-first to the least loaded column (LPT) under the isotropic model
+// weight = 1 / (1 + 0.9 d)^1.6, d = distance from the centre in cells: max / mean load 1.12 on the measured counts.
+// Passed to the kernel by value (1.5 KB of kernel arguments: nothing is allocated or copied).
+struct StemOwners { unsigned short e[736]; };
+
+static void stem_dw_owners(int K3, int nq, StemOwners* own) {
+    int K = 1;
+    while (K * K * K < K3) ++K;
+    const bool cube = K * K * K == K3;
+    const int ncol = SDW_WAVES * nq, h = K >> 1;
+    float wgt[736];
+    int order[736];
+    for (int k = 0; k < K3; ++k) {
+        float d = 0.f;
+        if (cube) {
+            const int dx = k % K - h, dy = (k / K) % K - h, dz = k / (K * K) - h;
+            d = sqrtf((float)(dx * dx + dy * dy + dz * dz));
+        }
+        wgt[k] = d == 0.f ? 1.f : 1.f / powf(1.f + 0.9f * d, 1.6f);
+        order[k] = k;
+    }
+    for (int i = 1; i < K3; ++i) {                    // stable insertion sort, weight descending (K3 <= 729)
+        const int k = order[i];
+        int p = i;
+        while (p > 0 && wgt[order[p - 1]] < wgt[k]) { order[p] = order[p - 1]; --p; }
+        order[p] = k;
+    }
+    float load[256];
+    int cnt[256];
+    for (int c = 0; c < ncol; ++c) { load[c] = 0.f; cnt[c] = 0; }
+    for (int i = 0; i < K3; ++i) {
+        const int k = order[i];
+        int best = -1;
+        for (int c = 0; c < ncol; ++c)
+            if (cnt[c] < SDW_OPW && (best < 0 || load[c] < load[best])) best = c;
+        own->e[k] = (unsigned short)((best << 4) | cnt[best]);
+        load[best] += wgt[k];
+        ++cnt[best];
+    }
+}
 
 static StemDwGeo stem_dw_geometry(int n_out, int K3) {
     StemDwGeo g;
@@ -71,7 +117,7 @@ template <bool PROBE>
 __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict__ X, const float* __restrict__ dY, int ldy,
                                                         const int32_t* __restrict__ nbr, long long nbr_stride,
                                                         float* __restrict__ part, int n_out, int K3, int nq, int nchunks,
-                                                        int nparts, StemGrid sg) {
+                                                        int nparts, StemGrid sg, StemOwners own) {
     __shared__ __attribute__((aligned(16))) float s_dy[2][SDW_R * 64];
     __shared__ unsigned s_list[SDW_WAVES][2][SDW_R];     // two pair lists per wave: the current step's and the next one's
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -80,6 +126,23 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
     f32x4 acc[SDW_OPW];
 #pragma unroll
     for (int j = 0; j < SDW_OPW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- which offsets this wave owns: own.e[k] = (column << 4) | j, column = wave * nq + class (host: stem_dw_owners)
+    // lane j of a wave keeps the wave's j-th offset (-1: none).  Scratch: the second dy buffer, not yet in use.
+    int own_v = -1;
+    {
+        int* s_own = reinterpret_cast<int*>(s_dy[1]);
+        if (tid < SDW_WAVES * SDW_OPW) s_own[tid] = -1;
+        __syncthreads();
+        if (tid < K3) {
+            const int e = own.e[tid], col = e >> 4, j = e & 15;
+            if (col % nq == q) s_own[(col / nq) * SDW_OPW + j] = tid;
+        }
+        __syncthreads();
+        if (lane < SDW_OPW) own_v = s_own[w * SDW_OPW + lane];
+        __syncthreads();
+    }
+#define SDW_OWN(J) __builtin_amdgcn_readlane(own_v, (J))
 
     // dy chunk staging: thread t moves four float4 (row t >> 2 of the chunk, columns 16 (t & 3) .. + 15)
     // (four named registers and macros, not an array written inside a lambda: those stay in scratch memory)
@@ -121,10 +184,10 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
     } while (0)
 #define SDW_LOAD_IDX(CH, J, C0, C1, C2, C3, I0, I1, I2, I3)                                                         \
     do {                                                                                                            \
-        const int k_ = ((J) * SDW_WAVES + w) * nq + q;                                                               \
+        const int k_ = SDW_OWN(J);                                                                                   \
         const int r0_ = (CH) * SDW_R;                                                                                \
         I0 = I1 = I2 = I3 = -1;                                                                                      \
-        if (k_ < K3 && (CH) < nchunks) {                                                                             \
+        if (k_ >= 0 && (CH) < nchunks) {                                                                             \
             if (PROBE) {                                                                                             \
                 const int dk_ = stem_delta(sg, k_);                                                                  \
                 const int a0_ = sg.grid[(C0) + dk_];                                                                 \
@@ -253,11 +316,12 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
     float* dst = part + (long long)rp * K3 * 256;
 #pragma unroll
     for (int j = 0; j < SDW_OPW; ++j) {
-        const int k = (j * SDW_WAVES + w) * nq + q;
-        if (k >= K3) continue;
+        const int k = SDW_OWN(j);
+        if (k < 0) continue;
 #pragma unroll
         for (int c = 0; c < 4; ++c) dst[(long long)k * 256 + c * 64 + lane] = acc[j][c];
     }
+#undef SDW_OWN
 }
 
 // dW[e] += sum over the row partitions (ascending) of part[rp][e]
@@ -285,15 +349,17 @@ int agb_stem_dw_launch(const float* X, const float* dY, int ldy, const int32_t* 
         return AGB_EINVAL;
     }
     StemGrid sg{};
+    StemOwners own;
+    stem_dw_owners(K3, g.nq, &own);
     if (nbr == nullptr) {
         sg.coords = (const int4*)coords; sg.grid = grid;
         sg.ox = desc[0]; sg.oy = desc[1]; sg.oz = desc[2]; sg.X = desc[3]; sg.Y = desc[4]; sg.Z = desc[5]; sg.ts = desc[6];
         sg.K = K;
         AGB_LAUNCH((k_stem_dw_pairs<true>), dim3(g.nparts * g.nq), dim3(1024), 0, s, X, dY, ldy, nbr, nbr_stride,
-                   (float*)workspace, n_out, K3, g.nq, g.nchunks, g.nparts, sg);
+                   (float*)workspace, n_out, K3, g.nq, g.nchunks, g.nparts, sg, own);
     } else {
         AGB_LAUNCH((k_stem_dw_pairs<false>), dim3(g.nparts * g.nq), dim3(1024), 0, s, X, dY, ldy, nbr, nbr_stride,
-                   (float*)workspace, n_out, K3, g.nq, g.nchunks, g.nparts, sg);
+                   (float*)workspace, n_out, K3, g.nq, g.nchunks, g.nparts, sg, own);
     }
     const long long n4 = (long long)K3 * 64;
     hipLaunchKernelGGL(k_stem_dw_fold, dim3((unsigned)agb_cdiv(n4, 256)), dim3(256), 0, s, (const float4*)workspace, g.nparts,
@@ -332,10 +398,10 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
                                                         const int32_t* __restrict__ grid, int ox, int oy, int oz, int GX, int GY,
                                                         int GZ, int ts, int K, int32_t* __restrict__ nbr_out,
                                                         long long nbr_out_stride) {
-    __shared__ int s_delta[SFW_DELTA_MAX + 8];
+    __shared__ int s_delta[SFW_DELTA_MAX + 16];
     __shared__ __attribute__((aligned(16))) float s_w[2][SFW_WB * 192];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int k = tid; k < SFW_DELTA_MAX + 8; k += 256) {
+    for (int k = tid; k < SFW_DELTA_MAX + 16; k += 256) {
         const int kc = min(k, K3 - 1);
         const int h = K >> 1, ix = kc % K, iy = (kc / K) % K, iz = kc / (K * K);
         s_delta[k] = ((iz - h) * GY + (iy - h)) * GX + (ix - h);
@@ -370,9 +436,10 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = (f32x4){bv, bv, bv, bv};
 
-    // rotating registers: cells of offsets k .. k + 3 (c0 = offset k when k % 4 == 0), feature rows of k and k + 1
+    // rotating registers: cells of offsets k .. k + 7 (c0 = offset k when k % 8 == 0), feature rows of k and k + 1
     int c0 = grid[base + s_delta[0]], c1 = grid[base + s_delta[1]], c2 = grid[base + s_delta[2]],
-        c3 = grid[base + s_delta[3]];
+        c3 = grid[base + s_delta[3]], c4 = grid[base + s_delta[4]], c5 = grid[base + s_delta[5]],
+        c6 = grid[base + s_delta[6]], c7 = grid[base + s_delta[7]];
     float xa0, xa1, xa2, xb0, xb1, xb2;
 #define SFW_GATHER(CELL, X0, X1, X2)                                                               \
     do {                                                                                           \
@@ -383,7 +450,8 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
     SFW_GATHER(c1, xb0, xb1, xb2);
     const int nblocks = (K3 + SFW_WB - 1) / SFW_WB;
     // one offset: CELL = its cell value; (X0, X1, X2) = its gathered feature row; afterwards CELL receives the probe of
-    // offset k + 4 and (X0, X1, X2) the gather of offset k + 2, whose cell value is CELL2
+    // offset k + 8 (a probe that misses the L2 comes from the Infinity Cache or HBM: ~1500 cycles; six offsets pass before
+    // its gather is issued) and (X0, X1, X2) the gather of offset k + 2, whose cell value is CELL2
 #define SFW_STEP(KK, CELL, CELL2, X0, X1, X2)                                                       \
     do {                                                                                           \
         const int k_ = kb * SFW_WB + (KK);                                                          \
@@ -391,7 +459,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
         const bool present_ = row_ok && cell_ != INT_MAX && k_ < K3;                                \
         const float w0_ = wb[(KK) * 192 + lane], w1_ = wb[(KK) * 192 + 64 + lane],                  \
                     w2_ = wb[(KK) * 192 + 128 + lane];                                              \
-        CELL = grid[base + s_delta[k_ + 4]];                                                        \
+        CELL = grid[base + s_delta[k_ + 8]];                                                        \
         if (WRITE_MAP) {                                                                            \
             if (row_ok && k_ < K3) nbr_out[(long long)k_ * nbr_out_stride + row] = present_ ? cell_ : -1; \
         }                                                                                           \
@@ -423,11 +491,15 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
         const float* wb = s_w[kb & 1];
         if (wave_ok) {
 #pragma unroll 1
-            for (int k4 = 0; k4 < SFW_WB; k4 += 4) {
-                SFW_STEP(k4 + 0, c0, c2, xa0, xa1, xa2);
-                SFW_STEP(k4 + 1, c1, c3, xb0, xb1, xb2);
-                SFW_STEP(k4 + 2, c2, c0, xa0, xa1, xa2);
-                SFW_STEP(k4 + 3, c3, c1, xb0, xb1, xb2);
+            for (int k8 = 0; k8 < SFW_WB; k8 += 8) {
+                SFW_STEP(k8 + 0, c0, c2, xa0, xa1, xa2);
+                SFW_STEP(k8 + 1, c1, c3, xb0, xb1, xb2);
+                SFW_STEP(k8 + 2, c2, c4, xa0, xa1, xa2);
+                SFW_STEP(k8 + 3, c3, c5, xb0, xb1, xb2);
+                SFW_STEP(k8 + 4, c4, c6, xa0, xa1, xa2);
+                SFW_STEP(k8 + 5, c5, c7, xb0, xb1, xb2);
+                SFW_STEP(k8 + 6, c6, c0, xa0, xa1, xa2);
+                SFW_STEP(k8 + 7, c7, c1, xb0, xb1, xb2);
             }
         }
         if (more) SFW_STORE_W((kb + 1) & 1);
