@@ -249,7 +249,7 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
         SDW_LOAD_IDX(chunk, 1, cc0, cc1, cc2, cc3, n0, n1, n2, n3);
         SDW_COMPACT(lcur, total_cur, t0, t1, t2, t3);
         e_first = lcur[g4];
-        a_first = X[(long long)(e_first >> 8) * 4 + c4];
+        a_first = X[(e_first >> 8) * 4u + (unsigned)c4];
     }
     for (int it = 0; chunk < nchunks; ++it, chunk += nparts) {
         const int buf = it & 1;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
             int total_nxt;
             SDW_COMPACT(lnxt, total_nxt, n0, n1, n2, n3);
             const unsigned e_nf = lnxt[g4];
-            const float a_nf = X[(long long)(e_nf >> 8) * 4 + c4];
+            const float a_nf = X[(e_nf >> 8) * 4u + (unsigned)c4];
             // (3) step s: one 4x4x1 MFMA per pair
             if (total_cur > 0) {
                 const int ngroups = (total_cur + 15) >> 4;
@@ -274,16 +274,18 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
                 float a = a_first;
                 f32x4 d = acc[j];
                 for (int g = 0; g < ngroups; ++g) {
-                    const unsigned e_cur = e;
+                    // byte offset of this lane group's dy row in the chunk buffer plus this lane's column: per pair only a
+                    // readlane and an add are left (the shift and mask of the packed entry are done here, once per 16 pairs)
+                    const int noff = (int)((e & 255u) << 8);
                     const float a_cur = (16 * g + g4 < total_cur) ? a : 0.f;
                     if (g + 1 < ngroups) {                          // next group's entries and gathered x in flight
                         e = lcur[16 * (g + 1) + g4];
-                        a = X[(long long)(e >> 8) * 4 + c4];
+                        a = X[(e >> 8) * 4u + (unsigned)c4];
                     }
 #pragma unroll
                     for (int p = 0; p < 16; ++p) {
-                        const int n = __builtin_amdgcn_readlane((int)e_cur, 4 * p) & 255;
-                        const float b = dyb[n * 64 + lane];
+                        const int nb = __builtin_amdgcn_readlane(noff, 4 * p);
+                        const float b = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dyb) + nb + 4 * lane);
                         // block p of `a_cur` (lanes 4p .. 4p+3: x[m_p][0..3]) is the A operand of all 16 blocks
                         switch (p) {
 #define SDW_CASE(P) case P: d = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur, b, d, 4, P, 0); break;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
     float xa0, xa1, xa2, xb0, xb1, xb2;
 #define SFW_GATHER(CELL, X0, X1, X2)                                                               \
     do {                                                                                           \
-        const float* xr_ = X + (long long)((row_ok && (CELL) != INT_MAX) ? (CELL) : 0) * 4;         \
+        const float* xr_ = X + (unsigned)((row_ok && (CELL) != INT_MAX) ? (CELL) : 0) * 4u;          \
         X0 = xr_[0]; X1 = xr_[1]; X2 = xr_[2];                                                      \
     } while (0)
     SFW_GATHER(c0, xa0, xa1, xa2);
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd_pairs(const float* __restrict_
         const bool present_ = row_ok && cell_ != INT_MAX && k_ < K3;                                \
         const float w0_ = wb[(KK) * 192 + lane], w1_ = wb[(KK) * 192 + 64 + lane],                  \
                     w2_ = wb[(KK) * 192 + 128 + lane];                                              \
-        CELL = grid[base + s_delta[k_ + 8]];                                                        \
+        CELL = grid[(unsigned)(base + s_delta[k_ + 8])];                                            \
         if (WRITE_MAP) {                                                                            \
             if (row_ok && k_ < K3) nbr_out[(long long)k_ * nbr_out_stride + row] = present_ ? cell_ : -1; \
         }                                                                                           \
