@@ -154,39 +154,23 @@ __device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((
 #define ACT_RELU 1
 #define ACT_GELU 2
 
-// GELU = z * Phi(z) with Phi through the five-term rational-exponential erfc of Abramowitz & Stegun 7.1.26 (absolute error of
-// erf <= 1.5e-7, i.e. <= 7.5e-8 on Phi: three orders below the 1e-4 parity bar, below bf16 resolution by five) instead of
-// libm's erff: value + derivative take 24 VALU instructions instead of 46 (the exponential is shared with the density term
-// of the derivative).  The element-wise kernels of the bf16-row mode move 2 + 2 bytes per element: at 5 TB/s that is 1.25 T
-// elements/s, and erff alone put them at the VALU roof (they ran at 3.4-3.9 TB/s where the fp32-row forms reach 5.3,
-// profiles/r03_pmc_senet50_rows.txt).
-//   q = 0.5 erfc(|z| / sqrt 2) in (0, 0.5];  Phi(z) = 1 - q (z >= 0), q (z < 0);  *e2 = exp(-z^2 / 2)
-__device__ __forceinline__ float agb_phi(float z, float* e2) {
-    const float ax = fabsf(z) * 0.70710678118654752440f;
-    const float e = __expf(-0.5f * z * z);                      // (v_exp_f32, 2 ulp)
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.f));
-    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-    p = __builtin_fmaf(t, p, 1.421413741f);
-    p = __builtin_fmaf(t, p, -0.284496736f);
-    p = __builtin_fmaf(t, p, 0.254829592f);
-    const float q = 0.5f * (p * t) * e;
-    *e2 = e;
-    return z >= 0.f ? 1.f - q : q;
-}
-
 __device__ __forceinline__ float act_fwd(float z, int act) {
     if (act == ACT_RELU) return z > 0.f ? z : 0.f;
-    if (act == ACT_GELU) { float e2; return z * agb_phi(z, &e2); }
+    if (act == ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
     return z;
 }
-// value and derivative at once (the GELU pair shares its exponential)
+// value and derivative at once (the GELU pair shares its erf)
+// (Round 4 measured a cheaper GELU — Phi through the five-term erfc of Abramowitz & Stegun 7.1.26, 24 instead of 46 VALU
+// instructions for value + derivative, 3e-7 absolute error — on the premise that the bf16-row element-wise kernels were at
+// the VALU roof: MSENet50 bf16 rows 1784 -> 1800, MPointNet 5525 -> 5531 plots/s: nothing, those passes are bound by
+// launch count and size (16-65 us kernels), not by erff.  Dropped: the exact erf stays — EXPERIMENTS.md.)
 __device__ __forceinline__ void act_fwd_grad(float z, int act, float* val, float* grad) {
     if (act == ACT_RELU) { *val = z > 0.f ? z : 0.f; *grad = z > 0.f ? 1.f : 0.f; return; }
     if (act == ACT_GELU) {
-        float e2;
-        const float cdf = agb_phi(z, &e2);
-        *val = z * cdf;                               // (the expressions of act_fwd / act_grad: same rounding)
-        *grad = cdf + z * (0.39894228040143267794f * e2);
+        const float e = erff(z * 0.70710678118654752440f);
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);   // (v_exp_f32: 2 ulp, the sums take 1e-7)
+        *val = 0.5f * z * (1.f + e);                  // (the expressions of act_fwd / act_grad: same rounding)
+        *grad = 0.5f * (1.f + e) + z * pdf;
         return;
     }
     *val = z; *grad = 1.f;
@@ -194,9 +178,9 @@ __device__ __forceinline__ void act_fwd_grad(float z, int act, float* val, float
 __device__ __forceinline__ float act_grad(float z, int act) {
     if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
     if (act == ACT_GELU) {
-        float e2;
-        const float cdf = agb_phi(z, &e2);
-        return cdf + z * (0.39894228040143267794f * e2);
+        float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+        float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);   // (v_exp_f32, 2 ulp)
+        return cdf + z * pdf;
     }
     return 1.f;
 }

@@ -1,0 +1,53 @@
+"""Host logic of sparse_ops.KernelOptions and of the model-level switch (no GPU): scopes, inheritance, validation — the
+options are carried by the MODEL, two models of different precision coexist, and an option a backbone cannot honour is
+refused when it is set instead of failing mid-network."""
+import pytest
+import torch
+
+
+def _model(name):
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import KPConvModel, MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_008))
+    if name == "KPConv":
+        return KPConvModel(Opt(MODEL_OPTIONS["KPConv"]), "kpconv", ds)
+    return MinkowskiBaselineModel(Opt(MODEL_OPTIONS[name]), "minkowski", ds)
+
+
+def test_scopes_and_inheritance():
+    from dpcr_agb_amd import sparse_ops as so
+    base = so.current()
+    assert base.precision == "fp32" and not base.deterministic_wgrad and not base.rows_bf16
+    with so.KernelOptions(precision="bf16") as a:
+        assert so.current() is a and a.low_precision and a.prec_id == 1
+        with so.KernelOptions(deterministic_wgrad=True) as b:          # inherits the enclosing scope
+            assert b.precision == "bf16" and b.deterministic_wgrad
+        assert so.current() is a
+    assert so.current() is base
+    with pytest.raises(ValueError):
+        so.KernelOptions(precision="fp16")
+    # bf16 rows need bf16 operands
+    assert not so.KernelOptions(precision="fp32", bf16_activations=True).rows_bf16
+    assert so.KernelOptions(precision="bf16", bf16_activations=True).rows_bf16
+
+
+def test_model_level_options_are_per_model():
+    m14, m50 = _model("SENet14"), _model("SENet50")
+    o14 = m14.set_kernel_options(precision="bf16", bf16_activations=True, deterministic_wgrad=True)
+    assert m50.model.kernel_options is None                         # another model is untouched
+    assert o14.rows_bf16 and o14.deterministic_wgrad
+    o14b = m14.set_kernel_options(precision="fp32")                  # later calls refine the model's own options
+    assert o14b.precision == "fp32" and o14b.deterministic_wgrad and not o14b.rows_bf16
+
+
+@pytest.mark.parametrize("name", ["MPointNet", "KPConv"])
+def test_bf16_row_storage_is_refused_where_it_does_not_exist(name):
+    """bf16 ROW storage exists for the sparse ResNet / SENet backbones only: the KP gather / max-pool kernels and the PointNet
+    pooling take fp32 rows."""
+    m = _model(name)
+    with pytest.raises(ValueError, match="bf16_activations"):
+        m.set_kernel_options(precision="bf16", bf16_activations=True)
+    m.set_kernel_options(precision="bf16")                           # the operand precision alone is fine
+    assert m.model.kernel_options.precision == "bf16"

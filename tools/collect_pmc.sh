@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prefetch > $OUT/$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-prefetch > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
 cd $ROOT
