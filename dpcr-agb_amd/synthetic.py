@@ -98,6 +98,8 @@ class PlotBatch:
         return getattr(self, k)
 
     def to(self, device, non_blocking=True):
+        # (a device -> host copy that returns before it has landed hands the caller garbage: only uploads are asynchronous)
+        non_blocking = bool(non_blocking) and torch.device(device).type != "cpu"
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)  # noqa: E731
         out = PlotBatch(mv(self.batch), mv(self.coords), mv(self.x), mv(self.pos), None, None, self._n,
                         self.coord_bounds)
