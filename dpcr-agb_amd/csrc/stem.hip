@@ -326,42 +326,19 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
 #undef SDW_OWN
 }
 
-// dW[e] += sum over the row partitions of part[rp][e], in a FIXED order: the partitions are cut into four consecutive
-// ranges, one per thread group, each range summed in ascending order (loads eight deep), the four range sums added in
-// ascending order.  (One thread per element walking all 128 partitions: 86 workgroups and 40 us for the 45 MB.)
+// dW[e] += sum over the row partitions (ascending) of part[rp][e]
+// (A four-range tree on 343 workgroups instead of 86 was measured: 40 -> 10 us of a 9.2 ms step — and, being another
+// summation order, another draw of the R2 table.  Not worth it: the plain ascending sum stays.)
 __global__ __launch_bounds__(256) void k_stem_dw_fold(const float4* __restrict__ part, int nparts, long long n4,
                                                       float4* __restrict__ dW) {
-    __shared__ float4 s_sum[4][64];
-    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long e = (long long)blockIdx.x * 64 + el;
-    const int per = (nparts + 3) >> 2;
-    const int c0 = grp * per, c1 = min(nparts, c0 + per);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < n4) {
-        int c = c0;
-        for (; c + 8 <= c1; c += 8) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(c + u) * n4 + e];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-        }
-        for (; c < c1; ++c) {
-            const float4 v = part[(long long)c * n4 + e];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    float4 s = dW[e];
+    for (int c = 0; c < nparts; ++c) {
+        const float4 v = part[(long long)c * n4 + e];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    s_sum[grp][el] = s;
-    __syncthreads();
-    if (grp == 0 && e < n4) {
-        float4 t = dW[e];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = s_sum[g][el];
-            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-        }
-        dW[e] = t;
-    }
+    dW[e] = s;
 }
 
 // dW [K3][4][64] += gathered(X)^T dY through `workspace` (agb_stem_dw_workspace_bytes): X rows 4 floats wide (channel 3 = 0).
@@ -389,7 +366,7 @@ int agb_stem_dw_launch(const float* X, const float* dY, int ldy, const int32_t* 
                    (float*)workspace, n_out, K3, g.nq, g.nchunks, g.nparts, sg, own);
     }
     const long long n4 = (long long)K3 * 64;
-    hipLaunchKernelGGL(k_stem_dw_fold, dim3((unsigned)agb_cdiv(n4, 64)), dim3(256), 0, s, (const float4*)workspace, g.nparts,
+    hipLaunchKernelGGL(k_stem_dw_fold, dim3((unsigned)agb_cdiv(n4, 256)), dim3(256), 0, s, (const float4*)workspace, g.nparts,
                        n4, (float4*)dW);
     return AGB_OK;
 }

@@ -124,8 +124,10 @@ def test_r2_gap_on_committed_trials():
           BARE_0P005_MET above, per leg and target: where it says True the bare +-0.005 IS asserted.  This tree: MET by the
           fp32 leg — the reference's arithmetic — on both targets (+0.0000 / +0.0012) and by bf16 rows (+0.0025 / -0.0006);
           NOT met by bf16 on fp32 rows (+0.0062 / +0.0058, the HIP medians ABOVE the CPU's), at 0.4 s.e. of a difference of
-          two medians of 13 — not resolvable from noise, and said plainly.  (The table before this round's stem kernels:
-          fp32 met / met, bf16 met / NOT met, bf16 rows NOT / NOT: every change of a summation order is a new draw.)
+          two medians of 13 — not resolvable from noise, and said plainly.  (The table was generated on three trees of round
+          4 that differ only in a summation order of the stem weight gradient: fp32 met / met, met / met, NOT (+0.0059) /
+          met; bf16 met / NOT, NOT / NOT, met / met; bf16 rows NOT / NOT, met / met, met / NOT — DESIGN.md section 6: every
+          change of a summation order is a new draw, and this table pins the draw of THIS tree.)
     REPORTED: the five-seed medians of the reference's protocol (with sd 0.015 a bare +-0.005 between two five-trial medians
     is met by chance about one time in three for identical implementations: it is printed, not asserted)."""
     c, rows = _gap_table()
