@@ -25,6 +25,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s m
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak
 MFMA_BF16_PEAK_TF = 2500.0  # bf16 MFMA dense peak (split-bf16x3 issues 3 bf16 MFMAs per product: priced at 2500 / 3)
 PRECISION = "fp32"         # operand precision of the convolution MFMAs (--precision)
+PMC_CONFIG = None          # "config5" for the MSENet50 bf16-row line: which committed PMC pass `roofline.traffic` reads
 
 
 def mfma_peak_tf():
@@ -85,14 +86,17 @@ def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, file it was read from) from the newest committed PMC pass
     (tools/collect_pmc.sh <tag> -> profiles/<tag>_pmc_traffic.json; separate --pmc runs of this same command, corrected as
     MI355X_MICROARCH.md prescribes) — counters cannot be collected from inside a running benchmark — or (None, None)."""
-    for tag in ("r04", "r03", "r02", "r01"):
-        rel = os.path.join("profiles", f"{tag}_pmc_traffic.json")
+    names = [f"{tag}_pmc_traffic.json" for tag in ("r04", "r03", "r02", "r01")]
+    if PMC_CONFIG:      # (another model / precision than the headline: its own PMC pass, tools/collect_pmc_configs.sh)
+        names = [f"r04_pmc_traffic_{PMC_CONFIG}.json"]
+    for name in names:
+        rel = os.path.join("profiles", name)
         try:
             data = json.load(open(os.path.join(ROOT, rel)))["kernels"]
         except Exception:
             continue
-        for name, v in data.items():
-            if name.replace("void ", "").strip() == kernel:
+        for kname, v in data.items():
+            if kname.replace("void ", "").strip() == kernel.split(" (")[0]:
                 return round(v["hbm_bytes_per_launch"]), rel
     return None, None
 
@@ -387,8 +391,12 @@ def main():
     import dpcr_agb_amd
     from dpcr_agb_amd import sparse_ops, synthetic
     dpcr_agb_amd.limit_host_threads()     # (the cpu_baseline leg sets its own thread count afterwards)
-    global PRECISION
+    global PRECISION, PMC_CONFIG
     PRECISION = args.precision
+    if args.model == "SENet50" and args.precision == "bf16" and args.bf16_rows:
+        PMC_CONFIG = "config5"
+    elif args.model != "SENet14" or args.precision != "fp32":
+        PMC_CONFIG = "none"
     from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
     from dpcr_agb_amd.dist import GradAllReduce, broadcast_parameters, shard_seeds
     from dpcr_agb_amd.instance import MinkowskiBaselineModel

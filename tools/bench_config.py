@@ -126,7 +126,22 @@ def shape_table(groups):
                 f"  {by / ms / 1e6 if by else 0:7.0f} GB/s")
 
 
-def roofline_entry(name, g, cost):
+def pmc_traffic(kernel, config):
+    """(HBM bytes per launch of `kernel`, file) from the committed PMC pass of this config (tools/collect_pmc_configs.sh ->
+    profiles/<tag>_pmc_traffic_<config>.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections), or (None, None)."""
+    for tag in ("r04",):
+        rel = os.path.join("profiles", f"{tag}_pmc_traffic_{config}.json")
+        try:
+            data = json.load(open(os.path.join(ROOT, rel)))["kernels"]
+        except Exception:
+            continue
+        for k, v in data.items():
+            if k.replace("void ", "").strip() == kernel.split(" (")[0]:
+                return round(v["hbm_bytes_per_launch"]), rel
+    return None, None
+
+
+def roofline_entry(name, g, cost, config=None):
     flops = sum(cost(a)[0] for a, _ in g["calls"])
     byts = sum(cost(a)[1] for a, _ in g["calls"])
     secs = g["ms"] / 1e3
@@ -140,7 +155,9 @@ def roofline_entry(name, g, cost):
     # the kernel(s) behind the entry point, by device time (the library notes what it launches: agb_last_kernel)
     kernels = {k: round(ms / g["ms"], 3) for k, ms in sorted(g.get("kernels", {}).items(), key=lambda kv: -kv[1])}
     kernel = next(iter(kernels), KERNEL_OF_ENTRY.get(name, name))
-    r.update(traffic=None, kernel=kernel, entry_point=name, kernels_time_share=kernels or None, launches=g["n"],
+    traffic, src = pmc_traffic(kernel, config) if config else (None, None)
+    r.update(traffic=traffic, traffic_source=src, kernel=kernel, entry_point=name, kernels_time_share=kernels or None,
+             launches=g["n"],
              avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2), alg_bytes_per_launch=round(byts / g["n"]),
              alg_flops_per_launch=round(flops / g["n"]))
     return r
@@ -211,7 +228,7 @@ def run_pointnet(a):
     costs = {"agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_fwd_lp": conv_call_cost,
              "agb_spconv_bwd_weight_lp": wgrad_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost}
     dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
-    roof = roofline_entry(dom, groups[dom], costs[dom])
+    roof = roofline_entry(dom, groups[dom], costs[dom], "config2")
     line = dict(metric="training plots/sec (16k-pt NFI plots) MPointNet", value=round(B * a.steps / dt, 2), unit="plots/s",
                 n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
                 scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -290,12 +307,12 @@ def run_kpconv(a):
              "agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost,
              "agb_spconv_bwd_weight_lp": wgrad_call_cost}
     dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
-    roof = roofline_entry(dom, groups[dom], costs[dom])
+    roof = roofline_entry(dom, groups[dom], costs[dom], "config3")
     index_names = ("agb_ball_query_fill", "agb_ball_query_fill_csr", "agb_ball_query_offsets", "agb_ball_query_count",
                    "agb_ball_grid_build", "agb_grid_subsample_ws", "agb_elem_bbox", "agb_elem_of_row", "agb_rotate_points")
     index_ms = sum(groups[n]["ms"] for n in index_names if n in groups) / 3
     fill = "agb_ball_query_fill_csr" if "agb_ball_query_fill_csr" in groups else "agb_ball_query_fill"
-    bq = roofline_entry(fill, groups[fill], costs[fill])
+    bq = roofline_entry(fill, groups[fill], costs[fill], "config3")
     line = dict(metric="training plots/sec KPConv rigid", value=round(B * a.steps / dt, 2), unit="plots/s", n_gpus=1,
                 steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
                 scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
