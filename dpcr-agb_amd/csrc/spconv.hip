@@ -2170,7 +2170,7 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             return AGB_EUNSUPPORTED;
         }
         dim3 grid(n_tiles_perm, agb_cdiv(a.Cout, BN), a.ksplit);
-        AGB_LAUNCH((k_spconv_pipe<64, true>), grid, block, 0, s, a);
+        AGB_LAUNCH((k_spconv_pipe<64, true, 64>), grid, block, 0, s, a);
     } else if (small) {
         dim3 grid(agb_cdiv(a.n_out, BM), agb_cdiv(a.Cout, BN));
         if (a.Cin == 4)
@@ -2194,10 +2194,10 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
             AGB_LAUNCH((k_spconv_pipe<128, false, 128>),
                                dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, 128), a.ksplit), block, 0, s, a);
         else
-            AGB_LAUNCH((k_spconv_pipe<128, false>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
+            AGB_LAUNCH((k_spconv_pipe<128, false, 64>), dim3(agb_cdiv(a.n_out, 128), agb_cdiv(a.Cout, BN), a.ksplit),
                                block, 0, s, a);
     } else {
-        AGB_LAUNCH((k_spconv_pipe<64, false>), dim3(agb_cdiv(a.n_out, 64), agb_cdiv(a.Cout, BN), a.ksplit),
+        AGB_LAUNCH((k_spconv_pipe<64, false, 64>), dim3(agb_cdiv(a.n_out, 64), agb_cdiv(a.Cout, BN), a.ksplit),
                            block, 0, s, a);
     }
     if (a.ksplit > 1) {
@@ -2416,8 +2416,8 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
     const bool x3 = precision == 2;
     if (perm) {
         dim3 grid(n_tiles, agb_cdiv(Cout, BN), ksplit);
-        if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<64, true, true>), grid, block, 0, s, a);
-        else AGB_LAUNCH((k_spconv_pipe_bf16<64, true, false>), grid, block, 0, s, a);
+        if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<64, true, true, 64>), grid, block, 0, s, a);
+        else AGB_LAUNCH((k_spconv_pipe_bf16<64, true, false, 64>), grid, block, 0, s, a);
     } else if (conv_tile_rows(n_out, Cin, Cout) == 128) {
         // 128-column tiles when the layer is wide enough and still fills the chip: the gathered and converted A tile
         // (the VALU / L2 cost of this kernel) serves twice the columns
@@ -2426,12 +2426,12 @@ int agb_spconv_fwd_lp(const float* X, int ldx, const float* Wt, const int32_t* n
         if (wide) {
             if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<128, false, true, 128>), grid, block, 0, s, a);
             else AGB_LAUNCH((k_spconv_pipe_bf16<128, false, false, 128>), grid, block, 0, s, a);
-        } else if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<128, false, true>), grid, block, 0, s, a);
-        else AGB_LAUNCH((k_spconv_pipe_bf16<128, false, false>), grid, block, 0, s, a);
+        } else if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<128, false, true, 64>), grid, block, 0, s, a);
+        else AGB_LAUNCH((k_spconv_pipe_bf16<128, false, false, 64>), grid, block, 0, s, a);
     } else {
         dim3 grid(agb_cdiv(n_out, 64), agb_cdiv(Cout, BN), ksplit);
-        if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<64, false, true>), grid, block, 0, s, a);
-        else AGB_LAUNCH((k_spconv_pipe_bf16<64, false, false>), grid, block, 0, s, a);
+        if (x3) AGB_LAUNCH((k_spconv_pipe_bf16<64, false, true, 64>), grid, block, 0, s, a);
+        else AGB_LAUNCH((k_spconv_pipe_bf16<64, false, false, 64>), grid, block, 0, s, a);
     }
     if (ksplit > 1) {
         long long total = (long long)n_out * (Cout / 4);
@@ -2754,16 +2754,16 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
             AGB_LAUNCH((k_spconv_dw_cmp<1, true, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out,
                                K3, Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 3)       // bf16 operands from bf16 twins (agb_spconv_bwd_weight_b16)
-            AGB_LAUNCH((k_spconv_dw_cmp<1, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH((k_spconv_dw_cmp<1, true, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 1)
-            AGB_LAUNCH(k_spconv_dw_cmp<1>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH((k_spconv_dw_cmp<1, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 2)
-            AGB_LAUNCH(k_spconv_dw_cmp<2>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH((k_spconv_dw_cmp<2, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else
-            AGB_LAUNCH(k_spconv_dw_cmp<0>, grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH((k_spconv_dw_cmp<0, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         if (part) {
             const long long n4 = (long long)K3 * Cin * Cout / 4;
@@ -2827,7 +2827,7 @@ static int fwd3_grid_lp_impl(const float* X, int ldx, const float* W, const int3
         AGB_LAUNCH((k_spconv_fwd3_lp<false, true>), grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy,
                            n_out, K * K * K, Cout, gp);
     else if (precision == 1)
-        AGB_LAUNCH(k_spconv_fwd3_lp<false>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy, n_out,
+        AGB_LAUNCH((k_spconv_fwd3_lp<false, false>), grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, bias, Y, ldy, n_out,
                            K * K * K, Cout, gp);
     else
         AGB_LAUNCH(k_spconv_fwd3<true>, grid3, dim3(256), 0, (hipStream_t)stream, X, ldx, W, nullptr, 0LL, 0, bias, Y,
