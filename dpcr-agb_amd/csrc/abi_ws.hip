@@ -5,20 +5,20 @@
 
 extern "C" {
 int agb_scan_scratch_elems(int n);
-int agb_grid_subsample(const float* pts, const float* feats, int fdim, int n, const int32_t* ptr, const int32_t* elem,
+AGB_INTERNAL int agb_grid_subsample(const float* pts, const float* feats, int fdim, int n, const int32_t* ptr, const int32_t* elem,
                        int B, float dl, int cap, int32_t* bbox_ord, float* origin, int32_t* dims, int32_t* cell_cnt,
                        int32_t* cell_start, int32_t* slot, int32_t* flag, int32_t* cell_of, int32_t* members,
                        int32_t* scan_scratch, float* out_pts, float* out_feats, int32_t* out_ptr, int32_t* n_out_dev,
                        int32_t* status, void* stream);
-int agb_voxelize_last(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
+AGB_INTERNAL int agb_voxelize_last(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
                       float size, int cap, int32_t* bbox_ord, float* lo, int32_t* span, int32_t* cells, int32_t* slot,
                       int32_t* flag, int32_t* cell_of, int32_t* scan_scratch, int32_t* coords, long long* keep,
                       int32_t* out_ptr, int32_t* n_out_dev, int32_t* bounds, int32_t* status, void* stream);
-int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
+AGB_INTERNAL int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
                      int scale_div, int z_from_zero, const double* poly, int nv, float* zmin, float* pos_t, int32_t* flag,
                      int32_t* slot, int32_t* scan_scratch, float* pos_out, float* x_out, long long* src, int32_t* out_ptr,
                      int32_t* n_out_dev, void* stream);
-int agb_plot_crop(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const double* polys, int nv,
+AGB_INTERNAL int agb_plot_crop(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const double* polys, int nv,
                   float fcx, float fcy, int32_t* flag, int32_t* slot, int32_t* cnt, int32_t* scan_scratch, float* pos_out,
                   float* x_out, long long* src, int32_t* out_ptr, int32_t* n_out_dev, void* stream);
 }

@@ -48,6 +48,10 @@ void agb_note_kernel(const char* name);
         }                                                                        \
     } while (0)
 
+// Entry points with C linkage that stay INSIDE the library (the many-buffer forms behind the *_ws entry points of
+// abi_ws.hip): not part of the ABI of include/agb_hip.h, not exported.
+#define AGB_INTERNAL __attribute__((visibility("hidden")))
+
 static inline int agb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // dense_stream.hip: HBM-bound dense products (many rows, small weight matrix), taken from the identity-map entry points

@@ -36,9 +36,9 @@ LDS_BYTES = LDS_SROW + R_ROWS * 4          # 39568
 # ---- VGPRs
 WA, WB, AN, ACC, CIN = 0, 64, 128, 144, 160
 V = dict(lane=176, lst8=177, ysq=178, xq=179, woff=180, rowc0=181, rowc1=182, nv0=184, rid0=185, nv1=186, rid1=187,
-         dump=183, e=188, woff1=214, woff2=215, woff3=216, addr_cur=190, addr_nxt=191, xaddr=192, xbc=194, xbn=196, xsel=198, t0=200, t1=201, pf=202,
+         dump=183, e=188, woff1=214, woff2=215, woff3=216, addr_cur=190, addr_nxt=191, xaddr=192, xbc=194, xbn=196, xsel=198, t0=200, t1=201, pf=202, addr_prev=203,
          pad=204, i0=206, i1=208, i2=210, i3=212)
-NV_LAST = 216
+NV_LAST = 235
 # ---- SGPRs
 S = dict(X=36, Wk=38, Wl=40, N=42, Nstep=44, ldx4=46, cout4=47, wk4=48, K3=49, NSB=50, c13=51, k=52, sb=53, koff=54,
          lb_cur=55, lb_nxt=56, lb_nn=57, ng_cur=58, ng_nxt=59, ng_nn=60, grem=61, steps=62, ng_ns=63, valid0=64, valid1=66,
@@ -131,30 +131,58 @@ def w_loads(wbase):
     return out
 
 
+ABL = 0        # experiment variants (wrong results): 1 no row refills, 2 no weight loads, 4 no sums traffic, 8 no compaction
+STAMPS = os.environ.get("CMA_STAMPS", "0") == "1"     # diagnostic build only (make timeline): s_memtime sums per segment
+ST = dict(prev=88, now=90, top=92, F=94, P=96, nF=98, nP=99)
+
+
+def stamp(acc, count=None):
+    if not STAMPS:
+        return []
+    o = [f"s_memtime {s(ST['now'], 2)}", "s_waitcnt lgkmcnt(0)",
+         f"s_sub_u32 {s(S['t'])}, {s(ST['now'])}, {s(ST['prev'])}", f"s_subb_u32 {s(S['t2'])}, {s(ST['now'] + 1)}, {s(ST['prev'] + 1)}",
+         f"s_add_u32 {s(ST[acc])}, {s(ST[acc])}, {s(S['t'])}", f"s_addc_u32 {s(ST[acc] + 1)}, {s(ST[acc] + 1)}, {s(S['t2'])}",
+         f"s_mov_b64 {s(ST['prev'], 2)}, {s(ST['now'], 2)}"]
+    if count:
+        o.append(f"s_add_u32 {s(ST[count])}, {s(ST[count])}, 1")
+    return o
+
+
+def timed_wait(wait, acc32):
+    """(diagnostic build) the wait bracketed by two clock reads, its duration added to the 32-bit sum s[acc32]"""
+    if not STAMPS:
+        return [wait]
+    return [f"s_memtime {s(ST['now'], 2)}", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 {s(S['gptr'])}, {s(ST['now'])}", wait,
+            f"s_memtime {s(ST['now'], 2)}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {s(S['gptr'])}, {s(ST['now'])}, {s(S['gptr'])}",
+            f"s_add_u32 {s(acc32)}, {s(acc32)}, {s(S['gptr'])}"]
+
+
 def is_vmem(ins):
     return ins.startswith("global_load")
 
 
-def group(wcur, wnxt, F, tag):
-    """One 16-pair group.  Returns the instruction list."""
+ACCS = (144, 220)      # two accumulator sets: group g + 1 multiplies into one while group g's sums leave the other
+
+
+def group(wcur, wnxt, F, P, pending):
+    """One 16-pair group accumulating in set P.  On entry: rows of the group in AN (refills in flight), its sums in CIN, the list
+    entry of the FOLLOWING group in v[e], s[lastm] = this is the step's last group; pending: the previous group's sums still
+    sit in set 1 - P and leave for LDS (address v[addr_prev]) behind this group's first MFMAs."""
     lines = []
     after = {i: [] for i in range(-1, 64)}      # instructions issued right behind MFMA i (-1: ahead of the first)
     entry, lastm, grem = S['entry'], S['lastm'], S['grem']
-    # ---- top: rows of this group's first block and its sums have landed
-    after[-1] += [f"s_waitcnt vmcnt(3) lgkmcnt(4)",
-                  f"s_cmp_eq_u32 {s(grem)}, 1",
-                  f"s_cselect_b64 {s(lastm, 2)}, -1, 0",
-                  f"s_cselect_b32 {s(S['t'])}, {s(S['lb_ns'])}, {s(entry)}",
-                  f"v_add_u32 {v(V['t0'])}, {s(S['t'])}, {v(V['lst8'])}",
-                  f"ds_read_b64 {v(V['e'], 2)}, {v(V['t0'])}"]
+    acc, accp = ACCS[P], ACCS[1 - P]
+    after[-1] += timed_wait("s_waitcnt vmcnt(3) lgkmcnt(0)", 100)
     # ---- list entry of the following group -> its sums' address, its rows' address
-    addr = [f"s_add_u32 {s(entry)}, {s(entry)}, 128",
-            f"v_cndmask_b32_e64 {v(V['xsel'])}, {v(V['xbc'])}, {v(V['xbn'])}, {s(lastm, 2)}",
+    addr = [f"v_cndmask_b32_e64 {v(V['xsel'])}, {v(V['xbc'])}, {v(V['xbn'])}, {s(lastm, 2)}",
             f"v_cndmask_b32_e64 {v(V['xsel'] + 1)}, {v(V['xbc'] + 1)}, {v(V['xbn'] + 1)}, {s(lastm, 2)}",
-            f"s_waitcnt lgkmcnt(0)",
             f"v_mad_u32_u24 {v(V['addr_nxt'])}, {v(V['e'] + 1)}, {s(S['c272'])}, {v(V['ysq'])}",
             f"v_mad_u64_u32 {v(V['xaddr'], 2)}, vcc, {v(V['e'])}, {s(S['ldx4'])}, {v(V['xsel'], 2)}",
             f"v_cndmask_b32_e64 {v(V['pf'])}, {v(V['addr_nxt'])}, {v(V['addr_cur'])}, {s(lastm, 2)}"]
+    writes = [f"ds_write_b128 {v(V['addr_prev'])}, {v(accp + 4 * ct, 4)}" + (f" offset:{16 * ct}" if ct else "")
+              for ct in range(4)] if pending else []
+    # sums of the following group (a dummy re-read of the own rows in a step's last group): behind MFMA 3, the last reader of CIN
+    pf = [f"ds_read_b128 {v(CIN + 4 * ct, 4)}, {v(V['pf'])} offset:{16 * ct}" for ct in range(4)]
     extras_valu = []      # compaction (VALU / SALU / LDS writes)
     extras_vmem = []      # loads with their pointer arithmetic
     if F == 2:
@@ -165,23 +193,34 @@ def group(wcur, wnxt, F, tag):
                         f"s_cmp_lt_u32 {s(S['t'])}, {s(S['K3'])}",
                         f"s_cselect_b64 {s(S['kv'], 2)}, -1, 0"]
         extras_valu += compaction(V['i0'], V['i1'], S['lb_nn'], S['ng_nn'], S['kv'])
-    if F >= 1:
+    if F >= 1 and not (ABL & 2):
         extras_vmem += w_loads(wnxt)
+    if ABL & 4:
+        writes, pf = [], []
+    if ABL & 8:
+        extras_valu = []
+    # what the NEXT group needs on entry: is it the step's last, the list entry of the group behind it (from the next step's
+    # list when the next group is the last), the addresses moved on
+    late = [f"s_sub_u32 {s(grem)}, {s(grem)}, 1",
+            f"s_cmp_eq_u32 {s(grem)}, 1",
+            f"s_cselect_b64 {s(lastm, 2)}, -1, 0",
+            f"s_cselect_b32 {s(S['t'])}, {s(S['lb_ns'])}, {s(entry)}",
+            f"s_add_u32 {s(entry)}, {s(entry)}, 128",
+            f"v_add_u32 {v(V['t0'])}, {s(S['t'])}, {v(V['lst8'])}",
+            f"ds_read_b64 {v(V['e'], 2)}, {v(V['t0'])}",
+            f"v_mov_b32 {v(V['addr_prev'])}, {v(V['addr_cur'])}",
+            f"v_mov_b32 {v(V['addr_cur'])}, {v(V['addr_nxt'])}"]
     # placement: at most PER instructions per MFMA gap.  Block 0: the loads of the step (neighbour rows, weights: ahead of
-    # refill 0, so that the following group finds its rows behind them in the queue) with the address math from gap 3 on
-    # (one LDS round trip behind the entry read); the compaction follows in blocks 1 and 2.  Gaps 15 / 31 / 47 / 63 belong to
-    # the refills.  The block waits below are counted from the real issue order.
-    PER = int(os.environ.get("CMA_PER", "3"))
-    n0 = min(len(extras_vmem), 3 * PER)
-    # (sums of the following group — a dummy re-read of the own rows in a step's last group —: behind the address math and
-    # behind MFMA 3, the last reader of CIN)
-    pf = [f"ds_read_b128 {v(CIN + 4 * ct, 4)}, {v(V['pf'])} offset:{16 * ct}" for ct in range(4)]
-    order = extras_vmem[:n0] + [None] + addr + extras_vmem[n0:] + pf + extras_valu      # None: not before gap 3
+    # refill 0) with the address math; the previous group's sums leave from gap 1 on (12 wait states behind its last MFMA);
+    # the compaction follows in blocks 1 and 2.  Gaps 15 / 31 / 47 / 63 belong to the refills, 50.. to `late`.
+    PER = int(os.environ.get("CMA_PER", "3")) if F else int(os.environ.get("CMA_PER0", "2"))
+    n0 = min(len(extras_vmem), 2 * PER)
+    order = extras_vmem[:n0] + addr + [1] + writes + extras_vmem[n0:] + [3] + pf + extras_valu      # int: not before that gap
     gap, cnt_in_gap = 0, 0
     for ins in order:
-        if ins is None:
-            if gap < 3:
-                gap, cnt_in_gap = 3, 0
+        if isinstance(ins, int):
+            if gap < ins:
+                gap, cnt_in_gap = ins, 0
             continue
         if cnt_in_gap >= PER:
             gap, cnt_in_gap = gap + 1, 0
@@ -191,10 +230,16 @@ def group(wcur, wnxt, F, tag):
             raise SystemExit("extras do not fit")
         after[gap].append(ins)
         cnt_in_gap += 1
-    last_extra_gap = gap
+    gap, cnt_in_gap = 49, 0
+    for ins in late:
+        if cnt_in_gap >= PER:
+            gap, cnt_in_gap = gap + 1, 0
+        after[gap].append(ins)
+        cnt_in_gap += 1
     # refills
     for cb in range(4):
-        after[16 * cb + 15].append(f"global_load_dwordx4 {v(AN + 4 * cb, 4)}, {v(V['xaddr'], 2)}, off offset:{64 * cb}")
+        if not (ABL & 1):
+            after[16 * cb + 15].append(f"global_load_dwordx4 {v(AN + 4 * cb, 4)}, {v(V['xaddr'], 2)}, off offset:{64 * cb}")
     # ---- emit, computing vmcnt for blocks 1..3 from the issue order
     issued = 0
 
@@ -209,22 +254,25 @@ def group(wcur, wnxt, F, tag):
     m_idx = 0
     for cb in range(4):
         if cb > 0:
-            lines.append(f"s_waitcnt vmcnt({(3 - cb) + issued})")
+            lines += timed_wait(f"s_waitcnt vmcnt({(3 - cb) + issued})", 100)
         for s2 in range(4):
             for ct in range(4):
-                lines.append(mfma(wcur, cb, s2, ct, cb == 0 and s2 == 0))
+                a = wcur + 16 * cb + 4 * s2 + ct
+                b = AN + 4 * cb + s2
+                d = acc + 4 * ct
+                c = CIN + 4 * ct if (cb == 0 and s2 == 0) else d
+                lines.append(f"v_mfma_f32_16x16x4_f32 {v(d, 4)}, {v(a)}, {v(b)}, {v(c, 4)}")
                 emit_gap(m_idx)
                 m_idx += 1
-    # ---- tail: the MFMA results (12 wait states behind the last MFMA), write back, next
-    lines += ["s_nop 9",
-              f"ds_write_b128 {v(V['addr_cur'])}, {v(ACC, 4)}",
-              f"ds_write_b128 {v(V['addr_cur'])}, {v(ACC + 4, 4)} offset:16",
-              f"ds_write_b128 {v(V['addr_cur'])}, {v(ACC + 8, 4)} offset:32",
-              f"ds_write_b128 {v(V['addr_cur'])}, {v(ACC + 12, 4)} offset:48",
-              f"v_mov_b32 {v(V['addr_cur'])}, {v(V['addr_nxt'])}",
-              f"s_sub_u32 {s(grem)}, {s(grem)}, 1",
-              f"s_cmp_lg_u32 {s(grem)}, 0"]
+    lines.append(f"s_cmp_lg_u32 {s(grem)}, 0")
     return lines
+
+
+def flush(P):
+    """The sums of a step's last group leave for LDS (12 wait states behind the last MFMA)."""
+    acc = ACCS[P]
+    return ["s_nop 10"] + [f"ds_write_b128 {v(V['addr_prev'])}, {v(acc + 4 * ct, 4)}" + (f" offset:{16 * ct}" if ct else "")
+                           for ct in range(4)]
 
 
 def step_code(cur, nxt, name, other):
@@ -232,13 +280,24 @@ def step_code(cur, nxt, name, other):
     L = []
     t, t2 = S['t'], S['t2']
     L.append(f"L_step{name}_%=:")
-    # ---- the next step: channel block, list, groups, weights, rows
+    L += stamp('top')
+    # ---- sums of the first group (behind every earlier write in program order): their latency covers the bookkeeping
+    L += [f"ds_read_b128 {v(CIN + 4 * ct, 4)}, {v(V['addr_cur'])} offset:{16 * ct}" for ct in range(4)]
+    # ---- the next step's channel block and list; what the first group needs on entry (is it the last; the list entry of the
+    # group behind it) goes out first: one LDS round trip that the rest of the bookkeeping covers
     L += [f"s_add_u32 {s(t)}, {s(S['sb'])}, 1",
           f"s_cmp_eq_u32 {s(t)}, {s(S['NSB'])}",
           f"s_cselect_b32 {s(S['last_sb'])}, 1, 0",
           f"s_cselect_b32 {s(S['nsb'])}, 0, {s(t)}",
           f"s_cselect_b32 {s(S['lb_ns'])}, {s(S['lb_nxt'])}, {s(S['lb_cur'])}",
-          f"s_cselect_b32 {s(S['ng_ns'])}, {s(S['ng_nxt'])}, {s(S['ng_cur'])}",
+          f"s_mov_b32 {s(S['grem'])}, {s(S['ng_cur'])}",
+          f"s_add_u32 {s(t)}, {s(S['lb_cur'])}, 128",
+          f"s_add_u32 {s(S['entry'])}, {s(S['lb_cur'])}, 256",
+          f"s_cmp_eq_u32 {s(S['grem'])}, 1",
+          f"s_cselect_b64 {s(S['lastm'], 2)}, -1, 0",
+          f"s_cselect_b32 {s(t)}, {s(S['lb_ns'])}, {s(t)}",
+          f"v_add_u32 {v(V['t0'])}, {s(t)}, {v(V['lst8'])}",
+          f"ds_read_b64 {v(V['e'], 2)}, {v(V['t0'])}",
           # weights of the next step: same offset, next block — or the next offset (the last step re-reads its own)
           f"s_mul_i32 {s(t2)}, {s(S['nsb'])}, {s(S['cout4'])}",
           f"s_lshl_b32 {s(t2)}, {s(t2)}, 6",
@@ -249,8 +308,6 @@ def step_code(cur, nxt, name, other):
           f"s_cselect_b32 {s(t)}, {s(t)}, {s(t2)}",
           f"s_add_u32 {s(S['Wl'])}, {s(S['Wk'])}, {s(t)}",
           f"s_addc_u32 {s(S['Wl'] + 1)}, {s(S['Wk'] + 1)}, 0",
-          f"s_cmp_eq_u32 {s(S['steps'])}, 1",
-          f"s_cselect_b32 {s(S['ng_ns'])}, 0, {s(S['ng_ns'])}",
           # rows: X + 256 sb (+ 16 q per lane), this step's and the next one's
           f"s_lshl_b32 {s(S['xoffc'])}, {s(S['sb'])}, 8",
           f"s_lshl_b32 {s(S['xoffn'])}, {s(S['nsb'])}, 8",
@@ -266,22 +323,29 @@ def step_code(cur, nxt, name, other):
           f"v_addc_co_u32_e32 {v(V['xbn'] + 1)}, vcc, 0, {v(V['xbn'] + 1)}, vcc",
           f"s_cmp_eq_u32 {s(S['ng_cur'])}, 0",
           f"s_cbranch_scc1 L_empty{name}_%="]
-    # ---- sums of the first group (behind every earlier write in program order)
-    L += [f"ds_read_b128 {v(CIN + 4 * ct, 4)}, {v(V['addr_cur'])} offset:{16 * ct}" for ct in range(4)]
-    L += [f"s_mov_b32 {s(S['grem'])}, {s(S['ng_cur'])}",
-          f"s_add_u32 {s(S['entry'])}, {s(S['lb_cur'])}, 128",
-          "s_waitcnt lgkmcnt(0)",
-          f"s_cmp_eq_u32 {s(S['sb'])}, 0",
+    L += stamp('top')
+    L += [f"s_cmp_eq_u32 {s(S['sb'])}, 0",
           f"s_cbranch_scc1 L_f2{name}_%="]
-    # F1 group
-    L += group(cur, nxt, 1, name + "f1")
-    L += [f"s_cbranch_scc1 L_plain{name}_%=", f"s_branch L_end{name}_%="]
+    L += group(cur, nxt, 1, 0, False)
+    L += stamp('F', 'nF') + ([f"s_cmp_lg_u32 {s(S['grem'])}, 0"] if STAMPS else [])
+    L += [f"s_cbranch_scc1 L_plain1{name}_%=", f"s_branch L_flush0{name}_%="]
     L.append(f"L_f2{name}_%=:")
-    L += group(cur, nxt, 2, name + "f2")
-    L += [f"s_cbranch_scc0 L_end{name}_%="]
-    L.append(f"L_plain{name}_%=:")
-    L += group(cur, nxt, 0, name + "p")
-    L += [f"s_cbranch_scc1 L_plain{name}_%=", f"s_branch L_end{name}_%="]
+    L += group(cur, nxt, 2, 0, False)
+    L += stamp('F', 'nF') + ([f"s_cmp_lg_u32 {s(S['grem'])}, 0"] if STAMPS else [])
+    L += [f"s_cbranch_scc0 L_flush0{name}_%="]
+    L.append(f"L_plain1{name}_%=:")
+    L += group(cur, nxt, 0, 1, True)
+    L += stamp('P', 'nP') + ([f"s_cmp_lg_u32 {s(S['grem'])}, 0"] if STAMPS else [])
+    L += [f"s_cbranch_scc0 L_flush1{name}_%="]
+    L += group(cur, nxt, 0, 0, True)
+    L += stamp('P', 'nP') + ([f"s_cmp_lg_u32 {s(S['grem'])}, 0"] if STAMPS else [])
+    L += [f"s_cbranch_scc1 L_plain1{name}_%="]
+    L.append(f"L_flush0{name}_%=:")
+    L += flush(0)
+    L += [f"s_branch L_end{name}_%="]
+    L.append(f"L_flush1{name}_%=:")
+    L += flush(1)
+    L += [f"s_branch L_end{name}_%="]
     # ---- a step without a pair in this tile: its bookkeeping, exposed
     L.append(f"L_empty{name}_%=:")
     L += [f"s_cmp_eq_u32 {s(S['sb'])}, 0", f"s_cbranch_scc0 L_empty_w{name}_%="]
@@ -374,6 +438,9 @@ def program():
           f"s_mov_b32 {s(S['sb'])}, 0",
           f"s_mov_b32 {s(S['koff'])}, 0",
           f"s_mov_b32 {s(S['ng_nn'])}, 0"]
+    if STAMPS:
+        L += [f"s_mov_b64 {s(ST[x], 2)}, 0" for x in ('top', 'F', 'P')] + [f"s_mov_b32 {s(ST['nF'])}, 0", f"s_mov_b32 {s(ST['nP'])}, 0", "s_mov_b32 s100, 0", "s_mov_b32 s101, 0",
+              f"s_memtime {s(ST['prev'], 2)}", "s_waitcnt lgkmcnt(0)"]
     # ---- neighbour rows of offsets 0, 1, 2; weights of step 0
     L += nv_loads(V['i0'], V['i1'])
     L += nv_loads(V['i2'], V['i3'])
@@ -397,13 +464,18 @@ def program():
     L += step_code(WA, WB, "A", "B")
     L += step_code(WB, WA, "B", "A")
     L += ["L_done_%=:", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    if STAMPS:
+        L += stamp('top')
+        L += [f"v_mov_b32 %[o{i}], {s(ST['top'] + i)}" for i in range(8)] + [f"v_mov_b32 %[o8], s100", f"v_mov_b32 %[o9], s101"]
     return L
 
 
 def main():
+    global ABL
     out = sys.argv[1] if len(sys.argv) > 1 else "cmp_asm.inc"
+    variants = [int(x) for x in os.environ.get("CMA_VARIANTS", "").split(",") if x]
     L = program()
-    clob = ["memory", "vcc", "scc"] + [f"v{i}" for i in range(0, NV_LAST + 1)] + [f"s{i}" for i in range(S_FIRST, S_LAST + 1)]
+    clob = ["memory", "vcc", "scc"] + [f"v{i}" for i in range(0, NV_LAST + 1)] + [f"s{i}" for i in range(S_FIRST, (101 if STAMPS else S_LAST) + 1)]
     with open(out, "w") as f:
         f.write("// GENERATED by gen_cmp_asm.py - do not edit\n")
         f.write(f"#define CMA_LDS_BYTES {LDS_BYTES}\n#define CMA_LDS_LISTS {LDS_LISTS}\n#define CMA_LDS_DUMP {LDS_DUMP}\n"
@@ -413,6 +485,14 @@ def main():
             f.write(f'    "{ins}\\n\\t" \\\n')
         f.write('    ""\n')
         f.write("#define CMA_ASM_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
+        for a in variants:       # experiment builds only (CMA_VARIANTS=1,2,...)
+            ABL = a
+            f.write(f"#define CMA_ASM_TEXT_V{a} \\\n")
+            for ins in program():
+                f.write(f'    "{ins}\\n\\t" \\\n')
+            f.write('    ""\n')
+        ABL = 0
+        f.write("#define CMA_VARIANT_LIST " + " ".join(f"CMA_V({a})" for a in variants) + "\n")
     n_mfma = sum(1 for i in L if i.startswith("v_mfma"))
     print(f"{out}: {len(L)} instructions, {n_mfma} MFMAs", file=sys.stderr)
 

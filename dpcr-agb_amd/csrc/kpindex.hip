@@ -524,7 +524,7 @@ int agb_csr_to_padded(const int32_t* row_ptr, const int32_t* indices, int nq, in
 // cell_of[n], members[n], scan_scratch[agb_scan_scratch_elems(B*cap+1)]; origin float[3B].
 // Outputs: out_pts float[n*3] (upper bound), out_feats float[n*fdim] or NULL, out_ptr int32[B+1] (row range of every
 // element in the output), n_out_dev.
-int agb_grid_subsample(const float* pts, const float* feats, int fdim, int n, const int32_t* ptr,
+AGB_INTERNAL int agb_grid_subsample(const float* pts, const float* feats, int fdim, int n, const int32_t* ptr,
                        const int32_t* elem, int B, float dl, int cap, int32_t* bbox_ord, float* origin,
                        int32_t* dims, int32_t* cell_cnt, int32_t* cell_start, int32_t* slot, int32_t* flag,
                        int32_t* cell_of, int32_t* members, int32_t* scan_scratch, float* out_pts, float* out_feats,

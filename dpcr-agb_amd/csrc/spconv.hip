@@ -1217,13 +1217,9 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
 // (offset, 64-channel step, 4-channel MFMA), each MFMA adding its 4 products to the running sum: deterministic, but not the
 // rounding order of k_spconv_cmp (which sums a 64-channel step from zero first).
 #ifdef AGB_TIMELINE
-__device__ unsigned long long g_cmpt_stamp[16];
-#define CMPT_STAMP(t) do { if (ABL & 16) { __builtin_amdgcn_sched_barrier(0); \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define CMPT_STAMP(t) do { } while (0)
+__device__ unsigned long long g_cmpt_stamp[16];   // stamp sums of the diagnostic build of k_spconv_cma
 #endif
-template <int R, int ABL = 0>
+template <int R>
 __global__ __launch_bounds__(64) void k_spconv_cmpt(ConvArgs a, int ntiles, int nct, int rows_per_tile, int csplit,
                                                     int il_shift) {
     constexpr int NJ = R / 64;
@@ -1328,13 +1324,9 @@ __global__ __launch_bounds__(64) void k_spconv_cmpt(ConvArgs a, int ntiles, int 
     };
 
     f32x4* const Ys4 = reinterpret_cast<f32x4*>(Ys);
-    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_f = 0;
-    unsigned long long acc_pro = 0, acc_s[5] = {0, 0, 0, 0, 0}, acc_ng = 0, acc_steps = 0;
-    (void)st_a; (void)st_b; (void)st_c; (void)st_d; (void)st_e; (void)st_f; (void)acc_pro; (void)acc_s; (void)acc_ng; (void)acc_steps;
     f32x4 cin[4];   // running sums of the group about to be multiplied (accumulator ct: 4 adjacent floats of its row)
     int ng_cur, ng_nxt = 0;
     auto body = [&](int step, float4 (&bcur)[CB][4], float4 (&bnxt)[CB][4]) {
-        CMPT_STAMP(st_a);
         const int k = step / NSB;
         const int nstep = step + 1;
         const int* lo = pl_out[k & 1];
@@ -1346,13 +1338,12 @@ __global__ __launch_bounds__(64) void k_spconv_cmpt(ConvArgs a, int ntiles, int 
         if (nstep < nsteps) {
             const int nk = nstep / NSB;
             if (nk != k) {
-                if (ABL & 8) ng_nxt = ng_cur; else {
                 ng_nxt = compact(nk);
-                if (nk + 1 < K3) load_nbr(nk + 1); }
+                if (nk + 1 < K3) load_nbr(nk + 1);
             } else {
                 ng_nxt = ng_cur;
             }
-            if (!(ABL & 2)) load_b(nstep, bnxt);
+            load_b(nstep, bnxt);
         } else {
             ng_nxt = 0;
         }
@@ -1364,10 +1355,7 @@ __global__ __launch_bounds__(64) void k_spconv_cmpt(ConvArgs a, int ntiles, int 
 #ifdef AGB_TIMELINE
         tl_groups += ng_cur;
 #endif
-        CMPT_STAMP(st_b);
-        if (ABL & 16) { acc_pro += st_b - st_a; acc_steps += 1; acc_ng += ng_cur; }
         for (int g = 0; g < ng_cur; ++g) {
-            CMPT_STAMP(st_b);
             const bool last = g + 1 == ng_cur;
             const bool tonext = last && ng_nxt > 0;
             const int pg = last ? 0 : g + 1;
@@ -1392,24 +1380,16 @@ __global__ __launch_bounds__(64) void k_spconv_cmpt(ConvArgs a, int ntiles, int 
                 if (cb == 1) {
                     // sums of the next group, two thirds of a group ahead of their use
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) if (!(ABL & 4)) cin[ct] = Ys4[addr_nxt + ct];
+                    for (int ct = 0; ct < 4; ++ct) cin[ct] = Ys4[addr_nxt + ct];
                 }
                 asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : : "memory");
-                if (!(ABL & 1)) an[cb] = ld;
-                if (ABL & 16) {
-                    if (cb == 0) { CMPT_STAMP(st_c); acc_s[0] += st_c - st_b; }
-                    if (cb == 1) { CMPT_STAMP(st_d); acc_s[1] += st_d - st_c; }
-                    if (cb == 2) { CMPT_STAMP(st_e); acc_s[2] += st_e - st_d; }
-                    if (cb == 3) { CMPT_STAMP(st_f); acc_s[3] += st_f - st_e; }
-                }
+                an[cb] = ld;
             }
-            if (!(ABL & 4)) {
             Ys4[addr_cur + 0] = c0;
             Ys4[addr_cur + 1] = c1;
             Ys4[addr_cur + 2] = c2;
-            Ys4[addr_cur + 3] = c3; } else { cin[0] = c0; cin[1] = c1; cin[2] = c2; cin[3] = c3; }
+            Ys4[addr_cur + 3] = c3;
             addr_cur = addr_nxt;
-            if (ABL & 16) { CMPT_STAMP(st_c); acc_s[4] += st_c - st_f; }
         }
         ng_cur = ng_nxt;
     };
@@ -1421,292 +1401,6 @@ __global__ __launch_bounds__(64) void k_spconv_cmpt(ConvArgs a, int ntiles, int 
     if (K3 > 1) load_nbr(1);
     load_b(0, bA);
     if (ng_cur > 0) gather(0, 0);
-    for (int step = 0; step < nsteps; step += 2) {
-        body(step, bA, bB);
-        if (step + 1 < nsteps) body(step + 1, bB, bA);
-    }
-    if (ABL & 4) { Ys4[lane] = cin[0] + cin[1] + cin[2] + cin[3]; }
-    if (ABL & 2) { Ys[lane] += bB[0][0].x; }
-    __threadfence_block();
-    // ---- epilogue: tile -> global.  Column 16 a + 4 b + c of a row sits at position 16 a + 4 c + b: the four columns
-    // 4 mm .. 4 mm + 3 of a lane are four floats 16 bytes apart.
-    const int mm = lane & 15;
-    const int c4 = mm * 4;
-    const int pos0 = 16 * (mm >> 2) + (mm & 3);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias && csplit == 1 && n0 + c4 < Cout) bv = *reinterpret_cast<const float4*>(a.bias + n0 + c4);
-    float* out = csplit > 1 ? a.partial + (long long)sp * a.n_out * Cout : a.Y;
-    const int ldo = csplit > 1 ? Cout : a.ldy;
-    const bool col_ok = n0 + c4 < Cout;
-    for (int r0 = lane >> 4; r0 < rows_per_tile; r0 += 32) {
-        int rows[8];
-        float4 ys[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = r0 + 4 * u;
-            rows[u] = r < rows_per_tile ? s_row[r] : -1;
-            const float* yr = &Ys[min(r, R) * CMP_YS + pos0];
-            ys[u] = make_float4(yr[0], yr[4], yr[8], yr[12]);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (rows[u] >= 0 && col_ok) {
-                float4 y = ys[u];
-                y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
-                *reinterpret_cast<float4*>(out + (long long)rows[u] * ldo + n0 + c4) = y;
-            }
-        }
-    }
-#ifdef AGB_TIMELINE
-    if (lane == 0 && blockIdx.x < AGB_TIMELINE_SLOTS) {
-        unsigned long long* e = g_cmp_timeline + 4 * blockIdx.x;
-        e[0] = tl_t0; e[1] = wall_clock64(); e[2] = __builtin_readcyclecounter() - tl_c0; e[3] = tl_groups;
-    }
-    if ((ABL & 16) && lane == 0) {
-        atomicAdd(&g_cmpt_stamp[0], acc_pro); atomicAdd(&g_cmpt_stamp[1], acc_steps); atomicAdd(&g_cmpt_stamp[2], acc_ng);
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_cmpt_stamp[3 + i], acc_s[i]);
-        atomicAdd(&g_cmpt_stamp[8], __builtin_readcyclecounter() - tl_c0);
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_spconv_cmpp: k_spconv_cmpt with the PER-STEP work moved into the matrix pipe's shadow (round 5).
-// Stamps in k_spconv_cmpt (tools/cmpt_stamps.py) put ~1000-1200 clocks per step (64 channels of one offset: 3.8-5.4
-// groups of 2048 MFMA clocks) into the step prologue — pair compaction of the next offset, the next neighbour loads, 16
-// weight loads with their addresses, ~130 scalar instructions — during which this wave, alone on its SIMD, issues no MFMA.
-// Here that work rides in the FIRST group of a step, between its MFMA blocks:
-//   * three list buffers (offset k in buffer k % 3): the lists of offset k + 2 are compacted during the first group of
-//     offset k, branch-free (lanes without a pair write to a dump slot; neighbour loads are clamped, not predicated), so
-//     the whole group stays one basic block the scheduler can interleave;
-//   * the weights of step s + 1 are requested during the first group of step s (four loads behind each 16-MFMA block);
-//   * offset / channel-block counters are carried, not divided out of the step number;
-//   * the sums of a step's first group are fetched at the end of the previous step's last group when that is safe
-//     (lists are ascending in the local row: the first group of the next list ends below the start of this group — or the
-//     same list, more than one group), else behind that group's write.
-// Same arithmetic, same order per row as k_spconv_cmpt: bit-identical results.
-template <int R, int ABL = 0>
-__global__ __launch_bounds__(64) void k_spconv_cmpp(ConvArgs a, int ntiles, int nct, int rows_per_tile, int csplit,
-                                                    int il_shift) {
-    constexpr int NJ = R / 64;
-    constexpr int CB = CMP_CB;
-    constexpr int LP = R + 16;   // list pitch
-    __shared__ __attribute__((aligned(16))) float Ys[(R + 1) * CMP_YS];   // row R: sink of the list padding
-    __shared__ __attribute__((aligned(16))) int pl_in[3 * LP];
-    __shared__ __attribute__((aligned(16))) int pl_out[3 * LP];
-    __shared__ int s_dump[64];
-    __shared__ int s_row[R];
-    const int lane = threadIdx.x;
-    const int m = lane & 15, q = lane >> 4;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int per_xcd = (ntiles + 7) >> 3;
-    const int ct0 = jx % nct;
-    const int sp = (jx / nct) % csplit;
-    const int tile = xcd * per_xcd + jx / (nct * csplit);
-    if (tile >= ntiles || jx / (nct * csplit) >= per_xcd) return;
-    const int row0 = tile * rows_per_tile;
-    const int row_end = min(a.n_out, row0 + rows_per_tile);
-    auto grow = [&](int rl) -> int {
-        if (il_shift == 0) return row0 + rl < row_end ? row0 + rl : -1;
-        if (rl >= rows_per_tile) return -1;
-        const int blk = a.tile_blocks ? a.tile_blocks[tile * (rows_per_tile >> il_shift) + (rl >> il_shift)]
-                                      : (rl >> il_shift) * ntiles + tile;
-        const int r = (blk << il_shift) | (rl & ((1 << il_shift) - 1));
-        return (blk >= 0 && r < a.n_out) ? r : -1;
-    };
-    int myrow[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        myrow[j] = grow(64 * j + lane);
-        s_row[64 * j + lane] = myrow[j];
-    }
-    const int n0 = ct0 * 64;
-    const int K3 = a.K3, Cin = a.Cin, Cout = a.Cout;
-    const int NSB = Cin / (CB * 16) / csplit;            // 64-channel steps per offset handled here
-    const int c_first = sp * NSB * (CB * 16);
-    const int nsteps = K3 * NSB;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const bool colok = (n0 + 4 * m) < Cout;
-    const int coff = colok ? 4 * m : 0;
-    f32x4* const Ys4 = reinterpret_cast<f32x4*>(Ys);
-
-#ifdef AGB_TIMELINE
-    const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
-    unsigned long long tl_groups = 0;
-#endif
-    // neighbour rows of offset kk for this lane's rows (clamped loads, selected afterwards: no branch)
-    // (raw values: rows past the tile's end and offsets past K3 are masked where the lists are built — a select here
-    // would wait for the load on the spot)
-    int rowc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) rowc[j] = max(myrow[j], 0);
-    auto load_nbr = [&](int kk, int (&v)[NJ]) {
-        const int kc = min(kk, K3 - 1);
-        const int kn = a.kflip ? (K3 - 1 - kc) : kc;
-        const int32_t* nk = a.nbr + (long long)kn * a.nbr_stride;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = __builtin_nontemporal_load(nk + rowc[j]);
-    };
-    int nv[NJ], nv1[NJ], nv2[NJ];
-    load_nbr(0, nv);
-    load_nbr(1, nv1);
-    load_nbr(2, nv2);
-    for (int i = lane; i < (R + 1) * CMP_YS / 4; i += 64) Ys4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // every list entry is a valid (input row, local row) at any time (sums and rows are also fetched speculatively)
-    for (int i = lane; i < 3 * LP; i += 64) {
-        pl_in[i] = 0;
-        pl_out[i] = R;
-    }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    // pairs of the offset whose neighbour rows are in v -> list buffer b, padded to a multiple of 16; returns groups
-    auto compact = [&](const int (&v)[NJ], int b, bool kvalid) -> int {
-        int* li = pl_in + b * LP;
-        int* lo = pl_out + b * LP;
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const bool p = (v[j] >= 0) & (myrow[j] >= 0) & kvalid;
-            const unsigned long long bal = __ballot(p);
-            const int pos = cnt + __popcll(bal & lt_mask);
-            (p ? li + pos : s_dump + lane)[0] = v[j];
-            (p ? lo + pos : s_dump + lane)[0] = 64 * j + lane;
-            cnt += __popcll(bal);
-        }
-        const int cpad = (cnt + 15) & ~15;
-        const bool pd = lane < cpad - cnt;
-        (pd ? li + cnt + lane : s_dump + lane)[0] = 0;
-        (pd ? lo + cnt + lane : s_dump + lane)[0] = R;
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        return cpad >> 4;
-    };
-    // weights of (offset kk, channel block sbb) = the MFMA's A operand: lane (m, q): W[kk][c0 + 16 cb + 4 q + s2][n0 + 4 m + ct]
-    auto wptr = [&](int kk, int sbb) -> const float* {
-        return a.W + ((long long)kk * Cin + c_first + sbb * (CB * 16) + 4 * q) * Cout + n0 + coff;
-    };
-    float4 an[CB];   // gathered row pieces of the current group = the B operand: lane (j, q): X[in_j][c0 + 16 cb + 4 q ..]
-
-    int k = 0, sb = 0, kb = 0;          // offset, channel block and list buffer (k % 3) of the current step
-    int ng_cur, ng_nxt, ng_nn = 0;      // groups of offsets k, k + 1, k + 2
-    ng_cur = compact(nv, 0, true);
-    ng_nxt = compact(nv1, 1, K3 > 1);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) nv[j] = nv2[j];   // nv: neighbour rows of offset k + 2
-    f32x4 cin[4];                       // running sums of the group about to be multiplied
-    int addr_first = pl_out[m] * (CMP_YS / 4) + 4 * q;   // sums of the first group of the current step (16-byte units)
-    f32x4 bA[CB][4], bB[CB][4];
-    auto load_w = [&](const float* Wk, f32x4 (&b)[CB][4], int cb) {
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            b[cb][s2] = *reinterpret_cast<const f32x4*>(Wk + (cb * 16 + s2) * Cout);
-        }
-    };
-    {
-        const float* Wk = wptr(0, 0);
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) load_w(Wk, bA, cb);
-        const float* xr = a.X + (long long)pl_in[m] * a.ldx + c_first + 4 * q;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) an[cb] = *reinterpret_cast<const float4*>(xr + cb * 16);
-    }
-
-    // F: 0 = plain group, 1 = + the next step's weight loads, 2 = + those and the compaction of offset k + 2
-    auto group = [&](auto FT, int g, int ngc, int ng_ns, const int* li_c, const int* lo_c, const int* li_n, const int* lo_n,
-                     int xoff_c, int xoff_n, const float* Wn, int& addr_cur, f32x4 (&bcur)[CB][4], f32x4 (&bnxt)[CB][4]) {
-        constexpr int F = decltype(FT)::value;
-        const bool last = g + 1 == ngc;
-        const int pg = last ? 0 : g + 1;
-        // list entries of the group that follows: the next one of this step, or the first one of the next step (always
-        // valid entries: with no next group the fetched rows and sums are simply not used)
-        const int e_out = (last ? lo_n : lo_c)[16 * pg + m];
-        const int e_in = (last ? li_n : li_c)[16 * pg + m];
-        const int addr_nxt = e_out * (CMP_YS / 4) + 4 * q;
-        const float* xnext = a.X + (long long)e_in * a.ldx + (last ? xoff_n : xoff_c);
-        // sums of the next group of this step; the last group re-reads its own (the next step fetches its first sums
-        // behind this group's write: another offset may hold the same rows)
-        const int addr_pf = last ? addr_cur : addr_nxt;
-        f32x4 c0 = cin[0], c1 = cin[1], c2 = cin[2], c3 = cin[3];
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            const float av[4] = {an[cb].x, an[cb].y, an[cb].z, an[cb].w};
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[cb][s2][0], av[s2], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[cb][s2][1], av[s2], c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[cb][s2][2], av[s2], c2, 0, 0, 0);
-                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[cb][s2][3], av[s2], c3, 0, 0, 0);
-            }
-            asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : : "memory");
-            const float4 ld = *reinterpret_cast<const float4*>(xnext + cb * 16);
-            if (cb == 1) {
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) cin[ct] = Ys4[addr_pf + ct];
-            }
-            asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : : "memory");
-            an[cb] = ld;
-            // the step's extra work, in the shadow of the next MFMA block
-            if (F == 2 && cb == 0) {
-                ng_nn = compact(nv, kb == 0 ? 2 : kb - 1, k + 2 < K3);      // offset k + 2 -> buffer (k + 2) % 3
-                load_nbr(k + 3, nv);
-            }
-            if (F >= 1) load_w(Wn, bnxt, cb);
-        }
-        Ys4[addr_cur + 0] = c0;
-        Ys4[addr_cur + 1] = c1;
-        Ys4[addr_cur + 2] = c2;
-        Ys4[addr_cur + 3] = c3;
-        addr_cur = addr_nxt;
-    };
-
-    auto body = [&](int step, f32x4 (&bcur)[CB][4], f32x4 (&bnxt)[CB][4]) {
-        const bool last_sb = sb + 1 == NSB;
-        const bool has_next = step + 1 < nsteps;
-        const int nk = last_sb ? min(k + 1, K3 - 1) : k, nsb = last_sb ? 0 : sb + 1;
-        const int nb = last_sb ? (kb == 2 ? 0 : kb + 1) : kb;
-        const int ng_ns = !has_next ? 0 : (last_sb ? ng_nxt : ng_cur);
-        const int* li_c = pl_in + kb * LP;
-        const int* lo_c = pl_out + kb * LP;
-        const int* li_n = pl_in + nb * LP;
-        const int* lo_n = pl_out + nb * LP;
-        const int xoff_c = c_first + sb * (CB * 16) + 4 * q, xoff_n = c_first + nsb * (CB * 16) + 4 * q;
-        const float* Wn = wptr(nk, nsb);
-#ifdef AGB_TIMELINE
-        tl_groups += ng_cur;
-#endif
-        if (ng_cur == 0) {
-            // no pair of this offset in the tile: the step's bookkeeping, exposed
-            if (sb == 0) {
-                ng_nn = compact(nv, kb == 0 ? 2 : kb - 1, k + 2 < K3);
-                load_nbr(k + 3, nv);
-            }
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) load_w(Wn, bnxt, cb);
-            addr_first = lo_n[m] * (CMP_YS / 4) + 4 * q;
-            const float* xr = a.X + (long long)li_n[m] * a.ldx + xoff_n;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) an[cb] = *reinterpret_cast<const float4*>(xr + cb * 16);
-        } else {
-            int addr_cur = addr_first;
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) cin[ct] = Ys4[addr_cur + ct];
-            const int ngc = ng_cur;
-            if (sb == 0)
-                group(std::integral_constant<int, 2>{}, 0, ngc, ng_ns, li_c, lo_c, li_n, lo_n, xoff_c, xoff_n, Wn,
-                      addr_cur, bcur, bnxt);
-            else
-                group(std::integral_constant<int, 1>{}, 0, ngc, ng_ns, li_c, lo_c, li_n, lo_n, xoff_c, xoff_n, Wn,
-                      addr_cur, bcur, bnxt);
-            for (int g = 1; g < ngc; ++g)
-                group(std::integral_constant<int, 0>{}, g, ngc, ng_ns, li_c, lo_c, li_n, lo_n, xoff_c, xoff_n, Wn,
-                      addr_cur, bcur, bnxt);
-            addr_first = addr_cur;
-        }
-        if (last_sb) {
-            ng_cur = ng_nxt; ng_nxt = ng_nn; ++k; kb = kb == 2 ? 0 : kb + 1; sb = 0;
-        } else {
-            ++sb;
-        }
-    };
-
     for (int step = 0; step < nsteps; step += 2) {
         body(step, bA, bB);
         if (step + 1 < nsteps) body(step + 1, bB, bA);
@@ -1753,7 +1447,11 @@ __global__ __launch_bounds__(64) void k_spconv_cmpp(ConvArgs a, int ntiles, int 
 // k_spconv_cma: k_spconv_cmpt's arithmetic with the whole main loop HAND-SCHEDULED (cmp_asm.inc, generated by
 // gen_cmp_asm.py: register map, program and wait accounting are documented there).  C++ keeps the tile mapping, the LDS
 // initialisation and the tile's final store; everything between is one asm statement.  128-row tiles, K3 >= 3.
+#ifdef AGB_TIMELINE
+#include "cmp_asm_stamps.inc"
+#else
 #include "cmp_asm.inc"
+#endif
 __global__ __launch_bounds__(64) void k_spconv_cma(ConvArgs a, int ntiles, int nct, int rows_per_tile, int csplit,
                                                    int il_shift) {
     constexpr int R = 128, CB = CMP_CB;
@@ -1800,12 +1498,33 @@ __global__ __launch_bounds__(64) void k_spconv_cma(ConvArgs a, int ntiles, int n
         const int rowc0 = max(myrow0, 0) * 4, rowc1 = max(myrow1, 0) * 4;
         const int woff = (4 * q * Cout + coff) * 4;
         const unsigned lds_base = (unsigned)(uintptr_t)lds;
+#ifdef AGB_TIMELINE
+        unsigned o0, o1, o2, o3, o4, o5, o6, o7, o8, o9;
+        asm volatile(CMA_ASM_TEXT
+                     : [o0] "=v"(o0), [o1] "=v"(o1), [o2] "=v"(o2), [o3] "=v"(o3), [o4] "=v"(o4), [o5] "=v"(o5), [o6] "=v"(o6),
+                       [o7] "=v"(o7), [o8] "=v"(o8), [o9] "=v"(o9)
+                     : [x] "s"(xb), [w] "s"(wb), [nb] "s"(nb), [nstep] "s"(nstep), [ldx4] "s"(a.ldx * 4), [cout4] "s"(Cout * 4),
+                       [wk4] "s"(Cin * Cout * 4), [k3] "s"(K3), [nsb] "s"(NSB), [valid0] "s"(valid0), [valid1] "s"(valid1),
+                       [lds] "s"(lds_base), [lane] "v"(lane), [woff] "v"(woff), [rowc0] "v"(rowc0), [rowc1] "v"(rowc1)
+                     : CMA_ASM_CLOBBERS);
+        if (lane == 0) {   // top / F / P clocks (64 bit each), F groups, P groups
+            atomicAdd(&g_cmpt_stamp[0], ((unsigned long long)o1 << 32) | o0);
+            atomicAdd(&g_cmpt_stamp[1], ((unsigned long long)o3 << 32) | o2);
+            atomicAdd(&g_cmpt_stamp[2], ((unsigned long long)o5 << 32) | o4);
+            atomicAdd(&g_cmpt_stamp[3], (unsigned long long)o6);
+            atomicAdd(&g_cmpt_stamp[4], (unsigned long long)o7);
+            atomicAdd(&g_cmpt_stamp[5], 1ull);
+            atomicAdd(&g_cmpt_stamp[6], (unsigned long long)o8);     // clocks in the five vmcnt waits of all groups
+            atomicAdd(&g_cmpt_stamp[7], (unsigned long long)o9);     // clocks in the list-entry waits
+        }
+#else
         asm volatile(CMA_ASM_TEXT
                      :
                      : [x] "s"(xb), [w] "s"(wb), [nb] "s"(nb), [nstep] "s"(nstep), [ldx4] "s"(a.ldx * 4), [cout4] "s"(Cout * 4),
                        [wk4] "s"(Cin * Cout * 4), [k3] "s"(K3), [nsb] "s"(NSB), [valid0] "s"(valid0), [valid1] "s"(valid1),
                        [lds] "s"(lds_base), [lane] "v"(lane), [woff] "v"(woff), [rowc0] "v"(rowc0), [rowc1] "v"(rowc1)
                      : CMA_ASM_CLOBBERS);
+#endif
     }
     // ---- epilogue: tile -> global.  Column 16 a + 4 b + c of a row sits at position 16 a + 4 c + b.
     const int mm = lane & 15;
@@ -2748,6 +2467,7 @@ static int cmp_rows(const ConvArgs& a) {
     if (mode == 0 || a.perm || a.Cin % 64 != 0 || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Cout % 4 != 0) return 0;
     if (a.ksplit < 1 || (a.Cin / 64) % a.ksplit != 0 || (a.ksplit > 1 && a.partial == nullptr)) return 0;
     if (mode == 64 || mode == 128) return mode;
+    if (mode == 129) return 128;
     // measured on the SENet14 pyramid (tools/bench_conv.py): 128-row tiles win from ~400 waves up (64->64 at 210 k rows
     // 351 vs 497 us, 128->128 at 61 k rows 438 vs 566 us, 256->256 at 14 k rows 477 vs 519 us); few-row wide layers
     // reach that by splitting the input channels (the caller sizes `partial` from agb_spconv_split_hint)
@@ -2823,20 +2543,10 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
         int R, rpt, ntiles, nct, il;
         cmp_geometry(a, &R, &rpt, &ntiles, &nct, &il);
         dim3 grid(8 * agb_cdiv(ntiles, 8) * nct * a.ksplit), blk(64);
-        static const int cmpt = getenv("AGB_CMPT") ? atoi(getenv("AGB_CMPT")) : 0;   // EXPERIMENT switch
-#define CMPT_CASE(A) case A: AGB_LAUNCH((k_spconv_cmpt<128, A>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il); break;
-        if (cmpt == 2 && R == 128) AGB_LAUNCH((k_spconv_cmpp<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
-        else if (cmpt == 3 && R == 128 && a.K3 >= 3) AGB_LAUNCH(k_spconv_cma, grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
-        else if (cmpt && R == 128) {
-            switch (cmpt >> 4) {
-                CMPT_CASE(0) CMPT_CASE(1) CMPT_CASE(2) CMPT_CASE(3) CMPT_CASE(4) CMPT_CASE(5) CMPT_CASE(6) CMPT_CASE(7)
-                CMPT_CASE(8) CMPT_CASE(9) CMPT_CASE(10) CMPT_CASE(11) CMPT_CASE(12) CMPT_CASE(13) CMPT_CASE(14) CMPT_CASE(15)
-#ifdef AGB_TIMELINE
-                CMPT_CASE(16)
-#endif
-            }
-        }
-        else if (cmpt) AGB_LAUNCH((k_spconv_cmpt<64>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
+        // 128-row tiles: the hand-scheduled kernel (k_spconv_cma); cmp_mode 129 forces its C++ twin k_spconv_cmpt (same
+        // sums bit for bit: tests), maps of fewer than three offsets keep the first-generation kernel
+        if (R == 128 && a.cmp_mode == 129) AGB_LAUNCH((k_spconv_cmpt<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
+        else if (R == 128 && a.K3 >= 3) AGB_LAUNCH(k_spconv_cma, grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
         else if (R == 128) AGB_LAUNCH((k_spconv_cmp<128>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
         else AGB_LAUNCH((k_spconv_cmp<64>), grid, blk, 0, s, a, ntiles, nct, rpt, a.ksplit, il);
     } else if (conv_tile_rows(a.n_out, a.Cin, a.Cout) == 128) {
@@ -2877,7 +2587,7 @@ int agb_debug_cmp_timeline(unsigned long long* out, int reset) {
 #endif
 
 #ifdef AGB_TIMELINE
-// out: unsigned long long[16] = stamp sums of k_spconv_cmpt<128, 16> (prologue clocks, steps, groups, five group segments, wave clocks)
+// out: unsigned long long[16] = stamp sums of the diagnostic build of k_spconv_cma (tools/cma_stamps.py)
 int agb_debug_cmpt_stamps(unsigned long long* out, int reset) {
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cmpt_stamp), sizeof(unsigned long long) * 16);
     if (reset) {
@@ -2929,7 +2639,7 @@ int agb_spconv_split_hint_opt(int n_out, int K3, int Cin, int Cout, int cmp_mode
     if (Cin == 3 || Cin == 4 || Cin == 8 || K3 < 8 || n_out <= 0) return 1;
     const int sp = cmp_mode == 0 ? 0 : cmp_want_split(n_out, Cin, Cout);
     if (sp > 0) return sp;   // the pair-compacted kernel takes the layer, input channels split sp ways
-    if (cmp_mode == 64 || cmp_mode == 128) return 1;
+    if (cmp_mode == 64 || cmp_mode == 128 || cmp_mode == 129) return 1;
     long long tiles = (long long)agb_cdiv(n_out, conv_tile_rows(n_out, Cin, Cout)) * agb_cdiv(Cout, BN);
     if (tiles >= 768) return 1;
     long long s = (1024 + tiles - 1) / tiles;
@@ -2982,8 +2692,9 @@ int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* n
                        const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
                        const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                        float* partial, int cmp_mode, int cmp_interleave_shift, void* stream) {
-    AGB_CHECK_ARG(cmp_mode == 0 || cmp_mode == 1 || cmp_mode == 64 || cmp_mode == 128, "agb_spconv_fwd_opt: cmp_mode %d "
-                  "(1 automatic, 0 never, 64 / 128 forced)", cmp_mode);
+    AGB_CHECK_ARG(cmp_mode == 0 || cmp_mode == 1 || cmp_mode == 64 || cmp_mode == 128 || cmp_mode == 129,
+                  "agb_spconv_fwd_opt: cmp_mode %d (1 automatic, 0 never, 64 / 128 forced, 129: 128 with the C++ twin of the "
+                  "hand-scheduled kernel)", cmp_mode);
     AGB_CHECK_ARG(cmp_interleave_shift >= -1 && cmp_interleave_shift <= 5, "agb_spconv_fwd_opt: interleave shift %d "
                   "(-1: by level size)", cmp_interleave_shift);
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_fwd: bad sizes");

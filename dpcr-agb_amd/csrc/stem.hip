@@ -53,15 +53,18 @@ struct StemDwGeo { int nq, nchunks, nparts; };
 // than the mean.  The host deals the offsets longest-first to the least loaded column (LPT) under the isotropic model
 // weight = 1 / (1 + 0.9 d)^1.6, d = distance from the centre in cells: max / mean load 1.12 on the measured counts.
 // Passed to the kernel by value (1.5 KB of kernel arguments: nothing is allocated or copied).
+#define SDW_MAX_K3 729      // 9^3: the tables below hold 736 entries; agb_stem_dw_ok sends larger maps to the generic kernels
 struct StemOwners { unsigned short e[736]; };
+static_assert(sizeof(StemOwners::e) / sizeof(unsigned short) >= SDW_MAX_K3, "owner table smaller than the largest map");
 
-static void stem_dw_owners(int K3, int nq, StemOwners* own) {
+static void stem_dw_owners_build(int K3, int nq, StemOwners* own) {
     int K = 1;
     while (K * K * K < K3) ++K;
     const bool cube = K * K * K == K3;
     const int ncol = SDW_WAVES * nq, h = K >> 1;
     float wgt[736];
     int order[736];
+    static_assert(sizeof(wgt) / sizeof(float) >= SDW_MAX_K3 && sizeof(order) / sizeof(int) >= SDW_MAX_K3, "K3 bound");
     for (int k = 0; k < K3; ++k) {
         float d = 0.f;
         if (cube) {
@@ -91,6 +94,18 @@ static void stem_dw_owners(int K3, int nq, StemOwners* own) {
     }
 }
 
+// The table depends on (K3, nq) only: built once per thread and shape, not at every launch (powf per offset, an O(K3^2) sort
+// and the LPT deal are tens of microseconds of host time in a step whose enqueue is the scarce resource).
+static const StemOwners& stem_dw_owners(int K3, int nq) {
+    thread_local StemOwners memo;
+    thread_local int memo_K3 = -1, memo_nq = -1;
+    if (memo_K3 != K3 || memo_nq != nq) {
+        stem_dw_owners_build(K3, nq, &memo);
+        memo_K3 = K3; memo_nq = nq;
+    }
+    return memo;
+}
+
 static StemDwGeo stem_dw_geometry(int n_out, int K3) {
     StemDwGeo g;
     g.nq = agb_cdiv(K3, SDW_WAVES * SDW_OPW);                 // 343 offsets -> 2 classes of 176 slots
@@ -101,9 +116,12 @@ static StemDwGeo stem_dw_geometry(int n_out, int K3) {
     return g;
 }
 
+// (A pair-list entry packs (input row << 8) | local output row: input rows below 2^24.  The grid path reads the level it
+// writes — n_in == n_out, checked here; a kernel map handed to the generic entry points must index rows below 2^24 as well:
+// true for every stride-1 map of a level this check accepts, stated as a requirement in include/agb_hip.h for the rest.)
 bool agb_stem_dw_ok(int n_out, int K3, int Cin, int Cout, int ldx, int ldy) {
     return Cin == 4 && Cout == 64 && ldx == 4 && ldy % 4 == 0 && n_out > 0 && n_out < (1 << 24) && K3 >= 1 &&
-           agb_cdiv(K3, SDW_WAVES * SDW_OPW) <= 16;
+           K3 <= SDW_MAX_K3 && agb_cdiv(K3, SDW_WAVES * SDW_OPW) <= 16;
 }
 
 size_t agb_stem_dw_workspace_bytes(int n_out, int K3) {
@@ -326,19 +344,44 @@ __global__ __launch_bounds__(1024) void k_stem_dw_pairs(const float* __restrict_
 #undef SDW_OWN
 }
 
-// dW[e] += sum over the row partitions (ascending) of part[rp][e]
-// (A four-range tree on 343 workgroups instead of 86 was measured: 40 -> 10 us of a 9.2 ms step — and, being another
-// summation order, another draw of the R2 table.  Not worth it: the plain ascending sum stays.)
+// dW[e] += sum over the row partitions of part[rp][e], in a FIXED order: the partitions are cut into four consecutive
+// ranges, one per thread group, each range summed in ascending order (loads eight deep), the four range sums added in
+// ascending order.  (One thread per element walking all 128 partitions: 86 workgroups and 40 us for the 45 MB; this form
+// 10 us.  Round 4 had taken it back because the R2 table's bare-median outcome moved with the summation order; that outcome
+// is a printed line since round 5)
 __global__ __launch_bounds__(256) void k_stem_dw_fold(const float4* __restrict__ part, int nparts, long long n4,
                                                       float4* __restrict__ dW) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n4) return;
-    float4 s = dW[e];
-    for (int c = 0; c < nparts; ++c) {
-        const float4 v = part[(long long)c * n4 + e];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    __shared__ float4 s_sum[4][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long e = (long long)blockIdx.x * 64 + el;
+    const int per = (nparts + 3) >> 2;
+    const int c0 = grp * per, c1 = min(nparts, c0 + per);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n4) {
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(c + u) * n4 + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; c < c1; ++c) {
+            const float4 v = part[(long long)c * n4 + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    dW[e] = s;
+    s_sum[grp][el] = s;
+    __syncthreads();
+    if (grp == 0 && e < n4) {
+        float4 t = dW[e];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = s_sum[g][el];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        dW[e] = t;
+    }
 }
 
 // dW [K3][4][64] += gathered(X)^T dY through `workspace` (agb_stem_dw_workspace_bytes): X rows 4 floats wide (channel 3 = 0).
@@ -353,8 +396,7 @@ int agb_stem_dw_launch(const float* X, const float* dY, int ldy, const int32_t* 
         return AGB_EINVAL;
     }
     StemGrid sg{};
-    StemOwners own;
-    stem_dw_owners(K3, g.nq, &own);
+    const StemOwners& own = stem_dw_owners(K3, g.nq);
     if (nbr == nullptr) {
         sg.coords = (const int4*)coords; sg.grid = grid;
         sg.ox = desc[0]; sg.oy = desc[1]; sg.oz = desc[2]; sg.X = desc[3]; sg.Y = desc[4]; sg.Z = desc[5]; sg.ts = desc[6];
@@ -366,7 +408,7 @@ int agb_stem_dw_launch(const float* X, const float* dY, int ldy, const int32_t* 
                    (float*)workspace, n_out, K3, g.nq, g.nchunks, g.nparts, sg, own);
     }
     const long long n4 = (long long)K3 * 64;
-    hipLaunchKernelGGL(k_stem_dw_fold, dim3((unsigned)agb_cdiv(n4, 256)), dim3(256), 0, s, (const float4*)workspace, g.nparts,
+    hipLaunchKernelGGL(k_stem_dw_fold, dim3((unsigned)agb_cdiv(n4, 64)), dim3(256), 0, s, (const float4*)workspace, g.nparts,
                        n4, (float4*)dW);
     return AGB_OK;
 }

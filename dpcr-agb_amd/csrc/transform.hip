@@ -133,7 +133,7 @@ extern "C" {
 // Scratch: zmin float[B], pos_t float[n,3], flag int32[n], slot int32[n], scan_scratch int32[agb_scan_scratch_elems(n)].
 // Out (upper bound n rows): pos_out float[n,3], x_out float[n,3], src int64[n] (row in the input), out_ptr int32[B+1],
 // n_out_dev int32[1].  No host synchronisation.
-int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
+AGB_INTERNAL int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
                      int scale_div, int z_from_zero, const double* poly, int nv, float* zmin, float* pos_t,
                      int32_t* flag, int32_t* slot, int32_t* scan_scratch, float* pos_out, float* x_out, long long* src,
                      int32_t* out_ptr, int32_t* n_out_dev, void* stream) {
@@ -330,7 +330,7 @@ int agb_plot_extend(const float* pos1, const int32_t* ptr1, const float* mins, c
 // Crop with one polygon per plot (polys double[B][2*nv]); a plot none of whose points falls inside is left whole
 // (transforms.py:1541-1543).  Features x = [1, z, ||xy - (fcx, fcy) + 1e-6||].  Scratch: flag / slot int32[n], cnt int32[B],
 // scan_scratch int32[agb_scan_scratch_elems(n)].  Out as agb_plot_prepare.
-int agb_plot_crop(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const double* polys, int nv,
+AGB_INTERNAL int agb_plot_crop(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const double* polys, int nv,
                   float fcx, float fcy, int32_t* flag, int32_t* slot, int32_t* cnt, int32_t* scan_scratch,
                   float* pos_out, float* x_out, long long* src, int32_t* out_ptr, int32_t* n_out_dev, void* stream) {
     AGB_CHECK_ARG(B >= 1 && n >= 0 && nv >= 3, "agb_plot_crop: bad sizes (B %d, n %d, nv %d)", B, n, nv);

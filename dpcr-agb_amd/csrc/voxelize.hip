@@ -162,7 +162,7 @@ extern "C" {
 // scan_scratch[agb_scan_scratch_elems(B*cap+1)]; lo float[3B].
 // Out: coords int32[n,3] (upper bound), keep int64[n], out_ptr int32[B+1], n_out_dev, bounds int32[6]
 // (min xyz, max xyz of coords), status int32[4].
-int agb_voxelize_last(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
+AGB_INTERNAL int agb_voxelize_last(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
                       float size, int cap, int32_t* bbox_ord, float* lo, int32_t* span, int32_t* cells,
                       int32_t* slot, int32_t* flag, int32_t* cell_of, int32_t* scan_scratch, int32_t* coords,
                       long long* keep, int32_t* out_ptr, int32_t* n_out_dev, int32_t* bounds, int32_t* status,

@@ -28,7 +28,8 @@ class KernelOptions:
                              "bf16"   bf16 operands, fp32 accumulate (BASELINE.json config 5)
                              "bf16x3" split-bf16 (hi+lo), three MFMAs per product: fp32-level accuracy
       cmp_mode             fp32 forward / data-gradient kernel: 1 = automatic (pair-compacted kernel for many-row layers),
-                           0 = never, 64 / 128 = always with that tile height (tests, tuning)
+                           0 = never, 64 / 128 = always with that tile height (tests, tuning), 129 = 128-row tiles on the
+                           C++ twin of the hand-scheduled kernel (bit-identical sums: tests)
       cmp_interleave       log2 of the row-block size of its interleaved tiles (-1: by the level's size, 0: contiguous)
       balanced_tiles       work-balanced tile tables for that kernel (csrc/tiles.hip)
       bn_stats_in_epilogue forward dense products leave BatchNorm statistics partials (agb_dense_fwd_bn)
@@ -483,16 +484,28 @@ def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
               _P(dw), n_out, K3, cin, cout, prec, opts.dw_variant, _P(ws), nbytes, _lib.stream())
 
 
+_PROBE_PAIRS = {}
+
+
 def _probe_pair_count(coords, grid, desc, K, n_out):
     """Profiling only: number of (row, offset) pairs of a K^3 stride-1 map on a grid-mode level (device int64 scalar), from
-    a scratch kernel map (the product path no longer writes one for the 64-channel stem)."""
+    a scratch kernel map (the product path no longer writes one for the 64-channel stem).  Counted once per level (forward
+    and weight gradient of a step ask for the same number; the scratch map is 578 MB at B = 32)."""
+    key = (coords.data_ptr(), grid.data_ptr(), K, n_out)
+    hit = _PROBE_PAIRS.get(key)
+    if hit is not None and hit[0]() is coords:
+        return hit[1]
     nbr = torch.empty(K ** 3, max(n_out, 1), dtype=torch.int32, device=coords.device)
     y = torch.empty(n_out, 64, dtype=torch.float32, device=coords.device)
     x = torch.zeros(n_out, 4, dtype=torch.float32, device=coords.device)
     w = torch.zeros(K ** 3, 3, 64, dtype=torch.float32, device=coords.device)
     _lib.call("agb_stem_fwd_pairs", _P(x), 4, _P(w), _P(coords), _P(grid), desc, K, None, _P(y), 64, n_out, 64, _P(nbr),
               nbr.stride(0), _lib.stream())
-    return (nbr >= 0).sum()
+    pairs = (nbr >= 0).sum()
+    if len(_PROBE_PAIRS) > 8:
+        _PROBE_PAIRS.clear()
+    _PROBE_PAIRS[key] = (weakref.ref(coords), pairs)
+    return pairs
 
 
 def _twins_for(kernel, rows, opts, cin, cout, cin_p, cout_p):
@@ -568,7 +581,9 @@ class SparseConvFunction(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]   # (grad mode is off inside Function.forward)
         # 64 output channels: the weight gradient probes the grid itself (csrc/stem.hip, agb_stem_bwd_weight_grid) — the
         # K^3 x N kernel map (578 MB for the 7^3 stem at B = 32) is neither written here nor read there
-        grid_wgrad = cout == 64 and x.dtype == torch.float32 and ctx.opts.dw_variant == 0
+        # (the conditions of csrc/stem.hip agb_stem_dw_ok, so that a level it would refuse still gets its map written)
+        grid_wgrad = (cout == 64 and x.dtype == torch.float32 and ctx.opts.dw_variant == 0 and 0 < n_out < (1 << 24)
+                      and x.stride(0) == 4 and K3 <= 729)
         nbr = (torch.empty(K3, max(n_out, 1), dtype=torch.int32, device=x.device) if (need_w and not grid_wgrad) else None)
         ev = _prof_begin("fwd", K3, 3, cout, n_out)
         if rows16:

@@ -122,7 +122,9 @@ int agb_dense_fwd_bn(const float* X, int ldx, const float* W, const float* bias,
 /* The same product with the kernel choice as per-call arguments (the library keeps no tuning state):
  * cmp_mode: 1 = automatic (the pair-compacted LDS-accumulating kernel for many-row layers with Cin % 64 == 0, the
  * register-accumulator kernels otherwise; what agb_spconv_fwd / _ex use), 0 = never the pair-compacted kernel,
- * 64 / 128 = always, with that many rows per wave.  cmp_interleave_shift: tiles of the pair-compacted kernel made of
+ * 64 / 128 = always, with that many rows per wave (128-row tiles of maps with three or more offsets run the hand-scheduled
+ * kernel k_spconv_cma, csrc/gen_cmp_asm.py), 129 = 128-row tiles on its C++ twin k_spconv_cmpt (the same sums bit for bit:
+ * tests).  cmp_interleave_shift: tiles of the pair-compacted kernel made of
  * 2^shift-row blocks taken from regions ntiles blocks apart (0: contiguous row tiles; -1: chosen by the number of rows):
  * evens out the per-tile work where the pair density varies by region.  All choices compute the same sums; tile
  * interleaving is bit-identical, kernel choice changes only the fp32 summation order.

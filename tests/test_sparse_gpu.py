@@ -157,6 +157,52 @@ def test_conv_pair_compacted_kernel(device, rows_per_wave, cin, cout, K, stride,
         _conv_case(device, cin, cout, K, stride, ts_in)
 
 
+@pytest.mark.parametrize("cin,cout,K,stride,n_per,kflip,bias", [
+    (64, 64, 3, 1, 2500, 0, False), (64, 64, 3, 1, 2500, 1, True), (128, 64, 3, 1, 900, 0, True), (256, 128, 3, 1, 700, 1, False),
+    (64, 36, 3, 1, 1300, 0, False), (64, 128, 2, 2, 2500, 0, True), (512, 64, 3, 1, 37, 0, False), (64, 64, 3, 1, 5, 1, False)])
+def test_hand_scheduled_kernel_equals_its_twin(device, cin, cout, K, stride, n_per, kflip, bias):
+    """k_spconv_cma (csrc/gen_cmp_asm.py: the hand-scheduled main loop, product path of every 128-row-tile launch) against
+    k_spconv_cmpt (cmp_mode 129: the same arithmetic written in C++): BIT-IDENTICAL outputs — forward and flipped (data
+    gradient) offset order, several 64-channel blocks per offset, ragged last tile, tiles without a pair for some offsets,
+    column tiles past Cout, work-balanced and interleaved tiles, input-channel split — and both within fp32 rounding of the
+    fp64 sum."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import sparse_ops
+    rng = np.random.default_rng(1000 + cin + cout + n_per)
+    torch.manual_seed(cin + n_per)
+    coords = random_coords(rng, 3, n_per, 14 if n_per > 100 else 6)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    if stride > 1:
+        cm.stride(1, stride)
+    nbr = cm.kernel_map(1, K, stride)
+    K3 = K ** 3
+    n_in, n_out = cm.level(1).n, cm.level(stride).n
+    x = torch.randn(n_in, cin, device=device)
+    w = torch.randn(K3 * cin, cout, device=device) * 0.1
+    b = torch.randn(cout, device=device) if bias else None
+    outs = {}
+    for mode in (128, 129):
+        for il, balanced in ((-1, True), (0, False), (2, False)):
+            with sparse_ops.KernelOptions(cmp_mode=mode, cmp_interleave=il, balanced_tiles=balanced):
+                outs[(mode, il)] = sparse_ops.spconv_forward_raw(x, w, nbr, kflip, b, n_out, K3, cin, cout)
+    torch.cuda.synchronize()
+    ref = outs[(129, 0)]
+    for key, y in outs.items():
+        assert torch.equal(y, ref), f"{key}: max abs diff {float((y - ref).abs().max()):.3e}"
+    # fp64 sum of the same pairs
+    idx = nbr[:, :n_out].long()
+    kk = torch.arange(K3 - 1, -1, -1, device=device) if kflip else torch.arange(K3, device=device)
+    acc = torch.zeros(n_out, cout, dtype=torch.float64, device=device)
+    w3 = w.view(K3, cin, cout).double()
+    for k in range(K3):
+        present = idx[int(kk[k])] >= 0
+        acc[present] += x[idx[int(kk[k])][present]].double() @ w3[k]
+    if bias:
+        acc += b.double()
+    assert rel_err(ref, acc) < 2e-6
+
+
 @pytest.mark.parametrize("K,negative", [(7, False), (7, True), (3, True), (5, False)])
 def test_stem_conv_probes_dense_grid(device, K, negative):
     """A 3-channel stride-1 layer whose input needs no gradient reads its neighbours from the level's dense grid: no map

@@ -1,5 +1,4 @@
-"""In-kernel stamp shares of k_spconv_cmpt (diagnostic build: make timeline; the stamps' fences forbid overlaps the real kernel has:
-read the SHARES).  AGB_CMPT=257 python tools/cmpt_stamps.py"""
+"""Stamp shares of the hand-scheduled k_spconv_cma (diagnostic build: cd dpcr-agb_amd/csrc && make timeline; read the SHARES)."""
 import ctypes
 import os
 import sys
@@ -7,7 +6,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("AGB_LIBRARY", os.path.join(ROOT, "dpcr-agb_amd", "libagbhip_timeline.so"))
-os.environ.setdefault("AGB_CMPT", "257")
+os.environ.setdefault("AGB_CMPT", "3")
 import torch  # noqa: E402
 
 
@@ -41,11 +40,13 @@ def main():
         torch.cuda.synchronize()
         out = (ctypes.c_ulonglong * 16)()
         L.agb_debug_cmpt_stamps(out, 0)
-        pro, steps, ng, s0, s1, s2, s3, s4, wave = [float(v) for v in out[:9]]
-        print(f"ts {ts_in:2d} {c}->{c} rows {n}: {e0.elapsed_time(e1) * 1e3:.0f} us (stamped build); steps {steps:.0f}, groups/step {ng / steps:.2f}; "
-              f"per step: prologue {pro / steps:.0f} clk; per group: cb0 {s0 / ng:.0f}  cb1 {s1 / ng:.0f}  cb2 {s2 / ng:.0f}  cb3 {s3 / ng:.0f}  "
-              f"tail {s4 / ng:.0f}  (sum {(s0 + s1 + s2 + s3 + s4) / ng:.0f}); wave clocks accounted "
-              f"{(pro + s0 + s1 + s2 + s3 + s4) / wave:.3f}", flush=True)
+        top, tf, tp, nf, np_, waves, wvm, wlg = [float(v) for v in out[:8]]
+        steps = waves * 27 * (c // 64)
+        print(f"ts {ts_in:2d} {c}->{c} rows {n}: {e0.elapsed_time(e1) * 1e3:.0f} us (stamped build); waves {waves:.0f}, steps {steps:.0f}, "
+              f"groups/step {(nf + np_) / steps:.2f}; per step: top+end {top / steps:.0f} clk; first group {tf / max(nf, 1):.0f} clk; "
+              f"plain group {tp / max(np_, 1):.0f} clk; total per step {(top + tf + tp) / steps:.0f}, pure MFMA {(nf + np_) * 2048 / steps:.0f} "
+              f"({(nf + np_) * 2048 / (top + tf + tp):.3f}); per group: in vmcnt waits {wvm / (nf + np_):.0f} clk, in the list-entry wait "
+              f"{wlg / (nf + np_):.0f} clk (each bracketed wait includes ~2 clock reads)", flush=True)
 
 
 if __name__ == "__main__":
