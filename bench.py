@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated batches cycled per rank")
     ap.add_argument("--features", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deterministic", action="store_true", help="fixed-order weight-gradient sums (KernelOptions."
+                    "deterministic_wgrad): bitwise reproducible steps — what tests compare parameter checksums on; not the "
+                    "default the headline is measured with")
     ap.add_argument("--no-prefetch", action="store_true", help="build each batch's coordinate plan inside set_input")
     ap.add_argument("--force-prefetch", action="store_true", help="keep the side-stream input pipeline even where the ranks "
                     "of this node have fewer than 2.5 usable cores each (tools/host_budget.py measures both forms)")
@@ -381,8 +384,21 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # AGB_FORCE_GRAD_SYNC on one rank: the gradient exchange runs anyway, through a process group of ONE rank — RCCL's
+    # init, ReduceOp.AVG and its stream hand-off against the HIP kernels execute on a single-GPU box (tests/test_dist_gpu.py;
+    # arithmetically the identity, never a scaling number)
+    # (AGB_FORCE_GRAD_SYNC=buckets: the bucket path alone, no process group, no collective — the comparison run)
+    force_sync = bool(os.environ.get("AGB_FORCE_GRAD_SYNC"))
+    force_coll = force_sync and os.environ.get("AGB_FORCE_GRAD_SYNC") != "buckets"
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -408,12 +424,13 @@ def main():
     model.to(dev).train()
     if args.bf16_rows and args.precision != "bf16":
         raise SystemExit("--bf16-rows needs --precision bf16")
-    model.set_kernel_options(precision=args.precision, bf16_activations=args.bf16_rows)     # carried by the model
+    model.set_kernel_options(precision=args.precision, bf16_activations=args.bf16_rows,      # carried by the model
+                             deterministic_wgrad=args.deterministic)
     broadcast_parameters(model)
     model.init_train_objects(TRAINING_NFI)
     sync = None
-    if world > 1 or os.environ.get("AGB_FORCE_GRAD_SYNC"):   # the env switch exercises the bucket path on one GPU
-        sync = GradAllReduce(model.parameters())
+    if world > 1 or force_sync:   # the env switch exercises the bucket path AND the collective on one GPU
+        sync = GradAllReduce(model.parameters(), force_collective=force_coll)
         model.grad_sync = sync
 
     # pre-generated, pre-voxelised, device-resident batches (disjoint seeds per rank)
@@ -534,7 +551,7 @@ def main():
     if world > 1:
         dist.all_reduce(slots, op=dist.ReduceOp.SUM)     # (a gather written as a sum: every backend has all_reduce)
     gathered = list(slots)
-    comm = dict(backend=(dist.get_backend() if world > 1 else None), world=world,
+    comm = dict(backend=(dist.get_backend() if dist.is_initialized() else None), world=world,
                 buckets=len(sync.buckets) if sync is not None else 0,
                 bytes_per_step=int(sum(b["flat"].numel() * b["flat"].element_size() for b in sync.buckets)) if sync else 0,
                 param_checksums=[float(g[0].item()) for g in gathered],
@@ -608,7 +625,7 @@ def main():
             torch.cuda.empty_cache()
             line["other_configs"] = run_other_configs()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

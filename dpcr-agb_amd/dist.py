@@ -25,10 +25,15 @@ class GradAllReduce:
     Usage:  sync = GradAllReduce(model.parameters()); model.grad_sync = sync   (called after backward)
     """
 
-    def __init__(self, params, bucket_bytes: int = 16 << 20, process_group=None, average: bool = True):
+    def __init__(self, params, bucket_bytes: int = 16 << 20, process_group=None, average: bool = True,
+                 force_collective: bool = False):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
+        # force_collective: issue the all-reduce per bucket also in a group of ONE rank (a no-op arithmetically: the
+        # average over one rank) — how a single-GPU box exercises RCCL's stream hand-off against the HIP kernels' stream
+        # (tests/test_dist_gpu.py); needs an initialised process group
+        self.force = bool(force_collective) and dist.is_initialized()
         params = [p for p in params if p.requires_grad]
         # reverse registration order ~ order in which backward produces gradients
         self.buckets: List[dict] = []
@@ -80,7 +85,7 @@ class GradAllReduce:
                 torch._foreach_copy_(dst, src)      # one multi-tensor launch per bucket
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         backend = dist.get_backend(self.pg)
         if self.average and backend == "nccl":

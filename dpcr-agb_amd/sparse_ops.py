@@ -47,17 +47,22 @@ class KernelOptions:
                            of its input: csrc/*_rows.inc, agb_spconv_fwd_h); accumulators, BatchNorm / SE statistics,
                            per-plot matrices, parameters and their gradients stay fp32.  Halves the HBM traffic of the
                            element-wise passes that dominate MSENet50 (BASELINE config 5).  Default off.
+      closed_form_bias_grad  the bias gradient of a convolution that feeds a BatchNorm is taken from the BatchNorm's backward in
+                           closed form (exactly 0 under batch statistics: INTEGRATION.md section A.1) instead of summing the
+                           incoming gradient's columns — the one deliberate difference of the training trajectory to the
+                           reference's (which sees fp32 rounding noise around that zero).  Default on; off = the column sums
+                           (a paired 13-seed run with it off).
 
     Use: ``model.kernel_options = KernelOptions(precision="bf16")`` (the backbones run their forward pass inside it), or
     ``with KernelOptions(cmp_mode=128): ...`` around direct calls.  Autograd nodes keep the options they were created
     under for their backward pass.  ``DEFAULTS`` (environment-initialised) applies where nothing else is set."""
     __slots__ = ("precision", "cmp_mode", "cmp_interleave", "balanced_tiles", "bn_stats_in_epilogue", "fused_tail",
-                 "deterministic_wgrad", "dw_variant", "bf16_storage", "bf16_activations")
+                 "deterministic_wgrad", "dw_variant", "bf16_storage", "bf16_activations", "closed_form_bias_grad")
     PRECISIONS = ("fp32", "bf16", "bf16x3")
 
     def __init__(self, precision=None, cmp_mode=None, cmp_interleave=None, balanced_tiles=None,
                  bn_stats_in_epilogue=None, fused_tail=None, deterministic_wgrad=None, dw_variant=None,
-                 bf16_storage=None, bf16_activations=None, base=None):
+                 bf16_storage=None, bf16_activations=None, closed_form_bias_grad=None, base=None):
         base = base if base is not None else (current() if "DEFAULTS" in globals() else None)
         pick = lambda v, name, dflt: v if v is not None else (getattr(base, name) if base is not None else dflt)  # noqa: E731
         self.precision = pick(precision, "precision", "fp32")
@@ -72,6 +77,7 @@ class KernelOptions:
         self.dw_variant = int(pick(dw_variant, "dw_variant", 0))
         self.bf16_storage = bool(pick(bf16_storage, "bf16_storage", True))
         self.bf16_activations = bool(pick(bf16_activations, "bf16_activations", False))
+        self.closed_form_bias_grad = bool(pick(closed_form_bias_grad, "closed_form_bias_grad", True))
 
     def replace(self, **kw):
         return KernelOptions(base=self, **kw)
@@ -607,7 +613,7 @@ class SparseConvFunction(torch.autograd.Function):
     def _backward_probe(ctx, dy):
         x, nbr = ctx.saved_tensors
         K3, cout, n_out, has_bias, bias_shape = ctx.dims
-        colsum = _colsum_hint(dy)
+        colsum = _colsum_hint(dy) if ctx.opts.closed_form_bias_grad else None
         dy = dy.contiguous()
         dk = db = None
         if ctx.needs_input_grad[1]:
@@ -642,7 +648,7 @@ class SparseConvFunction(torch.autograd.Function):
         x, w, nbr, nbrT = ctx.saved_tensors
         K3, cin, cout, cin_p, cout_p, n_in, n_out, has_T, has_bias, bias_shape = ctx.dims
         opts = ctx.opts
-        colsum = _colsum_hint(dy)
+        colsum = _colsum_hint(dy) if opts.closed_form_bias_grad else None
         dy = dy.contiguous()
         if cout_p != cout:
             dy = F.pad(dy, (0, cout_p - cout)).contiguous()
@@ -730,7 +736,7 @@ class DenseConvFunction(torch.autograd.Function):
         x, w = ctx.saved_tensors
         cin, cout = w.shape
         n = x.shape[0]
-        colsum = _colsum_hint(dy)
+        colsum = _colsum_hint(dy) if ctx.opts.closed_form_bias_grad else None
         dy = dy.contiguous()
         dx = dk = db = None
         opts = ctx.opts
@@ -823,7 +829,7 @@ class DenseLinearFunction(torch.autograd.Function):
         xp, wp = ctx.saved_tensors
         cin, cout, cin_p, cout_p, has_bias = ctx.dims
         n = xp.shape[0]
-        colsum = _colsum_hint(dy)
+        colsum = _colsum_hint(dy) if ctx.opts.closed_form_bias_grad else None
         dy = dy.contiguous()
         dyp = dy if cout_p == cout else F.pad(dy, (0, cout_p - cout)).contiguous()
         dx = dw = db = None

@@ -43,3 +43,34 @@ def test_two_rank_bench_dry_run_keeps_ranks_identical(mode):
     assert a == b and a != 0.0, comm                     # averaged gradients -> bit-identical replicas after 8 steps
     assert all(v > 0 for v in comm["host_cpu_ms_per_step_p50"])
     assert line["value"] > 0 and line["roofline"] is not None
+
+
+def _bench_line(extra_env, extra_args=()):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-other-configs",
+           "--deterministic", "--reserve-gib", "8"] + list(extra_args)
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_rccl_runs_in_a_group_of_one_rank():
+    """RCCL on the one GPU of the test box: bench.py as a fresh child process with AGB_FORCE_GRAD_SYNC=1 initialises
+    ``init_process_group("nccl", device_id=...)`` with ONE rank and GradAllReduce issues the ``ReduceOp.AVG`` all-reduce of
+    every gradient bucket from the backward hooks (dist.py, force_collective) — the collective, its stream hand-off against the
+    HIP kernels' stream and the fused optimiser reading the reduced bucket slices all execute.  The average over one rank is
+    the identity: with fixed-order weight-gradient sums (--deterministic) the parameters after eight steps equal those of
+    the run on the same buckets without any exchange (AGB_FORCE_GRAD_SYNC=buckets) BIT FOR BIT.  Not a scaling statement: no
+    multi-GPU box was available."""
+    plain = _bench_line({"AGB_FORCE_GRAD_SYNC": "buckets"})
+    forced = _bench_line({"AGB_FORCE_GRAD_SYNC": "1"})
+    assert plain["comm"]["backend"] is None and plain["comm"]["buckets"] == forced["comm"]["buckets"]
+    c = forced["comm"]
+    assert c["backend"] == "nccl" and c["world"] == 1 and c["buckets"] >= 2 and c["bytes_per_step"] >= 14_000_000 * 4
+    assert c["param_checksums"][0] == plain["comm"]["param_checksums"][0] != 0.0, (c, plain["comm"])
+    assert forced["n_gpus"] == 1 and forced["value"] > 0

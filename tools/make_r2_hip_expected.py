@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--trials", type=int, default=13)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r2_hip_expected.json"))
     ap.add_argument("--check-repeat", type=int, default=2, help="re-run the first N trials of every leg and require identity")
+    ap.add_argument("--bias-grad-leg", action="store_true", help="also run the fp32 leg with KernelOptions."
+                    "closed_form_bias_grad off (column sums of the incoming gradient, as the reference computes the bias "
+                    "gradient of a convolution in front of a BatchNorm): key 'fp32_colsum_bias' of the output, not a leg of the test")
     a = ap.parse_args()
     import torch
     from train_eval import acceptance_data, acceptance_gpu_trial
@@ -50,6 +53,12 @@ def main():
             print(json.dumps(dict(leg=leg, trial=t, repeat=again, identical=same)), flush=True)
             if not same:
                 raise SystemExit(f"leg {leg} trial {t} is not reproducible: {again} vs {out['legs'][leg][t]}")
+    if a.bias_grad_leg:
+        t0 = time.time()
+        res = [acceptance_gpu_trial(cfg, t, dev, "fp32", data, closed_form_bias_grad=False)["final"] for t in range(a.trials)]
+        out["fp32_colsum_bias"] = [r["r2_rs"] for r in res]
+        print(json.dumps(dict(leg="fp32, bias gradient by column sums", r2=out["fp32_colsum_bias"],
+                              seconds=round(time.time() - t0, 1))), flush=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)

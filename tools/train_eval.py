@@ -37,7 +37,8 @@ def acceptance_data(cfg, dev):
     return [b.to(dev) for b in train_h], [b.to(dev) for b in val_h], train_h, val_mean
 
 
-def acceptance_gpu_trial(cfg, trial, dev, precision="fp32", data=None, log=None, keep=None, deterministic=True):
+def acceptance_gpu_trial(cfg, trial, dev, precision="fp32", data=None, log=None, keep=None, deterministic=True,
+                         **kernel_options):
     """Trial `trial` of the schedule of tests/golden/make_r2_cpu_leg.py (same initial weights, batch order, drop-path draws,
     recipe, calibrate_bn passes, running-statistics evaluation) on the HIP path, in the given operand precision.
     Returns dict(history, final) with the reference's metric definitions."""
@@ -51,7 +52,7 @@ def acceptance_gpu_trial(cfg, trial, dev, precision="fp32", data=None, log=None,
     # ("bf16rows": bf16 operands AND bf16 row storage, KernelOptions.bf16_activations — BASELINE config 5's fastest mode)
     rows16 = precision == "bf16rows"
     model.set_kernel_options(precision="bf16" if rows16 else precision, bf16_activations=rows16,
-                             deterministic_wgrad=bool(deterministic))
+                             deterministic_wgrad=bool(deterministic), **kernel_options)
     model.init_train_objects(TRAINING_NFI)
     nb = len(train)
     random.seed(gen.trial_seeds(trial)["drop_seed"])
