@@ -418,6 +418,8 @@ def main():
     from dpcr_agb_amd.instance import MinkowskiBaselineModel
 
     torch.manual_seed(0)
+    import random
+    random.seed(20240 + rank)     # the drop-path draws (backbones/sparse.py: one python random number per plot and block)
     ds = synthetic.SyntheticDataset(feature_dimension=args.features, stat_seeds=range(10_000, 10_064))
     model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS[args.model]), "minkowski", ds)
     model_sd_cpu = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
