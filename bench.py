@@ -334,7 +334,14 @@ OTHER_CONFIGS = (
     ("config5_single_gpu_leg", "MSENet50 biomass+wood-volume, bf16 with fp32 index kernels (one rank's share: batch 32)",
      ["bench.py", "--model", "SENet50", "--precision", "bf16", "--bf16-rows", "--steps", "30", "--warmup", "8",
       "--no-other-configs"]),
+    ("end_to_end", "config 4 from raw points: sparse-xy.yaml train transform chain on the device + MSENet14 step",
+     [os.path.join("tools", "bench_config.py"), "end2end", "--steps", "20", "--warmup", "5"]),
 )
+# BASELINE.json's metric is "training plots/sec ...; val RMSE": a short fixed-seed training run (reproducible: fixed-order
+# weight-gradient sums, seeded drop-path draws) on synthetic labelled plots, evaluated as eval.py does
+# (trial 0 of the R2 acceptance schedule, tests/golden/make_r2_cpu_leg.py: 256 / 128 plots of 700-1600 points, batch 16, 150 epochs,
+# calibrate_bn, running-statistics evaluation; ~11 s; the same numbers as row 0 of the fp32 leg of tests/golden/r2_hip_expected.json)
+TRAIN_EVAL = [os.path.join("tools", "train_eval.py"), "--acceptance-trial", "0"]
 
 
 def run_other_configs(timeout_s=150):
@@ -357,7 +364,8 @@ def run_other_configs(timeout_s=150):
                             workload=d["config"]["workload"], roofline=d.get("roofline"),
                             cpu_baseline=d.get("cpu_baseline"), wall_s=round(time.perf_counter() - t0, 1),
                             command="python " + " ".join(argv))
-            for extra in ("ball_query_roofline", "index_path_ms_per_step", "step_ms_p50"):
+            for extra in ("ball_query_roofline", "index_path_ms_per_step", "step_ms_p50", "input_chain_device_ms_per_step",
+                          "host_draws_ms_per_step_p50", "entry_points_ms_per_step"):
                 if extra in d:
                     out[key][extra] = d[extra]
         except subprocess.TimeoutExpired:
@@ -366,6 +374,28 @@ def run_other_configs(timeout_s=150):
             out[key] = dict(baseline_config=name, error=f"{type(e).__name__}: {e}")
         log(f"other config {key}: " + (f"{out[key]['value']} {out[key]['unit']}" if "value" in out[key] else out[key]["error"]))
     return out
+
+
+def run_train_eval(timeout_s=150):
+    """val RMSE / R2 (instance_tracker.py:85-87 definitions, metrics.py) of a short fixed-seed training of MSENet14 on synthetic
+    labelled plots, as a fresh child process: {val_rmse: [biomass, volume], val_r2: [...], ...} or {error: ...}."""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable] + TRAIN_EVAL, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"final"' in ln]
+        if r.returncode != 0 or not lines:
+            return dict(error=f"rc {r.returncode}: " + (r.stderr or r.stdout)[-400:])
+        d = json.loads(lines[-1])
+        return dict(val_rmse=d["final"]["val_rmse"], val_r2=d["final"]["val_r2"], train_loss=d["final"]["train_loss"],
+                    epochs=d["final"]["epoch"] + 1, schedule=d["config"],
+                    reproducible=True, wall_s=round(time.perf_counter() - t0, 1), command="python " + " ".join(TRAIN_EVAL),
+                    note="synthetic labels (biomass = a * sum(height^b) of the plot's trees): the reference's NFI data is not "
+                         "available offline; metric definitions = the reference's (tests/test_metrics.py golden vectors)")
+    except subprocess.TimeoutExpired:
+        return dict(error=f"timeout after {timeout_s} s")
+    except Exception as e:      # noqa: BLE001
+        return dict(error=f"{type(e).__name__}: {e}")
 
 
 def main():
@@ -626,6 +656,10 @@ def main():
             # reserve 12-24 GiB each)
             torch.cuda.empty_cache()
             line["other_configs"] = run_other_configs()
+            te = run_train_eval()
+            line["train_eval"] = te
+            if "val_rmse" in te:
+                line["val_rmse"], line["val_r2"] = te["val_rmse"], te["val_r2"]
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -18,6 +18,7 @@
 // fp32 coordinates like matplotlib does: results are bit-identical to the CPU chain except for points lying exactly on
 // a polygon edge.  HBM-bound, a few bytes per point: N*(12 read + 12+12+8+4 written).
 #include "agb_common.h"
+#include <limits.h>
 #include "scan.h"
 
 struct PlotXform {
@@ -102,13 +103,31 @@ __global__ void k_plot_out_ptr(const int32_t* __restrict__ slot, const int32_t* 
     if (b == B) out_ptr[b] = *total;
 }
 
+// Rows are ordered by plot: a wave's 64 rows almost always belong to ONE plot — it then reduces in registers and issues one
+// atomic per axis.  (One atomic per row and axis was 1.1 M atomics on 96 addresses = 4.8 ms at B = 32 x 11 k voxels; same-address
+// atomics retire one per ~100 ns.  profiles/r05_end2end_kernel_stats.csv)
 __global__ void k_coords_max(const int32_t* __restrict__ coords, const int32_t* __restrict__ elem, int n,
                              int32_t* __restrict__ cmax) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int b = elem[i];
+    const bool live = i < n;
+    const int b = live ? elem[i] : -1;
+    int c[3] = {INT_MIN, INT_MIN, INT_MIN};
+    if (live) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) atomicMax(&cmax[3 * b + a], coords[3LL * i + a]);
+        for (int a = 0; a < 3; ++a) c[a] = coords[3LL * i + a];
+    }
+    const int b0 = __builtin_amdgcn_readfirstlane(b);
+    if (__all(b == b0 || !live) && b0 >= 0) {     // (a wave's first lane is live whenever any of its lanes is)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) c[a] = max(c[a], __shfl_xor(c[a], d, 64));
+            if ((threadIdx.x & 63) == 0) atomicMax(&cmax[3 * b0 + a], c[a]);
+        }
+    } else if (live) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) atomicMax(&cmax[3 * b + a], c[a]);
+    }
 }
 
 __global__ void k_coords_augment(int32_t* __restrict__ coords, const int32_t* __restrict__ elem, int n,
@@ -283,11 +302,18 @@ __global__ void k_plot_inside(const float* __restrict__ pos, const int32_t* __re
                               const double* __restrict__ polys, int nv, int32_t* __restrict__ flag,
                               int32_t* __restrict__ cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int b = elem[i];
-    const int in = point_in_polygon((double)pos[3LL * i], (double)pos[3LL * i + 1], polys + 2LL * nv * b, nv);
-    flag[i] = in;
-    if (in) atomicAdd(&cnt[b], 1);
+    const bool live = i < n;
+    const int b = live ? elem[i] : -1;
+    const int in = live ? point_in_polygon((double)pos[3LL * i], (double)pos[3LL * i + 1], polys + 2LL * nv * b, nv) : 0;
+    if (live) flag[i] = in;
+    // one atomic per wave where its rows belong to one plot (rows are ordered by plot), else one per row
+    const int b0 = __builtin_amdgcn_readfirstlane(b);
+    if (__all(b == b0 || !live) && b0 >= 0) {
+        const int c = __popcll(__ballot(in != 0));
+        if ((threadIdx.x & 63) == 0 && c > 0) atomicAdd(&cnt[b0], c);
+    } else if (in) {
+        atomicAdd(&cnt[b], 1);
+    }
 }
 
 __global__ void k_plot_keep_all_if_none(int32_t* __restrict__ flag, const int32_t* __restrict__ elem, int n,

@@ -111,14 +111,12 @@ __global__ void k_vox_flag(const int32_t* __restrict__ cells, int n, int32_t* fl
 __global__ void k_vox_emit(const float* __restrict__ pos, const long long* __restrict__ perm,
                            const int32_t* __restrict__ ptr, const int32_t* __restrict__ elem, int ncells, float size,
                            const int32_t* __restrict__ cells, const int32_t* __restrict__ slot,
-                           int32_t* __restrict__ coords, long long* __restrict__ keep, int32_t* bounds) {
+                           int32_t* __restrict__ coords, long long* __restrict__ keep) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    int v[3] = {INT_MAX, INT_MAX, INT_MAX};
-    bool on = false;
+    int v[3];
     if (c < ncells) {
         int i = cells[c];
         if (i >= 0) {
-            on = true;
             int b = elem[i];
             long long j = ptr[b] + perm[i];
             float r[3];
@@ -131,27 +129,28 @@ __global__ void k_vox_emit(const float* __restrict__ pos, const long long* __res
             keep[o] = j;  // index into the ORIGINAL (unshuffled) stacked point order
         }
     }
-    // bounding box of the integer coordinates over the whole batch
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        int mn = on ? v[a] : INT_MAX, mx = on ? v[a] : INT_MIN;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn = min(mn, __shfl_xor(mn, d, 64));
-            mx = max(mx, __shfl_xor(mx, d, 64));
-        }
-        if ((threadIdx.x & 63) == 0 && mx != INT_MIN) {
-            atomicMin(&bounds[a], mn);
-            atomicMax(&bounds[3 + a], mx);
-        }
-    }
 }
 
+// out_ptr; and the bounding box of the integer coordinates over the whole batch, from the per-cloud boxes of the rounded
+// positions (k_vox_bbox: every occupied cell is kept, so the box of the kept voxels is the box of all points).  Until round 5
+// k_vox_emit reduced it with wave-level atomics on six addresses — 1.1 M same-address atomics over the 17 M cells of a
+// B = 32 batch, 5.7 ms of a 6 ms chain (profiles/r05_end2end_kernel_stats.csv).
 __global__ void k_vox_out_ptr(const int32_t* __restrict__ slot, const int32_t* total, int cap, int B,
-                              int32_t* out_ptr) {
+                              int32_t* out_ptr, const int32_t* __restrict__ bbox_ord, int32_t* bounds) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) out_ptr[b] = slot[(long long)b * cap];
-    if (b == B) out_ptr[b] = *total;
+    if (b == B) {
+        out_ptr[b] = *total;
+        int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+        for (int c = 0; c < B; ++c) {
+            if (bbox_ord[6 * c + 3] == INT_MIN) continue;      // empty cloud
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = min(mn[a], (int)vord2f(bbox_ord[6 * c + a]));
+                mx[a] = max(mx[a], (int)vord2f(bbox_ord[6 * c + 3 + a]));
+            }
+        }
+        for (int a = 0; a < 3; ++a) { bounds[a] = mn[a]; bounds[3 + a] = mx[a]; }
+    }
 }
 
 extern "C" {
@@ -188,8 +187,9 @@ AGB_INTERNAL int agb_voxelize_last(const float* pos, const long long* perm, cons
     hipLaunchKernelGGL(k_vox_flag, dim3(agb_cdiv(nc, 256)), dim3(256), 0, s, cells, nc, flag);
     agb_launch_exclusive_scan(flag, nc, slot, scan_scratch, n_out_dev, s);
     hipLaunchKernelGGL(k_vox_emit, dim3(agb_cdiv(nc - 1, 256)), dim3(256), 0, s, pos, perm, ptr, elem, nc - 1, size,
-                       cells, slot, coords, keep, bounds);
-    hipLaunchKernelGGL(k_vox_out_ptr, dim3(agb_cdiv(B + 1, 64)), dim3(64), 0, s, slot, n_out_dev, cap, B, out_ptr);
+                       cells, slot, coords, keep);
+    hipLaunchKernelGGL(k_vox_out_ptr, dim3(agb_cdiv(B + 1, 64)), dim3(64), 0, s, slot, n_out_dev, cap, B, out_ptr, bbox_ord,
+                       bounds);
     AGB_CHECK_LAUNCH("agb_voxelize_last");
     return AGB_OK;
 }

@@ -330,9 +330,93 @@ def run_kpconv(a):
     print(json.dumps(line), flush=True)
 
 
+# ------------------------------------------------------------------------------------------------ end to end
+INPUT_ENTRY_PREFIXES = ("agb_plot_", "agb_voxelize", "agb_coords_augment", "agb_plot")
+
+
+def run_end2end(a):
+    """The training step FROM RAW POINTS (the reference runs the sparse-xy.yaml chain per sample on the
+    host before set_input: conf/data/instance/NFI/transforms/sparse-xy.yaml:4-104, core/data_transform/transforms.py,
+    grid_transform.py:112-128): raw 16 000-point plots resident on the device -> SparseTrainPipeline (ground removal, dropout,
+    noise, rotation, shift, added / copied points, polygon crop, features, GridSampling3D(last), flip / shift; the random draws
+    per sample on the host with the reference's generators, applied on the device) -> MSENet14 training step.  Inline (the
+    pipeline runs in front of the step on the compute stream; its counts come back to the host twice per batch)."""
+    import random
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, SparseTrainPipeline, draw_sample
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    B = a.batch or 32
+    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_064))
+    model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS["SENet14"]), "minkowski", ds)
+    model.to(dev).train()
+    model.init_train_objects(TRAINING_NFI)
+    model.reserve_workspace(dev, main_bytes=16 << 30, side_bytes=2 << 30)
+    cfg = NFITrainConfig()
+    pipe = SparseTrainPipeline(cfg)
+    pool = []
+    for i in range(3):
+        raws, ys = [], []
+        for seed in range(i * B, (i + 1) * B):
+            pos, _, y = synthetic.make_plot(seed, a.points)
+            # the raw frame of the reference: metres, centred on the plot centre, heights above an arbitrary datum
+            raws.append(np.stack([(pos[:, 0] - 0.5) * 30.0, (pos[:, 1] - 0.5) * 30.0, pos[:, 2] * 40.0 + 3.25], 1).astype(np.float32))
+            ys.append(y)
+        pool.append((raws, [torch.from_numpy(r).to(dev) for r in raws], np.stack(ys)))
+    host_draw_ms, voxels, points_in = [], [], []
+
+    def step(i):
+        raws_h, raws_d, y = pool[i % 3]
+        t0 = time.perf_counter()
+        draws = [draw_sample(torch.from_numpy(r), cfg) for r in raws_h]
+        host_draw_ms.append((time.perf_counter() - t0) * 1e3)
+        batch = pipe(raws_d, dev, y_reg=y, draws=draws)
+        voxels.append(int(batch.coords.shape[0]))
+        points_in.append(sum(len(d["sel"]) + d["n_add"] + (0 if d["cj_idx"] is None else len(d["cj_idx"])) for d in draws))
+        model.set_input(batch, dev)
+        model.optimize_parameters(epoch=0, batch_size=B, num_batches=133)
+
+    dt, gaps = timed_loop(step, a.steps, a.warmup)
+    with CallTimer() as ct:
+        for i in range(3):
+            step(i)
+    groups = ct.by_name()
+    top_table(groups, 12)
+    inp = {n: g for n, g in groups.items() if n.startswith(INPUT_ENTRY_PREFIXES)}
+    pipe_ms = sum(g["ms"] for g in inp.values()) / 3
+    dom = max(inp, key=lambda n: inp[n]["ms"])
+    g = inp[dom]
+    # SURVEY.md section 8(d): N (12 + 4 F) + M (12 + 4 F) + 8 N bytes for N points in, M voxels out, F = 3 features
+    N, M, F = float(np.mean(points_in[-3:])), float(np.mean(voxels[-3:])), 3
+    byts = N * (12 + 4 * F) + M * (12 + 4 * F) + 8 * N
+    avg_us = g["ms"] / g["n"] * 1e3
+    roof = dict(bound="hbm", achieved=round(byts / (avg_us * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(byts / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), traffic=None, traffic_source=None,
+                kernel=KERNEL_OF_ENTRY.get(dom, dom), entry_point=dom, launches=g["n"], avg_launch_us=round(avg_us, 2),
+                alg_bytes_per_launch=round(byts),
+                note="the dominant entry point of the input chain; bytes = the whole chain's per-batch figure of SURVEY 8(d): the "
+                     "chain is a dozen launches of 5-60 us each, bound by launch count and two host read-backs, not by bytes")
+    hd = sorted(host_draw_ms[-a.steps:])
+    line = dict(metric="training plots/sec (16k-pt NFI plots) MSENet14, from raw points", value=round(B * a.steps / dt, 2),
+                unit="plots/s", n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload=f"raw {a.points}-pt synthetic plots resident on the device -> sparse-xy.yaml train chain on "
+                                     f"the device (crop, jitter, rotation, features, GridSampling3D(last) at 0.0125, flip / shift; "
+                                     f"per-sample draws on the host) -> SENet14 training step, batch {B}, ~{M / B:.0f} voxels/plot "
+                                     "after augmentation", global_batch=B, parallelism="dp1",
+                            input_pipeline="inline, compute stream", final_loss=round(float(model.loss.detach()), 5)),
+                roofline=roof, step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
+                input_chain_device_ms_per_step=round(pipe_ms, 3), host_draws_ms_per_step_p50=round(hd[len(hd) // 2], 3),
+                entry_points_ms_per_step={n: round(gg["ms"] / 3, 3) for n, gg in
+                                          sorted(inp.items(), key=lambda kv: -kv[1]["ms"])[:8]})
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", choices=["pointnet", "kpconv"])
+    ap.add_argument("which", choices=["pointnet", "kpconv", "end2end"])
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0)
@@ -348,7 +432,7 @@ def main():
     # hiccups of the KPConv loop: host stalls with zero device allocations and no pageable copy in flight).
     import dpcr_agb_amd
     dpcr_agb_amd.limit_host_threads()
-    (run_pointnet if a.which == "pointnet" else run_kpconv)(a)
+    {"pointnet": run_pointnet, "kpconv": run_kpconv, "end2end": run_end2end}[a.which](a)
 
 
 if __name__ == "__main__":

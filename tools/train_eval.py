@@ -113,6 +113,17 @@ def main():
         return
     if "--acceptance" in sys.argv:
         sys.exit(0 if acceptance(torch.device("cuda:0")) else 1)
+    if "--acceptance-trial" in sys.argv:        # ONE trial of the acceptance schedule (bench.py's val_rmse / val_r2), ~11 s
+        trial = int(sys.argv[sys.argv.index("--acceptance-trial") + 1])
+        cfg = _load_cpu_leg_module().CFG
+        dev = torch.device("cuda:0")
+        t0 = time.time()
+        res = acceptance_gpu_trial(cfg, trial, dev, "fp32", acceptance_data(cfg, dev))
+        f = res["final"]
+        print(json.dumps(dict(model=cfg["model"], trial=trial, final=dict(epoch=f["epoch"] - 1, val_rmse=f["rmse_rs"], val_r2=f["r2_rs"],
+                                                                          train_loss=f["train_loss"]),
+                              config=cfg, seconds=round(time.time() - t0, 1))), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--train", type=int, default=1024)
     ap.add_argument("--val", type=int, default=256)
@@ -120,6 +131,8 @@ def main():
     ap.add_argument("--points", type=int, default=16000)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--model", default="SENet14")
+    ap.add_argument("--deterministic", action="store_true", help="fixed-order weight-gradient sums and seeded drop-path draws: "
+                    "the run is bitwise repeatable (what bench.py reports as val_rmse / val_r2)")
     a = ap.parse_args()
     from dpcr_agb_amd import synthetic
     from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
@@ -136,6 +149,10 @@ def main():
     ds._stats = {"mean": ys.mean(0).numpy(), "std": ys.std(0).numpy(), "min": ys.min(0).values.numpy(),
                  "max": ys.max(0).values.numpy()}
     model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS[a.model]), "minkowski", ds).to(dev)
+    if a.deterministic:
+        import random
+        random.seed(0)
+        model.set_kernel_options(deterministic_wgrad=True)
     model.init_train_objects(TRAINING_NFI)
     print(f"data ready in {time.time() - t0:.1f}s: {len(train)} train / {len(val)} val batches", flush=True)
     nb = len(train)
