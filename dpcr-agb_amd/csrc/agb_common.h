@@ -68,6 +68,12 @@ size_t agb_dwreg_workspace_bytes(int n_out, int K3, int Cin, int Cout);
 int agb_dwreg_launch(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride, float* dW,
                      int n_out, int K3, int Cin, int Cout, void* workspace, size_t workspace_bytes, hipStream_t st);
 
+// dwa.hip: fp32 weight gradient with persistent accumulators and a hand-scheduled main loop (Cin, Cout multiples of 64)
+bool agb_dwa_ok(int n_out, int K3, int Cin, int Cout, int ldx, int ldy, bool force = false);
+size_t agb_dwa_workspace_bytes(int n_out, int K3, int Cin, int Cout);
+int agb_dwa_launch(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride, float* dW,
+                   int n_out, int K3, int Cin, int Cout, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 // stem.hip: pair-sparse weight gradient of the 3-channel stem (one 4x4x1 MFMA per pair, fixed-order fold)
 bool agb_stem_dw_ok(int n_out, int K3, int Cin, int Cout, int ldx, int ldy);
 size_t agb_stem_dw_workspace_bytes(int n_out, int K3);

@@ -3005,10 +3005,25 @@ size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cou
         }
         return bytes;
     }
-    if (dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0, true))
-        return agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
-    const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, dense != 0, precision);
-    return (size_t)g.chunks * K3 * Cin * Cout * sizeof(float);
+    // fp32 maps with Cin, Cout multiples of 64: the persistent-accumulator kernel of dwa.hip (whether it takes the call also
+    // depends on the row strides: the workspace serves either kernel)
+    size_t dwa = 0;
+    if (!dense && precision == 0 && agb_dwa_ok(n_out, K3, Cin, Cout, Cin, Cout, true)) dwa = agb_dwa_workspace_bytes(n_out, K3, Cin, Cout);
+    size_t other;
+    if (dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0, true)) {
+        other = agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
+    } else {
+        const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, dense != 0, precision);
+        other = (size_t)g.chunks * K3 * Cin * Cout * sizeof(float);
+    }
+    return dwa > other ? dwa : other;
+}
+
+// 1 when agb_spconv_bwd_weight_ws(precision 0, variant 0, a workspace of agb_spconv_bwd_weight_workspace_bytes) runs the
+// persistent-accumulator kernel (dwa.hip) for this shape: the caller then passes the workspace whether or not it asked for
+// reproducible sums (the kernel's partial tiles ARE the product path; its sums are reproducible by construction).
+int agb_spconv_bwd_weight_persistent(int n_out, int K3, int Cin, int Cout, int ldx, int ldy) {
+    return agb_dwa_ok(n_out, K3, Cin, Cout, ldx, ldy, false) ? 1 : 0;
 }
 
 int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr, long long nbr_stride,
@@ -3054,8 +3069,8 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
                            float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
                            size_t workspace_bytes, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_bwd_weight: bad sizes");
-    AGB_CHECK_ARG(variant >= 0 && variant <= 2, "agb_spconv_bwd_weight_ws: variant %d (0 automatic, 1 LDS-staged, 2 register "
-                  "operands)", variant);
+    AGB_CHECK_ARG(variant >= 0 && variant <= 3, "agb_spconv_bwd_weight_ws: variant %d (0 automatic, 1 LDS-staged, 2 register "
+                  "operands, 3 persistent accumulators)", variant);
     AGB_CHECK_ARG(nbr != nullptr || K3 == 1, "agb_spconv_bwd_weight: the identity map (nbr == NULL) needs K3 == 1");
     AGB_CHECK_ARG(nbr != nullptr || (Cin != 4 && Cin != 8), "agb_spconv_bwd_weight: the identity map needs Cin >= 12");
     AGB_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
@@ -3068,6 +3083,16 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (dense, streaming)");
         return AGB_OK;
     }
+    if (nbr != nullptr && precision == 0 && (variant == 0 || variant == 3) && workspace != nullptr &&
+        agb_dwa_ok(n_out, K3, Cin, Cout, ldx, ldy, variant == 3) &&
+        workspace_bytes >= agb_dwa_workspace_bytes(n_out, K3, Cin, Cout)) {
+        // persistent accumulators, hand-scheduled main loop, fixed-order fold (dwa.hip): the fp32 product path since round 5
+        int rc = agb_dwa_launch(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, workspace, workspace_bytes, s);
+        if (rc) return rc;
+        AGB_CHECK_LAUNCH("agb_spconv_bwd_weight (persistent accumulators)");
+        return AGB_OK;
+    }
+    if (variant == 3) variant = 0;      // (a shape the persistent kernel does not take: the automatic choice)
     if (dw_takes_reg_kernel(nbr, n_out, Cin, Cout, precision, variant, workspace != nullptr)) {
         int rc = agb_dwreg_launch(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, workspace, workspace_bytes, s);
         if (rc) return rc;

@@ -39,7 +39,8 @@ class KernelOptions:
                            stem's grouped sub-chunks, the HBM-bound dense shapes included; bf16 / bf16x3: partial tiles of
                            k_spconv_dw_cmp folded in ascending order): bitwise reproducible training, 3.7 % slower MSENet14
                            fp32 step than the default (LDS-staged kernels, fp32 atomic accumulation)
-      dw_variant           0 = automatic, 1 = LDS-staged weight-gradient kernel, 2 = register-operand kernel (A/B measurements)
+      dw_variant           0 = automatic, 1 = LDS-staged weight-gradient kernel, 2 = register-operand kernel, 3 = persistent
+                           accumulators (csrc/dwa.hip; opt-in: equal to the staged kernel inside the step) (A/B measurements)
       bf16_storage         precision "bf16": convolutions read bf16 twins of their inputs (rows and weights converted once,
                            gathered as 2-byte channels) instead of converting fp32 rows while staging them
       bf16_activations     precision "bf16" on the sparse backbones: every activation / gradient ROW MATRIX of the network is
@@ -152,6 +153,7 @@ _lib.declare("agb_spconv_fwd_opt", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _l
                                     _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int,
                                     _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p])
 _lib.declare("agb_spconv_split_hint_opt", [_lib.c_int] * 5)
+_lib.declare("agb_spconv_bwd_weight_persistent", [_lib.c_int] * 6)
 _lib.declare("agb_spconv_cmp_geometry", [_lib.c_int] * 8 + [_lib.c_void_p])
 _lib.declare("agb_spconv_balance_tiles_workspace_bytes", [_lib.c_int] * 3)
 _lib.declare("agb_spconv_balance_tiles", [_lib.c_void_p, _lib.c_ll, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int,
@@ -483,13 +485,22 @@ def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
     # dense-over-offsets kernel AND reproducible
     stem = (cin == 4 and cout == 64 and nbr is not None and x.stride(0) == 4 and opts.dw_variant == 0
             and x.dtype == torch.float32 and dy.dtype == torch.float32)
+    # fp32 maps with Cin, Cout multiples of 64 (every 3^3 / 2^3 layer of the SENets): with a workspace the library runs the
+    # persistent-accumulator kernel (csrc/dwa.hip) — the product path, AND reproducible; KernelOptions.dw_variant 1 / 2
+    # still select the older kernels for A/B measurements
+    persistent = (prec == 0 and nbr is not None and x.dtype == torch.float32 and dy.dtype == torch.float32 and
+                  (opts.dw_variant == 3 or (opts.dw_variant == 0 and PERSISTENT_WGRAD and _lib.load().
+                   agb_spconv_bwd_weight_persistent(n_out, K3, cin, cout, x.stride(0), dy.stride(0)) == 1)))
     nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) \
-        if (det or stem) else 0
+        if (det or stem or persistent) else 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     _lib.call("agb_spconv_bwd_weight_ws", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), 0 if nbr is None else nbr.stride(0),
               _P(dw), n_out, K3, cin, cout, prec, opts.dw_variant, _P(ws), nbytes, _lib.stream())
 
 
+# The persistent-accumulator weight gradient (csrc/dwa.hip) is OPT-IN: measured equal to the LDS-staged kernel inside the
+# training step (EXPERIMENTS.md round 5: its kernels win 6-24 % on the shapes it takes, its 115 MB fold gives that back)
+PERSISTENT_WGRAD = os.environ.get("AGB_PERSISTENT_WGRAD", "0") != "0"
 _PROBE_PAIRS = {}
 
 

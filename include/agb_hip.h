@@ -259,8 +259,15 @@ int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, 
  * LDS-staged kernel writes one partial tile per row chunk, folded in ascending order) and the HBM-bound dense shapes (which
  * take the register-operand kernel instead of the streaming kernel's cross-workgroup atomics).
  * agb_spconv_bwd_weight_workspace_bytes (host helper; dense = 1 for nbr == NULL) returns 0 only for empty products.
- * variant: 0 automatic, 1 = LDS-staged kernel, 2 = register-operand kernel whatever the workspace (A/B measurements). */
+ * variant: 0 automatic, 1 = LDS-staged kernel, 2 = register-operand kernel whatever the workspace, 3 = the persistent-accumulator
+ * kernel for every shape it can take (A/B measurements, tests). */
 size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cout, int dense, int precision);
+/* fp32 maps (nbr != NULL) with Cin and Cout multiples of 64, 2 <= K3 <= 28 and >= 2048 rows: with a workspace, variant 0 runs
+ * the PERSISTENT-ACCUMULATOR kernel (csrc/dwa.hip, hand-scheduled: csrc/gen_dw_asm.py): one wave keeps the 64 x 64 tiles of up
+ * to seven offsets in registers for the whole launch, partial tiles leave once per wave, k_dwa_fold adds them in ascending
+ * order (reproducible).  agb_spconv_bwd_weight_persistent says whether a shape takes it: the Python side then always passes
+ * the workspace (this kernel is the fp32 product path, not only the reproducible option). */
+int agb_spconv_bwd_weight_persistent(int n_out, int K3, int Cin, int Cout, int ldx, int ldy);
 int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, int precision,
                              int variant, void* workspace, size_t workspace_bytes, void* stream);

@@ -203,6 +203,45 @@ def test_hand_scheduled_kernel_equals_its_twin(device, cin, cout, K, stride, n_p
     assert rel_err(ref, acc) < 2e-6
 
 
+@pytest.mark.parametrize("cin,cout,K,stride,n_per", [(64, 64, 3, 1, 2500), (128, 64, 3, 1, 1500), (64, 128, 2, 2, 2500),
+                                                      (64, 192, 3, 1, 1100)])
+def test_persistent_weight_gradient(device, cin, cout, K, stride, n_per):
+    """k_spconv_dwa (csrc/dwa.hip + gen_dw_asm.py; opt-in: sparse_ops.PERSISTENT_WGRAD): one wave keeps the 64 x 64 tiles of up
+    to seven offsets in registers, groups of four pairs, hand-scheduled gathers four groups ahead, fixed-order fold — against the
+    fp64 sum of the same pairs (fp32 rounding) and bitwise repeatable; ragged last chunk, chunks without a pair for some
+    offsets, several (ci, co) tiles, a strided 2^3 map, accumulation INTO dW."""
+    import dpcr_agb_amd.me_compat as ME
+    from dpcr_agb_amd import _lib, sparse_ops
+    rng = np.random.default_rng(2000 + cin + cout + n_per)
+    torch.manual_seed(cin + n_per)
+    coords = random_coords(rng, 3, n_per, 14)
+    st = ME.SparseTensor(torch.zeros(len(coords), 1), coordinates=torch.from_numpy(coords).int(), device=device)
+    cm = st.coordinate_manager
+    if stride > 1:
+        cm.stride(1, stride)
+    nbr = cm.kernel_map(1, K, stride)
+    K3 = K ** 3
+    n_in, n_out = cm.level(1).n, cm.level(stride).n
+    assert _lib.load().agb_spconv_bwd_weight_persistent(max(n_out, 40000), K3, cin, cout, cin, cout) == 1
+    x = torch.randn(n_in, cin, device=device)
+    dy = torch.randn(n_out, cout, device=device)
+    base = torch.randn(K3, cin, cout, device=device)
+    outs = []
+    for _ in range(2):
+        dw = base.clone()
+        sparse_ops.weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, sparse_ops.KernelOptions(dw_variant=3))
+        assert _lib.last_kernel().startswith("k_spconv_dwa")
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = base.double()
+    for k in range(K3):
+        idx = nbr[k, :n_out].long()
+        pres = idx >= 0
+        ref[k] += x[idx[pres]].double().t() @ dy[pres].double()
+    assert rel_err(outs[0], ref) < 2e-6
+
+
 @pytest.mark.parametrize("K,negative", [(7, False), (7, True), (3, True), (5, False)])
 def test_stem_conv_probes_dense_grid(device, K, negative):
     """A 3-channel stride-1 layer whose input needs no gradient reads its neighbours from the level's dense grid: no map
