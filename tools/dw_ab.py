@@ -19,7 +19,7 @@ def main():
     coords = torch.cat([b.batch[:, None].int(), b.coords.int()], 1).to(dev)
     cm = CoordinateManager(coords, device=dev, batch_size=32, bounds=b.coord_bounds)
     ts = 1
-    variants = (("persistent", dict(dw_variant=3)), ("staged", dict(dw_variant=1)), ("reg", dict(dw_variant=2)))
+    variants = (("auto", {}), ("persistent", dict(dw_variant=3)), ("staged", dict(dw_variant=1)), ("reg", dict(dw_variant=2)))
     cases = []
     for ts_in, c in ((2, 64), (4, 128), (8, 256), (16, 512)):
         while ts < ts_in:
@@ -51,7 +51,7 @@ def main():
                 torch.cuda.synchronize()
                 if rep == 0:
                     err[tag] = float((dw.double() - ref).abs().max() / ref.abs().max())
-                    if tag == "persistent":
+                    if tag == "persistent":      # (auto = the product's choice: staged 64 x 64 or 128 x 64 tiles, atomics)
                         dw2 = torch.zeros(K3, cin, cout, device=dev)
                         sparse_ops.weight_grad_raw(x, dy, nbr, dw2, n_out, K3, cin, cout, opts)
                         err["repeat"] = bool(torch.equal(dw, dw2))
@@ -64,7 +64,7 @@ def main():
                 if rep > 0:
                     tot[tag] += e0.elapsed_time(e1) / 5 * 1e3
         print(f"{name} ({pairs / 1e6:.2f} M pairs): " + "  ".join(
-            f"[{t}] {tot[t] / 4:6.1f} us {2.0 * pairs * cin * cout / (tot[t] / 4) / 1e6:5.1f} TF (err {err[t]:.1e})" for t, _ in variants)
+            f"[{t}] {tot[t] / 4:6.1f} us {2.0 * pairs * cin * cout / (tot[t] / 4) / 1e6:5.1f} TF ({err[t]:.0e})" for t, _ in variants)
             + f"  persistent bitwise repeatable: {err['repeat']}", flush=True)
 
 
