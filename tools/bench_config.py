@@ -141,7 +141,23 @@ def pmc_traffic(kernel, config):
     return None, None
 
 
-def roofline_entry(name, g, cost, config=None):
+def step_shares(groups, top=8):
+    """Share of the instrumented steps' bracketed device time per KERNEL (the name the library noted when it launched it, else
+    the entry point): what decides which kernel dominates a config's step (round-4 review: the share inside one entry point
+    says nothing about the step)."""
+    per = {}
+    for name, g in groups.items():
+        noted = sum(g.get("kernels", {}).values())
+        for k, ms in g.get("kernels", {}).items():
+            per[k] = per.get(k, 0.0) + ms
+        if g["ms"] - noted > 1e-6:
+            key = KERNEL_OF_ENTRY.get(name, name)
+            per[key] = per.get(key, 0.0) + g["ms"] - noted
+    total = sum(per.values()) or 1.0
+    return {k: round(v / total, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:top]}
+
+
+def roofline_entry(name, g, cost, config=None, groups=None):
     flops = sum(cost(a)[0] for a, _ in g["calls"])
     byts = sum(cost(a)[1] for a, _ in g["calls"])
     secs = g["ms"] / 1e3
@@ -156,8 +172,10 @@ def roofline_entry(name, g, cost, config=None):
     kernels = {k: round(ms / g["ms"], 3) for k, ms in sorted(g.get("kernels", {}).items(), key=lambda kv: -kv[1])}
     kernel = next(iter(kernels), KERNEL_OF_ENTRY.get(name, name))
     traffic, src = pmc_traffic(kernel, config) if config else (None, None)
-    r.update(traffic=traffic, traffic_source=src, kernel=kernel, entry_point=name, kernels_time_share=kernels or None,
-             launches=g["n"],
+    r.update(traffic=traffic, traffic_source=src, kernel=kernel, entry_point=name,
+             kernels_time_share=step_shares(groups) if groups is not None else (kernels or None),
+             kernels_time_share_of="the step's bracketed device time (three instrumented steps)" if groups is not None
+             else "this entry point", launches=g["n"],
              avg_launch_us=round(g["ms"] / g["n"] * 1e3, 2), alg_bytes_per_launch=round(byts / g["n"]),
              alg_flops_per_launch=round(flops / g["n"]))
     return r
@@ -228,7 +246,7 @@ def run_pointnet(a):
     costs = {"agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_fwd_lp": conv_call_cost,
              "agb_spconv_bwd_weight_lp": wgrad_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost}
     dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
-    roof = roofline_entry(dom, groups[dom], costs[dom], "config2")
+    roof = roofline_entry(dom, groups[dom], costs[dom], "config2", groups)
     line = dict(metric="training plots/sec (16k-pt NFI plots) MPointNet", value=round(B * a.steps / dt, 2), unit="plots/s",
                 n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
                 scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -307,7 +325,7 @@ def run_kpconv(a):
              "agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost,
              "agb_spconv_bwd_weight_lp": wgrad_call_cost}
     dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
-    roof = roofline_entry(dom, groups[dom], costs[dom], "config3")
+    roof = roofline_entry(dom, groups[dom], costs[dom], "config3", groups)
     index_names = ("agb_ball_query_fill", "agb_ball_query_fill_csr", "agb_ball_query_offsets", "agb_ball_query_count",
                    "agb_ball_grid_build", "agb_grid_subsample_ws", "agb_elem_bbox", "agb_elem_of_row", "agb_rotate_points")
     index_ms = sum(groups[n]["ms"] for n in index_names if n in groups) / 3
