@@ -89,9 +89,9 @@ def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, file it was read from) from the newest committed PMC pass
     (tools/collect_pmc.sh <tag> -> profiles/<tag>_pmc_traffic.json; separate --pmc runs of this same command, corrected as
     MI355X_MICROARCH.md prescribes) — counters cannot be collected from inside a running benchmark — or (None, None)."""
-    names = [f"{tag}_pmc_traffic.json" for tag in ("r04", "r03", "r02", "r01")]
+    names = [f"{tag}_pmc_traffic.json" for tag in ("r05", "r04", "r03", "r02", "r01")]
     if PMC_CONFIG:      # (another model / precision than the headline: its own PMC pass, tools/collect_pmc_configs.sh)
-        names = [f"r04_pmc_traffic_{PMC_CONFIG}.json"]
+        names = [f"{tag}_pmc_traffic_{PMC_CONFIG}.json" for tag in ("r05", "r04")]
     for name in names:
         rel = os.path.join("profiles", name)
         try:

@@ -129,7 +129,7 @@ def shape_table(groups):
 def pmc_traffic(kernel, config):
     """(HBM bytes per launch of `kernel`, file) from the committed PMC pass of this config (tools/collect_pmc_configs.sh ->
     profiles/<tag>_pmc_traffic_<config>.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections), or (None, None)."""
-    for tag in ("r04",):
+    for tag in ("r05", "r04"):
         rel = os.path.join("profiles", f"{tag}_pmc_traffic_{config}.json")
         try:
             data = json.load(open(os.path.join(ROOT, rel)))["kernels"]
