@@ -27,6 +27,8 @@ GRID_MAX_CELLS = 1 << 28  # 1 GiB of int32 per level at most; beyond that the ha
 GRID_HALO = 3             # empty cells around every level's grid: stride-1 kernels up to 7^3 probe it without bounds checks
 
 
+_PINNED_COUNTS = {}      # (numel, dtype) -> idle pinned read-back buffers (prefetch_strides / finish_prefetch)
+
 class CoordinateMapKey:
     """Identifies one coordinate level: the isotropic tensor stride (0 = the pooled 'one row per batch' level)."""
 
@@ -286,7 +288,10 @@ class CoordinateManager:
             status = self.levels[self.origin_ts].status
             vals_dev = torch.cat([lv.n_dev for lv in pending] + [status])
             if defer:
-                host = torch.empty(vals_dev.shape, dtype=vals_dev.dtype, pin_memory=True)
+                # pinned landing buffers are recycled here: handing them back to torch's pinned allocator costs an event
+                # record + queries per buffer (and a completion callback in the runtime per query of an unfinished event)
+                pool = _PINNED_COUNTS.setdefault((vals_dev.numel(), vals_dev.dtype), [])
+                host = pool.pop() if pool else torch.empty(vals_dev.shape, dtype=vals_dev.dtype, pin_memory=True)
                 host.copy_(vals_dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
@@ -307,7 +312,9 @@ class CoordinateManager:
         pending, host, ev, _keep = d
         self._deferred = None
         ev.synchronize()
-        self._apply_counts(pending, host.tolist())
+        vals = host.tolist()
+        _PINNED_COUNTS.setdefault((host.numel(), host.dtype), []).append(host)
+        self._apply_counts(pending, vals)
 
     def grid_probe(self, ts, K, stride=1, dilation=1):
         """(coords, grid, desc) of level ts if a K^3 stride-1 convolution can probe the level's dense grid directly

@@ -8,6 +8,7 @@ torch_points3d/models/instance/base.py:54-208 (target standardisation buffers :8
 smooth-L1 on standardised targets weighted by mean(task weights) :154-179, de-standardised report :181-185).
 Mixed precision: the reference's published sparse models run fp32; GradScaler is a no-op here.
 """
+import os
 from collections import OrderedDict
 from typing import List
 
@@ -274,6 +275,27 @@ class InstanceBase(torch.nn.Module):
         ring = self.__dict__.setdefault("_pace_ring", [])
         ev = torch.cuda.Event(blocking=True)
         ev.record()
-        ring.append(ev)
+        held = self.__dict__.get("_held_inputs")
+        ring.append((ev, held))      # everything consumed on the compute stream so far is finished when ev is
+        self.__dict__["_held_inputs"] = []
         if len(ring) > self.PACE_DEPTH:
-            ring.pop(0).synchronize()
+            old, _inputs = ring.pop(0)
+            old.synchronize()         # (_inputs dropped here: their memory returns to the side stream's pool)
+
+    # Tensors built on the side stream and consumed on the compute stream.  ``Tensor.record_stream`` would make the caching
+    # allocator record an event per freed block and poll it with hipEventQuery — and every query of an unfinished event
+    # makes the runtime enqueue a marker with a completion callback on the other queue: ~100 callbacks per step kept the
+    # runtime's signal-handler thread spinning (8.5-9.5 ms of CPU per 8.9 ms step, profiles/r03_host_cpu.txt).  Instead
+    # the step keeps a reference until the pacing event recorded after it has been waited for.
+    HOLD_LIMIT = 8
+
+    def _hold_input(self, obj, tensors, stream):
+        if self.PACE_DEPTH <= 0 or os.environ.get("AGB_INPUT_RECORD_STREAM", "0") != "0":
+            for t in tensors:
+                t.record_stream(stream)
+            return
+        held = self.__dict__.setdefault("_held_inputs", [])
+        held.append((obj, list(tensors)))
+        if len(held) > self.HOLD_LIMIT:       # a loop that never calls optimize_parameters (evaluation): allocator's way
+            for t in held.pop(0)[1]:
+                t.record_stream(stream)

@@ -179,11 +179,13 @@ class KPConvModel(InstanceBase):
             data._prefetched = None
             cur = torch.cuda.current_stream(device)
             cur.wait_event(ev)
-            for v in inp.values():      # built on the side stream, consumed on the compute stream
+            used = []                   # built on the side stream, consumed on the compute stream
+            for v in inp.values():
                 for t in (v if isinstance(v, (list, tuple)) else [v]):
                     for u in (t.tensors() if hasattr(t, "tensors") else [t]):
                         if isinstance(u, torch.Tensor) and u.is_cuda:
-                            u.record_stream(cur)
+                            used.append(u)
+            self._hold_input(inp, used, cur)
             self.input = Opt(inp)
         else:
             self.input = Opt(self._pyramid(data, device))

@@ -111,8 +111,7 @@ class MinkowskiBaselineModel(InstanceBase):
             self.input = inp
             cur = torch.cuda.current_stream(device)
             cur.wait_event(ev)
-            self.input.coordinate_manager.record_stream(cur)
-            self.input.F.record_stream(cur)
+            self._hold_input(inp, list(inp.coordinate_manager.tensors()) + [inp.F], cur)
         else:
             self.input = self._build_input(data, device)
         if len(self.loss_fns) > 0:
