@@ -267,7 +267,7 @@ class InstanceBase(torch.nn.Module):
     # queue is full — where the runtime SPINS for a free slot: one core per rank burnt for nothing, and under a CPU quota
     # shared by eight ranks a reason to be throttled.  Instead the host sleeps on a blocking event (interrupt-driven wait)
     # until the step issued PACE_DEPTH steps ago is done: the device queue always holds that many whole steps.
-    PACE_DEPTH = 3
+    PACE_DEPTH = int(os.environ.get("AGB_PACE_DEPTH", "3"))      # 0: no pacing (the host runs ahead until the queue is full)
 
     def _pace_host(self):
         if not torch.cuda.is_available() or self.PACE_DEPTH <= 0:

@@ -73,16 +73,22 @@ class MinkowskiBaselineModel(InstanceBase):
     def _build_input(self, data, device):
         return self._stage_b(self._stage_a(data, device, defer=False))
 
+    def input_stream(self, device):
+        """The side stream the input pipeline runs on (created on first use): a caller that BUILDS its batches on the device
+        (``train_transforms.SparseTrainPipeline``) does so under ``torch.cuda.stream(model.input_stream(device))`` before
+        ``prefetch_input``; ``set_input`` keeps such a batch alive until the step that consumed it is done."""
+        if not hasattr(self, "_side_stream"):
+            self._side_stream = torch.cuda.Stream(device=device)
+            self._staged = None
+        return self._side_stream
+
     def prefetch_input(self, data, device):
         """Input pipeline on a side stream, two batches deep, with no host wait: this call enqueues stage A of `data`
         (coordinate levels; the row counts travel to pinned memory asynchronously) and stage B (kernel maps) of the
         batch staged by the PREVIOUS call, whose counts landed a whole step ago.  ``set_input`` picks a batch up at
         whatever stage it is in.  Call it after ``optimize_parameters`` with the batch two steps ahead (or one step
         ahead: stage B then runs inside ``set_input``, still on the side stream)."""
-        if not hasattr(self, "_side_stream"):
-            self._side_stream = torch.cuda.Stream(device=device)
-            self._staged = None
-        side = self._side_stream
+        side = self.input_stream(device)
         # NOTE: no wait on the compute stream here (that would serialise the plan behind the whole running step):
         # the batch tensors must already be materialised (data-loader output / device-resident pool).
         with torch.cuda.stream(side):
@@ -111,7 +117,9 @@ class MinkowskiBaselineModel(InstanceBase):
             self.input = inp
             cur = torch.cuda.current_stream(device)
             cur.wait_event(ev)
-            self._hold_input(inp, list(inp.coordinate_manager.tensors()) + [inp.F], cur)
+            # (data too: a batch built on the side stream — its targets are read by the loss on the compute stream)
+            self._hold_input((inp, data), list(inp.coordinate_manager.tensors()) + [inp.F] +
+                             [t for t in getattr(data, "__dict__", {}).values() if isinstance(t, torch.Tensor) and t.is_cuda], cur)
         else:
             self.input = self._build_input(data, device)
         if len(self.loss_fns) > 0:

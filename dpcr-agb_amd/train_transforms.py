@@ -78,7 +78,7 @@ def rotation_matrix(thetas: torch.Tensor) -> torch.Tensor:
 def draw_sample(raw: torch.Tensor, cfg: NFITrainConfig) -> dict:
     """All random draws of one sample for RandomGroundRemoval .. RandomPolygon2dExtend, in the reference's order.
     raw: float32 [n, 3] on the host (the ground-removal decision needs the raw heights)."""
-    d = dict(zsub=0.0)
+    d = dict(zsub=0.0, n_raw=len(raw))
     sel = None
     # RandomGroundRemoval (transforms.py:1140-1150)
     if random.random() < cfg.ground_p:
@@ -139,63 +139,116 @@ def draw_sample(raw: torch.Tensor, cfg: NFITrainConfig) -> dict:
     return d
 
 
+def collate_draws(draws: List[dict], cfg: Optional[NFITrainConfig] = None) -> dict:
+    """The draws of a batch as a handful of stacked HOST tensors (what ``SparseTrainPipeline.augment`` uploads): row
+    selections as indices into the stacked raw plots, per-sample parameter rows, noise tables, counts.  Runs wherever the
+    draws were made — as the ``collate_fn`` of a DataLoader it runs in the worker process, and the batch crosses to the
+    training process as ten tensors instead of a hundred small ones."""
+    c = cfg or NFITrainConfig()
+    B = len(draws)
+    n_raw = np.asarray([int(d["n_raw"]) for d in draws], dtype=np.int64)
+    raw_off = np.concatenate([[0], np.cumsum(n_raw)])
+    n1s = np.asarray([len(d["sel"]) for d in draws], dtype=np.int64)
+    aug = torch.zeros(B, 24, dtype=torch.float32)
+    for b, d in enumerate(draws):
+        sh = d["shift"].reshape(-1).tolist() if d["shift"] is not None else [0.0, 0.0, 0.0]
+        aug[b, :19] = torch.tensor([np.float32(d["zsub"]), *c.scale, *d["M"].reshape(-1).tolist(), *sh, *c.center],
+                                   dtype=torch.float32)
+    nv = len(draws[0]["polygon"])
+    if any(len(d["polygon"]) != nv for d in draws):
+        raise NotImplementedError("polygons of one batch must have the same number of vertices")
+    n_cj = np.asarray([0 if d["cj_idx"] is None else len(d["cj_idx"]) for d in draws], dtype=np.int64)
+    return dict(
+        B=B, nv=nv, n_raw=torch.from_numpy(n_raw), n1s=torch.from_numpy(n1s),
+        sel=torch.cat([d["sel"].long() + int(raw_off[b]) for b, d in enumerate(draws)]), aug=aug,
+        noise=torch.cat([d["noise"] if d["noise"] is not None else torch.zeros(len(d["sel"]), 3) for d in draws]),
+        n_add=torch.from_numpy(np.asarray([d["n_add"] for d in draws], dtype=np.int32)), n_cj=torch.from_numpy(n_cj),
+        cj_idx=torch.cat([d["cj_idx"] if d["cj_idx"] is not None else torch.zeros(0, dtype=torch.long)
+                          for d in draws] + [torch.zeros(1, dtype=torch.long)]),
+        cj_noise=torch.cat([d["cj_noise"] if d["cj_noise"] is not None else torch.zeros(0, 3)
+                            for d in draws] + [torch.zeros(1, 3)]),
+        polys=torch.from_numpy(np.stack([d["polygon"] for d in draws]).reshape(B, -1)))
+
+
+class SampleDraws(torch.utils.data.Dataset):
+    """The per-sample random draws as a map-style dataset, so that they run where the reference runs its transforms: in the
+    worker processes of a ``torch.utils.data.DataLoader`` (torch_points3d/datasets/base_dataset.py: the loaders are built
+    with ``num_workers`` from the training config; every worker has its own ``random`` / numpy / torch generator state, seeded
+    by the loader).  Item i = ``draw_sample`` of raw plot ``i % len(raws)``; collate with ``collate_draws`` (in the worker):
+
+        loader = DataLoader(SampleDraws(raws), batch_size=B, num_workers=4, collate_fn=collate_draws, pin_memory=True,
+                            worker_init_fn=SampleDraws.seed_worker, persistent_workers=True)
+        for draws in loader: batch = pipeline(raws_on_device[...], device, draws=draws)
+    """
+
+    def __init__(self, raws, cfg: Optional[NFITrainConfig] = None, length: Optional[int] = None):
+        self.raws = [torch.as_tensor(r, dtype=torch.float32).reshape(-1, 3) for r in raws]
+        self.cfg = cfg or NFITrainConfig()
+        self.length = len(self.raws) if length is None else int(length)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        return draw_sample(self.raws[i % len(self.raws)], self.cfg)
+
+    @staticmethod
+    def seed_worker(worker_id):
+        # the loader seeds ``torch`` and ``random`` per worker; numpy's global generator (np.random.choice / rand in
+        # CopyJitterRandomPoints and RandomPolygon2dExtend) would otherwise be a copy of the parent's in every worker
+        np.random.seed((torch.initial_seed() + worker_id) % (1 << 32))
+        torch.set_num_threads(1)
+
+
 class SparseTrainPipeline:
     """sparse-xy.yaml train_transform for a batch of raw plots -> PlotBatch on the device."""
 
-    def __init__(self, cfg: Optional[NFITrainConfig] = None):
+    def __init__(self, cfg: Optional[NFITrainConfig] = None, device_shuffle: bool = False):
+        """device_shuffle: draw the voxel shuffle of GridSampling3D on the device (``voxelize.device_permutations``) instead
+        of one host ``torch.randperm`` per plot."""
         self.cfg = cfg or NFITrainConfig()
         c = self.cfg
         # the deterministic tail (counts, features, voxelisation, coordinate augmentation) is the test pipeline's
         self.tail = SparsePlotPipeline(nfi_test_transform(c.scale, c.center[:2], c.voxel) + nfi_coord_augmentation())
+        self.tail.device_shuffle = bool(device_shuffle)
 
-    def augment(self, plots: List, draws: List[dict], device):
-        """Applies the per-sample draws on the device.  Returns (pos [M,3], x [M,3], src [M], out_ptr int32 [B+1]):
-        the rows kept by RandomPolygon2dExtend, their features, their position in the pre-crop stacking."""
+    def augment(self, plots: List, draws, device):
+        """Applies the per-sample draws (a list of ``draw_sample`` dicts or their ``collate_draws``) on the device.  Returns
+        (pos [M,3], x [M,3], src [M], out_ptr int32 [B+1]): the rows kept by RandomPolygon2dExtend, their features, their
+        position in the pre-crop stacking."""
         c = self.cfg
         dev = torch.device(device)
         B = len(plots)
-        raw_lens = np.asarray([int(p.shape[0]) for p in plots], dtype=np.int64)
-        raw_off = np.concatenate([[0], np.cumsum(raw_lens)])
-        raw = torch.cat([torch.as_tensor(p, dtype=torch.float32).reshape(-1, 3) for p in plots]).to(dev)
-        sel = torch.cat([d["sel"].long() + int(raw_off[b]) for b, d in enumerate(draws)]).to(dev)
-        n1s = np.asarray([len(d["sel"]) for d in draws], dtype=np.int64)
+        if not isinstance(draws, dict):
+            draws = collate_draws(draws, c)
+        if draws["B"] != B or draws["n_raw"].tolist() != [int(p.shape[0]) for p in plots]:
+            raise ValueError("the draws were made for other plots than the ones passed")
+        up = lambda t: t.to(dev, non_blocking=True)     # noqa: E731  (pinned by the loader: asynchronous; else blocking)
+        raw = torch.cat([torch.as_tensor(p, dtype=torch.float32).reshape(-1, 3).to(dev) for p in plots])
+        sel, aug, noise = up(draws["sel"]), up(draws["aug"]), up(draws["noise"])
+        n1s = draws["n1s"].numpy()
         n1 = int(n1s.sum())
         ptr1 = _ptr_tensor(n1s, dev)
         elem1 = _elem_of_row(ptr1, B, n1, dev)
-        aug = torch.zeros(B, 24, dtype=torch.float32)
-        for b, d in enumerate(draws):
-            sh = d["shift"].reshape(-1).tolist() if d["shift"] is not None else [0.0, 0.0, 0.0]
-            aug[b, :19] = torch.tensor([np.float32(d["zsub"]), *c.scale, *d["M"].reshape(-1).tolist(), *sh, *c.center],
-                                       dtype=torch.float32)
-        aug = aug.to(dev)
-        noise = torch.cat([d["noise"] if d["noise"] is not None else torch.zeros(len(d["sel"]), 3)
-                           for d in draws]).to(dev)
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
         i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)      # noqa: E731
         pos1, mins = f32(max(n1, 1), 3), f32(3 * B)
         _lib.call("agb_plot_augment", _P(raw), _P(sel), _P(elem1), _P(ptr1), B, n1, _P(aug), _P(noise), _P(pos1),
                   _P(mins), _lib.stream())
         # StartZFromZero + AddRandomPoints + CopyJitterRandomPoints: all counts are known to the host
-        n_add = np.asarray([d["n_add"] for d in draws], dtype=np.int32)
-        n_cj = np.asarray([0 if d["cj_idx"] is None else len(d["cj_idx"]) for d in draws], dtype=np.int64)
-        n2s = n1s + n_add + n_cj
+        n_cj = draws["n_cj"].numpy()
+        n2s = n1s + draws["n_add"].numpy() + n_cj
         n2 = int(n2s.sum())
         ptr2 = _ptr_tensor(n2s, dev)
         elem2 = _elem_of_row(ptr2, B, n2, dev)
         cj_ptr = _ptr_tensor(n_cj, dev)
-        cj_idx = torch.cat([d["cj_idx"] if d["cj_idx"] is not None else torch.zeros(0, dtype=torch.long)
-                            for d in draws] + [torch.zeros(1, dtype=torch.long)]).to(dev)
-        cj_noise = torch.cat([d["cj_noise"] if d["cj_noise"] is not None else torch.zeros(0, 3)
-                              for d in draws] + [torch.zeros(1, 3)]).to(dev)
-        n_add_d = torch.from_numpy(n_add).to(dev)
+        cj_idx, cj_noise, n_add_d = up(draws["cj_idx"]), up(draws["cj_noise"]), up(draws["n_add"])
         pos2 = f32(max(n2, 1), 3)
         _lib.call("agb_plot_extend", _P(pos1), _P(ptr1), _P(mins), _P(ptr2), _P(elem2), B, n2, _P(n_add_d), _P(cj_ptr),
                   _P(cj_idx), _P(cj_noise), _P(pos2), _lib.stream())
         # RandomPolygon2dExtend + features
-        nv = len(draws[0]["polygon"])
-        if any(len(d["polygon"]) != nv for d in draws):
-            raise NotImplementedError("polygons of one batch must have the same number of vertices")
-        polys = torch.from_numpy(np.stack([d["polygon"] for d in draws]).reshape(B, -1)).to(dev)
+        nv = int(draws["nv"])
+        polys = up(draws["polys"])
         nn_ = max(n2, 1)
         ws = torch.empty(_lib.size_call("agb_plot_workspace_bytes", n2, B), dtype=torch.uint8, device=dev)
         pos_o, x_o = f32(nn_, 3), f32(nn_, 3)

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .kp_index import _elem_of_row, _ptr_tensor
-from .voxelize import draw_permutations, voxelize_last
+from .voxelize import device_permutations, draw_permutations, voxelize_last
 
 _P = _lib.ptr
 _V, _I = _lib.c_void_p, _lib.c_int
@@ -230,7 +230,12 @@ class SparsePlotPipeline:
             batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(lens)).to(dev)
             out = PlotBatch(batch, None, x, pos, None, None, B, None)
         else:
-            perm = draw_permutations(lens) if perms is None else perms
+            if perms is not None:
+                perm = perms
+            elif getattr(self, "device_shuffle", False):
+                perm = device_permutations(lens, dev)
+            else:
+                perm = draw_permutations(lens)
             coords, keep, vlens, bounds = voxelize_last(pos, lens, self.grid.size, perm=perm)
             coords = coords.contiguous()
             batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(vlens)).to(dev)

@@ -230,3 +230,61 @@ def test_device_train_chain_matches_oracle(device):
     out = pipe(raws, device, y_reg=np.ones((len(raws), 2), np.float32))
     assert out.coords.shape[0] == out.x.shape[0] == out.batch.shape[0] and out.coords.dtype == torch.int32
     assert int(out.batch.max()) == len(raws) - 1
+
+
+def test_collated_draws_and_loader_workers():
+    """collate_draws stacks a batch's draws without changing them, and SampleDraws behind a DataLoader with worker processes
+    (where the reference runs its transforms) yields such batches with a different generator state in every worker."""
+    from functools import partial
+    from torch.utils.data import DataLoader
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, SampleDraws, collate_draws, draw_sample
+    cfg = NFITrainConfig()
+    raws = [torch.from_numpy(raw_plot(700 + i, n)[0]) for i, n in enumerate([3000, 5000, 700, 300])]
+    _seed_all(3)
+    drs = [draw_sample(r, cfg) for r in raws]
+    col = collate_draws(drs, cfg)
+    n_raw = [len(r) for r in raws]
+    assert col["B"] == 4 and col["n_raw"].tolist() == n_raw
+    off = np.concatenate([[0], np.cumsum(n_raw)])
+    assert torch.equal(col["sel"], torch.cat([d["sel"] + int(off[b]) for b, d in enumerate(drs)]))
+    assert col["n1s"].tolist() == [len(d["sel"]) for d in drs] and col["noise"].shape == (int(col["n1s"].sum()), 3)
+    assert col["n_add"].tolist() == [d["n_add"] for d in drs]
+    assert col["cj_idx"].shape[0] == int(col["n_cj"].sum()) + 1 == col["cj_noise"].shape[0]
+    assert torch.equal(col["aug"][:, 4:13].reshape(4, 3, 3), torch.stack([d["M"] for d in drs]))
+    assert col["polys"].shape == (4, 2 * col["nv"])
+    loader = DataLoader(SampleDraws(raws, cfg, length=16), batch_size=4, num_workers=2, collate_fn=partial(collate_draws, cfg=cfg),
+                        worker_init_fn=SampleDraws.seed_worker)
+    got = list(loader)
+    assert len(got) == 4 and all(g["n_raw"].tolist() == n_raw for g in got)
+    # batches 0 and 1 come from different workers: different rotations and polygons
+    assert not torch.equal(got[0]["aug"], got[1]["aug"]) and not torch.equal(got[0]["polys"], got[1]["polys"])
+
+
+@pytest.mark.gpu
+def test_device_shuffle_is_a_permutation_per_cloud_and_collated_draws_give_the_same_rows(device):
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, SparseTrainPipeline, collate_draws, draw_sample
+    from dpcr_agb_amd.voxelize import device_permutations
+    lens = [5000, 0, 1, 13000, 77]
+    a, b = device_permutations(lens, device).cpu(), device_permutations(lens, device).cpu()
+    assert a.shape[0] == sum(lens) and not torch.equal(a, b)
+    o = 0
+    for n in lens:
+        assert torch.equal(torch.sort(a[o:o + n]).values, torch.arange(n))
+        o += n
+    # a uniform shuffle: the first shuffled position of the 13 000-row cloud over 200 draws covers the range evenly
+    firsts = torch.stack([device_permutations(lens, device)[5001] for _ in range(200)]).float().cpu()
+    assert 0.40 * 13000 < float(firsts.mean()) < 0.60 * 13000 and float(firsts.std()) > 0.2 * 13000
+    raws = [raw_plot(800 + i, n)[0] for i, n in enumerate([9000, 16000, 700])]
+    cfg = NFITrainConfig()
+    _seed_all(5)
+    draws = [draw_sample(torch.from_numpy(r), cfg) for r in raws]
+    pipe = SparseTrainPipeline(cfg, device_shuffle=True)
+    r1 = pipe.augment(raws, draws, device)
+    r2 = pipe.augment([torch.from_numpy(r).to(device) for r in raws], collate_draws(draws, cfg), device)
+    m = int(r1[3][-1])
+    assert torch.equal(r1[3], r2[3]) and torch.equal(r1[0][:m], r2[0][:m]) and torch.equal(r1[2][:m], r2[2][:m])
+    _seed_all(6)
+    out = pipe(raws, device, y_reg=np.ones((3, 2), np.float32))
+    assert out.coords.shape[0] == out.x.shape[0] and int(out.batch.max()) == 2
+    with pytest.raises(ValueError):
+        pipe.augment(raws[:2] + [raws[0]], draws, device)

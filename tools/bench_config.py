@@ -373,7 +373,7 @@ def run_end2end(a):
     model.init_train_objects(TRAINING_NFI)
     model.reserve_workspace(dev, main_bytes=16 << 30, side_bytes=2 << 30)
     cfg = NFITrainConfig()
-    pipe = SparseTrainPipeline(cfg)
+    pipe = SparseTrainPipeline(cfg, device_shuffle=not a.host_shuffle)
     pool = []
     for i in range(3):
         raws, ys = [], []
@@ -384,17 +384,44 @@ def run_end2end(a):
             ys.append(y)
         pool.append((raws, [torch.from_numpy(r).to(dev) for r in raws], np.stack(ys)))
     host_draw_ms, voxels, points_in = [], [], []
+    # The per-sample draws run in DataLoader worker processes (where the reference runs its transforms); the device part of
+    # the chain and the coordinate maps of a batch are enqueued on the model's input stream two steps ahead of its training
+    # step, so that the chain's two count read-backs wait for an idle side stream, not for the training steps in the queue.
+    from collections import deque
+    from torch.utils.data import DataLoader
+    from dpcr_agb_amd.train_transforms import SampleDraws, collate_draws
+    from functools import partial
+    workers = 0 if a.inline_draws else max(1, min(6, usable_cores() - 2))
+    loader = DataLoader(SampleDraws([r for raws, _, _ in pool for r in raws], cfg, length=1 << 30), batch_size=B, shuffle=False,
+                        num_workers=workers, collate_fn=partial(collate_draws, cfg=cfg), pin_memory=workers > 0,
+                        worker_init_fn=SampleDraws.seed_worker, persistent_workers=workers > 0,
+                        prefetch_factor=4 if workers else None)
+    draws_it = iter(loader)
+    side = model.input_stream(dev)
+    queue = deque()
+
+    def stage(i):
+        _, raws_d, y = pool[i % 3]
+        t0 = time.perf_counter()
+        draws = next(draws_it)
+        host_draw_ms.append((time.perf_counter() - t0) * 1e3)
+        with torch.cuda.stream(side):
+            batch = pipe(raws_d, dev, y_reg=y, draws=draws)
+        voxels.append(int(batch.coords.shape[0]))
+        points_in.append(int(draws["n1s"].sum() + draws["n_add"].sum() + draws["n_cj"].sum()))
+        model.prefetch_input(batch, dev)
+        queue.append(batch)
+
+    stage(0)
+    stage(1)
+    staged = [2]
 
     def step(i):
-        raws_h, raws_d, y = pool[i % 3]
-        t0 = time.perf_counter()
-        draws = [draw_sample(torch.from_numpy(r), cfg) for r in raws_h]
-        host_draw_ms.append((time.perf_counter() - t0) * 1e3)
-        batch = pipe(raws_d, dev, y_reg=y, draws=draws)
-        voxels.append(int(batch.coords.shape[0]))
-        points_in.append(sum(len(d["sel"]) + d["n_add"] + (0 if d["cj_idx"] is None else len(d["cj_idx"])) for d in draws))
+        batch = queue.popleft()
         model.set_input(batch, dev)
         model.optimize_parameters(epoch=0, batch_size=B, num_batches=133)
+        stage(staged[0])
+        staged[0] += 1
 
     dt, gaps = timed_loop(step, a.steps, a.warmup)
     with CallTimer() as ct:
@@ -422,9 +449,10 @@ def run_end2end(a):
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                 config=dict(workload=f"raw {a.points}-pt synthetic plots resident on the device -> sparse-xy.yaml train chain on "
                                      f"the device (crop, jitter, rotation, features, GridSampling3D(last) at 0.0125, flip / shift; "
-                                     f"per-sample draws on the host) -> SENet14 training step, batch {B}, ~{M / B:.0f} voxels/plot "
+                                     f"per-sample draws on the host, in DataLoader workers) -> SENet14 training step, batch {B}, ~{M / B:.0f} voxels/plot "
                                      "after augmentation", global_batch=B, parallelism="dp1",
-                            input_pipeline="inline, compute stream", final_loss=round(float(model.loss.detach()), 5)),
+                            input_pipeline=f"side stream, two batches ahead; per-sample draws in {workers} DataLoader worker "
+                                           f"process(es)", final_loss=round(float(model.loss.detach()), 5)),
                 roofline=roof, step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
                 input_chain_device_ms_per_step=round(pipe_ms, 3), host_draws_ms_per_step_p50=round(hd[len(hd) // 2], 3),
                 entry_points_ms_per_step={n: round(gg["ms"] / 3, 3) for n, gg in
@@ -440,6 +468,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--points", type=int, default=16000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inline-draws", action="store_true", help="end2end: per-sample draws in the training process, no workers")
+    ap.add_argument("--host-shuffle", action="store_true", help="end2end: GridSampling3D's shuffle with torch.randperm on the host")
     ap.add_argument("--shapes", action="store_true", help="per-shape table of the dense products / gathers")
     a = ap.parse_args()
     if not torch.cuda.is_available():
