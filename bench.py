@@ -335,7 +335,7 @@ OTHER_CONFIGS = (
      ["bench.py", "--model", "SENet50", "--precision", "bf16", "--bf16-rows", "--steps", "30", "--warmup", "8",
       "--no-other-configs"]),
     ("end_to_end", "config 4 from raw points: sparse-xy.yaml train transform chain on the device + MSENet14 step",
-     [os.path.join("tools", "bench_config.py"), "end2end", "--steps", "20", "--warmup", "5"]),
+     [os.path.join("tools", "bench_config.py"), "end2end", "--steps", "60", "--warmup", "10"]),
 )
 # BASELINE.json's metric is "training plots/sec ...; val RMSE": a short fixed-seed training run (reproducible: fixed-order
 # weight-gradient sums, seeded drop-path draws) on synthetic labelled plots, evaluated as eval.py does

@@ -199,8 +199,7 @@ class BatchNormAddActFunction(torch.autograd.Function):
                   _P(dgb[0]), _P(dgb[1]), act_id, int(training), n, c, _R(dz), 0 if dz is None else dz.stride(0), _R(dr),
                   0 if dr is None else dr.stride(0), _lib.stream())
         if dz is not None:
-            colsum = torch.zeros(c, dtype=torch.float32, device=dev) if training else \
-                (stats[1] * dgb[0] * (gamma if gamma is not None else 1.0))
+            colsum = int(c) if training else (stats[1] * dgb[0] * (gamma if gamma is not None else 1.0))
             dz.agb_colsum = (colsum, dz._version)
         return dz, dr, (dgb[1] if has_g else None), (dgb[0] if has_b else None), None, None, None, None, None, None, None, \
             None

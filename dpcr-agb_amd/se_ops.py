@@ -194,8 +194,7 @@ class SEBlockTailFunction(torch.autograd.Function):
         if dz is not None:
             # column sums of dz = the bias gradient of the convolution that produced z: 0 with batch statistics (the
             # BatchNorm is blind to a constant), gamma * rstd * dbeta with the running ones (norm_ops.BatchNormActFunction)
-            colsum = torch.zeros(C, dtype=torch.float32, device=dev) if training else \
-                (stats[1] * dgb[0] * (gamma if gamma is not None else 1.0))
+            colsum = int(C) if training else (stats[1] * dgb[0] * (gamma if gamma is not None else 1.0))
             dz.agb_colsum = (colsum, dz._version)
         return (dz, dr, dgb[1] if has_g else None, dgb[0] if has_b else None, None, None, None, None, None, None, None, None,
                 None, dw1, db1, dw2, db2, None, None, None)

@@ -245,7 +245,11 @@ def _colsum_hint(dy):
     if hint is None:
         return None
     colsum, version = hint
-    return colsum if dy._version == version else None
+    if dy._version != version:
+        return None
+    if isinstance(colsum, int):       # training-mode BatchNorm: the sums are zero; the buffer is only made when someone asks
+        return torch.zeros(colsum, dtype=torch.float32, device=dy.device)
+    return colsum
 
 
 def _pad_cols(x, mult):
@@ -624,7 +628,7 @@ class SparseConvFunction(torch.autograd.Function):
     def _backward_probe(ctx, dy):
         x, nbr = ctx.saved_tensors
         K3, cout, n_out, has_bias, bias_shape = ctx.dims
-        colsum = _colsum_hint(dy) if ctx.opts.closed_form_bias_grad else None
+        colsum = _colsum_hint(dy) if (ctx.opts.closed_form_bias_grad and has_bias) else None
         dy = dy.contiguous()
         dk = db = None
         if ctx.needs_input_grad[1]:
@@ -659,7 +663,7 @@ class SparseConvFunction(torch.autograd.Function):
         x, w, nbr, nbrT = ctx.saved_tensors
         K3, cin, cout, cin_p, cout_p, n_in, n_out, has_T, has_bias, bias_shape = ctx.dims
         opts = ctx.opts
-        colsum = _colsum_hint(dy) if opts.closed_form_bias_grad else None
+        colsum = _colsum_hint(dy) if (opts.closed_form_bias_grad and has_bias) else None
         dy = dy.contiguous()
         if cout_p != cout:
             dy = F.pad(dy, (0, cout_p - cout)).contiguous()
@@ -747,7 +751,7 @@ class DenseConvFunction(torch.autograd.Function):
         x, w = ctx.saved_tensors
         cin, cout = w.shape
         n = x.shape[0]
-        colsum = _colsum_hint(dy) if ctx.opts.closed_form_bias_grad else None
+        colsum = _colsum_hint(dy) if (ctx.opts.closed_form_bias_grad and ctx.has_bias) else None
         dy = dy.contiguous()
         dx = dk = db = None
         opts = ctx.opts
@@ -840,7 +844,7 @@ class DenseLinearFunction(torch.autograd.Function):
         xp, wp = ctx.saved_tensors
         cin, cout, cin_p, cout_p, has_bias = ctx.dims
         n = xp.shape[0]
-        colsum = _colsum_hint(dy) if ctx.opts.closed_form_bias_grad else None
+        colsum = _colsum_hint(dy) if (ctx.opts.closed_form_bias_grad and has_bias) else None
         dy = dy.contiguous()
         dyp = dy if cout_p == cout else F.pad(dy, (0, cout_p - cout)).contiguous()
         dx = dw = db = None

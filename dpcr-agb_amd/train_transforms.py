@@ -264,3 +264,4 @@ class SparseTrainPipeline:
         pos, x, src, out_ptr = self.augment(plots, draws, device)
         pos, x, src, lens = self.tail.fix_counts(pos, x, src, out_ptr)
         return self.tail.finish(pos, x, src, lens, len(plots), y_reg=y_reg, perms=perms)
+

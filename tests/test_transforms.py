@@ -288,3 +288,4 @@ def test_device_shuffle_is_a_permutation_per_cloud_and_collated_draws_give_the_s
     assert out.coords.shape[0] == out.x.shape[0] and int(out.batch.max()) == 2
     with pytest.raises(ValueError):
         pipe.augment(raws[:2] + [raws[0]], draws, device)
+

@@ -451,8 +451,8 @@ def run_end2end(a):
                                      f"the device (crop, jitter, rotation, features, GridSampling3D(last) at 0.0125, flip / shift; "
                                      f"per-sample draws on the host, in DataLoader workers) -> SENet14 training step, batch {B}, ~{M / B:.0f} voxels/plot "
                                      "after augmentation", global_batch=B, parallelism="dp1",
-                            input_pipeline=f"side stream, two batches ahead; per-sample draws in {workers} DataLoader worker "
-                                           f"process(es)", final_loss=round(float(model.loss.detach()), 5)),
+                            input_pipeline="side stream, two batches ahead; "
+                                           f"per-sample draws in {workers} DataLoader worker process(es)", final_loss=round(float(model.loss.detach()), 5)),
                 roofline=roof, step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
                 input_chain_device_ms_per_step=round(pipe_ms, 3), host_draws_ms_per_step_p50=round(hd[len(hd) // 2], 3),
                 entry_points_ms_per_step={n: round(gg["ms"] / 3, 3) for n, gg in
