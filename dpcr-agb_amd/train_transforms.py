@@ -221,10 +221,13 @@ class SparseTrainPipeline:
         B = len(plots)
         if not isinstance(draws, dict):
             draws = collate_draws(draws, c)
-        if draws["B"] != B or draws["n_raw"].tolist() != [int(p.shape[0]) for p in plots]:
+        ready = all(torch.is_tensor(p) and p.device == dev and p.dtype == torch.float32 and p.dim() == 2 for p in plots)
+        if not ready:
+            plots = [torch.as_tensor(p, dtype=torch.float32).reshape(-1, 3).to(dev) for p in plots]
+        if draws["B"] != B or draws["n_raw"].tolist() != [p.shape[0] for p in plots]:
             raise ValueError("the draws were made for other plots than the ones passed")
         up = lambda t: t.to(dev, non_blocking=True)     # noqa: E731  (pinned by the loader: asynchronous; else blocking)
-        raw = torch.cat([torch.as_tensor(p, dtype=torch.float32).reshape(-1, 3).to(dev) for p in plots])
+        raw = torch.cat(plots)
         sel, aug, noise = up(draws["sel"]), up(draws["aug"]), up(draws["noise"])
         n1s = draws["n1s"].numpy()
         n1 = int(n1s.sum())
@@ -262,6 +265,6 @@ class SparseTrainPipeline:
         if draws is None:
             draws = [draw_sample(torch.as_tensor(p, dtype=torch.float32).reshape(-1, 3), self.cfg) for p in plots]
         pos, x, src, out_ptr = self.augment(plots, draws, device)
-        pos, x, src, lens = self.tail.fix_counts(pos, x, src, out_ptr)
-        return self.tail.finish(pos, x, src, lens, len(plots), y_reg=y_reg, perms=perms)
+        pos, x, src, lens = self.tail.fix_counts(pos, x, src, out_ptr, with_extent=True)
+        return self.tail.finish(pos, x, src, lens, len(plots), y_reg=y_reg, perms=perms, extent_hint=self.tail.grid_extent)
 

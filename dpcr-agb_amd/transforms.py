@@ -188,10 +188,24 @@ class SparsePlotPipeline:
                   _P(ws), _P(pos_o), _P(x_o), _P(src), _P(out_ptr), _P(n_out), _lib.stream())
         return self.fix_counts(pos_o, x_o, src, out_ptr)
 
-    def fix_counts(self, pos_o, x_o, src, out_ptr):
-        """MaxPoints / MinPoints on the cropped rows (out_ptr: device int32 [B+1] offsets)."""
+    def fix_counts(self, pos_o, x_o, src, out_ptr, with_extent=False):
+        """MaxPoints / MinPoints on the cropped rows (out_ptr: device int32 [B+1] offsets).
+        with_extent: the per-axis extent of the widest cloud in voxel cells — what ``voxelize_last`` sizes its cell grid
+        from — is computed on the device and comes back in the SAME host read as the lengths (self.grid_extent; MaxPoints /
+        MinPoints keep a subset / repeat rows: the extent stays an upper bound): one synchronisation less per batch."""
         dev = pos_o.device
-        optr = np.asarray(out_ptr.tolist(), dtype=np.int64)       # one host read: the lengths after the crop
+        self.grid_extent = None
+        if with_extent and self.grid is not None:
+            from .kp_index import elem_bbox
+            B = int(out_ptr.shape[0]) - 1
+            bb = elem_bbox(pos_o, out_ptr, B)
+            ext = (bb[:, 3:] - bb[:, :3]).max(0).values / float(np.float32(self.grid.size))
+            host = torch.cat([out_ptr.double(), ext.double()]).tolist()      # ONE host read: lengths + extent
+            optr = np.asarray(host[:B + 1], dtype=np.int64)
+            if all(np.isfinite(host[B + 1:])):
+                self.grid_extent = [float(v) for v in host[B + 1:]]
+        else:
+            optr = np.asarray(out_ptr.tolist(), dtype=np.int64)   # one host read: the lengths after the crop
         new_lens = np.diff(optr)
         m = int(optr[-1])
         pos_o, x_o, src = pos_o[:m], x_o[:m], src[:m]
@@ -222,7 +236,7 @@ class SparsePlotPipeline:
         pos, x, src, lens = self.prepare(plots, device)
         return self.finish(pos, x, src, lens, len(plots), y_reg=y_reg, perms=perms)
 
-    def finish(self, pos, x, src, lens, B, y_reg=None, perms=None):
+    def finish(self, pos, x, src, lens, B, y_reg=None, perms=None, extent_hint=None):
         """GridSampling3D + coordinate augmentation + batch assembly on prepared rows."""
         from .synthetic import PlotBatch
         dev = pos.device
@@ -236,9 +250,12 @@ class SparsePlotPipeline:
                 perm = device_permutations(lens, dev)
             else:
                 perm = draw_permutations(lens)
-            coords, keep, vlens, bounds = voxelize_last(pos, lens, self.grid.size, perm=perm)
+            coords, keep, vlens, bounds = voxelize_last(pos, lens, self.grid.size, perm=perm, extent_hint=extent_hint)
             coords = coords.contiguous()
-            batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(vlens)).to(dev)
+            ptr = _ptr_tensor(vlens, dev)
+            m = int(coords.shape[0])
+            elem = _elem_of_row(ptr, B, m, dev)
+            batch = elem[:m].to(torch.int64)           # (on the device: no 8-byte-per-row upload)
             if self.flip is not None or self.shift is not None:
                 flips, shifts = np.zeros((B, 3), np.int32), np.zeros((B, 3), np.int32)
                 for b in range(B):   # the reference draws per sample: flip axes first, then the shift
@@ -248,15 +265,18 @@ class SparsePlotPipeline:
                                 flips[b, ax] = 1
                     if self.shift is not None and self.shift.apply_shift and random.random() < self.shift.p:
                         shifts[b] = (torch.rand(3) * 100).to(torch.int32).numpy()
-                ptr = _ptr_tensor(vlens, dev)
-                m = int(coords.shape[0])
-                elem = _elem_of_row(ptr, B, m, dev)
                 cmax = torch.empty(3 * B, dtype=torch.int32, device=dev)
                 # named tensors: a temporary would be freed (and its block reused) as soon as its pointer is taken
                 flips_d, shifts_d = torch.from_numpy(flips).to(dev), torch.from_numpy(shifts).to(dev)
                 _lib.call("agb_coords_augment", _P(coords), _P(elem), B, m, _P(flips_d), _P(shifts_d), _P(cmax),
                           _lib.stream())
-                bounds = None   # recomputed from the coordinates by PlotBatch
+                # Box of the augmented coordinates WITHOUT reading them back: a flipped axis of cloud b becomes
+                # max_b - c in [0, max_b - min_b], inside [0, max - min] of the batch; the shift is known here.  An upper
+                # bound of the true box (the coordinate manager sizes its lookup grid from it and checks rows against it).
+                lo, hi = np.asarray(bounds[:3], np.int64), np.asarray(bounds[3:], np.int64)
+                lo_b = np.where(flips != 0, 0, lo[None, :]) + shifts
+                hi_b = np.where(flips != 0, (hi - lo)[None, :], hi[None, :]) + shifts
+                bounds = tuple(int(v) for v in lo_b.min(0)) + tuple(int(v) for v in hi_b.max(0))
             out = PlotBatch(batch, coords, x[keep], pos[keep], None, None, B, bounds)
             out.src = src[keep]
         if y_reg is not None:
