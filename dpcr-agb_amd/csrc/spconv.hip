@@ -1835,6 +1835,8 @@ __global__ __launch_bounds__(256) void k_spconv_dw(const float* __restrict__ X, 
 // chunk, so the chunk's dY / X rows are re-read from that XCD's L2 instead of crossing to HBM/MALL 27 times.
 #define DW_KS 64
 #define DW_MAXROWS 2048
+#define DW_CMP_ROWS_F32 1280     // fp32 operands: 16 + 16 KB of staged rows + 7.5 KB of pair list = 40 KB -> four workgroups per CU
+static_assert(DW_CMP_ROWS_F32 == 1280, "the launch below spells the literal");
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 // PREC = 1 / 2: bf16 / split-bf16x3 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The reduction index of
 //   this product is the PAIR, which is the slow index of both operands in memory, while the bf16 MFMA wants 8 consecutive
@@ -1862,7 +1864,7 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned short* p) {
     const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
     return __builtin_bit_cast(uint2, v);
 }
-template <int PREC, bool IN16 = false, bool TR16 = false>
+template <int PREC, bool IN16 = false, bool TR16 = false, int MAXR = DW_MAXROWS>
 __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ dY, int ldy,
                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
@@ -1878,7 +1880,10 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     // fp32: As [pair][m], Bs [pair][n];  bf16: At [m][pair/2] / Bt [n][pair/2] (transposed, swizzled), hi (and lo) planes
     __shared__ __attribute__((aligned(16))) float As[PREC == 0 ? DW_KS * 64 : NP * 64 * DWT_LD];
     __shared__ __attribute__((aligned(16))) float Bs[PREC == 0 ? DW_KS * 64 : NP * 64 * DWT_LD];
-    __shared__ int p_in[DW_MAXROWS], p_out[DW_MAXROWS];
+    // pair list of the chunk: input row (global) and output row as its LOCAL index in the chunk (16 bits: with MAXR = 1280 the
+    // workgroup's LDS is 40 KB — four workgroups per CU instead of three)
+    __shared__ int p_in[MAXR];
+    __shared__ unsigned short p_out[MAXR];
     __shared__ int s_wcnt[2][4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1913,7 +1918,8 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     // latency per workgroup instead of one per 256 rows: the prologue was ~30 % of a workgroup's time)
     int total = 0;
     const int nrows = r_end - r_begin;
-    constexpr int NIT = DW_MAXROWS / 256;
+    constexpr int NIT = MAXR / 256;
+    static_assert(MAXR % 256 == 0 && MAXR <= 65536, "chunk rows: whole passes of the workgroup, 16-bit local indices");
     int idxs[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1940,7 +1946,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
         if (idx >= 0) {
             int p = off + __popcll(bal & ((1ull << lane) - 1ull));
             p_in[p] = idx;
-            p_out[p] = grow(i);
+            p_out[p] = (unsigned short)i;
         }
         total += round;
     }
@@ -1982,7 +1988,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     auto load_data = [&](int pb) {
         if constexpr (TR16) {
             const int p0 = min(pb + t8_p, total - 1), p1 = min(pb + t8_p + 32, total - 1);
-            const int i0 = p_in[p0], o0 = p_out[p0], i1 = p_in[p1], o1 = p_out[p1];
+            const int i0 = p_in[p0], o0 = grow(p_out[p0]), i1 = p_in[p1], o1 = grow(p_out[p1]);
             a8_0 = *reinterpret_cast<const uint4*>(X16 + (long long)i0 * ldx + a8_col);
             b8_0 = *reinterpret_cast<const uint4*>(dY16 + (long long)o0 * ldy + b8_col);
             a8_1 = *reinterpret_cast<const uint4*>(X16 + (long long)i1 * ldx + a8_col);
@@ -1992,7 +1998,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < LJ; ++j) {
             const int p = min(pb + pair_of(j), total - 1);
-            const int in = p_in[p], out = p_out[p];
+            const int in = p_in[p], out = grow(p_out[p]);
             if constexpr (IN16) {
                 a16[j] = *reinterpret_cast<const uint2*>(X16 + (long long)in * ldx + a_col);
                 b16[j] = *reinterpret_cast<const uint2*>(dY16 + (long long)out * ldy + b_col);
@@ -2963,7 +2969,11 @@ static bool dw_takes_reg_kernel(const int32_t* nbr, int n_out, int Cin, int Cout
 // Row chunks of the LDS-staged pair-compacted kernel k_spconv_dw_cmp (Cin >= 12; every operand precision).
 // precision 3 = bf16 operands read from bf16 storage (agb_spconv_bwd_weight_b16).
 struct DwCmpGeo { int rows, chunks, il, m_tiles, cin_tiles, n_tiles; };
-static DwCmpGeo dw_cmp_geometry(int n_out, int K3, int Cin, int Cout, bool dense, int precision) {
+static int dw_cmp_maxr(int n_out, int precision, int variant) {
+    static const bool old_chunks = getenv("AGB_DW_CMP_2048") != nullptr;      // (A/B inside a training step)
+    return (precision == 0 && variant != 4 && n_out >= 8192 && !old_chunks) ? DW_CMP_ROWS_F32 : DW_MAXROWS;
+}
+static DwCmpGeo dw_cmp_geometry(int n_out, int K3, int Cin, int Cout, bool dense, int precision, int maxr = DW_MAXROWS) {
     DwCmpGeo g;
     g.cin_tiles = agb_cdiv(Cin, 64);
     g.m_tiles = K3 * g.cin_tiles;
@@ -2978,7 +2988,7 @@ static DwCmpGeo dw_cmp_geometry(int n_out, int K3, int Cin, int Cout, bool dense
     long long rows = (n_out + target_chunks - 1) / target_chunks;
     if (rows < 256) rows = 256;
     rows = (rows + 31) / 32 * 32;
-    if (rows > DW_MAXROWS) rows = DW_MAXROWS;     // (the LDS pair list)
+    if (rows > maxr) rows = maxr;                 // (the LDS pair list)
     g.rows = (int)rows;
     g.chunks = agb_cdiv(n_out, g.rows);
     g.il = g.chunks >= 16 ? cmp_interleave(n_out, -1) : 0;
@@ -3013,7 +3023,7 @@ size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cou
     if (dw_takes_reg_kernel(dense ? nullptr : &some_map, n_out, Cin, Cout, precision, 0, true)) {
         other = agb_dwreg_workspace_bytes(n_out, K3, Cin, Cout);
     } else {
-        const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, dense != 0, precision);
+        const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, dense != 0, precision, dw_cmp_maxr(n_out, precision, 0));
         other = (size_t)g.chunks * K3 * Cin * Cout * sizeof(float);
     }
     return dwa > other ? dwa : other;
@@ -3069,8 +3079,13 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
                            float* dW, int n_out, int K3, int Cin, int Cout, int precision, int variant, void* workspace,
                            size_t workspace_bytes, void* stream) {
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 1 && Cout >= 1, "agb_spconv_bwd_weight: bad sizes");
-    AGB_CHECK_ARG(variant >= 0 && variant <= 3, "agb_spconv_bwd_weight_ws: variant %d (0 automatic, 1 LDS-staged, 2 register "
-                  "operands, 3 persistent accumulators)", variant);
+    AGB_CHECK_ARG(variant >= 0 && variant <= 4, "agb_spconv_bwd_weight_ws: variant %d (0 automatic, 1 LDS-staged, 2 register "
+                  "operands, 3 persistent accumulators, 4 LDS-staged with 2048-row chunks)", variant);
+    // the fp32 LDS-staged kernel walks chunks of at most DW_CMP_ROWS_F32 rows (40 KB of LDS: four workgroups per CU instead of
+    // three: 64->64 -4 %, 128->128 -10 %, the 3^3 stride-2 maps -3 %; levels of a few thousand rows +1 %: they keep 2048);
+    // variant 4 = the 2048-row chunks of rounds 2-4 everywhere, kept for A/B measurements
+    const int dw_maxr = dw_cmp_maxr(n_out, precision, variant);
+    if (variant == 4) variant = 1;
     AGB_CHECK_ARG(nbr != nullptr || K3 == 1, "agb_spconv_bwd_weight: the identity map (nbr == NULL) needs K3 == 1");
     AGB_CHECK_ARG(nbr != nullptr || (Cin != 4 && Cin != 8), "agb_spconv_bwd_weight: the identity map needs Cin >= 12");
     AGB_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
@@ -3139,7 +3154,7 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         }
     } else {
         // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
-        const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, nbr == nullptr, precision);
+        const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, nbr == nullptr, precision, dw_maxr);
         const int rows = g.rows, chunks = g.chunks, il = g.il, m_tiles = g.m_tiles, cin_tiles = g.cin_tiles;
         const dim3 block(256);
         float* part = nullptr;
@@ -3165,6 +3180,10 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         else if (precision == 2)
             AGB_LAUNCH((k_spconv_dw_cmp<2, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
+        else if (dw_maxr == DW_CMP_ROWS_F32)
+            // (the literal, not the macro: the noted kernel name must equal the symbol rocprof prints)
+            AGB_LAUNCH((k_spconv_dw_cmp<0, false, false, 1280>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride,
+                               dW, n_out, K3, Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else
             AGB_LAUNCH((k_spconv_dw_cmp<0, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);

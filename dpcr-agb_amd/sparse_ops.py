@@ -40,7 +40,8 @@ class KernelOptions:
                            k_spconv_dw_cmp folded in ascending order): bitwise reproducible training, 3.7 % slower MSENet14
                            fp32 step than the default (LDS-staged kernels, fp32 atomic accumulation)
       dw_variant           0 = automatic, 1 = LDS-staged weight-gradient kernel, 2 = register-operand kernel, 3 = persistent
-                           accumulators (csrc/dwa.hip; opt-in: equal to the staged kernel inside the step) (A/B measurements)
+                           accumulators (csrc/dwa.hip; opt-in: equal to the staged kernel inside the step), 4 = LDS-staged with
+                           the 2048-row chunks of rounds 2-4 (A/B measurements)
       bf16_storage         precision "bf16": convolutions read bf16 twins of their inputs (rows and weights converted once,
                            gathered as 2-byte channels) instead of converting fp32 rows while staging them
       bf16_activations     precision "bf16" on the sparse backbones: every activation / gradient ROW MATRIX of the network is

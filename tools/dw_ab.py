@@ -19,7 +19,8 @@ def main():
     coords = torch.cat([b.batch[:, None].int(), b.coords.int()], 1).to(dev)
     cm = CoordinateManager(coords, device=dev, batch_size=32, bounds=b.coord_bounds)
     ts = 1
-    variants = (("auto", {}), ("persistent", dict(dw_variant=3)), ("staged", dict(dw_variant=1)), ("reg", dict(dw_variant=2)))
+    variants = (("auto", {}), ("persistent", dict(dw_variant=3)), ("staged", dict(dw_variant=1)), ("staged2048", dict(dw_variant=4)),
+                ("reg", dict(dw_variant=2)))
     cases = []
     for ts_in, c in ((2, 64), (4, 128), (8, 256), (16, 512)):
         while ts < ts_in:
@@ -31,6 +32,7 @@ def main():
         for ts_in, c in ((2, 64), (4, 128), (8, 256)):
             n_in, n_out = cm.level(ts_in).n, cm.level(2 * ts_in).n
             cases.append((f"ts{ts_in:2d} 2^3 s2 {c}->{2 * c}", cm.kernel_map(ts_in, 2, 2), n_in, n_out, 8, c, 2 * c))
+            cases.append((f"ts{ts_in:2d} 3^3 s2 {c}->{2 * c}", cm.kernel_map(ts_in, 3, 2), n_in, n_out, 27, c, 2 * c))
     for name, nbr, n_in, n_out, K3, cin, cout in cases:
         x = torch.randn(n_in, cin, device=dev)
         dy = torch.randn(n_out, cout, device=dev)
