@@ -1836,7 +1836,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw(const float* __restrict__ X, 
 #define DW_KS 64
 #define DW_MAXROWS 2048
 #define DW_CMP_ROWS_F32 1280     // fp32 operands: 16 + 16 KB of staged rows + 7.5 KB of pair list = 40 KB -> four workgroups per CU
-static_assert(DW_CMP_ROWS_F32 == 1280, "the launch below spells the literal");
+static_assert(DW_CMP_ROWS_F32 == 1280 && DW_MAXROWS == 2048, "the launches below spell the literals");
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 // PREC = 1 / 2: bf16 / split-bf16x3 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The reduction index of
 //   this product is the PAIR, which is the slow index of both operands in memory, while the bf16 MFMA wants 8 consecutive
@@ -1864,7 +1864,7 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned short* p) {
     const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
     return __builtin_bit_cast(uint2, v);
 }
-template <int PREC, bool IN16 = false, bool TR16 = false, int MAXR = DW_MAXROWS>
+template <int PREC, bool IN16 = false, bool TR16 = false, int MAXR = DW_MAXROWS, int KS = DW_KS>
 __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__ X, int ldx,
                                                        const float* __restrict__ dY, int ldy,
                                                        const int32_t* __restrict__ nbr, long long nbr_stride,
@@ -1878,8 +1878,8 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     // on dW, whose arrival order differs from run to run.
     constexpr int NP = PREC == 2 ? 2 : 1;
     // fp32: As [pair][m], Bs [pair][n];  bf16: At [m][pair/2] / Bt [n][pair/2] (transposed, swizzled), hi (and lo) planes
-    __shared__ __attribute__((aligned(16))) float As[PREC == 0 ? DW_KS * 64 : NP * 64 * DWT_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[PREC == 0 ? DW_KS * 64 : NP * 64 * DWT_LD];
+    __shared__ __attribute__((aligned(16))) float As[PREC == 0 ? KS * 64 : NP * 64 * DWT_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[PREC == 0 ? KS * 64 : NP * 64 * DWT_LD];
     // pair list of the chunk: input row (global) and output row as its LOCAL index in the chunk (16 bits: with MAXR = 1280 the
     // workgroup's LDS is 40 KB — four workgroups per CU instead of three)
     __shared__ int p_in[MAXR];
@@ -1969,7 +1969,8 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
         return;
     }
 
-    constexpr int LJ = DW_KS / 16;
+    static_assert(KS == DW_KS || PREC == 0, "only the fp32 form takes another step length");
+    constexpr int LJ = KS / 16;
     float4 a_reg[LJ], b_reg[LJ];
     uint2 a16[IN16 ? LJ : 1], b16[IN16 ? LJ : 1];
     uint4 a8_0, a8_1, b8_0, b8_1;                             // TR16: pair (tid >> 3) + 32 j, channels 8 (tid & 7) ..
@@ -2009,7 +2010,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
         }
     };
     load_data(0);
-    for (int pb = 0; pb < total; pb += DW_KS) {
+    for (int pb = 0; pb < total; pb += KS) {
         if constexpr (PREC == 0) {
 #pragma unroll
             for (int j = 0; j < LJ; ++j) {
@@ -2080,12 +2081,12 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
             }
         }
         __syncthreads();
-        if (pb + DW_KS < total) load_data(pb + DW_KS);   // in flight during the MFMAs below
+        if (pb + KS < total) load_data(pb + KS);   // in flight during the MFMAs below
         if constexpr (PREC == 0) {
             const float* ap = &As[wr * 32 + li];
             const float* bp = &Bs[wc * 32 + li];
 #pragma unroll
-            for (int s2 = 0; s2 < DW_KS / 2; ++s2) {
+            for (int s2 = 0; s2 < KS / 2; ++s2) {
                 float av = ap[(2 * s2 + lh) * 64];
                 float bv = bp[(2 * s2 + lh) * 64];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
@@ -3085,6 +3086,7 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
     // three: 64->64 -4 %, 128->128 -10 %, the 3^3 stride-2 maps -3 %; levels of a few thousand rows +1 %: they keep 2048);
     // variant 4 = the 2048-row chunks of rounds 2-4 everywhere, kept for A/B measurements
     const int dw_maxr = dw_cmp_maxr(n_out, precision, variant);
+    const bool dw_old = variant == 4;
     if (variant == 4) variant = 1;
     AGB_CHECK_ARG(nbr != nullptr || K3 == 1, "agb_spconv_bwd_weight: the identity map (nbr == NULL) needs K3 == 1");
     AGB_CHECK_ARG(nbr != nullptr || (Cin != 4 && Cin != 8), "agb_spconv_bwd_weight: the identity map needs Cin >= 12");
@@ -3155,6 +3157,8 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
     } else {
         // pair-compacted kernel: row chunks of at most DW_MAXROWS rows (the LDS pair list), XCD-aware 1-D grid
         const DwCmpGeo g = dw_cmp_geometry(n_out, K3, Cin, Cout, nbr == nullptr, precision, dw_maxr);
+        static const bool ks64_env = getenv("AGB_DW_KS64") != nullptr;       // (A/B inside a training step)
+        const bool ks64 = ks64_env || dw_old;
         const int rows = g.rows, chunks = g.chunks, il = g.il, m_tiles = g.m_tiles, cin_tiles = g.cin_tiles;
         const dim3 block(256);
         float* part = nullptr;
@@ -3180,6 +3184,14 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         else if (precision == 2)
             AGB_LAUNCH((k_spconv_dw_cmp<2, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
+        // fp32, maps of >= 9 offsets: 32-pair steps — 8 + 8 KB of staged rows: six (1280-row chunks) / five (2048) workgroups
+        // per CU instead of four / three; a further -1 .. -2.5 % per launch (the 2^3 maps and the dense product keep 64)
+        else if (dw_maxr == DW_CMP_ROWS_F32 && !ks64 && K3 >= 9)
+            AGB_LAUNCH((k_spconv_dw_cmp<0, false, false, 1280, 32>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride,
+                               dW, n_out, K3, Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
+        else if (!ks64 && K3 >= 9)
+            AGB_LAUNCH((k_spconv_dw_cmp<0, false, false, 2048, 32>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride,
+                               dW, n_out, K3, Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (dw_maxr == DW_CMP_ROWS_F32)
             // (the literal, not the macro: the noted kernel name must equal the symbol rocprof prints)
             AGB_LAUNCH((k_spconv_dw_cmp<0, false, false, 1280>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride,
