@@ -260,13 +260,16 @@ int agb_spconv_bwd_weight_lp(const float* X, int ldx, const float* dY, int ldy, 
  * take the register-operand kernel instead of the streaming kernel's cross-workgroup atomics).
  * agb_spconv_bwd_weight_workspace_bytes (host helper; dense = 1 for nbr == NULL) returns 0 only for empty products.
  * variant: 0 automatic, 1 = LDS-staged kernel, 2 = register-operand kernel whatever the workspace, 3 = the persistent-accumulator
- * kernel for every shape it can take (A/B measurements, tests). */
+ * kernel for every shape it can take, 4 = LDS-staged in its round-2..4 geometry (2048-row chunks, 64-pair steps; since round 5
+ * the fp32 form walks 1280-row chunks in 32-pair steps: 23.5 KB of LDS, six workgroups per CU) (A/B measurements, tests). */
 size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cout, int dense, int precision);
-/* fp32 maps (nbr != NULL) with Cin and Cout multiples of 64, 2 <= K3 <= 28 and >= 2048 rows: with a workspace, variant 0 runs
- * the PERSISTENT-ACCUMULATOR kernel (csrc/dwa.hip, hand-scheduled: csrc/gen_dw_asm.py): one wave keeps the 64 x 64 tiles of up
- * to seven offsets in registers for the whole launch, partial tiles leave once per wave, k_dwa_fold adds them in ascending
- * order (reproducible).  agb_spconv_bwd_weight_persistent says whether a shape takes it: the Python side then always passes
- * the workspace (this kernel is the fp32 product path, not only the reproducible option). */
+/* fp32 maps (nbr != NULL) with Cin and Cout multiples of 64, 2 <= K3 <= 28 and >= 2048 rows can run on the
+ * PERSISTENT-ACCUMULATOR kernel (csrc/dwa.hip, hand-scheduled: csrc/gen_dw_asm.py): one wave keeps the 64 x 64 tiles of up to
+ * four offsets in its AGPRs for the whole launch, partial tiles leave once per wave, k_dwa_fold adds them in ascending order
+ * (reproducible).  With a workspace, variant 0 takes it for the shapes it was measured faster on (agb_spconv_bwd_weight_persistent:
+ * K3 <= 8, or >= 40000 rows with Cin >= 128), variant 3 for every shape it can take.  Inside the training step it is equal to
+ * the staged kernel: the Python side passes the workspace only on request (AGB_PERSISTENT_WGRAD, KernelOptions.dw_variant = 3,
+ * or the reproducible mode). */
 int agb_spconv_bwd_weight_persistent(int n_out, int K3, int Cin, int Cout, int ldx, int ldy);
 int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, int precision,
