@@ -3173,16 +3173,16 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
         dim3 grid1((chunks >= 16 ? 8 * agb_cdiv(chunks, 8) : chunks) * m_tiles, g.n_tiles);
         if (precision == 3 && Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0)
             // bf16 twins, rows staged as they are and transposed by the LDS reads (ds_read_b64_tr_b16)
-            AGB_LAUNCH((k_spconv_dw_cmp<1, true, true>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out,
+            AGB_LAUNCH((k_spconv_dw_cmp<1, true, true, 2048, 64>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out,
                                K3, Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 3)       // bf16 operands from bf16 twins (agb_spconv_bwd_weight_b16)
-            AGB_LAUNCH((k_spconv_dw_cmp<1, true, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH((k_spconv_dw_cmp<1, true, false, 2048, 64>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 1)
-            AGB_LAUNCH((k_spconv_dw_cmp<1, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH((k_spconv_dw_cmp<1, false, false, 2048, 64>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (precision == 2)
-            AGB_LAUNCH((k_spconv_dw_cmp<2, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH((k_spconv_dw_cmp<2, false, false, 2048, 64>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         // fp32, maps of >= 9 offsets: 32-pair steps — 8 + 8 KB of staged rows: six (1280-row chunks) / five (2048) workgroups
         // per CU instead of four / three; a further -1 .. -2.5 % per launch (the 2^3 maps and the dense product keep 64)
@@ -3193,11 +3193,11 @@ static int bwd_weight_impl(const float* X, int ldx, const float* dY, int ldy, co
             AGB_LAUNCH((k_spconv_dw_cmp<0, false, false, 2048, 32>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride,
                                dW, n_out, K3, Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else if (dw_maxr == DW_CMP_ROWS_F32)
-            // (the literal, not the macro: the noted kernel name must equal the symbol rocprof prints)
-            AGB_LAUNCH((k_spconv_dw_cmp<0, false, false, 1280>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride,
+            // (literals and every template argument spelled out: the noted kernel name must equal the symbol rocprof prints)
+            AGB_LAUNCH((k_spconv_dw_cmp<0, false, false, 1280, 64>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride,
                                dW, n_out, K3, Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         else
-            AGB_LAUNCH((k_spconv_dw_cmp<0, false, false>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
+            AGB_LAUNCH((k_spconv_dw_cmp<0, false, false, 2048, 64>), grid1, block, 0, s, X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3,
                                Cin, Cout, rows, cin_tiles, chunks, m_tiles, il, part);
         if (part) {
             const long long n4 = (long long)K3 * Cin * Cout / 4;
