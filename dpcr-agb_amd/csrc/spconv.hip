@@ -2983,7 +2983,9 @@ static DwCmpGeo dw_cmp_geometry(int n_out, int K3, int Cin, int Cout, bool dense
     // (dense products with bf16 operands: the MFMA work of a workgroup is small against the 64 x 64 tile it ends with —
     // 4096 workgroups put 13 M atomics on the 256 x 1024 gradient of a 14 k-row layer: 71 us, 512 workgroups: 34 us;
     // 211 k x 64 x 256: 120 -> 41 us.  The 3^3 maps sit at the 2048-row cap of the pair list either way.)
-    const int target_wgs = (dense && (precision == 1 || precision == 3)) ? 512 : 4096;
+    // (fp32 maps since round 5: ~6144 — with six workgroups resident per CU instead of three, 4096 were 2.7 rounds of the
+    // chip; measured in the step 3072 / 4096 / 6144 / 8192 / 12288: weight gradient 1.96 / 1.91 / 1.87 / 2.02 / 2.08 ms)
+    const int target_wgs = (dense && (precision == 1 || precision == 3)) ? 512 : (precision == 0 && !dense) ? 6144 : 4096;
     long long target_chunks = target_wgs / ((long long)g.m_tiles * g.n_tiles);
     if (target_chunks < 1) target_chunks = 1;
     long long rows = (n_out + target_chunks - 1) / target_chunks;
