@@ -2985,7 +2985,10 @@ static DwCmpGeo dw_cmp_geometry(int n_out, int K3, int Cin, int Cout, bool dense
     // 211 k x 64 x 256: 120 -> 41 us.  The 3^3 maps sit at the 2048-row cap of the pair list either way.)
     // (fp32 maps since round 5: ~6144 — with six workgroups resident per CU instead of three, 4096 were 2.7 rounds of the
     // chip; measured in the step 3072 / 4096 / 6144 / 8192 / 12288: weight gradient 1.96 / 1.91 / 1.87 / 2.02 / 2.08 ms)
-    const int target_wgs = (dense && (precision == 1 || precision == 3)) ? 512 : (precision == 0 && !dense) ? 6144 : 4096;
+    // (fp32 dense products: ~2048 — every workgroup ends in 4096 atomics on the gradient; MPointNet step 11.71 ms at 4096,
+    // 11.51-11.58 at 512 .. 2048, 11.64 at 6144)
+    const int target_wgs = (dense && (precision == 1 || precision == 3)) ? 512 : (precision == 0 && !dense) ? 6144
+                           : (precision == 0 && dense) ? 2048 : 4096;
     long long target_chunks = target_wgs / ((long long)g.m_tiles * g.n_tiles);
     if (target_chunks < 1) target_chunks = 1;
     long long rows = (n_out + target_chunks - 1) / target_chunks;
