@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 
 def main():
-    modes = sys.argv[1:] or ["128", "129"]
+    modes = sys.argv[1:] or ["128", "129"]      # "128:3" = cmp_mode 128 with cmp_interleave 3; "128:-1:0" = ... without balanced tiles
     from dpcr_agb_amd import sparse_ops, synthetic
     from dpcr_agb_amd.coords import CoordinateManager
     from dpcr_agb_amd.sparse_ops import spconv_forward_raw
@@ -34,7 +34,10 @@ def main():
         res = {}
         for rep in range(6):
             for m in modes:
-                sparse_ops.DEFAULTS.cmp_mode = int(m)
+                parts = m.split(":")
+                sparse_ops.DEFAULTS.cmp_mode = int(parts[0])
+                sparse_ops.DEFAULTS.cmp_interleave = int(parts[1]) if len(parts) > 1 else -1
+                sparse_ops.DEFAULTS.balanced_tiles = bool(int(parts[2])) if len(parts) > 2 else True
                 y = spconv_forward_raw(x, w, nbr, 0, None, n, 27, c, c)
                 torch.cuda.synchronize()
                 if rep == 0:
