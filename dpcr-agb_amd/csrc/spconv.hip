@@ -2987,6 +2987,8 @@ static DwCmpGeo dw_cmp_geometry(int n_out, int K3, int Cin, int Cout, bool dense
     // chip; measured in the step 3072 / 4096 / 6144 / 8192 / 12288: weight gradient 1.96 / 1.91 / 1.87 / 2.02 / 2.08 ms)
     // (fp32 dense products: ~2048 — every workgroup ends in 4096 atomics on the gradient; MPointNet step 11.71 ms at 4096,
     // 11.51-11.58 at 512 .. 2048, 11.64 at 6144)
+    // (bf16 operands re-measured in round 5 on MSENet50: maps 2048 / 4096 equal, 6144 +13 %, 8192 +43 %; dense 256 +8 %, 512 / 1024
+    // equal, 2048 +33 %: they stay)
     const int target_wgs = (dense && (precision == 1 || precision == 3)) ? 512 : (precision == 0 && !dense) ? 6144
                            : (precision == 0 && dense) ? 2048 : 4096;
     long long target_chunks = target_wgs / ((long long)g.m_tiles * g.n_tiles);
