@@ -353,28 +353,24 @@ INPUT_ENTRY_PREFIXES = ("agb_plot_", "agb_voxelize", "agb_coords_augment", "agb_
 
 
 def run_end2end(a):
-    """The training step FROM RAW POINTS (the reference runs the sparse-xy.yaml chain per sample on the
-    host before set_input: conf/data/instance/NFI/transforms/sparse-xy.yaml:4-104, core/data_transform/transforms.py,
+    """The training step FROM RAW POINTS (the reference runs the sparse-xy.yaml chain per sample in its
+    DataLoader workers before set_input: conf/data/instance/NFI/transforms/sparse-xy.yaml:4-104, core/data_transform/transforms.py,
     grid_transform.py:112-128): raw 16 000-point plots resident on the device -> SparseTrainPipeline (ground removal, dropout,
     noise, rotation, shift, added / copied points, polygon crop, features, GridSampling3D(last), flip / shift; the random draws
-    per sample on the host with the reference's generators, applied on the device) -> MSENet14 training step.  Inline (the
-    pipeline runs in front of the step on the compute stream; its counts come back to the host twice per batch)."""
+    per sample in DataLoader workers with the reference's generators, applied on the device) -> MSENet14 training step.  The
+    chain and the model's input staging run on the input stream two batches ahead of the step that consumes them."""
     import random
+    from collections import deque
+    from functools import partial
+    from torch.utils.data import DataLoader
     from dpcr_agb_amd import synthetic
     from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
     from dpcr_agb_amd.instance import MinkowskiBaselineModel
-    from dpcr_agb_amd.train_transforms import NFITrainConfig, SparseTrainPipeline, draw_sample
-    dev = torch.device("cuda:0")
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, SampleDraws, SparseTrainPipeline, collate_draws
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
     B = a.batch or 32
-    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_064))
-    model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS["SENet14"]), "minkowski", ds)
-    model.to(dev).train()
-    model.init_train_objects(TRAINING_NFI)
-    model.reserve_workspace(dev, main_bytes=16 << 30, side_bytes=2 << 30)
     cfg = NFITrainConfig()
-    pipe = SparseTrainPipeline(cfg, device_shuffle=not a.host_shuffle)
-    pool = []
+    host_pool = []
     for i in range(3):
         raws, ys = [], []
         for seed in range(i * B, (i + 1) * B):
@@ -382,21 +378,26 @@ def run_end2end(a):
             # the raw frame of the reference: metres, centred on the plot centre, heights above an arbitrary datum
             raws.append(np.stack([(pos[:, 0] - 0.5) * 30.0, (pos[:, 1] - 0.5) * 30.0, pos[:, 2] * 40.0 + 3.25], 1).astype(np.float32))
             ys.append(y)
-        pool.append((raws, [torch.from_numpy(r).to(dev) for r in raws], np.stack(ys)))
-    host_draw_ms, voxels, points_in = [], [], []
-    # The per-sample draws run in DataLoader worker processes (where the reference runs its transforms); the device part of
-    # the chain and the coordinate maps of a batch are enqueued on the model's input stream two steps ahead of its training
-    # step, so that the chain's two count read-backs wait for an idle side stream, not for the training steps in the queue.
-    from collections import deque
-    from torch.utils.data import DataLoader
-    from dpcr_agb_amd.train_transforms import SampleDraws, collate_draws
-    from functools import partial
+        host_pool.append((raws, np.stack(ys)))
+    # The per-sample draws run in DataLoader worker processes (where the reference runs its transforms).  The workers are
+    # forked HERE, before this process touches the GPU (a forked copy of an initialised HIP runtime is nothing to rely on).
     workers = 0 if a.inline_draws else max(1, min(6, usable_cores() - 2))
-    loader = DataLoader(SampleDraws([r for raws, _, _ in pool for r in raws], cfg, length=1 << 30), batch_size=B, shuffle=False,
+    loader = DataLoader(SampleDraws([r for raws, _ in host_pool for r in raws], cfg, length=1 << 30), batch_size=B, shuffle=False,
                         num_workers=workers, collate_fn=partial(collate_draws, cfg=cfg), pin_memory=workers > 0,
                         worker_init_fn=SampleDraws.seed_worker, persistent_workers=workers > 0,
                         prefetch_factor=4 if workers else None)
     draws_it = iter(loader)
+    dev = torch.device("cuda:0")
+    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_064))
+    model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS["SENet14"]), "minkowski", ds)
+    model.to(dev).train()
+    model.init_train_objects(TRAINING_NFI)
+    model.reserve_workspace(dev, main_bytes=16 << 30, side_bytes=2 << 30)
+    pipe = SparseTrainPipeline(cfg, device_shuffle=not a.host_shuffle)
+    pool = [(raws, [torch.from_numpy(r).to(dev) for r in raws], y) for raws, y in host_pool]
+    host_draw_ms, voxels, points_in = [], [], []
+    # the device part of the chain and the coordinate maps of a batch are enqueued on the model's input stream two steps ahead
+    # of its training step, so that the chain's two count read-backs wait for an idle side stream, not for the queued steps
     side = model.input_stream(dev)
     queue = deque()
 
@@ -472,7 +473,8 @@ def main():
     ap.add_argument("--host-shuffle", action="store_true", help="end2end: GridSampling3D's shuffle with torch.randperm on the host")
     ap.add_argument("--shapes", action="store_true", help="per-shape table of the dense products / gathers")
     a = ap.parse_args()
-    if not torch.cuda.is_available():
+    # (device_count does not initialise the HIP runtime, is_available does: the end2end line forks its loader workers first)
+    if torch.cuda.device_count() < 1:
         raise SystemExit("needs a HIP device")
     # The host side of a step only issues launches and shuffles a few small CPU tensors: keep torch's intra-op pool small.
     # With one OpenMP thread per VISIBLE core (256 on the GPU box, 16 allowed by the cgroup quota) the spinning workers
