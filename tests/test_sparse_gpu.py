@@ -1106,6 +1106,9 @@ def test_weight_gradient_register_kernel(device, n_plots, npts, cin, cout, K):
     assert rel_err(a, want) < 2e-6
     assert rel_err(run(dw_variant=2), want) < 2e-6               # same kernel, fp32 atomic accumulation (no workspace)
     assert rel_err(run(), want) < 2e-6                           # the default: LDS-staged kernel, atomic accumulation
+    if cin >= 12:
+        assert rel_err(run(dw_variant=1), want) < 2e-6           # ... forced (round-5 geometry: 1280-row chunks, 32-pair steps)
+        assert rel_err(run(dw_variant=4), want) < 2e-6           # ... in its round-2..4 geometry (2048-row chunks, 64-pair steps)
     # accumulation contract: dW is added to
     dw = torch.ones(K3, cin, cout, device=device)
     sparse_ops.weight_grad_raw(xg, dyg, nbr, dw, n, K3, cin, cout, sparse_ops.KernelOptions(deterministic_wgrad=True))
