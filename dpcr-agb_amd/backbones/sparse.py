@@ -372,10 +372,33 @@ class ResNetBase(nn.Module):
     kernel_options = None      # sparse_ops.KernelOptions of this model (None: the ones in force / the defaults)
     supports_bf16_rows = True  # KernelOptions.bf16_activations: every row kernel of this backbone has a bf16-row form
 
+    def _fused_plan(self):
+        """Which stages the one-call-per-block path (fused_blocks.py) can take: (stem, [[block, ...] per stage]); a matter of
+        module structure, decided once."""
+        plan = self.__dict__.get("_agb_fused_plan")
+        if plan is None:
+            from .. import fused_blocks as FB
+            stages = list(self.blocks)
+            plan = (FB.stem_supported(stages[0]), [[FB.block_supported(b) for b in st] for st in stages[1:]])
+            self.__dict__["_agb_fused_plan"] = plan
+        return plan
+
     def forward(self, x):
         with model_scope(self):
-            for block in self.blocks:
-                x = block(x)
+            from .. import fused_blocks as FB
+            opts = current_options()
+            if not FB.options_allow(opts):
+                for block in self.blocks:
+                    x = block(x)
+            else:
+                stem_ok, stages_ok = self._fused_plan()
+                stages = list(self.blocks)
+                out = FB.run_stem(stages[0], x, opts) if stem_ok else None
+                x = out if out is not None else stages[0](x)
+                for stage, oks in zip(stages[1:], stages_ok):
+                    for blk, ok in zip(stage, oks):
+                        out = FB.run_block(blk, x, opts) if ok else None
+                        x = out if out is not None else blk(x)
             x = self.glob_avg(x)
             return self.final(x)
 

@@ -632,6 +632,36 @@ int agb_segment_scale_add_h(const float* S, const float* T, const int32_t* coord
                             const uint16_t* M, int ldm, uint16_t* out, int ldo, int n, int C, void* stream);
 int agb_segment_max_bwd_h(const float* dY, const int32_t* argmax, uint16_t* dX, int ldx, int B, int C, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * One call per network block (dpcr-agb_amd/csrc/net.hip).  Replaces, as ONE entry point per direction,
+ *   modules/MinkowskiEngine/SENet.py:47-53      the stem: conv K^3 (3 -> 64) -> norm -> activation -> max pool 3^3 stride 2
+ *   modules/MinkowskiEngine/senet_block.py:80-96 on resnet_block.py:62-73   SEBasicBlock.forward: conv1 -> norm1 -> act ->
+ *       conv2 -> norm2 -> squeeze-excite -> drop path -> (+ downsample(x) | x) -> act
+ * and their backward passes (ME + autograd in the reference).  The block is a fixed operator sequence; driving it launch by
+ * launch from the host language costs the enqueuing thread more than the device needs for the small kernels.  The library
+ * enqueues the SAME kernels, in the same order and geometry, as the per-operator entry points above: bit-identical results.
+ *
+ * f: HOST table of 64-bit fields (device pointers, sizes, options).  agb_net_fields() returns the comma-separated field
+ * names in index order (agb_net_field_count() of them) so that a binding builds its index map from the library itself:
+ *   x ldx n_in n_out B coords ptr y ldy | dy lddy dx lddx need_dx | training act stride has_down | cmp_mode cmp_il
+ *   dw_variant det persistent | per convolution c1 / c2 / cd (downsample): _w _b _K3 _cin _cout, its BatchNorm _g _be _rm
+ *   _rv _nbt _eps _mom (eps, mom: IEEE-754 double bit patterns), kernel maps _nbr _nbr_ld _nbrT _nbrT_ld, the class
+ *   partition of a strided data gradient _perm _tile_cls _cls_tab _n_tiles, balanced tile tables _tf _tf_t _tf_b (forward)
+ *   _tb _tb_t _tb_b (data gradient), _wt (W^T kept by the caller, or 0), gradients out _dw _db _dg _dbe | se_act se_H se_w1
+ *   se_b1 se_w2 se_b2 keep (drop-path scale float[B] or 0) d_se_w1 d_se_b1 d_se_w2 d_se_b2 | stem only: feat ldf fdim
+ *   grid desc (HOST int32[8], as agb_spconv_fwd3_grid) K pool_nbr pool_nbr_ld pool_nbrT pool_nbrT_ld pool_K3 n_pool.
+ * saved: device arena the forward pass fills and the backward pass of the same call table reads (agb_net_*_bytes(f, 0));
+ * scratch: device arena of temporaries (agb_net_*_bytes(f, 1) forward, (f, 2) backward); both 256-byte aligned.
+ * The backward entry points take BatchNorm in batch-statistics mode (training != 0); the forward ones both modes. */
+const char* agb_net_fields(void);
+int agb_net_field_count(void);
+size_t agb_net_stem_bytes(const int64_t* f, int which);
+int agb_net_stem_fwd(const int64_t* f, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+int agb_net_stem_bwd(const int64_t* f, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+size_t agb_net_block_bytes(const int64_t* f, int which);
+int agb_net_block_fwd(const int64_t* f, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+int agb_net_block_bwd(const int64_t* f, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,150 @@
+"""The one-call-per-block path (dpcr_agb_amd/fused_blocks.py -> csrc/net.hip agb_net_stem_* / agb_net_block_*) against the
+operator-by-operator path it replaces (me_compat / sparse_ops / norm_ops / se_ops): the same kernels in the same order, so
+every output, every gradient and every running statistic must be BIT-IDENTICAL (fixed-order weight-gradient sums; with the
+default atomic accumulation the weight gradients are compared at 2e-5).  Reference: senet_block.py:80-96, resnet_block.py:62-73,
+SENet.py:47-53,113-118."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_and_batch(device, n_points, seeds, drop_path=0.0, name="SENet14"):
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, Opt
+    from dpcr_agb_amd.instance import MinkowskiBaselineModel
+    torch.manual_seed(0)
+    ds = synthetic.SyntheticDataset(feature_dimension=3, stat_seeds=range(10_000, 10_032))
+    opt = Opt(MODEL_OPTIONS[name])
+    opt["drop_path"] = drop_path
+    model = MinkowskiBaselineModel(opt, "minkowski", ds)
+    batch = synthetic.make_sparse_batch(seeds, n_points=n_points)
+    return model.to(device), batch
+
+
+def _run(model, batch, device, fused, train=True, backward=True, seed=5, **opts):
+    model.set_kernel_options(fused_blocks=fused, **opts)
+    model.train(train)
+    for p in model.parameters():
+        p.grad = None
+    random.seed(seed)
+    model.set_input(batch, device)
+    if backward:
+        model.forward()
+        model.loss.backward()
+    else:
+        with torch.no_grad():
+            model.forward()
+    torch.cuda.synchronize()
+    out = model.output.detach().clone()
+    grads = {k: p.grad.detach().clone() for k, p in model.model.named_parameters() if p.grad is not None}
+    bufs = {k: v.detach().clone() for k, v in model.model.named_buffers()}
+    return out, grads, bufs
+
+
+def _calls_of(model, batch, device, fused, **opts):
+    """Names of the library entry points one forward + backward pass goes through."""
+    from dpcr_agb_amd import _lib
+    names = []
+    orig = _lib.call
+
+    def spy(name, *a):
+        names.append(name)
+        return orig(name, *a)
+    _lib.call = spy
+    try:
+        _run(model, batch, device, fused, **opts)
+    finally:
+        _lib.call = orig
+    return names
+
+
+@pytest.mark.parametrize("n_points,seeds,cmp_mode", [(1500, [0, 1, 2], 1), (1500, [3, 4], 128), (16000, [11, 12], 1), (16000, [13, 14], 128)])
+def test_fused_blocks_equal_operator_path_bitwise(device, n_points, seeds, cmp_mode):
+    model, batch = _model_and_batch(device, n_points, seeds, drop_path=0.3)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = _run(model, batch, device, False, deterministic_wgrad=True, cmp_mode=cmp_mode)
+    model.load_state_dict(sd0)
+    got = _run(model, batch, device, True, deterministic_wgrad=True, cmp_mode=cmp_mode)
+    assert torch.equal(ref[0], got[0]), float((ref[0] - got[0]).abs().max())
+    assert set(ref[1]) == set(got[1])
+    for k in ref[1]:
+        assert ref[1][k].shape == got[1][k].shape, k
+        assert torch.equal(ref[1][k], got[1][k]), (k, float((ref[1][k] - got[1][k]).abs().max()))
+    for k in ref[2]:
+        assert torch.equal(ref[2][k], got[2][k]), k
+    # the fused run really went through the block entry points (and the other one did not)
+    names = _calls_of(model, batch, device, True, deterministic_wgrad=True, cmp_mode=cmp_mode)
+    assert names.count("agb_net_block_fwd") == 4 and names.count("agb_net_block_bwd") == 4, names
+    assert names.count("agb_net_stem_fwd") == 1 and names.count("agb_net_stem_bwd") == 1, names
+    # (tile tables and kernel maps are still built operator by operator: agb_spconv_balance_tiles, agb_grid_kernel_map ...)
+    per_op = ("agb_spconv_fwd", "agb_spconv_bwd", "agb_spconv_weight", "agb_bn_", "agb_se_", "agb_maxpool", "agb_stem_")
+    assert not any(n.startswith(per_op) for n in names), names
+    names = _calls_of(model, batch, device, False, deterministic_wgrad=True, cmp_mode=cmp_mode)
+    assert not any(n.startswith("agb_net_") for n in names)
+
+
+def test_fused_blocks_default_weight_gradients(device):
+    """Default options (fp32 atomic accumulation of the weight gradients): outputs, data path and BatchNorm / SE gradients
+    bitwise, weight gradients to rounding of the accumulation order."""
+    model, batch = _model_and_batch(device, 1500, [0, 1, 2])
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = _run(model, batch, device, False)
+    model.load_state_dict(sd0)
+    got = _run(model, batch, device, True)
+    assert torch.equal(ref[0], got[0])
+    for k in ref[1]:
+        a, b = ref[1][k], got[1][k]
+        if k.endswith("kernel"):
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, k
+        else:
+            assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_blocks_forward_only_modes(device, train):
+    """No-grad forward passes: train mode (calibrate_bn: batch statistics, running statistics updated) and eval mode
+    (running statistics)."""
+    model, batch = _model_and_batch(device, 1200, [0, 1])
+    # running statistics that are not the initial (0, 1)
+    _run(model, batch, device, False)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = _run(model, batch, device, False, train=train, backward=False)
+    model.load_state_dict(sd0)
+    got = _run(model, batch, device, True, train=train, backward=False)
+    assert torch.equal(ref[0], got[0])
+    for k in ref[2]:
+        assert torch.equal(ref[2][k], got[2][k]), k
+
+
+def test_fused_blocks_training_steps_bitwise(device):
+    """Four optimiser steps (fused AdaBelief) on two alternating batches: identical parameters afterwards."""
+    from dpcr_agb_amd.config import TRAINING_NFI
+    results = []
+    for fused in (False, True):
+        model, b0 = _model_and_batch(device, 1400, [0, 1, 2], drop_path=0.1)
+        _, b1 = _model_and_batch(device, 1400, [3, 4, 5])
+        model.set_kernel_options(fused_blocks=fused, deterministic_wgrad=True)
+        model.train()
+        model.init_train_objects(TRAINING_NFI)
+        random.seed(9)
+        for i in range(4):
+            model.set_input((b0, b1)[i % 2], device)
+            model.optimize_parameters(epoch=0, batch_size=3, num_batches=50)
+        torch.cuda.synchronize()
+        results.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k
+
+
+def test_fused_blocks_fall_back_where_they_do_not_apply(device):
+    """bf16 operands, a backbone of bottleneck blocks, instrumented runs: the operator path, silently and correctly."""
+    model, batch = _model_and_batch(device, 1000, [0, 1])
+    names = _calls_of(model, batch, device, True, precision="bf16")
+    assert not any(n.startswith("agb_net_") for n in names)
+    model.set_kernel_options(precision="fp32")
+    model50, batch = _model_and_batch(device, 1000, [0, 1], name="SENet50")
+    names = _calls_of(model50, batch, device, True)
+    assert names.count("agb_net_stem_fwd") == 1 and names.count("agb_net_block_fwd") == 0
