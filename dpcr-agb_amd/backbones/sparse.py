@@ -384,6 +384,10 @@ class ResNetBase(nn.Module):
         return plan
 
     def forward(self, x):
+        return self.final(self.forward_features(x))
+
+    def forward_features(self, x):
+        """Everything in front of the head: stem, stages, global pooling (SENet.py:113-117) -> SparseTensor [B, C]."""
         with model_scope(self):
             from .. import fused_blocks as FB
             opts = current_options()
@@ -399,8 +403,7 @@ class ResNetBase(nn.Module):
                     for blk, ok in zip(stage, oks):
                         out = FB.run_block(blk, x, opts) if ok else None
                         x = out if out is not None else blk(x)
-            x = self.glob_avg(x)
-            return self.final(x)
+            return self.glob_avg(x)
 
 
 def _variant(name, block, layers, strides=(1, 2, 2, 2), init_dim=64, planes=(64, 128, 256, 512)):

@@ -54,6 +54,20 @@ void agb_note_kernel(const char* name);
 
 static inline int agb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// spconv.hip: the convolution entry points with an addend in the final store (Y = addend + (bias + sum); the public form is
+// agb_spconv_bwd_data of include/agb_hip.h)
+extern "C" AGB_INTERNAL int agb_spconv_fwd_opt_add(const float* X, int ldx, const float* W, const int32_t* nbr,
+                                                  long long nbr_stride, int kflip, const float* bias, float* Y, int ldy,
+                                                  int n_out, int K3, int Cin, int Cout, const int32_t* perm,
+                                                  const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                                                  float* partial, int cmp_mode, int cmp_interleave_shift, const float* addend,
+                                                  int ld_add, void* stream);
+extern "C" AGB_INTERNAL int agb_spconv_fwd_tiles_add(const float* X, int ldx, const float* W, const int32_t* nbr,
+                                                    long long nbr_stride, int kflip, const float* bias, float* Y, int ldy,
+                                                    int n_out, int K3, int Cin, int Cout, int ksplit, float* partial,
+                                                    int cmp_mode, int cmp_interleave_shift, const int32_t* tile_blocks,
+                                                    int tb_tiles, int tb_blocks, const float* addend, int ld_add, void* stream);
+
 // dense_stream.hip: HBM-bound dense products (many rows, small weight matrix), taken from the identity-map entry points
 bool agb_dense_stream_ok(int n, int Cin, int Cout);
 bool agb_dense_stream_wgrad_ok(int n, int Cin, int Cout);

@@ -143,18 +143,19 @@ size_t conv_dgrad_scratch(const Opts& o, const Conv& c, int n_in) {
     return sp > 1 ? (size_t)sp * nz(n_in) * c.cin : 0;
 }
 int conv_dgrad(const Opts& o, const Conv& c, const float* wt, const float* dy, int lddy, int n_in, float* dx, int lddx,
-               float* partial, void* st) {
+               float* partial, const float* addend, void* st) {
     const int sp = dgrad_split(o, c, n_in);
     float* part = sp > 1 ? partial : nullptr;
+    const int lda = addend ? lddx : 0;
     if (c.nbrT)      // strided layer: transposed map, class partition of the input rows
-        return agb_spconv_fwd_opt(dy, lddy, wt, c.nbrT, c.nbrT_ld, 0, nullptr, dx, lddx, n_in, c.K3, c.cout, c.cin, c.perm,
-                                  c.perm ? c.tile_cls : nullptr, c.perm ? c.cls_tab : nullptr, c.perm ? c.n_tiles : 0, sp,
-                                  part, o.cmp_mode, o.cmp_il, st);
+        return agb_spconv_fwd_opt_add(dy, lddy, wt, c.nbrT, c.nbrT_ld, 0, nullptr, dx, lddx, n_in, c.K3, c.cout, c.cin, c.perm,
+                                      c.perm ? c.tile_cls : nullptr, c.perm ? c.cls_tab : nullptr, c.perm ? c.n_tiles : 0, sp,
+                                      part, o.cmp_mode, o.cmp_il, addend, lda, st);
     if (c.tb)
-        return agb_spconv_fwd_tiles(dy, lddy, wt, c.nbr, c.nbr_ld, 1, nullptr, dx, lddx, n_in, c.K3, c.cout, c.cin, sp, part,
-                                    o.cmp_mode, o.cmp_il, c.tb, c.tb_t, c.tb_b, st);
-    return agb_spconv_fwd_opt(dy, lddy, wt, c.nbr, c.nbr_ld, 1, nullptr, dx, lddx, n_in, c.K3, c.cout, c.cin, nullptr, nullptr,
-                              nullptr, 0, sp, part, o.cmp_mode, o.cmp_il, st);
+        return agb_spconv_fwd_tiles_add(dy, lddy, wt, c.nbr, c.nbr_ld, 1, nullptr, dx, lddx, n_in, c.K3, c.cout, c.cin, sp, part,
+                                        o.cmp_mode, o.cmp_il, c.tb, c.tb_t, c.tb_b, addend, lda, st);
+    return agb_spconv_fwd_opt_add(dy, lddy, wt, c.nbr, c.nbr_ld, 1, nullptr, dx, lddx, n_in, c.K3, c.cout, c.cin, nullptr,
+                                  nullptr, nullptr, 0, sp, part, o.cmp_mode, o.cmp_il, addend, lda, st);
 }
 // workspace of the weight gradient: sparse_ops.weight_grad_raw (fixed-order sums on request, or the persistent kernel)
 size_t conv_wgrad_bytes(const Opts& o, const Conv& c, int n_out, int ldx, int lddy) {
@@ -189,15 +190,6 @@ __global__ __launch_bounds__(256) void k_net_take3(const float* __restrict__ dWp
     const int k = e / (3 * C), rem = e - k * 3 * C;
     dW[e] = dWp[(long long)k * 4 * C + rem];
 }
-// Y = A + Bm (the gradient sum at a residual join: what autograd's accumulation computes, one rounding)
-__global__ __launch_bounds__(256) void k_net_add(const float4* __restrict__ A, const float4* __restrict__ Bm, long long n4,
-                                                 float4* __restrict__ Y) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n4) return;
-    const float4 a = A[e], b = Bm[e];
-    Y[e] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-}
-
 // ---- BatchNorm + activation of a convolution's output ----------------------------------------------------------------
 int bn_fwd(const Opts& o, const Conv& c, const float* z, int n, int act, float* stats, float* part, float* out, void* st) {
     NET_TRY(agb_bn_stats_tracked(z, c.cout, n, c.cout, c.eps, c.mom, o.training, part, stats, stats + c.cout, c.rm, c.rv, c.nbt,
@@ -268,7 +260,7 @@ void block_fwd_scratch(Arena& A, const int64_t* f, BlockFwdScratch* s) {
     s->part = A.take<float>(chunks * 3 * C);
 }
 struct BlockBwdScratch {
-    float *S, *spart, *ds, *dz2se, *dh, *dp, *dte, *dz2, *dr, *da1, *dz1, *dzd, *dxa, *dxb, *partial, *part, *wt, *colsum;
+    float *S, *spart, *ds, *dz2se, *dh, *dp, *dte, *dz2, *dr, *da1, *dz1, *dzd, *dxb, *partial, *part, *wt, *colsum;
     void* ws;
     size_t ws_bytes;
 };
@@ -290,7 +282,8 @@ void block_bwd_scratch(Arena& A, const int64_t* f, BlockBwdScratch* s) {
     s->da1 = A.take<float>(nc);
     s->dz1 = A.take<float>(nc);
     s->dzd = down ? A.take<float>(nc) : nullptr;
-    s->dxa = A.take<float>(nz(n_in) * Cin);      // the two addends of dx: conv1's data gradient and the downsample branch's
+    // the downsample branch's data gradient (level of the block's INPUT); conv1's data gradient takes it — or, without a
+    // downsample, the tail's dr — as the addend of its final store: dx leaves in one pass
     s->dxb = down ? A.take<float>(nz(n_in) * Cin) : nullptr;
     size_t pmax = conv_dgrad_scratch(o, c2, n), q = conv_dgrad_scratch(o, c1, n_in);
     if (q > pmax) pmax = q;
@@ -483,30 +476,24 @@ int agb_net_block_bwd(const int64_t* f, void* saved, size_t saved_bytes, void* s
     // ---- conv2: data gradient, weight gradient
     const float* wt = nullptr;
     NET_TRY(conv_wt(c2, T.wt, &wt, stream));
-    NET_TRY(conv_dgrad(o, c2, wt, T.dz2, C, n, T.da1, C, T.partial, stream));
+    NET_TRY(conv_dgrad(o, c2, wt, T.dz2, C, n, T.da1, C, T.partial, nullptr, stream));
     NET_TRY(conv_wgrad(o, c2, S.a1, C, T.dz2, C, n, T.ws, conv_wgrad_bytes(o, c2, n, C, C), stream));
     // ---- BatchNorm1 + act
     NET_TRY(bn_bwd(o, c1, S.z1, T.da1, n, act, S.st1, T.part, T.dz1, T.colsum, stream));
-    // ---- conv1
+    // ---- residual branch: its gradient with respect to x is the addend of conv1's data gradient
     const bool need_dx = I(f, F_need_dx) != 0;
-    float* dx1 = T.dxa;
-    NET_TRY(conv_wt(c1, T.wt, &wt, stream));
-    if (need_dx) NET_TRY(conv_dgrad(o, c1, wt, T.dz1, C, n_in, dx1, Cin, T.partial, stream));
-    NET_TRY(conv_wgrad(o, c1, x, Cin, T.dz1, C, n, T.ws, conv_wgrad_bytes(o, c1, n, Cin, C), stream));
-    // ---- residual branch
     const float* second = T.dr;      // no downsample: the residual IS x
     if (down) {
         NET_TRY(bn_bwd(o, cd, S.zd, T.dr, n, ACT_NONE, S.std_, T.part, T.dzd, T.colsum, stream));
         NET_TRY(conv_wt(cd, T.wt, &wt, stream));
-        if (need_dx) NET_TRY(conv_dgrad(o, cd, wt, T.dzd, C, n_in, T.dxb, Cin, T.partial, stream));
-        second = T.dxb;
+        if (need_dx) NET_TRY(conv_dgrad(o, cd, wt, T.dzd, C, n_in, T.dxb, Cin, T.partial, nullptr, stream));
         NET_TRY(conv_wgrad(o, cd, x, Cin, T.dzd, C, n, T.ws, conv_wgrad_bytes(o, cd, n, Cin, C), stream));
+        second = T.dxb;
     }
-    if (need_dx) {
-        const long long n4 = (long long)n_in * Cin / 4;
-        hipLaunchKernelGGL(k_net_add, dim3((unsigned)agb_cdiv(n4, 256)), dim3(256), 0, s, (const float4*)dx1, (const float4*)second,
-                           n4, (float4*)dx);
-    }
+    // ---- conv1
+    NET_TRY(conv_wt(c1, T.wt, &wt, stream));
+    if (need_dx) NET_TRY(conv_dgrad(o, c1, wt, T.dz1, C, n_in, dx, Cin, T.partial, second, stream));
+    NET_TRY(conv_wgrad(o, c1, x, Cin, T.dz1, C, n, T.ws, conv_wgrad_bytes(o, c1, n, Cin, C), stream));
     AGB_CHECK_LAUNCH("agb_net_block_bwd");
     return AGB_OK;
 }

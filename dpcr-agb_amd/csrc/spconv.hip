@@ -346,6 +346,8 @@ struct ConvArgs {
                     // the partial statistics of the BatchNorm that follows (register-accumulator kernels, no split)
     const int32_t* tile_blocks;   // optional [tiles][rows per tile >> il]: the row blocks of every tile of the pair-compacted
                                   // kernel (work-balanced tiles, agb_spconv_balance_tiles) instead of the fixed interleave
+    const float* addend; int ld_add;   // optional [n_out][ld_add]: Y = addend + (bias + sum): the gradient sum at a residual join
+                                       // rides in the data-gradient kernel's final store (fp32 kernels; may alias Y)
 };
 
 // CW: output columns per workgroup (64, or 128 for wide dense layers: the staged A tile serves twice the columns)
@@ -479,6 +481,7 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* out = a.ksplit > 1 ? a.partial + (long long)blockIdx.z * a.n_out * Cout : a.Y;
     const int ldo = a.ksplit > 1 ? Cout : a.ldy;
+    const float* __restrict__ addp = a.ksplit > 1 ? nullptr : a.addend;
     // the 16 permutation entries of this lane are loaded together (a load + branch per register serialised 16 memory
     // latencies at the end of every workgroup)
     int rows[16];
@@ -500,7 +503,11 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + (wn * NT + nt) * 32 + li;
-            if (col < Cout) out[(long long)row * ldo + col] = acc[nt][reg] + bvs[nt];
+            if (col < Cout) {
+                float v = acc[nt][reg] + bvs[nt];
+                if (addp) v += addp[(long long)row * a.ld_add + col];
+                out[(long long)row * ldo + col] = v;
+            }
         }
     }
     // Partial BatchNorm statistics of the tile while it is still in registers: the statistics pass of the BatchNorm
@@ -1186,6 +1193,10 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
             if (rows[u] >= 0 && col_ok) {
                 float4 y = ys[u];
                 y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+                if (a.addend && csplit == 1) {
+                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4);
+                    y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+                }
                 *reinterpret_cast<float4*>(out + (long long)rows[u] * ldo + n0 + c4) = y;
             }
         }
@@ -1431,6 +1442,10 @@ __global__ __launch_bounds__(64) void k_spconv_cmpt(ConvArgs a, int ntiles, int 
             if (rows[u] >= 0 && col_ok) {
                 float4 y = ys[u];
                 y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+                if (a.addend && csplit == 1) {
+                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4);
+                    y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+                }
                 *reinterpret_cast<float4*>(out + (long long)rows[u] * ldo + n0 + c4) = y;
             }
         }
@@ -1550,6 +1565,10 @@ __global__ __launch_bounds__(64) void k_spconv_cma(ConvArgs a, int ntiles, int n
             if (rows[u] >= 0 && col_ok) {
                 float4 y = ys[u];
                 y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+                if (a.addend && csplit == 1) {
+                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4);
+                    y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+                }
                 *reinterpret_cast<float4*>(out + (long long)rows[u] * ldo + n0 + c4) = y;
             }
         }
@@ -1559,7 +1578,8 @@ __global__ __launch_bounds__(64) void k_spconv_cma(ConvArgs a, int ntiles, int n
 // Y[r, :] = bias + sum_s partial[s][r, :]   (fixed order)
 template <typename T = float>
 __global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_out, int C4,
-                               const float* __restrict__ bias, T* __restrict__ Y, int ldy) {
+                               const float* __restrict__ bias, T* __restrict__ Y, int ldy,
+                               const float* addend = nullptr, int ld_add = 0) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int r = (int)(t / C4), c = (int)(t % C4) * 4;
     if (r >= n_out) return;
@@ -1567,6 +1587,10 @@ __global__ void k_split_reduce(const float* __restrict__ partial, int S, int n_o
     for (int s = 0; s < S; ++s) {
         float4 v = *reinterpret_cast<const float4*>(partial + ((long long)s * n_out + r) * (C4 * 4) + c);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (addend) {      // (the sum first, then the addend: the value an addition after the convolution would give)
+        const float4 ad = *reinterpret_cast<const float4*>(addend + (long long)r * ld_add + c);
+        acc.x += ad.x; acc.y += ad.y; acc.z += ad.z; acc.w += ad.w;
     }
     st4(Y + (long long)r * ldy + c, acc);
 }
@@ -2574,7 +2598,7 @@ static int launch_conv(const ConvArgs& a, int n_tiles_perm, hipStream_t s) {
     if (a.ksplit > 1) {
         long long total = (long long)a.n_out * (a.Cout / 4);
         hipLaunchKernelGGL(k_split_reduce<float>, dim3(agb_cdiv(total, 256)), dim3(256), 0, s, a.partial, a.ksplit, a.n_out,
-                           a.Cout / 4, a.bias, a.Y, a.ldy);
+                           a.Cout / 4, a.bias, a.Y, a.ldy, a.addend, a.ld_add);
     }
     return AGB_OK;
 }
@@ -2695,10 +2719,28 @@ int agb_spconv_split_hint(int n_out, int K3, int Cin, int Cout) {
     return agb_spconv_split_hint_opt(n_out, K3, Cin, Cout, 1);
 }
 
+// agb_spconv_fwd_opt with an ADDEND: Y = addend + (bias + sum) — the second gradient of a residual join added in the
+// final store of the data-gradient kernel instead of by a separate pass (addend float [n_out][ld_add], may alias Y; fp32
+// kernels; with a split reduction the addend joins in k_split_reduce).  Internal: behind agb_spconv_bwd_data and csrc/net.hip.
+AGB_INTERNAL int agb_spconv_fwd_opt_add(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride,
+                                        int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                                        const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles,
+                                        int ksplit, float* partial, int cmp_mode, int cmp_interleave_shift,
+                                        const float* addend, int ld_add, void* stream);
+
 int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
                        const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
                        const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                        float* partial, int cmp_mode, int cmp_interleave_shift, void* stream) {
+    return agb_spconv_fwd_opt_add(X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls,
+                                  cls_tab, n_tiles, ksplit, partial, cmp_mode, cmp_interleave_shift, nullptr, 0, stream);
+}
+
+int agb_spconv_fwd_opt_add(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                           const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                           const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
+                           float* partial, int cmp_mode, int cmp_interleave_shift, const float* addend, int ld_add,
+                           void* stream) {
     AGB_CHECK_ARG(cmp_mode == 0 || cmp_mode == 1 || cmp_mode == 64 || cmp_mode == 128 || cmp_mode == 129,
                   "agb_spconv_fwd_opt: cmp_mode %d (1 automatic, 0 never, 64 / 128 forced, 129: 128 with the C++ twin of the "
                   "hand-scheduled kernel)", cmp_mode);
@@ -2714,9 +2756,11 @@ int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* n
     AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_ex: ksplit needs `partial`");
     AGB_CHECK_ARG(perm == nullptr || (tile_cls != nullptr && cls_tab != nullptr && n_tiles > 0),
                   "agb_spconv_fwd_ex: perm needs tile_cls, cls_tab and n_tiles");
+    AGB_CHECK_ARG(addend == nullptr || (ld_add >= Cout && ld_add % 4 == 0 && Cin >= 12),
+                  "agb_spconv_fwd: an addend needs ld_add >= Cout, a multiple of 4, and Cin >= 12 (ld_add %d)", ld_add);
     if (n_out == 0) return AGB_OK;
     // HBM-bound dense products (many rows, a weight matrix that fits LDS): the streaming kernels of dense_stream.hip
-    if (nbr == nullptr && ksplit == 1 && agb_dense_stream_ok(n_out, Cin, Cout)) {
+    if (nbr == nullptr && ksplit == 1 && addend == nullptr && agb_dense_stream_ok(n_out, Cin, Cout)) {
         int rc = agb_dense_stream_launch(X, ldx, W, bias, Y, ldy, n_out, Cin, Cout, (hipStream_t)stream);
         if (rc) return rc;
         AGB_CHECK_LAUNCH("agb_spconv_fwd (dense, streaming)");
@@ -2724,10 +2768,26 @@ int agb_spconv_fwd_opt(const float* X, int ldx, const float* W, const int32_t* n
     }
     ConvArgs a{X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit,
                partial, cmp_mode, cmp_interleave_shift};
+    a.addend = addend; a.ld_add = ld_add;
     int rc = launch_conv(a, n_tiles, (hipStream_t)stream);
     if (rc) return rc;
     AGB_CHECK_LAUNCH("agb_spconv_fwd");
     return AGB_OK;
+}
+
+// The data gradient of the generalized sparse convolution under its own name:
+//   dX[q] = [addend[q] +] sum_k dY[map[k][q]] W[k]^T
+// map: the transposed kernel map (kflip 0; strided layers: with the class partition perm / tile_cls / cls_tab of
+// agb_parity_partition) or the forward map of a stride-1 odd kernel read backwards (kflip 1).  Wt [K3][Cout][Cin]: the
+// per-offset transposes (agb_spconv_weight_transpose).  Cin = channels of dX, Cout = channels of dY.  The same kernels as
+// agb_spconv_fwd_ex with the operand roles swapped; addend (optional, [n_in][ld_add], may alias dX): the other gradient of
+// a residual join.  Reference: ME's ConvolutionBackward behind resnet_block.py:62-73 / senet_block.py:80-96.
+int agb_spconv_bwd_data(const float* dY, int lddy, const float* Wt, const int32_t* map, long long map_stride, int kflip,
+                        float* dX, int lddx, int n_in, int K3, int Cin, int Cout, const int32_t* perm,
+                        const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit, float* partial,
+                        const float* addend, int ld_add, void* stream) {
+    return agb_spconv_fwd_opt_add(dY, lddy, Wt, map, map_stride, kflip, nullptr, dX, lddx, n_in, K3, Cout, Cin, perm, tile_cls,
+                                  cls_tab, n_tiles, ksplit, partial, 1, -1, addend, ld_add, stream);
 }
 
 // Tile geometry the pair-compacted kernel uses for this call: out[0] = tile height R (0: another kernel takes the layer),
@@ -2752,10 +2812,23 @@ int agb_spconv_cmp_geometry(int n_out, int Cin, int Cout, int ldx, int ldy, int 
 // agb_spconv_fwd_opt with WORK-BALANCED tiles for the pair-compacted kernel: tile_blocks int32[tb_tiles][tb_blocks] from
 // agb_spconv_balance_tiles for the geometry agb_spconv_cmp_geometry reports for this call (checked).  Same sums, bit for
 // bit, as without the table: a row's sum does not depend on the tile it is computed in.
+AGB_INTERNAL int agb_spconv_fwd_tiles_add(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride,
+                                          int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
+                                          int ksplit, float* partial, int cmp_mode, int cmp_interleave_shift,
+                                          const int32_t* tile_blocks, int tb_tiles, int tb_blocks, const float* addend,
+                                          int ld_add, void* stream);
 int agb_spconv_fwd_tiles(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
                          const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, int ksplit,
                          float* partial, int cmp_mode, int cmp_interleave_shift, const int32_t* tile_blocks, int tb_tiles,
                          int tb_blocks, void* stream) {
+    return agb_spconv_fwd_tiles_add(X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, ksplit, partial,
+                                    cmp_mode, cmp_interleave_shift, tile_blocks, tb_tiles, tb_blocks, nullptr, 0, stream);
+}
+int agb_spconv_fwd_tiles_add(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,
+                             const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout, int ksplit,
+                             float* partial, int cmp_mode, int cmp_interleave_shift, const int32_t* tile_blocks, int tb_tiles,
+                             int tb_blocks, const float* addend, int ld_add, void* stream) {
+    AGB_CHECK_ARG(addend == nullptr || (ld_add >= Cout && ld_add % 4 == 0), "agb_spconv_fwd_tiles: addend ld_add %d", ld_add);
     AGB_CHECK_ARG(tile_blocks != nullptr && nbr != nullptr, "agb_spconv_fwd_tiles: tile_blocks and nbr required");
     int32_t g[4];
     int rc = agb_spconv_cmp_geometry(n_out, Cin, Cout, ldx, ldy, ksplit, cmp_mode, cmp_interleave_shift, g);
@@ -2768,6 +2841,7 @@ int agb_spconv_fwd_tiles(const float* X, int ldx, const float* W, const int32_t*
     AGB_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || partial != nullptr), "agb_spconv_fwd_tiles: ksplit needs `partial`");
     ConvArgs a{X, ldx, W, nbr, nbr_stride, kflip, bias, Y, ldy, n_out, K3, Cin, Cout, nullptr, nullptr, nullptr, ksplit,
                partial, cmp_mode, cmp_interleave_shift, nullptr, tile_blocks};
+    a.addend = addend; a.ld_add = ld_add;
     rc = launch_conv(a, 0, (hipStream_t)stream);
     if (rc) return rc;
     AGB_CHECK_LAUNCH("agb_spconv_fwd_tiles");

@@ -102,8 +102,9 @@ class MinkowskiBaselineModel(InstanceBase):
             self._staged = data
 
     def set_input(self, data, device):
-        self.batch_idx = data.batch.squeeze()
-        self.data_visual = data
+        d = self.__dict__     # (plain attributes: nn.Module.__setattr__ costs ~20 us per tensor assignment)
+        d["batch_idx"] = data.batch.squeeze()
+        d["data_visual"] = data
         pre = getattr(data, "_prefetched", None)
         if pre is not None:
             inp, ev, stage = pre
@@ -114,23 +115,51 @@ class MinkowskiBaselineModel(InstanceBase):
                 with torch.cuda.stream(self._side_stream):
                     inp = self._stage_b(inp)
                     ev = self._side_stream.record_event()
-            self.input = inp
+            d["input"] = inp
             cur = torch.cuda.current_stream(device)
             cur.wait_event(ev)
             # (data too: a batch built on the side stream — its targets are read by the loss on the compute stream)
             self._hold_input((inp, data), list(inp.coordinate_manager.tensors()) + [inp.F] +
                              [t for t in getattr(data, "__dict__", {}).values() if isinstance(t, torch.Tensor) and t.is_cuda], cur)
         else:
-            self.input = self._build_input(data, device)
+            d["input"] = self._build_input(data, device)
         if len(self.loss_fns) > 0:
             bs = len(data)
             if self.has_reg_targets and data.y_reg is not None:
                 mask_all = getattr(data, "y_reg_mask_all", None)  # host-side flag: no device sync in the loss
-                self._reg_mask_all = bool(data.y_reg_mask.all()) if mask_all is None else mask_all
-                self.reg_y_mask = data.y_reg_mask.to(device, non_blocking=True).view(bs, -1)
-                self.reg_y = data.y_reg.to(device, non_blocking=True).view(bs, -1)
+                d["_reg_mask_all"] = bool(data.y_reg_mask.all()) if mask_all is None else mask_all
+                d["reg_y_mask"] = data.y_reg_mask.to(device, non_blocking=True).view(bs, -1)
+                d["reg_y"] = data.y_reg.to(device, non_blocking=True).view(bs, -1)
+
+    def _fused_head(self):
+        """Loss-function mask of the one-launch head + loss (head_ops.py, csrc/head.hip) when this model / batch is one it
+        takes — the plain configuration of the reference (linear output activation, smooth-L1 / L2 / L1, every target
+        present) on a backbone with ``forward_features`` — else None."""
+        from ..head_ops import MAX_TARGETS, loss_mask
+        from ..sparse_ops import current
+        m = self.model
+        opts = getattr(m, "kernel_options", None) or current()
+        if not (getattr(opts, "fused_head", True) and hasattr(m, "forward_features") and self.has_reg_targets
+                and isinstance(m.final, SeparateLinear) and self.opt.get("reg_out_activation", "linear").lower() == "linear"
+                and self._reg_mask_all is True and 1 <= len(m.final.linears) <= MAX_TARGETS
+                and len(m.final.linears) == self.num_reg_classes and getattr(self, "reg_y", None) is not None):
+            return None
+        return loss_mask(self.loss_fns.get("reg") or [])
 
     def forward(self, *args, **kwargs):
-        self.output = self.model(self.input)
+        mask = self._fused_head() if len(self.loss_fns) > 0 else None
+        if mask is not None:
+            pooled = self.model.forward_features(self.input).F
+            if pooled.is_cuda and pooled.dtype == torch.float32 and self.reg_y.dtype == torch.float32:
+                from ..head_ops import reg_head_loss
+                d = self.__dict__      # (plain attributes: nn.Module.__setattr__ costs ~20 us per tensor assignment)
+                d["output"], d["loss_reg"], d["loss"] = reg_head_loss(
+                    pooled, self.model.final.linears, self.reg_y, self.reg_center_targets, self.reg_scale_targets,
+                    self.reg_weights, mask)
+                d["reg_out"] = self.output
+                return
+            self.output = torch.cat([lin(pooled) for lin in self.model.final.linears], 1)
+        else:
+            self.output = self.model(self.input)
         self.reg_out = self.convert_outputs(self.output)
         self.compute_loss()

@@ -191,6 +191,17 @@ size_t agb_stem_bwd_weight_grid_workspace_bytes(int n_out, int K);
 int agb_stem_bwd_weight_grid(const float* X, int ldx, const float* dY, int ldy, const int32_t* coords, const int32_t* grid,
                              const int32_t* desc, int K, float* dW, int n_out, int Cout, void* workspace,
                              size_t workspace_bytes, void* stream);
+/* The data gradient under its own name (SURVEY.md section 8(b) agb_spconv_bwd_data; ME's ConvolutionBackward behind
+ * resnet_block.py:62-73 / senet_block.py:80-96):   dX[q] = [addend[q] +] sum_k dY[map[k][q]] @ Wt[k]
+ * map: the TRANSPOSED kernel map (kflip 0; strided layers with the class partition perm / tile_cls / cls_tab / n_tiles of
+ * agb_parity_partition, else NULL / 0) or the forward map of a stride-1 odd kernel read backwards (kflip 1).
+ * Wt [K3][Cout][Cin] from agb_spconv_weight_transpose; Cin = channels of dX, Cout = channels of dY.  ksplit / partial as
+ * agb_spconv_fwd_ex.  addend (optional, float [n_in][ld_add], may alias dX): the other gradient of a residual join, added in
+ * the kernel's final store (after the sum: the value a separate addition would give) instead of by one more pass. */
+int agb_spconv_bwd_data(const float* dY, int lddy, const float* Wt, const int32_t* map, long long map_stride, int kflip,
+                        float* dX, int lddx, int n_in, int K3, int Cin, int Cout, const int32_t* perm,
+                        const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit, float* partial,
+                        const float* addend, int ld_add, void* stream);
 /* WT [K3][C][R] = per-offset transpose of W [K3][R][C] (R, C multiples of 4): the operand of the data gradient
  * dX = sum_k dY[nbrT[k]] @ W[k]^T, rebuilt once per layer per step (ME does the same inside its backward GEMMs with
  * a transposed-operand flag: MinkowskiEngine/src/convolution_kernel.cu ConvolutionBackwardKernelGPU). */
@@ -661,6 +672,21 @@ int agb_net_stem_bwd(const int64_t* f, void* saved, size_t saved_bytes, void* sc
 size_t agb_net_block_bytes(const int64_t* f, int which);
 int agb_net_block_fwd(const int64_t* f, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
 int agb_net_block_bwd(const int64_t* f, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- regression head + loss (dpcr-agb_amd/csrc/head.hip) --------------------------------------------------------------
+ * models/instance/minkowski.py:16-26 (SeparateLinear: one nn.Linear(C, 1) per regression target on the pooled features) and
+ * models/instance/base.py:139-146,154-179 (targets standardised with the train statistics: d = out - (y - center) / scale;
+ * smooth-L1 (beta 1) / L2 / L1 with mean reduction, summed over the configured functions; weighted by mean(task weights)).
+ * One launch forward, one backward.  W, bias, dW, dbias: HOST arrays of T <= 8 DEVICE pointers (weight [C], bias [1] of
+ * every target's layer; bias / gradient pointers may be NULL).  pooled [B][ldp]; y [B][T]; center, scale, weights [T].
+ * loss_mask: 1 smooth-L1 | 2 L2 | 4 L1.  fwd out: out [B][T], dout [B][T] = dloss/dout (kept for bwd), loss_reg and loss
+ * (device scalars).  bwd: gloss = device scalar arriving at `loss` (NULL: 1); dW_t [C], dbias_t [1], dpooled [B][lddp] or
+ * NULL; the plots are summed in order (deterministic). */
+int agb_reg_head_fwd(const float* pooled, int ldp, int B, int C, int T, const float* const* W, const float* const* bias,
+                     const float* y, const float* center, const float* scale, const float* weights, int loss_mask, float* out,
+                     float* dout, float* loss_reg, float* loss, void* stream);
+int agb_reg_head_bwd(const float* pooled, int ldp, int B, int C, int T, const float* const* W, const float* dout,
+                     const float* gloss, float* const* dW, float* const* dbias, float* dpooled, int lddp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ def test_binding_covers_header():
     from dpcr_agb_amd import _lib
     import dpcr_agb_amd.kp_index, dpcr_agb_amd.kpconv_ops, dpcr_agb_amd.norm_ops, dpcr_agb_amd.voxelize  # noqa: F401,E401
     import dpcr_agb_amd.sparse_ops, dpcr_agb_amd.transforms, dpcr_agb_amd.se_ops, dpcr_agb_amd.train_transforms  # noqa: F401,E401
-    import dpcr_agb_amd.fused_blocks  # noqa: F401
+    import dpcr_agb_amd.fused_blocks, dpcr_agb_amd.head_ops  # noqa: F401,E401
     _lib.load()
     bound = set(_lib._SIGNATURES) | {"agb_last_error", "agb_last_kernel"}
     assert set(declared_symbols()) <= bound, sorted(set(declared_symbols()) - bound)

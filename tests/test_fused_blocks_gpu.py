@@ -24,8 +24,9 @@ def _model_and_batch(device, n_points, seeds, drop_path=0.0, name="SENet14"):
     return model.to(device), batch
 
 
-def _run(model, batch, device, fused, train=True, backward=True, seed=5, **opts):
-    model.set_kernel_options(fused_blocks=fused, **opts)
+def _run(model, batch, device, fused, train=True, backward=True, seed=5, fused_head=False, **opts):
+    # (the head + loss launch has its own summation order: the bitwise comparisons of the BLOCKS keep the library head)
+    model.set_kernel_options(fused_blocks=fused, fused_head=fused_head, **opts)
     model.train(train)
     for p in model.parameters():
         p.grad = None
@@ -126,7 +127,7 @@ def test_fused_blocks_training_steps_bitwise(device):
     for fused in (False, True):
         model, b0 = _model_and_batch(device, 1400, [0, 1, 2], drop_path=0.1)
         _, b1 = _model_and_batch(device, 1400, [3, 4, 5])
-        model.set_kernel_options(fused_blocks=fused, deterministic_wgrad=True)
+        model.set_kernel_options(fused_blocks=fused, fused_head=False, deterministic_wgrad=True)
         model.train()
         model.init_train_objects(TRAINING_NFI)
         random.seed(9)
@@ -148,3 +149,27 @@ def test_fused_blocks_fall_back_where_they_do_not_apply(device):
     model50, batch = _model_and_batch(device, 1000, [0, 1], name="SENet50")
     names = _calls_of(model50, batch, device, True)
     assert names.count("agb_net_stem_fwd") == 1 and names.count("agb_net_block_fwd") == 0
+
+
+@pytest.mark.parametrize("loss_fn", ["smoothl1", "l2,l1"])
+def test_fused_head_and_loss_match_the_library_head(device, loss_fn):
+    """csrc/head.hip (SeparateLinear + standardised targets + loss, one launch per direction) against torch's nn.Linear /
+    F.smooth_l1_loss / mse / l1 graph (minkowski.py:16-26, base.py:154-179): outputs, loss and every gradient of the network to
+    fp32 rounding of the summation order."""
+    from dpcr_agb_amd.instance.base import REG_LOSSES
+    model, batch = _model_and_batch(device, 1500, [0, 1, 2])
+    model.loss_fns["reg"] = [REG_LOSSES[n] for n in loss_fn.split(",")]
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = _run(model, batch, device, True, deterministic_wgrad=True)
+    ref_loss, ref_reg = float(model.loss.detach()), float(model.loss_reg.detach())
+    model.load_state_dict(sd0)
+    got = _run(model, batch, device, True, deterministic_wgrad=True, fused_head=True)
+    assert type(model.loss.grad_fn).__name__.startswith("RegHeadLoss"), type(model.loss.grad_fn)
+    assert abs(float(model.loss.detach()) - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss))
+    assert abs(float(model.loss_reg.detach()) - ref_reg) <= 2e-6 * max(1.0, abs(ref_reg))
+    assert float((ref[0] - got[0]).abs().max()) <= 2e-6 * float(ref[0].abs().max())
+    assert torch.equal(model.get_reg_output(), model.output * model.reg_scale_targets + model.reg_center_targets)
+    gmax = max(float(g.abs().max()) for g in ref[1].values())
+    for k in ref[1]:
+        den = max(float(ref[1][k].abs().max()), 1e-3 * gmax)
+        assert float((ref[1][k] - got[1][k]).abs().max()) <= 1e-5 * den, k
