@@ -48,35 +48,61 @@ class MinkowskiDropPath(nn.Module):
     # executed the copy that read it (one event per row)
     _RING, _ring, _slot, _done = 64, None, 0, None
 
-    def scale_vector(self, x):
-        """float[B] on the device: keep/(1-p) per batch element, or None when nothing is to be applied."""
-        if not self.training:
-            return None
-        B = x.coordinate_manager.batch_size
+    def _draw(self, B):
         keep_prob = 1 - self.drop_prob
         keep = [1.0 if random.uniform(0, 1) > self.drop_prob else 0.0 for _ in range(B)]
         if keep_prob > 0.0 and self.scale_by_keep:
             keep = [k / keep_prob for k in keep]
+        return keep
+
+    @staticmethod
+    def _upload(values, device):
+        """float[len(values)] on the device through a ring of pinned staging rows (asynchronous copy)."""
         cls = MinkowskiDropPath
-        if cls._ring is None or cls._ring.shape[1] < B:
+        n = len(values)
+        if cls._ring is None or cls._ring.shape[1] < n:
             if cls._done is not None:
                 for ev in cls._done:
                     if ev is not None:
                         ev.synchronize()
-            cls._ring = torch.empty(cls._RING, max(B, 256), dtype=torch.float32).pin_memory()
+            cls._ring = torch.empty(cls._RING, max(n, 1024), dtype=torch.float32).pin_memory()
             cls._done = [None] * cls._RING
         slot = cls._slot % cls._RING
         cls._slot += 1
         if cls._done[slot] is not None:
             cls._done[slot].synchronize()
-        row = cls._ring[slot, :B]
-        row.copy_(torch.tensor(keep, dtype=torch.float32))
-        out = row.to(x.device, non_blocking=True)
+        row = cls._ring[slot, :n]
+        row.copy_(torch.tensor(values, dtype=torch.float32))
+        out = row.to(device, non_blocking=True)
         if out.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
             cls._done[slot] = ev
         return out
+
+    def scale_vector(self, x):
+        """float[B] on the device: keep/(1-p) per batch element, or None when nothing is to be applied."""
+        if not self.training:
+            return None
+        preset = self.__dict__.pop("_preset", None)
+        if preset is not None:          # (drawn at the start of this forward pass together with the other blocks' vectors)
+            return preset
+        return self._upload(self._draw(x.coordinate_manager.batch_size), x.device)
+
+    @staticmethod
+    def predraw(blocks, B, device):
+        """The drop-path vectors of all `blocks` (modules with a ``drop_path``) of one forward pass, drawn NOW in block order
+        — the same ``random`` sequence as one draw per block while it runs, provided nothing else draws in between — and
+        uploaded with ONE copy; every block's ``scale_vector`` then returns its slice."""
+        dps = [b.drop_path for b in blocks if isinstance(b.drop_path, MinkowskiDropPath) and b.drop_path.training]
+        if not dps:
+            return
+        values = []
+        for dp in dps:
+            values += dp._draw(B)
+        flat = MinkowskiDropPath._upload(values, device)
+        for i, dp in enumerate(dps):
+            dp.__dict__["_preset"] = flat[i * B:(i + 1) * B]
 
     def forward(self, x):
         scale = self.scale_vector(x)
@@ -397,11 +423,19 @@ class ResNetBase(nn.Module):
             else:
                 stem_ok, stages_ok = self._fused_plan()
                 stages = list(self.blocks)
+                fused = [blk for stage, oks in zip(stages[1:], stages_ok) for blk, ok in zip(stage, oks) if ok]
+                wt = None
+                if fused and torch.is_grad_enabled():
+                    wt = FB.weight_transposes(self, fused)
+                    wt.ensure()       # one launch per step: W^T of every fused convolution, for the data gradients
+                if fused and self.training and all(all(oks) for oks in stages_ok):
+                    # every residual block runs fused: their drop-path vectors in one draw + one upload
+                    MinkowskiDropPath.predraw(fused, x.coordinate_manager.batch_size, x.F.device)
                 out = FB.run_stem(stages[0], x, opts) if stem_ok else None
                 x = out if out is not None else stages[0](x)
                 for stage, oks in zip(stages[1:], stages_ok):
                     for blk, ok in zip(stage, oks):
-                        out = FB.run_block(blk, x, opts) if ok else None
+                        out = FB.run_block(blk, x, opts, wt) if ok else None
                         x = out if out is not None else blk(x)
             return self.glob_avg(x)
 

@@ -25,7 +25,7 @@
 
 #define AGB_NET_FIELDS(X)                                                                                              \
     X(x) X(ldx) X(n_in) X(n_out) X(B) X(coords) X(ptr) X(y) X(ldy)                                                     \
-    X(dy) X(lddy) X(dx) X(lddx) X(need_dx)                                                                             \
+    X(dy) X(lddy) X(dx) X(lddx) X(need_dx) X(gzero) X(gzero_bytes)                                                     \
     X(training) X(act) X(stride) X(has_down)                                                                           \
     X(cmp_mode) X(cmp_il) X(dw_variant) X(det) X(persistent)                                                           \
     AGB_NET_CONV(X, c1) AGB_NET_CONV(X, c2) AGB_NET_CONV(X, cd)                                                        \
@@ -304,9 +304,10 @@ void block_bwd_scratch(Arena& A, const int64_t* f, BlockBwdScratch* s) {
 
 // W^T of one convolution for its data gradient: the step's cached copy when the caller keeps one, else made here (the
 // launch also clears the weight-gradient buffer, as SparseConvFunction.backward does)
-int conv_wt(const Conv& c, float* wt_scratch, const float** wt_out, void* st) {
+int conv_wt(const Conv& c, float* wt_scratch, const float** wt_out, bool cleared, void* st) {
     if (c.wt) {
         *wt_out = c.wt;
+        if (cleared) return AGB_OK;      // (the block's gradient buffer was cleared in one go: `gzero`)
         return hipMemsetAsync(c.dw, 0, sizeof(float) * (size_t)c.K3 * c.cin * c.cout, (hipStream_t)st) == hipSuccess ? AGB_OK
                                                                                                                       : AGB_ELAUNCH;
     }
@@ -471,11 +472,18 @@ int agb_net_block_bwd(const int64_t* f, void* saved, size_t saved_bytes, void* s
                                  stream));
     NET_TRY(agb_se_tail_bwd_apply(S.z2, C, r, C, dy, lddy, coords, mean2, rstd2, c2.g, c2.be, S.s, keep, T.dte, c2.dbe, c2.dg, act,
                                   o.training, n, C, T.dz2, C, T.dr, C, stream));
-    // (bias of a convolution in front of a training-mode BatchNorm: its gradient is exactly zero, norm_ops.py)
-    if (c2.db && hipMemsetAsync(c2.db, 0, sizeof(float) * C, s) != hipSuccess) return AGB_ELAUNCH;
+    // gzero: the caller laid the buffers that must start at zero (the three weight gradients, conv2's bias gradient) out
+    // contiguously: one fill for the block instead of one per buffer
+    const bool cleared = P<char>(f, F_gzero) != nullptr;
+    if (cleared) {
+        if (hipMemsetAsync(P<char>(f, F_gzero), 0, (size_t)f[F_gzero_bytes], s) != hipSuccess) return AGB_ELAUNCH;
+    } else if (c2.db && hipMemsetAsync(c2.db, 0, sizeof(float) * C, s) != hipSuccess) {
+        // (bias of a convolution in front of a training-mode BatchNorm: its gradient is exactly zero, norm_ops.py)
+        return AGB_ELAUNCH;
+    }
     // ---- conv2: data gradient, weight gradient
     const float* wt = nullptr;
-    NET_TRY(conv_wt(c2, T.wt, &wt, stream));
+    NET_TRY(conv_wt(c2, T.wt, &wt, cleared, stream));
     NET_TRY(conv_dgrad(o, c2, wt, T.dz2, C, n, T.da1, C, T.partial, nullptr, stream));
     NET_TRY(conv_wgrad(o, c2, S.a1, C, T.dz2, C, n, T.ws, conv_wgrad_bytes(o, c2, n, C, C), stream));
     // ---- BatchNorm1 + act
@@ -485,13 +493,13 @@ int agb_net_block_bwd(const int64_t* f, void* saved, size_t saved_bytes, void* s
     const float* second = T.dr;      // no downsample: the residual IS x
     if (down) {
         NET_TRY(bn_bwd(o, cd, S.zd, T.dr, n, ACT_NONE, S.std_, T.part, T.dzd, T.colsum, stream));
-        NET_TRY(conv_wt(cd, T.wt, &wt, stream));
+        NET_TRY(conv_wt(cd, T.wt, &wt, cleared, stream));
         if (need_dx) NET_TRY(conv_dgrad(o, cd, wt, T.dzd, C, n_in, T.dxb, Cin, T.partial, nullptr, stream));
         NET_TRY(conv_wgrad(o, cd, x, Cin, T.dzd, C, n, T.ws, conv_wgrad_bytes(o, cd, n, Cin, C), stream));
         second = T.dxb;
     }
     // ---- conv1
-    NET_TRY(conv_wt(c1, T.wt, &wt, stream));
+    NET_TRY(conv_wt(c1, T.wt, &wt, cleared, stream));
     if (need_dx) NET_TRY(conv_dgrad(o, c1, wt, T.dz1, C, n_in, dx, Cin, T.partial, second, stream));
     NET_TRY(conv_wgrad(o, c1, x, Cin, T.dz1, C, n, T.ws, conv_wgrad_bytes(o, c1, n, Cin, C), stream));
     AGB_CHECK_LAUNCH("agb_net_block_bwd");

@@ -1626,6 +1626,43 @@ __global__ __launch_bounds__(256) void k_weight_transpose(const float* __restric
     }
 }
 
+// The same for EVERY convolution of a model in one launch (the transposes live in a buffer the caller keeps until the next
+// optimiser step): tab int64 [n][6] = (W, WT, K3, R, C, first tile) per layer, tiles = 64 x 64 pieces of one offset.
+__global__ __launch_bounds__(256) void k_weight_transpose_batched(const long long* __restrict__ tab, int n) {
+    __shared__ float tile[64][65];
+    __shared__ long long s_e[6];
+    if (threadIdx.x == 0) {
+        int i = 0;
+        while (i + 1 < n && (long long)blockIdx.x >= tab[(i + 1) * 6 + 5]) ++i;
+        for (int j = 0; j < 6; ++j) s_e[j] = tab[i * 6 + j];
+    }
+    __syncthreads();
+    const int R = (int)s_e[3], C = (int)s_e[4];
+    const int tx = (C + 63) >> 6, ty = (R + 63) >> 6;
+    const int t = (int)((long long)blockIdx.x - s_e[5]);
+    const int k = t / (tx * ty), rem = t - k * tx * ty;
+    const float* w = reinterpret_cast<const float*>(s_e[0]) + (long long)k * R * C;
+    float* wt = reinterpret_cast<float*>(s_e[1]) + (long long)k * R * C;
+    const int r0 = (rem / tx) * 64, c0 = (rem % tx) * 64;
+    const int g = threadIdx.x & 15, h = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = h + 16 * p;
+        if (r0 + r < R && c0 + 4 * g < C) {
+            float4 v = *reinterpret_cast<const float4*>(w + (long long)(r0 + r) * C + c0 + 4 * g);
+            tile[r][4 * g + 0] = v.x; tile[r][4 * g + 1] = v.y; tile[r][4 * g + 2] = v.z; tile[r][4 * g + 3] = v.w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = h + 16 * p;
+        if (c0 + c < C && r0 + 4 * g < R)
+            *reinterpret_cast<float4*>(wt + (long long)(c0 + c) * R + r0 + 4 * g) =
+                make_float4(tile[4 * g + 0][c], tile[4 * g + 1][c], tile[4 * g + 2][c], tile[4 * g + 3][c]);
+    }
+}
+
 // Both bf16 operand forms of a kernel W [K3][R][C] (fp32) in one launch: W16 [K3][R][C] (K-major for the data gradient)
 // and Wt16 [K3][C][R] (K-major for the forward pass), round to nearest even.  The bf16-row mode converted every layer's
 // weights with three launches per step (transpose, two conversions: 160 launches, 1.0 ms of MSENet50's 19.4 ms step).
@@ -2658,6 +2695,17 @@ int agb_weight_twins_bf16(const float* W, int K3, int R, int C, uint16_t* W16, u
     hipLaunchKernelGGL(k_weight_twins, dim3(agb_cdiv(C, 64), agb_cdiv(R, 64), K3), dim3(256), 0, (hipStream_t)stream, W, W16,
                        Wt16, R, C);
     AGB_CHECK_LAUNCH("agb_weight_twins_bf16");
+    return AGB_OK;
+}
+
+// Every layer of a model in ONE launch: tab (DEVICE) int64 [n][6] = (W, WT, K3, R, C, first tile) per layer with
+// first tile = the running sum of K3 * ceil(R / 64) * ceil(C / 64) over the layers before it; total_tiles = that sum over
+// all layers.  R, C multiples of 4.  Values identical to agb_spconv_weight_transpose layer by layer.
+int agb_spconv_weight_transpose_batched(const long long* tab, int n, long long total_tiles, void* stream) {
+    AGB_CHECK_ARG(tab != nullptr && n >= 1 && total_tiles >= 1 && total_tiles <= 0x7fffffffLL,
+                  "agb_spconv_weight_transpose_batched: %d layers, %lld tiles", n, total_tiles);
+    hipLaunchKernelGGL(k_weight_transpose_batched, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
+    AGB_CHECK_LAUNCH("agb_spconv_weight_transpose_batched");
     return AGB_OK;
 }
 

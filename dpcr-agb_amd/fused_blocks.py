@@ -175,16 +175,22 @@ def _opt_fields(tab, opts, training):
 
 # ------------------------------------------------------------------------------------------------------------ gradients
 class _GradLayout:
-    """Offsets (in floats, 64-float aligned) of the parameter gradients of one block inside one flat buffer."""
+    """Offsets (in floats, 64-float aligned) of the parameter gradients of one block inside one flat buffer.  zero_first: the
+    indices whose buffers must start at zero — laid out first and contiguously (`zero_floats`), cleared by ONE fill."""
 
-    def __init__(self, shapes):
-        self.offsets, off = [], 0
-        for shp in shapes:
+    def __init__(self, shapes, zero_first=()):
+        order = list(zero_first) + [i for i in range(len(shapes)) if i not in zero_first]
+        self.offsets, off = [None] * len(shapes), 0
+        self.zero_floats = 0
+        for i in order:
+            shp = shapes[i]
             n = 1
             for d in shp:
                 n *= d
-            self.offsets.append((off, n, shp))
+            self.offsets[i] = (off, n, shp)
             off += (n + 63) // 64 * 64
+            if i in zero_first:
+                self.zero_floats = off
         self.total = max(off, 64)
 
     def views(self, flat):
@@ -193,6 +199,65 @@ class _GradLayout:
     def ptrs(self, flat):
         base = flat.data_ptr()
         return [base + 4 * o for o, _n, _s in self.offsets]
+
+
+# ------------------------------------------------------------------------------------- transposed weights, kept per step
+class WeightTransposes:
+    """W^T [K3][cout][cin] of every convolution the fused blocks of one backbone differentiate through, made by ONE launch
+    (agb_spconv_weight_transpose_batched) the first time a step asks for them and kept until the weights change (the fused
+    optimiser's weight epoch / torch's version counters) — instead of one transpose launch per layer and backward pass."""
+
+    def __init__(self, convs, device):
+        self.convs = list(convs)
+        self.key = None
+        total, tiles, rows = 0, 0, []
+        self.offset = {}
+        for c in self.convs:
+            K3, cin, cout = c.kernel.shape
+            self.offset[id(c)] = total
+            rows.append([0, 0, K3, cin, cout, tiles])
+            total += K3 * cin * cout
+            tiles += K3 * ((cin + 63) // 64) * ((cout + 63) // 64)
+        self.flat = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+        self.tiles = tiles
+        self.rows = rows
+        self.table = None
+        self.ptrs = None
+
+    def _state(self):
+        return (sparse_ops._WEIGHT_EPOCH[0],) + tuple(c.kernel._version for c in self.convs) + \
+            tuple(c.kernel.data_ptr() for c in self.convs)
+
+    def ensure(self):
+        """Transposes of the CURRENT weights on the current stream (a no-op while nothing changed)."""
+        key = self._state()
+        if key == self.key:
+            return
+        ptrs = key[1 + len(self.convs):]
+        if ptrs != self.ptrs:       # (first use, or the parameters moved: model.to(), load_state_dict(assign=True))
+            base = self.flat.data_ptr()
+            tab = [[p, base + 4 * self.offset[id(c)]] + r[2:] for c, p, r in zip(self.convs, ptrs, self.rows)]
+            self.table = torch.tensor(tab, dtype=torch.int64).to(self.flat.device)
+            self.ptrs = ptrs
+        _lib.call("agb_spconv_weight_transpose_batched", self.table.data_ptr(), len(self.convs), self.tiles, _lib.stream())
+        self.key = key
+
+    def ptr(self, conv):
+        return self.flat.data_ptr() + 4 * self.offset[id(conv)]
+
+
+_lib.declare("agb_spconv_weight_transpose_batched", [_V, _I, _lib.c_ll, _V])
+
+
+def weight_transposes(model, blocks):
+    """The model's WeightTransposes over the convolutions of `blocks` (made on first use)."""
+    wt = model.__dict__.get("_agb_wt")
+    if wt is None:
+        convs = []
+        for blk in blocks:
+            convs += [blk.conv1, blk.conv2] + ([] if isinstance(blk.downsample, nn.Identity) else [blk.downsample[0]])
+        wt = model.__dict__["_agb_wt"] = WeightTransposes(convs, convs[0].kernel.device)
+    return wt
 
 
 # ----------------------------------------------------------------------------------------------------------------- stem
@@ -331,7 +396,8 @@ class SEBlockFunction(torch.autograd.Function):
         tab.setp("c2_", dw=gp[4], db=gp[5], dg=gp[6], dbe=gp[7])
         tab.setp("cd_", dw=gp[8], db=gp[9], dg=gp[10], dbe=gp[11])
         tab.set(d_se_w1=gp[12], d_se_b1=gp[13], d_se_w2=gp[14], d_se_b2=gp[15], x=x.data_ptr(), dy=dy.data_ptr(),
-                lddy=dy.stride(0), dx=_ptr(dx), lddx=call.Cin, need_dx=int(need_dx))
+                lddy=dy.stride(0), dx=_ptr(dx), lddx=call.Cin, need_dx=int(need_dx), gzero=flat.data_ptr(),
+                gzero_bytes=4 * call.layout.zero_floats)
         scratch = _scratch(call.bwd_bytes, dev)
         _lib.call("agb_net_block_bwd", tab.buf, saved.data_ptr(), saved.numel(), scratch.data_ptr(), scratch.numel(),
                   _lib.stream())
@@ -369,8 +435,9 @@ def _conv_fields(tab, prefix, conv, bn, cm, ts_in, opts, need_t, n_in, n_out):
     return keep
 
 
-def run_block(blk, x, opts):
-    """The fused SEBasicBlock on SparseTensor x, or None when this batch / mode is not one it takes."""
+def run_block(blk, x, opts, wt=None):
+    """The fused SEBasicBlock on SparseTensor x, or None when this batch / mode is not one it takes.  wt: the model's
+    WeightTransposes (the data gradients then read the step's cached W^T instead of transposing per layer)."""
     from .backbones.sparse import MinkowskiDropPath
     F = x.F
     if not (F.is_cuda and F.dtype == torch.float32 and F.dim() == 2 and F.is_contiguous()):
@@ -406,7 +473,7 @@ def run_block(blk, x, opts):
     lvl = cm.level(ts_out)
     ptr = cm.batch_ptr(ts_out)
     dp = blk.drop_path
-    keep = dp.scale_vector(x) if isinstance(dp, MinkowskiDropPath) else None
+    keep = dp.scale_vector(x) if isinstance(dp, MinkowskiDropPath) else None      # (or the step's pre-drawn vector)
     fc = blk.se.fc
     lin1, lin2 = fc[0].linear, fc[2].linear
     tab.set(n_in=n_in, n_out=n_out, B=cm.batch_size, coords=lvl.coords.data_ptr(), ptr=ptr.data_ptr(),
@@ -417,6 +484,7 @@ def run_block(blk, x, opts):
     lib = _lib.load()
     call = _BlockCall()
     call.tab, call.n_in, call.n_out, call.C, call.Cin, call.down = tab, n_in, n_out, C, Cin, down
+    call.keepalive = keepalive
     call.saved_bytes = lib.agb_net_block_bytes(tab.buf, 0)
     call.fwd_bytes = lib.agb_net_block_bytes(tab.buf, 1)
     call.bwd_bytes = lib.agb_net_block_bytes(tab.buf, 2) if needs_grad else 0
@@ -425,11 +493,16 @@ def run_block(blk, x, opts):
     shapes = [tuple(c1.kernel.shape), (1, C), (C,), (C,), tuple(c2.kernel.shape), (1, C), (C,), (C,),
               tuple(dsc.kernel.shape) if down else (1,), (1, C), (C,), (C,), (H, C), (H,), (C, H), (C,)]
     call.layout = _block_layout(tuple(shapes))
+    if wt is not None and needs_grad:      # (ensured for this step's weights by the caller: ResNetBase.forward_features)
+        tab.setp("c1_", wt=wt.ptr(c1))
+        tab.setp("c2_", wt=wt.ptr(c2))
+        if down:
+            tab.setp("cd_", wt=wt.ptr(dsc))
+        call.keepalive.append(wt.flat)
     params = [c1.kernel, c1.bias, bns[0].weight, bns[0].bias, c2.kernel, c2.bias, bns[1].weight, bns[1].bias,
               dsc.kernel if down else None, dsc.bias if down else None, bns[2].weight if down else None,
               bns[2].bias if down else None, lin1.weight, lin1.bias, lin2.weight, lin2.bias]
     call.has = tuple(p is not None for p in params)
-    call.keepalive = keepalive
     out = SEBlockFunction.apply(F, call, *params)
     return ME.SparseTensor(out, coordinate_map_key=ME.CoordinateMapKey(ts_out), coordinate_manager=cm)
 
@@ -440,5 +513,7 @@ _LAYOUTS = {}
 def _block_layout(shapes):
     lay = _LAYOUTS.get(shapes)
     if lay is None:
-        lay = _LAYOUTS[shapes] = _GradLayout(shapes)
+        # the weight gradients (accumulated into) and conv2's bias gradient (exactly zero in front of a training-mode
+        # BatchNorm) start at zero: first in the buffer, one fill
+        lay = _LAYOUTS[shapes] = _GradLayout(shapes, zero_first=(0, 4, 8, 5))
     return lay

@@ -206,6 +206,10 @@ int agb_spconv_bwd_data(const float* dY, int lddy, const float* Wt, const int32_
  * dX = sum_k dY[nbrT[k]] @ W[k]^T, rebuilt once per layer per step (ME does the same inside its backward GEMMs with
  * a transposed-operand flag: MinkowskiEngine/src/convolution_kernel.cu ConvolutionBackwardKernelGPU). */
 int agb_spconv_weight_transpose(const float* W, float* WT, int K3, int R, int C, void* stream);
+/* every layer of a model in ONE launch: tab (DEVICE) int64 [n][6] = (W, WT, K3, R, C, first tile), first tile = running sum of
+ * K3 * ceil(R / 64) * ceil(C / 64) over the layers before; total_tiles = the sum over all layers.  The caller keeps the
+ * transposes until the weights change (one launch per optimiser step instead of one per layer and backward pass). */
+int agb_spconv_weight_transpose_batched(const long long* tab, int n, long long total_tiles, void* stream);
 /* the same, and `zero` (K3*R*C floats, or NULL) is cleared in the same pass: the weight-gradient buffer
  * agb_spconv_bwd_weight accumulates into, saving one fill launch per layer */
 int agb_spconv_weight_transpose_z(const float* W, float* WT, float* zero, int K3, int R, int C, void* stream);
