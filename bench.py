@@ -365,7 +365,8 @@ def run_other_configs(timeout_s=150):
                             cpu_baseline=d.get("cpu_baseline"), wall_s=round(time.perf_counter() - t0, 1),
                             command="python " + " ".join(argv))
             for extra in ("ball_query_roofline", "index_path_ms_per_step", "step_ms_p50", "input_chain_device_ms_per_step",
-                          "host_draws_ms_per_step_p50", "entry_points_ms_per_step"):
+                          "host_draws_ms_per_step_p50", "entry_points_ms_per_step", "host_enqueue_floor_ms", "step_ms_p10",
+                          "step_ms_p90", "step_mfma_frac", "achieved_hbm_gbs", "kernels_time_share"):
                 if extra in d:
                     out[key][extra] = d[extra]
         except subprocess.TimeoutExpired:
@@ -398,8 +399,30 @@ def run_train_eval(timeout_s=150):
         return dict(error=f"{type(e).__name__}: {e}")
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` as a plain command line (no launcher around it): start the N ranks as a FRESH CHILD PROCESS
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` — before this process has made any GPU call; never an
+    exec of this process — relay its output (rank 0 prints the one JSON line) and exit with its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    have = torch.cuda.device_count()        # (counting devices does not initialise the HIP runtime)
+    env = dict(os.environ)
+    if have < args.gpus and "AGB_BENCH_BACKEND" not in env:
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {have} device(s) (AGB_BENCH_BACKEND=gloo runs the ranks on the "
+                         "devices there are, as a dry run of the multi-rank code path — never a measurement)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without a launcher: starting the ranks with: {' '.join(cmd)}")
+    raise SystemExit(subprocess.run(cmd, env=env, cwd=os.getcwd()).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -570,6 +593,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(model.loss.detach())
+    # host time of a step on an EMPTY device queue (drained before every step; outside the timed region): what the enqueuing
+    # thread costs by itself
+    floor = []
+    for i in range(8):
+        torch.cuda.synchronize()
+        t_f = time.perf_counter()
+        _step(args.warmup + args.steps + i)
+        floor.append((time.perf_counter() - t_f) * 1e3)
+    torch.cuda.synchronize()
+    floor.sort()
     # what the exchange looked like, for the driver's scaling run: backend, ranks, buckets and bytes per step; a checksum
     # of every rank's parameters after the timed steps (identical on all ranks when the gradients were averaged) and each
     # rank's host CPU time per step (all threads of the process: what N ranks ask of the node's cores)
@@ -643,7 +676,8 @@ def main():
             "step_ms_p90": round(sorted(gaps)[int(len(gaps) * 0.9)], 3) if gaps else None,
             "step_ms_min": round(min(gaps), 3) if gaps else None,
             "device_allocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
-            "host_enqueue_ms_p50": round(hm[len(hm) // 2], 3), "host_cpu_ms_per_step_p50": round(hc[len(hc) // 2], 3),
+            "host_enqueue_ms_p50": round(hm[len(hm) // 2], 3), "host_enqueue_floor_ms": round(floor[len(floor) // 2], 3),
+            "host_cpu_ms_per_step_p50": round(hc[len(hc) // 2], 3),
             "host_main_thread_cpu_ms_p50": round(mc[len(mc) // 2], 3),
             "comm": comm,
             "kernels": summary, "kernels_from": f"{n_instr} fully bracketed warmup step(s), outside the timed region",

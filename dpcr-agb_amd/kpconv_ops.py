@@ -16,6 +16,14 @@ _lib.declare("agb_kpconv_gather_bwd_csr", [_V, _V, _V, _V, _I, _I, _V, _V, _I, _
 _lib.declare("agb_kp_maxpool_fwd_csr", [_V, _I, _V, _V, _I, _V, _I, _V, _V, _I, _I, _V])
 
 
+# the SURVEY 8(b) names: the whole layer as one call (csrc/aliases.hip); the autograd functions below drive the pieces
+_lib.declare("agb_hash_build", [_V, _I, _V, _V, _V, _I, _V, _V, _V])
+_lib.declare("agb_kpconv_fwd", [_V, _V, _V, _I, _I, _V, _I, _V, _I, _F, _V, _V, _V, _I, _I, _I, _I, _V])
+_lib.declare("agb_kpconv_bwd_workspace_bytes", [_I, _I, _I, _I])
+_lib.declare("agb_kpconv_bwd", [_V, _V, _V, _I, _I, _V, _V, _I, _V, _I, _F, _V, _V, _I, _V, _I, _I, _I, _V,
+                                __import__("ctypes").c_size_t, _V])
+
+
 def is_ragged(idx):
     return hasattr(idx, "row_ptr")
 

@@ -692,6 +692,21 @@ int agb_reg_head_fwd(const float* pooled, int ldp, int B, int C, int T, const fl
 int agb_reg_head_bwd(const float* pooled, int ldp, int B, int C, int T, const float* const* W, const float* dout,
                      const float* gloss, float* const* dW, float* const* dbias, float* dpooled, int lddp, void* stream);
 
+/* ---- the names SURVEY.md section 8(b) gave this ABI (dpcr-agb_amd/csrc/aliases.hip) ------------------------------------
+ * agb_hash_build = agb_coords_insert.  agb_kpconv_fwd / agb_kpconv_bwd: the whole rigid KPConv layer
+ * (modules/KPConv/blocks.py:264-400) as one call each: y = wf @ W with wf[n,k,:] = sum_h infl(n,h,k) x[idx[n,h],:] kept in
+ * wf [N][K*Cin] for the backward pass; backward: dW [K*Cin][Cout] += wf^T dy, dx [Ns][ldx] += gather^T(dy @ W^T) (both
+ * zero-filled by the caller; either may be NULL), workspace of agb_kpconv_bwd_workspace_bytes bytes.
+ * (agb_spconv_bwd_data is declared with the convolution entry points above.) */
+int agb_hash_build(const int32_t* coords, int n, const int32_t* n_dev, uint64_t* keys, int32_t* vals, int cap,
+                   int32_t* slot_of_row, int32_t* status, void* stream);
+int agb_kpconv_fwd(const float* q, const float* s, const int32_t* idx, int H, int Ns, const float* x, int ldx, const float* kp,
+                   int K, float extent, const float* W, float* wf, float* y, int ldy, int N, int Cin, int Cout, void* stream);
+size_t agb_kpconv_bwd_workspace_bytes(int N, int K, int Cin, int Cout);
+int agb_kpconv_bwd(const float* q, const float* s, const int32_t* idx, int H, int Ns, const float* wf, const float* dy, int lddy,
+                   const float* kp, int K, float extent, const float* W, float* dx, int ldx, float* dW, int N, int Cin, int Cout,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

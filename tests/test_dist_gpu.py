@@ -77,3 +77,40 @@ def test_rccl_runs_in_a_group_of_one_rank():
     assert c["backend"] == "nccl" and c["world"] == 1 and c["buckets"] >= 2 and c["bytes_per_step"] >= 14_000_000 * 4
     assert c["param_checksums"][0] == plain["comm"]["param_checksums"][0] != 0.0, (c, plain["comm"])
     assert forced["n_gpus"] == 1 and forced["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as a plain command line (no torch.distributed.run around it, no WORLD_SIZE in the
+    environment): bench.py starts its ranks itself as a fresh child process and relays rank 0's ONE JSON line.  On the
+    one-GPU test box the two ranks share the device (AGB_BENCH_BACKEND=gloo); where the node has a device per rank the
+    backend must be RCCL."""
+    import torch
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    have_two = torch.cuda.device_count() >= 2
+    if not have_two:
+        env["AGB_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--deterministic",
+           "--reserve-gib", "8"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64
+    comm = line["comm"]
+    assert comm["world"] == 2 and comm["backend"] == ("nccl" if have_two else "gloo")
+    a, b = comm["param_checksums"]
+    assert a == b and a != 0.0, comm
+
+
+def test_bench_refuses_more_ranks_than_devices_without_the_dry_run_switch():
+    """No GPU call, no child process: the plain command line on a node with too few devices says what to do."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AGB_BENCH_BACKEND"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "64"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode != 0 and "AGB_BENCH_BACKEND=gloo" in res.stderr

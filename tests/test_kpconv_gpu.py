@@ -269,3 +269,47 @@ def test_pyramid_of_plots_far_apart(device):
     for lvl in range(len(near["points"])):
         a, c = near["lengths"][lvl].double(), far["lengths"][lvl].double()
         assert float((a - c).abs().max()) <= 0.1 * float(a.max()) + 2, (lvl, a, c)    # (other grid phase: a few cells differ)
+
+
+def test_kpconv_layer_entry_points_of_the_survey_abi(device, g):
+    """agb_kpconv_fwd / agb_kpconv_bwd (SURVEY.md 8(b) names: the whole rigid KPConv layer as one C call each, csrc/aliases.hip)
+    against the golden vectors of the reference's blocks.py:264-400 on a layer whose widths the dense kernels take (Cin 8 -> K*Cin
+    = 120, Cout 12); and agb_hash_build == agb_coords_insert."""
+    from dpcr_agb_amd import _lib
+    import dpcr_agb_amd.kpconv_ops  # noqa: F401  (declares the entry points)
+    P = _lib.ptr
+    q, s = D(g["points0"], device).contiguous(), D(g["points0"], device).contiguous()
+    idx = D(g["neighbors0"], device).to(torch.int32).contiguous()
+    x = D(g["L_x"], device).contiguous()
+    W = D(g["L_w"], device).contiguous()            # [K, Cin, Cout]
+    kp = D(g["L_kp"], device).contiguous()
+    K, cin, cout = W.shape
+    N, H = idx.shape
+    Ns = x.shape[0]
+    ext = float(g["L_ext"])
+    wf = torch.empty(N, K * cin, device=device)
+    y = torch.empty(N, cout, device=device)
+    _lib.call("agb_kpconv_fwd", P(q), P(s), P(idx), H, Ns, P(x), x.stride(0), P(kp), K, ext, P(W), P(wf), P(y), cout, N, cin,
+              cout, _lib.stream())
+    assert rel(y, g["L_y"]) < RTOL
+    dy = D(g["L_g"], device).contiguous()
+    dx = torch.zeros(Ns, cin, device=device)
+    dW = torch.zeros(K * cin, cout, device=device)
+    nbytes = _lib.size_call("agb_kpconv_bwd_workspace_bytes", N, K, cin, cout)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _lib.call("agb_kpconv_bwd", P(q), P(s), P(idx), H, Ns, P(wf), P(dy), cout, P(kp), K, ext, P(W), P(dx), cin, P(dW), N, cin,
+              cout, P(ws), nbytes, _lib.stream())
+    assert rel(dx, g["L_dx"]) < RTOL
+    assert rel(dW.view(K, cin, cout), g["L_dw"]) < RTOL
+    # agb_hash_build: the same table as agb_coords_insert
+    coords = torch.tensor([[0, 1, 2, 3], [0, 4, 5, 6], [1, 1, 2, 3]], dtype=torch.int32, device=device)
+    cap = _lib.hash_capacity(3)
+    out = []
+    for name in ("agb_coords_insert", "agb_hash_build"):
+        keys = torch.empty(cap, dtype=torch.int64, device=device)
+        vals = torch.empty(cap, dtype=torch.int32, device=device)
+        slot = torch.empty(3, dtype=torch.int32, device=device)
+        status = torch.empty(4, dtype=torch.int32, device=device)
+        _lib.call(name, P(coords), 3, None, P(keys), P(vals), cap, P(slot), P(status), _lib.stream())
+        out.append((keys.clone(), vals.clone(), slot.clone(), status.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*out))

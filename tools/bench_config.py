@@ -210,6 +210,20 @@ def timed_loop(step, steps, warmup):
     return dt, gaps
 
 
+def host_floor(step, first, n=10):
+    """Host time of a step on an EMPTY device queue (the device is drained before every step: no launch ever waits for a queue
+    slot): what the enqueuing thread costs by itself — median ms over n steps, outside any timed region."""
+    ts = []
+    for i in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(first + i)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    ts.sort()
+    return round(ts[len(ts) // 2], 3)
+
+
 def top_table(groups, k=8):
     for name, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:k]:
         log(f"  {g['ms']:9.3f} ms  {g['n']:5d} calls  {name}")
@@ -425,6 +439,7 @@ def run_end2end(a):
         staged[0] += 1
 
     dt, gaps = timed_loop(step, a.steps, a.warmup)
+    floor_ms = host_floor(step, a.warmup + a.steps)
     with CallTimer() as ct:
         for i in range(3):
             step(i)
@@ -456,6 +471,7 @@ def run_end2end(a):
                                            f"per-sample draws in {workers} DataLoader worker process(es)", final_loss=round(float(model.loss.detach()), 5)),
                 roofline=roof, step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
                 input_chain_device_ms_per_step=round(pipe_ms, 3), host_draws_ms_per_step_p50=round(hd[len(hd) // 2], 3),
+                host_enqueue_floor_ms=floor_ms,
                 entry_points_ms_per_step={n: round(gg["ms"] / 3, 3) for n, gg in
                                           sorted(inp.items(), key=lambda kv: -kv[1]["ms"])[:8]})
     print(json.dumps(line), flush=True)
