@@ -89,9 +89,7 @@ def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, file it was read from) from the newest committed PMC pass
     (tools/collect_pmc.sh <tag> -> profiles/<tag>_pmc_traffic.json; separate --pmc runs of this same command, corrected as
     MI355X_MICROARCH.md prescribes) — counters cannot be collected from inside a running benchmark — or (None, None)."""
-    names = [f"{tag}_pmc_traffic.json" for tag in ("r05", "r04", "r03", "r02", "r01")]
-    if PMC_CONFIG:      # (another model / precision than the headline: its own PMC pass, tools/collect_pmc_configs.sh)
-        names = [f"{tag}_pmc_traffic_{PMC_CONFIG}.json" for tag in ("r05", "r04")]
+    names = pmc_files()
     for name in names:
         rel = os.path.join("profiles", name)
         try:
@@ -101,6 +99,27 @@ def pmc_traffic(kernel):
         for kname, v in data.items():
             if kname.replace("void ", "").strip() == kernel.split(" (")[0]:
                 return round(v["hbm_bytes_per_launch"]), rel
+    return None, None
+
+
+def pmc_files():
+    names = [f"{tag}_pmc_traffic.json" for tag in ("r06", "r05", "r04", "r03", "r02", "r01")]
+    if PMC_CONFIG:      # (another model / precision than the headline: its own PMC pass, tools/collect_pmc_configs.sh)
+        names = [f"{tag}_pmc_traffic_{PMC_CONFIG}.json" for tag in ("r06", "r05", "r04")]
+    return names
+
+
+def pmc_step_bytes():
+    """(HBM bytes per training step, file) of the newest committed PMC pass that recorded it (tools/pmc_summary.py: every
+    kernel of the profiled run over its steps), or (None, None)."""
+    for name in pmc_files():
+        rel = os.path.join("profiles", name)
+        try:
+            v = json.load(open(os.path.join(ROOT, rel))).get("hbm_bytes_per_step")
+        except Exception:
+            continue
+        if v:
+            return float(v), rel
     return None, None
 
 
@@ -654,6 +673,7 @@ def main():
             roof = roofline_of(dom, groups_timed[dom])
             roof["timed_steps_bracketed"] = len(range(0, args.steps, EV_EVERY))
         summary = kernel_summary(groups_all)
+        step_bytes, step_bytes_src = pmc_step_bytes()
         line = {
             "metric": f"training plots/sec (16k-pt NFI plots) M{args.model}",
             "value": round(world * args.batch * args.steps / elapsed, 2),
@@ -672,6 +692,13 @@ def main():
                                         args.precision] + ("; activation / gradient rows stored in bf16" if args.bf16_rows
                                                            else "")},
             "roofline": roof,
+            # the whole step against the MFMA roof: convolution FLOPs of one step (the fully bracketed warmup steps) over the
+            # step time; and against HBM: PMC bytes of one step (committed pass) over the step time
+            "step_mfma_frac": round(sum(g["flops"] for g in groups_all.values()) / max(n_instr, 1) / (elapsed / args.steps)
+                                    / 1e12 / mfma_peak_tf(), 4) if groups_all else None,
+            "achieved_hbm_gbs": (round(step_bytes / (elapsed / args.steps) / 1e9, 1) if step_bytes else None),
+            "achieved_hbm_source": step_bytes_src,
+            "step_ms_p10": round(sorted(gaps)[int(len(gaps) * 0.1)], 3) if gaps else None,
             "step_ms_p50": round(sorted(gaps)[len(gaps) // 2], 3) if gaps else None,
             "step_ms_p90": round(sorted(gaps)[int(len(gaps) * 0.9)], 3) if gaps else None,
             "step_ms_min": round(min(gaps), 3) if gaps else None,

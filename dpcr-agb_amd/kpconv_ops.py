@@ -66,6 +66,7 @@ class KPGatherFunction(torch.autograd.Function):
         if ctx.ragged is not None:
             q_pts, s_pts, kernel_points = ctx.saved_tensors
             r, K = ctx.ragged, kernel_points.shape[0]
+            _lib.CALL_NOTE = {"valid": int(r.indices.shape[0])}
             _lib.call("agb_kpconv_gather_bwd_csr", _P(q_pts), _P(s_pts), _P(r.row_ptr), _P(r.indices), r.limit, Ns, _P(dwf),
                       _P(kernel_points), K, extent, _P(dx), dx.stride(0), r.nq, cin, _lib.stream())
             return dx, None, None, None, None, None
@@ -83,6 +84,7 @@ def _gather(x, q_pts, s_pts, idx, kernel_points, extent):
     K = kernel_points.shape[0]
     wf = torch.empty(N, K, cin, dtype=torch.float32, device=x.device)
     if is_ragged(idx):
+        _lib.CALL_NOTE = {"valid": int(idx.indices.shape[0])}      # (for instrumented runs: the gather's pair count)
         _lib.call("agb_kpconv_gather_fwd_csr", _P(q_pts), _P(s_pts), _P(idx.row_ptr), _P(idx.indices), idx.limit, Ns, _P(x),
                   x.stride(0), _P(kernel_points), K, float(extent), _P(wf), N, cin, _lib.stream())
         return wf

@@ -61,7 +61,9 @@ class CallTimer:
             rc = self._orig(name, *args)
             e1.record()
             kern = self._lib.last_kernel() if name in KERNEL_NOTED else None
-            self.records.append((name, args, e0, e1, kern))
+            note = getattr(self._lib, "CALL_NOTE", None)     # (what a wrapper knows and the argument list does not: pair counts)
+            self._lib.CALL_NOTE = None
+            self.records.append((name, args, e0, e1, kern, note))
             return rc
         self._lib.call = timed
         import dpcr_agb_amd.sparse_ops as so, dpcr_agb_amd.norm_ops as no, dpcr_agb_amd.kpconv_ops as ko  # noqa: E401
@@ -75,12 +77,14 @@ class CallTimer:
     def by_name(self):
         torch.cuda.synchronize()
         out = {}
-        for name, args, e0, e1, kern in self.records:
-            g = out.setdefault(name, dict(ms=0.0, n=0, calls=[], kernels={}))
+        for name, args, e0, e1, kern, note in self.records:
+            g = out.setdefault(name, dict(ms=0.0, n=0, calls=[], kernels={}, call_kernels=[], call_notes=[]))
             ms = e0.elapsed_time(e1)
             g["ms"] += ms
             g["n"] += 1
             g["calls"].append((args, ms))
+            g["call_kernels"].append(kern)
+            g["call_notes"].append(note)
             if kern:
                 g["kernels"][kern] = g["kernels"].get(kern, 0.0) + ms
         return out
@@ -97,6 +101,122 @@ def wgrad_call_cost(args):
     """agb_spconv_bwd_weight_lp(X, ldx, dY, ldy, nbr, nbr_stride, dW, n_out, K3, Cin, Cout, precision)"""
     n, K3, cin, cout = args[7], args[8], args[9], args[10]
     return 2.0 * n * cin * cout, (n * (cin + cout) + K3 * cin * cout) * 4.0
+
+
+def dense_bn_call_cost(args):
+    """agb_dense_fwd_bn(X, ldx, W, bias, Y, ldy, n, Cin, Cout, bn_part, stream)"""
+    n, cin, cout = args[6], args[7], args[8]
+    return 2.0 * n * cin * cout, (n * (cin + cout) + cin * cout) * 4.0
+
+
+def kp_gather_fwd_cost(args, note=None):
+    """agb_kpconv_gather_fwd_csr(q, s, row_ptr, indices, limit, Ns, x, ldx, kp, K, extent, wf, N, Cin, stream): SURVEY.md 8(d)
+    KPConv gather: sum(valid) * (12 + Cin * 4) read + the gathered wf [N, K, Cin] written (the fused layer would write N * Cout
+    instead) ; FLOPs = sum(valid) * K * (10 + 2 Cin).  sum(valid) = neighbour entries of the rows (the wrapper's note)."""
+    K, N, cin = args[9], args[12], args[13]
+    valid = (note or {}).get("valid", 0)
+    return valid * K * (10.0 + 2.0 * cin), valid * (12.0 + cin * 4.0) + N * K * cin * 4.0 + N * 16.0
+
+
+def kp_gather_bwd_cost(args, note=None):
+    """agb_kpconv_gather_bwd_csr(q, s, row_ptr, indices, limit, Ns, dwf, kp, K, extent, dx, ldx, N, Cin, stream)"""
+    K, N, cin = args[8], args[12], args[13]
+    valid = (note or {}).get("valid", 0)
+    return valid * K * (10.0 + 2.0 * cin), valid * (12.0 + cin * 4.0) + N * K * cin * 4.0 + N * 16.0
+
+
+def pn_pool_fwd_cost(args):
+    """agb_pointnet_pool_fwd_aux(Z, ldz, n, C, ...): the [n, C] pre-activation read once (SURVEY 8(d) PointNet)"""
+    return 0.0, args[2] * args[3] * 4.0
+
+
+def pn_pool_bwd_cost(args):
+    """agb_pointnet_pool_bwd_aux(Z, ldz, n, C, ...): z read, dz written"""
+    return 0.0, 2.0 * args[2] * args[3] * 4.0
+
+
+def rows_cost(n_idx, c_idx, passes):
+    return lambda args: (0.0, passes * args[n_idx] * args[c_idx] * 4.0)
+
+
+# algorithmic (FLOPs, bytes) of one call of every entry point that can dominate a config's step
+ALL_COSTS = {
+    "agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_fwd_lp": conv_call_cost, "agb_spconv_fwd_tiles": conv_call_cost,
+    "agb_spconv_bwd_weight_lp": wgrad_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost,
+    "agb_dense_fwd_bn": dense_bn_call_cost,
+    "agb_kpconv_gather_fwd_csr": kp_gather_fwd_cost, "agb_kpconv_gather_bwd_csr": kp_gather_bwd_cost,
+    "agb_pointnet_pool_fwd_aux": pn_pool_fwd_cost, "agb_pointnet_pool_bwd_aux": pn_pool_bwd_cost,
+    "agb_bn_stats_tracked": rows_cost(2, 3, 1), "agb_bn_act_fwd": rows_cost(2, 3, 2), "agb_bn_act_bwd_colsum": rows_cost(4, 5, 3),
+}
+KERNEL_OF_ENTRY.update({"agb_kpconv_gather_fwd_csr": "k_kpconv_gather_mm_fwd", "agb_kpconv_gather_bwd_csr": "k_kpconv_gather_mm_bwd",
+                        "agb_pointnet_pool_fwd_aux": "k_pn_pool_fwd", "agb_pointnet_pool_bwd_aux": "k_pn_bwd"})
+
+
+def kernel_rooflines(groups, config=None, costs=None):
+    """The step's launches regrouped by KERNEL (the name the library noted, else the entry point's kernel): name ->
+    dict(ms, n, flops, bytes, entry).  The roofline entry of a config's line is the kernel with the largest share of the
+    step's bracketed device time — always (round-5 review: a cost function must not decide which kernel is reported)."""
+    costs = dict(ALL_COSTS, **(costs or {}))
+    per = {}
+    for name, g in groups.items():
+        cost = costs.get(name)
+        for (args, ms), kern, note in zip(g["calls"], g["call_kernels"], g["call_notes"]):
+            k = kern or KERNEL_OF_ENTRY.get(name, name)
+            e = per.setdefault(k, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, entry=name, priced=cost is not None))
+            e["ms"] += ms
+            e["n"] += 1
+            if cost is not None:
+                try:
+                    fl, by = cost(args, note) if cost in (kp_gather_fwd_cost, kp_gather_bwd_cost) else cost(args)
+                except Exception:
+                    fl, by = 0.0, 0.0
+                e["flops"] += fl
+                e["bytes"] += by
+    return per
+
+
+def dominant_roofline(groups, config=None, costs=None):
+    per = kernel_rooflines(groups, config, costs)
+    total = sum(e["ms"] for e in per.values()) or 1.0
+    shares = {k: round(e["ms"] / total, 3) for k, e in sorted(per.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+    dom = max(per, key=lambda k: per[k]["ms"])
+    e = per[dom]
+    secs = e["ms"] / 1e3
+    ridge = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if not e["priced"] or e["bytes"] <= 0:
+        r = dict(bound=None, achieved=None, peak=None, unit=None, frac=None,
+                 note="no algorithmic cost function for this entry point: named, not priced")
+    elif e["flops"] / e["bytes"] >= ridge:
+        ach = e["flops"] / secs / 1e12
+        r = dict(bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4))
+    else:
+        ach = e["bytes"] / secs / 1e9
+        r = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+    traffic, src = pmc_traffic(dom, config) if config else (None, None)
+    r.update(traffic=traffic, traffic_source=src, kernel=dom, entry_point=e["entry"], kernels_time_share=shares,
+             kernels_time_share_of="the step's bracketed device time (three instrumented steps)", launches=e["n"],
+             avg_launch_us=round(e["ms"] / e["n"] * 1e3, 2), alg_bytes_per_launch=round(e["bytes"] / e["n"]),
+             alg_flops_per_launch=round(e["flops"] / e["n"]))
+    return r, per
+
+
+def step_level(per, ms_per_step, config, instrumented_steps=3):
+    """step_mfma_frac: FLOPs of the priced MFMA products of one step over the step time and the fp32 MFMA peak;
+    achieved_hbm_gbs: PMC bytes of one step (the config's committed pass) over the step time."""
+    flops = sum(e["flops"] for e in per.values()) / instrumented_steps
+    out = dict(step_mfma_frac=round(flops / (ms_per_step / 1e3) / 1e12 / MFMA_F32_PEAK_TF, 4))
+    for tag in ("r06", "r05", "r04"):
+        rel = os.path.join("profiles", f"{tag}_pmc_traffic_{config}.json")
+        try:
+            v = json.load(open(os.path.join(ROOT, rel))).get("hbm_bytes_per_step")
+        except Exception:
+            continue
+        if v:
+            out.update(achieved_hbm_gbs=round(float(v) / (ms_per_step / 1e3) / 1e9, 1), achieved_hbm_source=rel)
+            break
+    else:
+        out.update(achieved_hbm_gbs=None, achieved_hbm_source=None)
+    return out
 
 
 def shape_table(groups):
@@ -129,7 +249,7 @@ def shape_table(groups):
 def pmc_traffic(kernel, config):
     """(HBM bytes per launch of `kernel`, file) from the committed PMC pass of this config (tools/collect_pmc_configs.sh ->
     profiles/<tag>_pmc_traffic_<config>.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections), or (None, None)."""
-    for tag in ("r05", "r04"):
+    for tag in ("r06", "r05", "r04"):
         rel = os.path.join("profiles", f"{tag}_pmc_traffic_{config}.json")
         try:
             data = json.load(open(os.path.join(ROOT, rel)))["kernels"]
@@ -257,10 +377,8 @@ def run_pointnet(a):
             step(i)
     groups = ct.by_name()
     top_table(groups)
-    costs = {"agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_fwd_lp": conv_call_cost,
-             "agb_spconv_bwd_weight_lp": wgrad_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost}
-    dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
-    roof = roofline_entry(dom, groups[dom], costs[dom], "config2", groups)
+    roof, per = dominant_roofline(groups, "config2")
+    lvl = step_level(per, dt / a.steps * 1e3, "config2")
     line = dict(metric="training plots/sec (16k-pt NFI plots) MPointNet", value=round(B * a.steps / dt, 2), unit="plots/s",
                 n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
                 scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -268,7 +386,8 @@ def run_pointnet(a):
                                      f"pooling, head) training step, {a.points}-pt synthetic plots, batch {B}, ~{voxels:.0f} "
                                      "voxels/plot", global_batch=B, parallelism="dp1",
                             final_loss=round(float(model.loss.detach()), 5)),
-                roofline=roof, step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
+                roofline=roof, step_ms_p10=round(gaps[int(len(gaps) * 0.1)], 3), step_ms_p50=round(gaps[len(gaps) // 2], 3),
+                step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3), **lvl,
                 entry_points_ms_per_step={n: round(g["ms"] / 3, 3) for n, g in
                                           sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:8]})
     if not a.no_cpu_baseline:
@@ -338,8 +457,8 @@ def run_kpconv(a):
     costs = {"agb_ball_query_fill": ballquery_cost, "agb_ball_query_fill_csr": ballquery_cost_csr,
              "agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost,
              "agb_spconv_bwd_weight_lp": wgrad_call_cost}
-    dom = max((n for n in groups if n in costs), key=lambda n: groups[n]["ms"])
-    roof = roofline_entry(dom, groups[dom], costs[dom], "config3", groups)
+    roof, per = dominant_roofline(groups, "config3", costs)
+    lvl = step_level(per, dt / a.steps * 1e3, "config3")
     index_names = ("agb_ball_query_fill", "agb_ball_query_fill_csr", "agb_ball_query_offsets", "agb_ball_query_count",
                    "agb_ball_grid_build", "agb_grid_subsample_ws", "agb_elem_bbox", "agb_elem_of_row", "agb_rotate_points")
     index_ms = sum(groups[n]["ms"] for n in index_names if n in groups) / 3
@@ -353,7 +472,8 @@ def run_kpconv(a):
                                      f"{a.points}-pt synthetic plots, batch {B}", global_batch=B, parallelism="dp1",
                             final_loss=round(float(model.loss.detach()), 5)),
                 roofline=roof, ball_query_roofline=bq, index_path_ms_per_step=round(index_ms, 3),
-                step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
+                step_ms_p10=round(gaps[int(len(gaps) * 0.1)], 3), step_ms_p50=round(gaps[len(gaps) // 2], 3),
+                step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3), **lvl,
                 entry_points_ms_per_step={n: round(g["ms"] / 3, 3) for n, g in
                                           sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:10]})
     if not a.no_cpu_baseline:
@@ -469,7 +589,8 @@ def run_end2end(a):
                                      "after augmentation", global_batch=B, parallelism="dp1",
                             input_pipeline="side stream, two batches ahead; "
                                            f"per-sample draws in {workers} DataLoader worker process(es)", final_loss=round(float(model.loss.detach()), 5)),
-                roofline=roof, step_ms_p50=round(gaps[len(gaps) // 2], 3), step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
+                roofline=roof, step_ms_p10=round(gaps[int(len(gaps) * 0.1)], 3), step_ms_p50=round(gaps[len(gaps) // 2], 3),
+                step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3),
                 input_chain_device_ms_per_step=round(pipe_ms, 3), host_draws_ms_per_step_p50=round(hd[len(hd) // 2], 3),
                 host_enqueue_floor_ms=floor_ms,
                 entry_points_ms_per_step={n: round(gg["ms"] / 3, 3) for n, gg in

@@ -19,7 +19,7 @@ def load(counter_dir, counter):
     return acc
 
 
-def main(out_dir, json_path):
+def main(out_dir, json_path, steps=None):
     fetch, write = load(f"{out_dir}/FETCH_SIZE", "FETCH_SIZE"), load(f"{out_dir}/WRITE_SIZE", "WRITE_SIZE")
     res = {}
     for name in sorted(set(fetch) | set(write)):
@@ -29,8 +29,13 @@ def main(out_dir, json_path):
         res[name] = dict(launches=n, fetch_bytes_per_launch=2.0 * fkb * 1024 / max(fn, 1),
                          write_bytes_per_launch=wkb * 1024 / max(wn, 1))
         res[name]["hbm_bytes_per_launch"] = res[name]["fetch_bytes_per_launch"] + res[name]["write_bytes_per_launch"]
-    json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = KB*1024, FETCH_SIZE x2 (gfx950)",
-                   kernels=res), open(json_path, "w"), indent=1)
+    total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in res.values())
+    doc = dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = KB*1024, FETCH_SIZE x2 (gfx950)",
+               total_hbm_bytes=total, kernels=res)
+    if steps:
+        # every kernel of the profiled command (its set-up included: a small overestimate) over the steps it ran
+        doc.update(steps=int(steps), hbm_bytes_per_step=total / int(steps))
+    json.dump(doc, open(json_path, "w"), indent=1)
     top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
     for k, v in top:
         print(f"{k[:60]:60s} n={v['launches']:4d} fetch={v['fetch_bytes_per_launch'] / 1e6:9.1f} MB "
@@ -38,4 +43,4 @@ def main(out_dir, json_path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
