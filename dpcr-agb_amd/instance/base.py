@@ -115,8 +115,8 @@ class InstanceBase(torch.nn.Module):
         return self.reg_out_act(outputs[:, :self.num_reg_classes])
 
     def compute_reg_loss(self):
-        if not (self.has_reg_targets and self.loss_fns.get("reg")):
-            return
+        if not (self.has_reg_targets and self.loss_fns.get("reg")) or getattr(self, "reg_y", None) is None:
+            return      # (no labels in this batch: a prediction-only forward pass)
         output = self.reg_out
         labels = (self.reg_y - self.reg_center_targets) / self.reg_scale_targets
         if self._reg_mask_all is False:

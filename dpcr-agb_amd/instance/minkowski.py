@@ -123,9 +123,10 @@ class MinkowskiBaselineModel(InstanceBase):
                              [t for t in getattr(data, "__dict__", {}).values() if isinstance(t, torch.Tensor) and t.is_cuda], cur)
         else:
             d["input"] = self._build_input(data, device)
+        d["reg_y"] = None          # (a batch without labels — prediction from a file: forward() then skips the loss)
         if len(self.loss_fns) > 0:
             bs = len(data)
-            if self.has_reg_targets and data.y_reg is not None:
+            if self.has_reg_targets and getattr(data, "y_reg", None) is not None:
                 mask_all = getattr(data, "y_reg_mask_all", None)  # host-side flag: no device sync in the loss
                 d["_reg_mask_all"] = bool(data.y_reg_mask.all()) if mask_all is None else mask_all
                 d["reg_y_mask"] = data.y_reg_mask.to(device, non_blocking=True).view(bs, -1)
@@ -141,8 +142,8 @@ class MinkowskiBaselineModel(InstanceBase):
         opts = getattr(m, "kernel_options", None) or current()
         if not (getattr(opts, "fused_head", True) and hasattr(m, "forward_features") and self.has_reg_targets
                 and isinstance(m.final, SeparateLinear) and self.opt.get("reg_out_activation", "linear").lower() == "linear"
-                and self._reg_mask_all is True and 1 <= len(m.final.linears) <= MAX_TARGETS
-                and len(m.final.linears) == self.num_reg_classes and getattr(self, "reg_y", None) is not None):
+                and self.__dict__.get("reg_y") is not None and self.__dict__.get("_reg_mask_all") is True
+                and 1 <= len(m.final.linears) <= MAX_TARGETS and len(m.final.linears) == self.num_reg_classes):
             return None
         return loss_mask(self.loss_fns.get("reg") or [])
 
