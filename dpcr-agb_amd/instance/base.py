@@ -296,6 +296,8 @@ class InstanceBase(torch.nn.Module):
             return
         held = self.__dict__.setdefault("_held_inputs", [])
         held.append((obj, list(tensors)))
-        if len(held) > self.HOLD_LIMIT:       # a loop that never calls optimize_parameters (evaluation): allocator's way
+        # a loop that never calls optimize_parameters (evaluation, calibrate_bn) has no pacing event to release on: it keeps
+        # two batches (the one in flight and the one being built), the rest goes the allocator's way
+        if len(held) > (self.HOLD_LIMIT if self.training and torch.is_grad_enabled() else 2):
             for t in held.pop(0)[1]:
                 t.record_stream(stream)

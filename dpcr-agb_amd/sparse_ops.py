@@ -508,14 +508,20 @@ def weight_grad_raw(x, dy, nbr, dw, n_out, K3, cin, cout, opts):
     # fp32 maps with Cin, Cout multiples of 64 (every 3^3 / 2^3 layer of the SENets): with a workspace the library runs the
     # persistent-accumulator kernel (csrc/dwa.hip) — the product path, AND reproducible; KernelOptions.dw_variant 1 / 2
     # still select the older kernels for A/B measurements
-    persistent = (prec == 0 and nbr is not None and x.dtype == torch.float32 and dy.dtype == torch.float32 and
+    # (k_spconv_dwa addresses the rows of X with 32-bit byte offsets and the ABI carries no n_in: a level whose rows reach
+    # past 4 GiB — none of the NFI shapes — keeps the staged kernel)
+    fits32 = x.shape[0] * x.stride(0) * 4 < (1 << 32) and dy.shape[0] * dy.stride(0) * 4 < (1 << 32)
+    persistent = (prec == 0 and nbr is not None and x.dtype == torch.float32 and dy.dtype == torch.float32 and fits32 and
                   (opts.dw_variant == 3 or (opts.dw_variant == 0 and PERSISTENT_WGRAD and _lib.load().
                    agb_spconv_bwd_weight_persistent(n_out, K3, cin, cout, x.stride(0), dy.stride(0)) == 1)))
     nbytes = _lib.size_call("agb_spconv_bwd_weight_workspace_bytes", n_out, K3, cin, cout, int(nbr is None), prec) \
         if (det or stem or persistent) else 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    variant = opts.dw_variant
+    if not fits32 and nbr is not None and prec == 0 and (det or variant == 3):
+        variant = 2        # (reproducible sums without the persistent kernel's 32-bit row offsets: the register-operand kernel)
     _lib.call("agb_spconv_bwd_weight_ws", _P(x), x.stride(0), _P(dy), dy.stride(0), _P(nbr), 0 if nbr is None else nbr.stride(0),
-              _P(dw), n_out, K3, cin, cout, prec, opts.dw_variant, _P(ws), nbytes, _lib.stream())
+              _P(dw), n_out, K3, cin, cout, prec, variant, _P(ws), nbytes, _lib.stream())
 
 
 # The persistent-accumulator weight gradient (csrc/dwa.hip) is OPT-IN: measured equal to the LDS-staged kernel inside the

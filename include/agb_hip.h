@@ -285,6 +285,9 @@ size_t agb_spconv_bwd_weight_workspace_bytes(int n_out, int K3, int Cin, int Cou
  * K3 <= 8, or >= 40000 rows with Cin >= 128), variant 3 for every shape it can take.  Inside the training step it is equal to
  * the staged kernel: the Python side passes the workspace only on request (AGB_PERSISTENT_WGRAD, KernelOptions.dw_variant = 3,
  * or the reproducible mode). */
+/* ROW BOUND of the persistent kernel: it addresses X and dY rows with 32-bit byte offsets and this ABI carries no n_in, so
+ * every row index of the map times ldx * 4 (ldy * 4) must stay below 2^32 (true for every stride <= 2 map of a level of
+ * n_out rows the check accepts; a caller-built map that reaches further must pass variant 1 or 2). */
 int agb_spconv_bwd_weight_persistent(int n_out, int K3, int Cin, int Cout, int ldx, int ldy);
 int agb_spconv_bwd_weight_ws(const float* X, int ldx, const float* dY, int ldy, const int32_t* nbr,
                              long long nbr_stride, float* dW, int n_out, int K3, int Cin, int Cout, int precision,

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+    config.addinivalue_line("markers", "slow: minutes of GPU time; gated by an environment switch named in its skip reason")
 
 
 def pytest_collection_modifyitems(config, items):

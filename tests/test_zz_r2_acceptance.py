@@ -160,6 +160,24 @@ def test_r2_regression_pin_five_seeds(device, leg):
 
 
 @pytest.mark.gpu
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("AGB_R2_FULL", "0") == "0", reason="the full 13-seed reproduction of every leg (~7 GPU-minutes): "
+                    "AGB_R2_FULL=1; the table is regenerated on the round's last tree (its `tree` field names the commit)")
+@pytest.mark.parametrize("leg", LEGS)
+def test_r2_regression_pin_all_thirteen_seeds(device, leg):
+    """Every row the CPU half of this file consumes (seeds 0-12 of every leg) reproduced by THIS tree to 1e-9 — the slow form
+    of test_r2_regression_pin_five_seeds (round-5 advisor finding: rows 5-12 were pinned by no test).  Run with AGB_R2_FULL=1
+    after kernel work; tools/make_r2_hip_expected.py regenerates the table and records the commit it was generated on."""
+    from train_eval import acceptance_data, acceptance_gpu_trial
+    exp = _hip_expected()
+    cfg = exp["config"]
+    data = acceptance_data(cfg, device)
+    want = np.array(exp["legs"][leg])
+    got = np.array([acceptance_gpu_trial(cfg, t, device, leg, data)["final"]["r2_rs"] for t in range(len(want))])
+    assert np.abs(got - want).max() <= 1e-9, (leg, np.abs(got - want).max(axis=1).tolist())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("leg,r2_tol,rmse_rtol", [("fp32", 1e-5, 1e-5), ("bf16", 5e-3, 2e-2), ("bf16rows", 5e-3, 2e-2)])
 def test_r2_same_weights(device, leg, r2_tol, rmse_rtol):
     """One HIP trial's trained weights (30 epochs; any trained state serves), evaluated (i) by the HIP path in the leg's own

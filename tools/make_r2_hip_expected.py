@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--bias-grad-leg", action="store_true", help="also run the fp32 leg with KernelOptions."
                     "closed_form_bias_grad off (column sums of the incoming gradient, as the reference computes the bias "
                     "gradient of a convolution in front of a BatchNorm): key 'fp32_colsum_bias' of the output, not a leg of the test")
+    ap.add_argument("--tree", default=os.environ.get("AGB_TREE"), help="commit hash of the tree the table is generated on (the "
+                    "GPU box holds a snapshot without .git: pass `git rev-parse HEAD` from the build container)")
     a = ap.parse_args()
     import torch
     from train_eval import acceptance_data, acceptance_gpu_trial
@@ -38,7 +40,7 @@ def main():
     cfg = ref["config"]
     dev = torch.device("cuda:0")
     data = acceptance_data(cfg, dev)
-    out = dict(config=cfg, trials=a.trials, legs={}, rmse={}, tree=subprocess.run(
+    out = dict(config=cfg, trials=a.trials, legs={}, rmse={}, tree=a.tree or subprocess.run(
         ["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "snapshot",
         device=torch.cuda.get_device_name(0))
     for leg in LEGS:
