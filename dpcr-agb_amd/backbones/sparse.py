@@ -418,6 +418,9 @@ class ResNetBase(nn.Module):
             from .. import fused_blocks as FB
             opts = current_options()
             if not FB.options_allow(opts):
+                if self.training:      # every block's drop-path vector: one draw in block order, one upload
+                    MinkowskiDropPath.predraw([b for st in list(self.blocks)[1:] for b in st if hasattr(b, "drop_path")],
+                                              x.coordinate_manager.batch_size, x.F.device)
                 for block in self.blocks:
                     x = block(x)
             else:

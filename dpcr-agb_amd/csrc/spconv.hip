@@ -1692,6 +1692,50 @@ __global__ __launch_bounds__(256) void k_weight_twins(const float* __restrict__ 
     }
 }
 
+// The same for EVERY layer of a model in one launch: tab int64 [n][7] = (W, W16, Wt16, K3, R, C, first tile).  A linear scan
+// of the table (n <= a few hundred): the binary-search-free form keeps the kernel trivial; 52 layers of SENet50.
+__global__ __launch_bounds__(256) void k_weight_twins_batched(const long long* __restrict__ tab, int n) {
+    __shared__ float tile[64][65];
+    __shared__ long long s_e[7];
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;           // last layer whose first tile is <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid * 7 + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        for (int j = 0; j < 7; ++j) s_e[j] = tab[lo * 7 + j];
+    }
+    __syncthreads();
+    const int R = (int)s_e[4], C = (int)s_e[5];
+    const int tx = (C + 63) >> 6, ty = (R + 63) >> 6;
+    const int t = (int)((long long)blockIdx.x - s_e[6]);
+    const int k = t / (tx * ty), rem = t - k * tx * ty;
+    const float* W = reinterpret_cast<const float*>(s_e[0]);
+    bf16_t* W16 = reinterpret_cast<bf16_t*>(s_e[1]);
+    bf16_t* Wt16 = reinterpret_cast<bf16_t*>(s_e[2]);
+    const long long base = (long long)k * R * C;
+    const int r0 = (rem / tx) * 64, c0 = (rem % tx) * 64;
+    const int g = threadIdx.x & 15, h = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = h + 16 * p;
+        if (r0 + r < R && c0 + 4 * g < C) {
+            const long long o = base + (long long)(r0 + r) * C + c0 + 4 * g;
+            const float4 v = *reinterpret_cast<const float4*>(W + o);
+            tile[r][4 * g + 0] = v.x; tile[r][4 * g + 1] = v.y; tile[r][4 * g + 2] = v.z; tile[r][4 * g + 3] = v.w;
+            st4(W16 + o, v);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = h + 16 * p;
+        if (c0 + c < C && r0 + 4 * g < R)
+            st4(Wt16 + base + (long long)(c0 + c) * R + r0 + 4 * g,
+                make_float4(tile[4 * g + 0][c], tile[4 * g + 1][c], tile[4 * g + 2][c], tile[4 * g + 3][c]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Lattice-parity partition of the rows of a level for a stride-s operator: class = (c/ts mod s) per axis.
 // perm [n + ncls*TM] receives the rows grouped by class, every class padded with -1 to a multiple of TM;
@@ -2695,6 +2739,16 @@ int agb_weight_twins_bf16(const float* W, int K3, int R, int C, uint16_t* W16, u
     hipLaunchKernelGGL(k_weight_twins, dim3(agb_cdiv(C, 64), agb_cdiv(R, 64), K3), dim3(256), 0, (hipStream_t)stream, W, W16,
                        Wt16, R, C);
     AGB_CHECK_LAUNCH("agb_weight_twins_bf16");
+    return AGB_OK;
+}
+
+// Both bf16 operand forms of EVERY layer in one launch: tab (DEVICE) int64 [n][7] = (W, W16, Wt16, K3, R, C, first tile), first
+// tile as in agb_spconv_weight_transpose_batched.  Values identical to agb_weight_twins_bf16 layer by layer.
+int agb_weight_twins_batched(const long long* tab, int n, long long total_tiles, void* stream) {
+    AGB_CHECK_ARG(tab != nullptr && n >= 1 && total_tiles >= 1 && total_tiles <= 0x7fffffffLL,
+                  "agb_weight_twins_batched: %d layers, %lld tiles", n, total_tiles);
+    hipLaunchKernelGGL(k_weight_twins_batched, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
+    AGB_CHECK_LAUNCH("agb_weight_twins_batched");
     return AGB_OK;
 }
 

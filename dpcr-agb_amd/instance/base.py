@@ -251,6 +251,8 @@ class InstanceBase(torch.nn.Module):
         # autograd assigns fresh gradient tensors (no zero-fill, no accumulate kernel per parameter); the data-parallel
         # hook packs them into its flat buckets with one multi-tensor copy per bucket (dist.GradAllReduce)
         self._optimizer.zero_grad(set_to_none=True)
+        from ..sparse_ops import ZERO_ARENA
+        ZERO_ARENA.new_step(self.loss.device)     # one fill for every zero-start gradient buffer of this backward pass
         self.loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()

@@ -248,6 +248,9 @@ int agb_spconv_fwd_h(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const
 /* Both bf16 operand forms of one layer's weights W float[K3][R][C] in one launch: W16 uint16 [K3][R][C] (the data
  * gradient's K-major form) and Wt16 uint16 [K3][C][R] (the forward pass's), round to nearest even. */
 int agb_weight_twins_bf16(const float* W, int K3, int R, int C, uint16_t* W16, uint16_t* Wt16, void* stream);
+/* both bf16 forms of EVERY layer in one launch: tab (DEVICE) int64 [n][7] = (W, W16, Wt16, K3, R, C, first tile), first tile =
+ * running sum of K3 * ceil(R / 64) * ceil(C / 64); kept by the caller until the weights change */
+int agb_weight_twins_batched(const long long* tab, int n, long long total_tiles, void* stream);
 int agb_spconv_fwd3_grid_h(const float* X, int ldx, const float* W, const int32_t* coords, const int32_t* grid,
                            const int32_t* desc, int K, const float* bias, uint16_t* Y16, int ldy16, int n_out, int Cout,
                            int32_t* nbr_out, long long nbr_out_stride, void* stream);

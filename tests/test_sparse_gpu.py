@@ -1488,7 +1488,10 @@ def test_weight_twins_one_launch_and_cache(device):
         with torch.no_grad():
             w.mul_(2.0)                                                   # torch in-place write: version counter
         assert torch.equal(sparse_ops.weight_twins(w)[0], (2.0 * w3 / 2.0).to(torch.bfloat16))
-        assert sparse_ops.weight_twins(w)[0] is not w16
+        # (round 6: the twins live in persistent buffers refreshed in place — by ONE launch for every registered kernel —
+        # the first time a step asks after the weights changed; launches of the stream that read the old values are ahead)
+        assert sparse_ops.weight_twins(w)[0] is w16 and torch.equal(w16, w3.to(torch.bfloat16))
+        assert torch.equal(sparse_ops.weight_twins(w)[1], w3.transpose(1, 2).contiguous().to(torch.bfloat16))
     # fused optimiser step: parameters move without torch noticing
     w = torch.nn.Parameter(torch.randn(27, 64, 64, device=device))
     opt = AdaBelief([w], lr=0.05, weight_decay=1e-2)
@@ -1499,6 +1502,22 @@ def test_weight_twins_one_launch_and_cache(device):
     after = sparse_ops.weight_twins(w)[0]
     assert torch.equal(after, w.detach().to(torch.bfloat16)) and not torch.equal(after, before)
     print("parameter version before / after the fused step:", version, w._version)
+    # one launch refreshes every registered kernel of the device: three kernels, one stale -> all three current, one call
+    from dpcr_agb_amd import _lib
+    ws = [torch.nn.Parameter(torch.randn(8, 64, 64, device=device)) for _ in range(3)]
+    for p in ws:
+        sparse_ops.weight_twins(p)
+    with torch.no_grad():
+        for p in ws:
+            p.add_(1.0)
+    calls, orig = [], _lib.call
+    _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        got = [sparse_ops.weight_twins(p)[0] for p in ws]
+    finally:
+        _lib.call = orig
+    assert calls.count("agb_weight_twins_batched") == 1 and "agb_weight_twins_bf16" not in calls, calls
+    assert all(torch.equal(g, p.detach().to(torch.bfloat16)) for g, p in zip(got, ws))
 
 
 def test_bf16_rows_refuse_kernels_without_a_bf16_form(device):
