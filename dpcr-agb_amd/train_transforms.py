@@ -268,3 +268,58 @@ class SparseTrainPipeline:
         pos, x, src, lens = self.tail.fix_counts(pos, x, src, out_ptr, with_extent=True)
         return self.tail.finish(pos, x, src, lens, len(plots), y_reg=y_reg, perms=perms, extent_hint=self.tail.grid_extent)
 
+    def staged(self, plots: List, device, y_reg=None, draws: Optional[List[dict]] = None, perms=None):
+        """``__call__`` as a generator that never waits for the device: at each of the chain's two count read-backs (rows after
+        the crop; voxels after GridSampling3D) it starts an asynchronous copy into pinned memory and YIELDS the pending read
+        (voxelize.AsyncRead); resumed later (``gen.send(read.value())``) — a step later in a pipelined loop, when the copy has
+        long landed — it continues with the values.  The PlotBatch is the generator's return value (StopIteration.value).
+        Same kernels, same draws, same batch as ``__call__``."""
+        from .voxelize import AsyncRead
+        if draws is None:
+            draws = [draw_sample(torch.as_tensor(p, dtype=torch.float32).reshape(-1, 3), self.cfg) for p in plots]
+        B = len(plots)
+        pos, x, src, out_ptr = self.augment(plots, draws, device)
+        host = yield AsyncRead(self.tail.fix_counts_begin(pos, out_ptr, with_extent=True))
+        pos, x, src, lens = self.tail.fix_counts_end(pos, x, src, host, B)
+        return (yield from self.tail.finish_staged(pos, x, src, lens, B, y_reg=y_reg, perms=perms,
+                                                   extent_hint=self.tail.grid_extent, reader=AsyncRead))
+
+
+class StagedBatches:
+    """A software pipeline over ``SparseTrainPipeline.staged``: every ``advance()`` moves each batch in flight one stage
+    further on the given stream (oldest first) and returns the batches that completed — the host thread never waits for a
+    count read-back, it picks each one up a step after it was started.  A batch needs three advances from ``submit``."""
+
+    def __init__(self, pipeline, device, stream=None):
+        self.pipe, self.device, self.stream = pipeline, device, stream
+        self.flight = []        # [generator, pending AsyncRead]
+
+    def submit(self, plots, y_reg=None, draws=None, perms=None):
+        with torch.cuda.stream(self.stream) if self.stream is not None else _null():
+            gen = self.pipe.staged(plots, self.device, y_reg=y_reg, draws=draws, perms=perms)
+            self.flight.append([gen, next(gen)])
+
+    def advance(self):
+        done, keep = [], []
+        with torch.cuda.stream(self.stream) if self.stream is not None else _null():
+            for item in self.flight:
+                gen, pending = item
+                try:
+                    item[1] = gen.send(pending.value())
+                    keep.append(item)
+                except StopIteration as fin:
+                    done.append(fin.value)
+        self.flight = keep
+        return done
+
+    def __len__(self):
+        return len(self.flight)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .kp_index import _elem_of_row, _ptr_tensor
-from .voxelize import device_permutations, draw_permutations, voxelize_last
+from .voxelize import voxelize_last_begin, voxelize_last_end, device_permutations, draw_permutations, voxelize_last
 
 _P = _lib.ptr
 _V, _I = _lib.c_void_p, _lib.c_int
@@ -188,24 +188,25 @@ class SparsePlotPipeline:
                   _P(ws), _P(pos_o), _P(x_o), _P(src), _P(out_ptr), _P(n_out), _lib.stream())
         return self.fix_counts(pos_o, x_o, src, out_ptr)
 
-    def fix_counts(self, pos_o, x_o, src, out_ptr, with_extent=False):
-        """MaxPoints / MinPoints on the cropped rows (out_ptr: device int32 [B+1] offsets).
-        with_extent: the per-axis extent of the widest cloud in voxel cells — what ``voxelize_last`` sizes its cell grid
-        from — is computed on the device and comes back in the SAME host read as the lengths (self.grid_extent; MaxPoints /
-        MinPoints keep a subset / repeat rows: the extent stays an upper bound): one synchronisation less per batch."""
-        dev = pos_o.device
-        self.grid_extent = None
+    def fix_counts_begin(self, pos_o, out_ptr, with_extent=False):
+        """The device tensor ``fix_counts_end`` needs on the host: the row offsets after the crop and — with_extent — the
+        per-axis extent of the widest cloud in voxel cells (what ``voxelize_last`` sizes its cell grid from), so that ONE host
+        read serves both."""
         if with_extent and self.grid is not None:
             from .kp_index import elem_bbox
             B = int(out_ptr.shape[0]) - 1
             bb = elem_bbox(pos_o, out_ptr, B)
             ext = (bb[:, 3:] - bb[:, :3]).max(0).values / float(np.float32(self.grid.size))
-            host = torch.cat([out_ptr.double(), ext.double()]).tolist()      # ONE host read: lengths + extent
-            optr = np.asarray(host[:B + 1], dtype=np.int64)
-            if all(np.isfinite(host[B + 1:])):
-                self.grid_extent = [float(v) for v in host[B + 1:]]
-        else:
-            optr = np.asarray(out_ptr.tolist(), dtype=np.int64)   # one host read: the lengths after the crop
+            return torch.cat([out_ptr.double(), ext.double()])
+        return out_ptr
+
+    def fix_counts_end(self, pos_o, x_o, src, host, B):
+        """MaxPoints / MinPoints on the cropped rows; host: the values of ``fix_counts_begin``'s tensor (a list)."""
+        dev = pos_o.device
+        self.grid_extent = None
+        optr = np.asarray(host[:B + 1], dtype=np.int64)
+        if len(host) > B + 1 and all(np.isfinite(host[B + 1:])):
+            self.grid_extent = [float(v) for v in host[B + 1:]]
         new_lens = np.diff(optr)
         m = int(optr[-1])
         pos_o, x_o, src = pos_o[:m], x_o[:m], src[:m]
@@ -230,6 +231,15 @@ class SparsePlotPipeline:
             new_lens = np.asarray(out_lens, dtype=np.int64)
         return pos_o, x_o, src, new_lens
 
+    def fix_counts(self, pos_o, x_o, src, out_ptr, with_extent=False):
+        """MaxPoints / MinPoints on the cropped rows (out_ptr: device int32 [B+1] offsets).
+        with_extent: the per-axis extent of the widest cloud in voxel cells — what ``voxelize_last`` sizes its cell grid
+        from — is computed on the device and comes back in the SAME host read as the lengths (self.grid_extent; MaxPoints /
+        MinPoints keep a subset / repeat rows: the extent stays an upper bound): one synchronisation less per batch."""
+        B = int(out_ptr.shape[0]) - 1
+        host = self.fix_counts_begin(pos_o, out_ptr, with_extent).tolist()      # ONE host read: lengths (+ extent)
+        return self.fix_counts_end(pos_o, x_o, src, host, B)
+
     # -- whole chain ---------------------------------------------------------------------------------------------
     def __call__(self, plots: List, device, y_reg=None, perms=None):
         """Returns a PlotBatch (batch, coords, x, pos, y_reg, ...) resident on `device`."""
@@ -238,6 +248,17 @@ class SparsePlotPipeline:
 
     def finish(self, pos, x, src, lens, B, y_reg=None, perms=None, extent_hint=None):
         """GridSampling3D + coordinate augmentation + batch assembly on prepared rows."""
+        gen = self.finish_staged(pos, x, src, lens, B, y_reg=y_reg, perms=perms, extent_hint=extent_hint)
+        try:
+            next(gen)
+        except StopIteration as done:
+            return done.value
+        raise RuntimeError("finish_staged yielded without a reader")
+
+    def finish_staged(self, pos, x, src, lens, B, y_reg=None, perms=None, extent_hint=None, reader=None):
+        """``finish`` as a generator: with a `reader` (device tensor -> pending read) it YIELDS the pending read of the
+        voxel counts instead of waiting for it, and is resumed with the values (``gen.send(values)``); the PlotBatch is the
+        generator's return value.  Without a reader it never yields (what ``finish`` runs)."""
         from .synthetic import PlotBatch
         dev = pos.device
         if self.grid is None:
@@ -250,7 +271,14 @@ class SparsePlotPipeline:
                 perm = device_permutations(lens, dev)
             else:
                 perm = draw_permutations(lens)
-            coords, keep, vlens, bounds = voxelize_last(pos, lens, self.grid.size, perm=perm, extent_hint=extent_hint)
+            state, to_read = voxelize_last_begin(pos, lens, self.grid.size, perm=perm, extent_hint=extent_hint)
+            if to_read is None:
+                host = None
+            elif reader is not None:       # a pipelined caller: the read-back is started here and finished a step later
+                host = yield reader(to_read)
+            else:
+                host = to_read.tolist()    # one host read: new lengths + coordinate bounds
+            coords, keep, vlens, bounds = voxelize_last_end(state, host)
             coords = coords.contiguous()
             ptr = _ptr_tensor(vlens, dev)
             m = int(coords.shape[0])

@@ -45,9 +45,31 @@ def device_permutations(lengths, device, generator=None):
     return order - ptr[elem]
 
 
-def voxelize_last(pos, lengths, size, perm=None, extent_hint=None):
-    """pos: float [N,3] stacked clouds (tensor, any device); lengths: int [B].
-    extent_hint: optional upper bound of (max - min) of pos/size per axis (saves the sizing read-back)."""
+class AsyncRead:
+    """A small device tensor on its way to the host WITHOUT a wait: asynchronous copy into a recycled pinned buffer on the
+    current stream + an event.  ``value()`` (a list) waits for the event — by then, in a pipelined caller, long past."""
+    _POOL = {}
+
+    def __init__(self, t):
+        key = (t.numel(), t.dtype)
+        pool = AsyncRead._POOL.setdefault(key, [])
+        self.host = pool.pop() if pool else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self.host.copy_(t, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._keep = t
+
+    def value(self):
+        self.event.synchronize()
+        out = self.host.tolist()
+        AsyncRead._POOL.setdefault((self.host.numel(), self.host.dtype), []).append(self.host)
+        self.host = self._keep = None
+        return out
+
+
+def voxelize_last_begin(pos, lengths, size, perm=None, extent_hint=None):
+    """First half of voxelize_last: everything up to (not including) the host read of the new lengths / bounds.  Returns
+    (state, to_read): `to_read` is the device tensor whose values ``voxelize_last_end`` needs (None: nothing to voxelize)."""
     lens = _lengths(lengths)
     B, n = len(lens), int(pos.shape[0])
     if int(lens.sum()) != n:
@@ -56,8 +78,7 @@ def voxelize_last(pos, lengths, size, perm=None, extent_hint=None):
         raise _lib.AgbError("voxelize_last needs a HIP device (no CPU fallback in the product path)")
     dev = pos.device if pos.is_cuda else torch.device("cuda", torch.cuda.current_device())
     if n == 0:      # nothing to voxelize: every cloud keeps zero voxels
-        return (torch.empty(0, 3, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
-                np.zeros(B, dtype=np.int64), (0,) * 6)
+        return (B, dev, None, None), None
     p = pos.to(device=dev, dtype=torch.float32).contiguous()
     if perm is None:
         perm = draw_permutations(lens)
@@ -83,12 +104,27 @@ def voxelize_last(pos, lengths, size, perm=None, extent_hint=None):
     out_ptr, n_out, bounds, status = i32(B + 1), i32(1), i32(6), i32(4)
     _lib.call("agb_voxelize_last_ws", _P(p), _P(perm), _P(ptr), _P(elem), B, n, size32, cap, _P(ws), _P(coords), _P(keep),
               _P(out_ptr), _P(n_out), _P(bounds), _P(status), _lib.stream())
-    host = torch.cat([out_ptr, bounds, status[:1]]).tolist()   # one host read: new lengths + coordinate bounds
+    return (B, dev, coords, keep), torch.cat([out_ptr, bounds, status[:1]])   # new lengths + coordinate bounds + status
+
+
+def voxelize_last_end(state, host):
+    """Second half: `host` = the values of ``voxelize_last_begin``'s `to_read` as a list."""
+    B, dev, coords, keep = state
+    if coords is None:
+        return (torch.empty(0, 3, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
+                np.zeros(B, dtype=np.int64), (0,) * 6)
     if host[-1]:
         raise _lib.AgbError("voxelize_last: a cloud exceeds the reserved cell capacity (extent_hint too small)")
     optr = np.asarray(host[:B + 1], dtype=np.int64)
     m = int(optr[-1])
-    return coords[:m], keep[:m], np.diff(optr).astype(np.int64), tuple(host[B + 1:B + 7])
+    return coords[:m], keep[:m], np.diff(optr).astype(np.int64), tuple(int(v) for v in host[B + 1:B + 7])
+
+
+def voxelize_last(pos, lengths, size, perm=None, extent_hint=None):
+    """pos: float [N,3] stacked clouds (tensor, any device); lengths: int [B].
+    extent_hint: optional upper bound of (max - min) of pos/size per axis (saves the sizing read-back)."""
+    state, to_read = voxelize_last_begin(pos, lengths, size, perm=perm, extent_hint=extent_hint)
+    return voxelize_last_end(state, None if to_read is None else to_read.tolist())   # one host read
 
 
 class GridSampling3D:

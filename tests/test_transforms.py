@@ -289,3 +289,48 @@ def test_device_shuffle_is_a_permutation_per_cloud_and_collated_draws_give_the_s
     with pytest.raises(ValueError):
         pipe.augment(raws[:2] + [raws[0]], draws, device)
 
+
+
+@pytest.mark.gpu
+def test_staged_train_chain_equals_the_waiting_one(device):
+    """SparseTrainPipeline.staged / StagedBatches (the chain's two count read-backs picked up a step later instead of
+    waited for): same draws, same voxel shuffle, same flips / shifts -> the same PlotBatch as ``__call__``, bit for bit,
+    also with several batches in flight on a side stream."""
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, SparseTrainPipeline, StagedBatches, draw_sample
+    cfg = NFITrainConfig()
+    # (plots that stay between MinPoints and MaxPoints after the crop: those two draw from torch's generator in the MIDDLE stage,
+    # which a pipelined loop runs for all batches in flight before any batch's last stage — a different, equally valid order)
+    sets = [[raw_plot(900 + 10 * j + i, n)[0] for i, n in enumerate([9000, 16000, 4000, 12000])] for j in range(3)]
+    _seed_all(7)
+    draws = [[draw_sample(torch.from_numpy(r), cfg) for r in raws] for raws in sets]
+    ys = [np.full((4, 2), float(j), np.float32) for j in range(3)]
+
+    def perms_for(pipe, raws, d):       # the voxel shuffle of this batch, fixed: lengths after the crop / MaxPoints
+        _seed_all(11)
+        pos, x, src, out_ptr = pipe.augment(raws, d, device)
+        lens = pipe.tail.fix_counts(pos, x, src, out_ptr, with_extent=True)[3]
+        g = torch.Generator().manual_seed(3)
+        return torch.cat([torch.randperm(int(n), generator=g) for n in lens])
+
+    pipe = SparseTrainPipeline(cfg)
+    perms = [perms_for(pipe, sets[j], draws[j]) for j in range(3)]
+    # reference: the three batches one after the other; the flips / shifts (the only draws left: no plot exceeds MaxPoints
+    # after the crop, the voxel shuffle is given) come from one seeded sequence
+    _seed_all(20)
+    want = [pipe(sets[j], device, y_reg=ys[j], draws=draws[j], perms=perms[j]) for j in range(3)]
+    # the staged form: three batches in flight on a side stream; first advance = the middle stages (no draws), second = the
+    # final stages in submission order, drawing the same sequence
+    side = torch.cuda.Stream()
+    flight = StagedBatches(SparseTrainPipeline(cfg), device, side)
+    for j in range(3):
+        flight.submit(sets[j], y_reg=ys[j], draws=draws[j], perms=perms[j])
+    assert len(flight) == 3
+    assert flight.advance() == [] and len(flight) == 3
+    _seed_all(20)
+    order = flight.advance()
+    side.synchronize()
+    assert len(order) == 3 and len(flight) == 0
+    for j, out in enumerate(order):
+        ref = want[j]
+        assert torch.equal(out.coords, ref.coords) and torch.equal(out.x, ref.x) and torch.equal(out.batch, ref.batch), j
+        assert torch.equal(out.y_reg, ref.y_reg) and out.coord_bounds == ref.coord_bounds, j

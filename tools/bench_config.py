@@ -535,21 +535,33 @@ def run_end2end(a):
     side = model.input_stream(dev)
     queue = deque()
 
+    from dpcr_agb_amd.train_transforms import StagedBatches
+    flight = StagedBatches(pipe, dev, side)
+
     def stage(i):
+        """One turn of the input pipeline: the chain of batch i starts, the batches in flight move one stage on (their count
+        read-backs were started a step ago: no wait), finished ones go to the model's input staging."""
         _, raws_d, y = pool[i % 3]
         t0 = time.perf_counter()
         draws = next(draws_it)
         host_draw_ms.append((time.perf_counter() - t0) * 1e3)
-        with torch.cuda.stream(side):
-            batch = pipe(raws_d, dev, y_reg=y, draws=draws)
-        voxels.append(int(batch.coords.shape[0]))
         points_in.append(int(draws["n1s"].sum() + draws["n_add"].sum() + draws["n_cj"].sum()))
-        model.prefetch_input(batch, dev)
-        queue.append(batch)
+        if a.sync_chain:        # (the round-5 form: the chain waits for its two read-backs where they occur)
+            with torch.cuda.stream(side):
+                done = [pipe(raws_d, dev, y_reg=y, draws=draws)]
+        else:
+            done = flight.advance()
+            flight.submit(raws_d, y_reg=y, draws=draws)
+        for batch in done:
+            voxels.append(int(batch.coords.shape[0]))
+            model.prefetch_input(batch, dev)
+            queue.append(batch)
 
-    stage(0)
-    stage(1)
-    staged = [2]
+    n_stage = 0
+    while len(queue) < 2:       # fill the pipeline: two batches staged for the model
+        stage(n_stage)
+        n_stage += 1
+    staged = [n_stage]
 
     def step(i):
         batch = queue.popleft()
@@ -608,6 +620,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inline-draws", action="store_true", help="end2end: per-sample draws in the training process, no workers")
     ap.add_argument("--host-shuffle", action="store_true", help="end2end: GridSampling3D's shuffle with torch.randperm on the host")
+    ap.add_argument("--sync-chain", action="store_true", help="end2end: the transform chain waits for its two count read-backs "
+                    "where they occur (round 5) instead of picking them up a step later (train_transforms.StagedBatches)")
     ap.add_argument("--shapes", action="store_true", help="per-shape table of the dense products / gathers")
     a = ap.parse_args()
     # (device_count does not initialise the HIP runtime, is_available does: the end2end line forks its loader workers first)
