@@ -169,12 +169,24 @@ def stream():
 
 
 _FN = {}     # entry point name -> ctypes function (one dictionary lookup per launch instead of load() + getattr)
+# An input pipeline that reads counts back asynchronously (instance/kpconv.py: the wait-free input pyramid) registers a
+# callable here: it is given a turn every POLL_EVERY library calls — i.e. every ~0.5 ms while a step is being enqueued —
+# to pick up the copies that have landed and enqueue its next stage.  None: nothing in flight.
+POLL_HOOK = None
+POLL_EVERY = 16
+_poll_count = [0]
+CALL_NOTE = None     # (instrumented runs: what a wrapper knows about the call it is about to make — tools/bench_config.py)
 
 
 def call(name, *args):
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(load(), name)
+    if POLL_HOOK is not None:
+        _poll_count[0] += 1
+        if _poll_count[0] >= POLL_EVERY:
+            _poll_count[0] = 0
+            POLL_HOOK()
     rc = fn(*args)
     if rc != 0:
         raise AgbError(f"{name} failed ({rc}): {load().agb_last_error().decode()}")

@@ -246,14 +246,20 @@ class InstanceBase(torch.nn.Module):
         meter.add(outs, ys, valid)
         return meter.value()
 
+    def poll_prefetch(self):
+        """Input pipelines that read counts back asynchronously (KPConvModel) move on here; called between the phases of a step."""
+
     def optimize_parameters(self, epoch, batch_size, num_batches):
+        self.poll_prefetch()
         self(epoch=epoch)
+        self.poll_prefetch()
         # autograd assigns fresh gradient tensors (no zero-fill, no accumulate kernel per parameter); the data-parallel
         # hook packs them into its flat buckets with one multi-tensor copy per bucket (dist.GradAllReduce)
         self._optimizer.zero_grad(set_to_none=True)
         from ..sparse_ops import ZERO_ARENA
         ZERO_ARENA.new_step(self.loss.device)     # one fill for every zero-start gradient buffer of this backward pass
         self.loss.backward()
+        self.poll_prefetch()
         if self.grad_sync is not None:
             self.grad_sync()
         if self._grad_clip > 0 and not getattr(self._optimizer, "fused", False):
@@ -263,7 +269,9 @@ class InstanceBase(torch.nn.Module):
         self._num_epochs = epoch
         self._num_batches += 1
         self._num_samples += batch_size
+        self.poll_prefetch()
         self._pace_host()
+        self.poll_prefetch()
 
     # The host enqueues a step in about half the time the device needs for it and would run ahead until the hardware
     # queue is full — where the runtime SPINS for a free slot: one core per rank burnt for nothing, and under a CPU quota

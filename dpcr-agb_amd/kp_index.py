@@ -167,6 +167,46 @@ def read_back(*tensors):
     return out
 
 
+class PendingRead:
+    """``read_back`` without the wait: the small device tensors are copied (one asynchronous copy into recycled pinned
+    memory, on the current stream) and an event is recorded; ``ready()`` polls it, ``values()`` returns what ``read_back``
+    would have (waiting only if the copy has not landed yet) — the building block of the wait-free input pyramid."""
+    _POOL = {}
+
+    def __init__(self, tensors):
+        self.shapes = [t.numel() for t in tensors]
+        self.host = self.event = None
+        if not tensors:
+            return
+        if all(not t.is_floating_point() for t in tensors):
+            flat = torch.cat([t.reshape(-1).to(torch.int64) for t in tensors])
+        else:
+            flat = torch.cat([t.reshape(-1).double() for t in tensors])
+        self.is_int = not flat.is_floating_point()
+        pool = PendingRead._POOL.setdefault((flat.numel(), flat.dtype), [])
+        self.host = pool.pop() if pool else torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+        self.host.copy_(flat, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._keep = flat
+
+    def ready(self):
+        return self.event is None or self.event.query()
+
+    def values(self):
+        if self.host is None:
+            return []
+        self.event.synchronize()
+        vals = self.host.tolist()
+        PendingRead._POOL.setdefault((self.host.numel(), self.host.dtype), []).append(self.host)
+        self.host = self._keep = None
+        out, off = [], 0
+        for n in self.shapes:
+            out.append(vals[off:off + n])
+            off += n
+        return out
+
+
 class Neighbors:
     """The radius neighbours of nq queries as RAGGED rows — what the kernels of this library walk (the
     ball query writes sum(counts) * 4 bytes instead of the nq x max_count matrix the reference pads to,
