@@ -261,6 +261,23 @@ def pmc_traffic(kernel, config):
     return None, None
 
 
+def pmc_traffic_prefix(prefixes, config):
+    """(HBM bytes per STEP of all kernels whose names start with one of `prefixes`, file) from the config's committed PMC pass —
+    for an entry point that launches several kernels (the voxeliser) — or (None, None)."""
+    for tag in ("r06", "r05", "r04"):
+        rel = os.path.join("profiles", f"{tag}_pmc_traffic_{config}.json")
+        try:
+            doc = json.load(open(os.path.join(ROOT, rel)))
+        except Exception:
+            continue
+        steps = doc.get("steps") or 1
+        tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in doc["kernels"].items()
+                  if k.replace("void ", "").strip().startswith(tuple(prefixes)))
+        if tot > 0:
+            return round(tot / steps), rel
+    return None, None
+
+
 def step_shares(groups, top=8):
     """Share of the instrumented steps' bracketed device time per KERNEL (the name the library noted when it launched it, else
     the entry point): what decides which kernel dominates a config's step (round-4 review: the share inside one entry point
@@ -588,8 +605,10 @@ def run_end2end(a):
     N, M, F = float(np.mean(points_in[-3:])), float(np.mean(voxels[-3:])), 3
     byts = N * (12 + 4 * F) + M * (12 + 4 * F) + 8 * N
     avg_us = g["ms"] / g["n"] * 1e3
+    # PMC bytes of the voxeliser's kernels per batch (k_vox_*: the entry point launches several), committed pass of this line
+    vox_traffic, vox_src = pmc_traffic_prefix(("k_vox", "k_voxel"), "end2end") if dom.startswith("agb_voxelize") else (None, None)
     roof = dict(bound="hbm", achieved=round(byts / (avg_us * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(byts / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), traffic=None, traffic_source=None,
+                frac=round(byts / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), traffic=vox_traffic, traffic_source=vox_src,
                 kernel=KERNEL_OF_ENTRY.get(dom, dom), entry_point=dom, launches=g["n"], avg_launch_us=round(avg_us, 2),
                 alg_bytes_per_launch=round(byts),
                 note="the dominant entry point of the input chain; bytes = the whole chain's per-batch figure of SURVEY 8(d): the "
