@@ -295,7 +295,9 @@ class SparsePlotPipeline:
                         shifts[b] = (torch.rand(3) * 100).to(torch.int32).numpy()
                 cmax = torch.empty(3 * B, dtype=torch.int32, device=dev)
                 # named tensors: a temporary would be freed (and its block reused) as soon as its pointer is taken
-                flips_d, shifts_d = torch.from_numpy(flips).to(dev), torch.from_numpy(shifts).to(dev)
+                # (through the pinned ring: a copy from pageable memory makes the runtime wait for the whole device)
+                from .kp_index import h2d_small
+                flips_d, shifts_d = h2d_small(flips, dev), h2d_small(shifts, dev)
                 _lib.call("agb_coords_augment", _P(coords), _P(elem), B, m, _P(flips_d), _P(shifts_d), _P(cmax),
                           _lib.stream())
                 # Box of the augmented coordinates WITHOUT reading them back: a flipped axis of cloud b becomes
@@ -308,7 +310,9 @@ class SparsePlotPipeline:
             out = PlotBatch(batch, coords, x[keep], pos[keep], None, None, B, bounds)
             out.src = src[keep]
         if y_reg is not None:
-            out.y_reg = torch.as_tensor(y_reg, dtype=torch.float32).to(dev)
+            from .kp_index import h2d_small
+            yr = y_reg.detach().cpu().numpy() if torch.is_tensor(y_reg) else np.asarray(y_reg)
+            out.y_reg = h2d_small(np.ascontiguousarray(yr, dtype=np.float32), dev)
             out.y_reg_mask = torch.ones_like(out.y_reg, dtype=torch.bool)
             out.y_reg_mask_all = True
         return out

@@ -37,7 +37,8 @@ def device_permutations(lengths, device, generator=None):
     dev = torch.device(device)
     if n == 0:
         return torch.zeros(0, dtype=torch.int64, device=dev)
-    lens_d = lens.to(dev)
+    from .kp_index import h2d_small      # (pinned ring: a pageable upload makes the runtime wait for the whole device)
+    lens_d = h2d_small(lens.numpy(), dev)
     elem = torch.repeat_interleave(torch.arange(len(lens), device=dev), lens_d, output_size=n)
     key = torch.randint(0, 1 << 40, (n,), dtype=torch.int64, device=dev, generator=generator)
     order = torch.argsort((elem << 40) | key)

@@ -13,4 +13,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "$C rc=$?"
 done
 cd $ROOT
-python3 tools/pmc_summary.py $OUT $ROOT/gpurun_out/pmc_traffic_$TAG.json 4
+python3 tools/pmc_summary.py $OUT $ROOT/gpurun_out/pmc_traffic_$TAG.json auto

@@ -16,7 +16,7 @@ run_cfg () {   # name, command...
     echo "$NAME $C rc=$?"
   done
   cd $ROOT
-  python3 tools/pmc_summary.py $OUT $ROOT/gpurun_out/pmc_traffic_${TAG}_$NAME.json ${STEPS:-4} | head -6
+  python3 tools/pmc_summary.py $OUT $ROOT/gpurun_out/pmc_traffic_${TAG}_$NAME.json auto | head -6
 }
 run_cfg config2 $ROOT/tools/bench_config.py pointnet --steps 3 --warmup 1 --no-cpu-baseline
 run_cfg config3 $ROOT/tools/bench_config.py kpconv --points 16000 --steps 3 --warmup 1 --no-cpu-baseline

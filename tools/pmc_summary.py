@@ -32,9 +32,13 @@ def main(out_dir, json_path, steps=None):
     total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in res.values())
     doc = dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = KB*1024, FETCH_SIZE x2 (gfx950)",
                total_hbm_bytes=total, kernels=res)
+    # training steps of the profiled command: one fused-optimiser launch (k_adabelief) per parameter group and step — every
+    # model wrapper of this repo has two groups (head, backbone); an explicit count (argv[3]) wins
+    ada = max((v["launches"] for k, v in res.items() if k.startswith("k_adabelief")), default=0)
+    steps = int(steps) if steps and str(steps) != "auto" else ada // 2
     if steps:
         # every kernel of the profiled command (its set-up included: a small overestimate) over the steps it ran
-        doc.update(steps=int(steps), hbm_bytes_per_step=total / int(steps))
+        doc.update(steps=steps, hbm_bytes_per_step=total / steps)
     json.dump(doc, open(json_path, "w"), indent=1)
     top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
     for k, v in top:
