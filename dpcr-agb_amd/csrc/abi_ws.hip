@@ -13,7 +13,8 @@ AGB_INTERNAL int agb_grid_subsample(const float* pts, const float* feats, int fd
 AGB_INTERNAL int agb_voxelize_last(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
                       float size, int cap, int32_t* bbox_ord, float* lo, int32_t* span, int32_t* cells, int32_t* slot,
                       int32_t* flag, int32_t* cell_of, int32_t* scan_scratch, int32_t* coords, long long* keep,
-                      int32_t* out_ptr, int32_t* n_out_dev, int32_t* bounds, int32_t* status, void* stream);
+                      int32_t* out_ptr, int32_t* n_out_dev, int32_t* bounds, int32_t* status, void* stream,
+                      unsigned long long seed);
 AGB_INTERNAL int agb_plot_prepare(const float* pos, const int32_t* ptr, const int32_t* elem, int B, int n, const float* xform,
                      int scale_div, int z_from_zero, const double* poly, int nv, float* zmin, float* pos_t, int32_t* flag,
                      int32_t* slot, int32_t* scan_scratch, float* pos_out, float* x_out, long long* src, int32_t* out_ptr,
@@ -89,8 +90,22 @@ int agb_voxelize_last_ws(const float* pos, const long long* perm, const int32_t*
                   "agb_voxelize_last_ws: workspace required, B %d, cap %d", B, cap);
     VoxWs o;
     vox_carve(workspace, n, B, cap, &o);
+    AGB_CHECK_ARG(perm != nullptr || n == 0, "agb_voxelize_last_ws: perm required (agb_voxelize_last_seeded_ws draws the "
+                  "shuffle on the device)");
     return agb_voxelize_last(pos, perm, ptr, elem, B, n, size, cap, o.bbox_ord, o.lo, o.span, o.cells, o.slot, o.flag,
-                             o.cell_of, o.scan, coords, keep, out_ptr, n_out_dev, bounds, status, stream);
+                             o.cell_of, o.scan, coords, keep, out_ptr, n_out_dev, bounds, status, stream, 0ull);
+}
+// The same with the shuffle drawn ON THE DEVICE from `seed` (no permutation tensor: csrc/voxelize.hip vox_perm — a keyed
+// pseudo-random bijection per cloud); same workspace.  A voxel's representative is uniformly random over its points.
+int agb_voxelize_last_seeded_ws(const float* pos, unsigned long long seed, const int32_t* ptr, const int32_t* elem, int B, int n,
+                                float size, int cap, void* workspace, int32_t* coords, long long* keep, int32_t* out_ptr,
+                                int32_t* n_out_dev, int32_t* bounds, int32_t* status, void* stream) {
+    AGB_CHECK_ARG(workspace != nullptr && B >= 1 && cap >= 1 && (long long)B * cap < 0x7FFFFFF0LL,
+                  "agb_voxelize_last_seeded_ws: workspace required, B %d, cap %d", B, cap);
+    VoxWs o;
+    vox_carve(workspace, n, B, cap, &o);
+    return agb_voxelize_last(pos, nullptr, ptr, elem, B, n, size, cap, o.bbox_ord, o.lo, o.span, o.cells, o.slot, o.flag,
+                             o.cell_of, o.scan, coords, keep, out_ptr, n_out_dev, bounds, status, stream, seed);
 }
 
 // ---- transform chain

@@ -83,15 +83,61 @@ __global__ void k_vox_geometry(const int32_t* __restrict__ bbox_ord, int B, int 
     if (cells > cap) atomicAdd(&status[0], 1);
 }
 
+// The shuffle WITHOUT a permutation tensor (perm == NULL): shuffled position i of a cloud of m points holds original point
+// vox_perm(i, m, seed of the cloud) — a pseudo-random BIJECTION of [0, m): four rounds of a balanced Feistel network on the
+// 2h >= log2(m) bits of the index (round function: a murmur-style mix keyed by the seed), cycle-walked into [0, m) (the
+// domain 2^(2h) is below 4 m: two iterations on average at worst).  GridSampling3D(mode="last") needs SOME uniformly random
+// order to pick a voxel's representative (grid_transform.py:118-121 shuffles with torch.randperm); drawing it as a keyed
+// bijection costs ~40 integer instructions per point here — the host-side alternative was one int64 sort of the batch plus
+// a random-number launch (2 ms of host time and 0.5 ms of device time per batch of 32 plots).
+__device__ __forceinline__ unsigned vox_mix(unsigned x, unsigned key) {
+    x ^= key;
+    x *= 0x85ebca6bu; x ^= x >> 13;
+    x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned vox_perm(unsigned i, unsigned m, unsigned long long seed) {
+    if (m <= 1) return 0;
+    int bits = 32 - __clz(m - 1);
+    if (bits < 2) bits = 2;
+    const int h = (bits + 1) >> 1;
+    const unsigned mask = (1u << h) - 1u;
+    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    unsigned x = i;
+    do {
+        unsigned L = x >> h, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned t = L ^ (vox_mix(R, (r & 1 ? k1 : k0) + 0x9e3779b9u * (unsigned)(r + 1)) & mask);
+            L = R;
+            R = t;
+        }
+        x = (L << h) | R;
+    } while (x >= m);
+    return x;
+}
+__device__ __forceinline__ unsigned long long vox_cloud_seed(unsigned long long seed, int b) {
+    unsigned long long k = seed + 0x9e3779b97f4a7c15ull * (unsigned long long)(b + 1);
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+// original position (inside its cloud) of shuffled position i (global row) of cloud b
+__device__ __forceinline__ long long vox_source(const long long* __restrict__ perm, const int32_t* __restrict__ ptr, int b,
+                                                int i, unsigned long long seed) {
+    if (perm) return perm[i];
+    const int beg = ptr[b];
+    return (long long)vox_perm((unsigned)(i - beg), (unsigned)(ptr[b + 1] - beg), vox_cloud_seed(seed, b));
+}
+
 // shuffled position i (global row beg+i of cloud b) holds original point beg + perm[beg+i]
 __global__ void k_vox_mark(const float* __restrict__ pos, const long long* __restrict__ perm,
                            const int32_t* __restrict__ ptr, const int32_t* __restrict__ elem, int n, float size,
                            int cap, const float* __restrict__ lo, const int32_t* __restrict__ span, int32_t* cells,
-                           int32_t* cell_of) {
+                           int32_t* cell_of, unsigned long long seed) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int b = elem[i];
-    long long j = ptr[b] + perm[i];
+    long long j = ptr[b] + vox_source(perm, ptr, b, i, seed);
     float c[3];
     rounded(pos, j, size, c);
     const float* l = lo + 3 * b;
@@ -111,14 +157,14 @@ __global__ void k_vox_flag(const int32_t* __restrict__ cells, int n, int32_t* fl
 __global__ void k_vox_emit(const float* __restrict__ pos, const long long* __restrict__ perm,
                            const int32_t* __restrict__ ptr, const int32_t* __restrict__ elem, int ncells, float size,
                            const int32_t* __restrict__ cells, const int32_t* __restrict__ slot,
-                           int32_t* __restrict__ coords, long long* __restrict__ keep) {
+                           int32_t* __restrict__ coords, long long* __restrict__ keep, unsigned long long seed) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     int v[3];
     if (c < ncells) {
         int i = cells[c];
         if (i >= 0) {
             int b = elem[i];
-            long long j = ptr[b] + perm[i];
+            long long j = ptr[b] + vox_source(perm, ptr, b, i, seed);
             float r[3];
             rounded(pos, j, size, r);
             int o = slot[c];
@@ -156,7 +202,8 @@ __global__ void k_vox_out_ptr(const int32_t* __restrict__ slot, const int32_t* t
 extern "C" {
 
 // pos float[n,3] (stacked clouds, ptr int32[B+1], elem int32[n] = cloud of every row); perm int64[n]: within-cloud
-// permutation (shuffled position -> original position in the cloud).  cap = cells reserved per cloud.
+// permutation (shuffled position -> original position in the cloud), or NULL: the keyed bijection vox_perm of `seed`.
+// cap = cells reserved per cloud.
 // Scratch int32: bbox_ord[6B], span[3B], cells[B*cap+1], slot[B*cap+1], flag[B*cap+1], cell_of[n],
 // scan_scratch[agb_scan_scratch_elems(B*cap+1)]; lo float[3B].
 // Out: coords int32[n,3] (upper bound), keep int64[n], out_ptr int32[B+1], n_out_dev, bounds int32[6]
@@ -165,7 +212,7 @@ AGB_INTERNAL int agb_voxelize_last(const float* pos, const long long* perm, cons
                       float size, int cap, int32_t* bbox_ord, float* lo, int32_t* span, int32_t* cells,
                       int32_t* slot, int32_t* flag, int32_t* cell_of, int32_t* scan_scratch, int32_t* coords,
                       long long* keep, int32_t* out_ptr, int32_t* n_out_dev, int32_t* bounds, int32_t* status,
-                      void* stream) {
+                      void* stream, unsigned long long seed) {
     hipStream_t s = (hipStream_t)stream;
     long long total = (long long)B * cap;
     AGB_CHECK_ARG(total > 0 && total < 0x7FFFFFF0LL, "agb_voxelize_last: %lld cells out of range", total);
@@ -183,11 +230,11 @@ AGB_INTERNAL int agb_voxelize_last(const float* pos, const long long* perm, cons
     (void)hipMemsetAsync(cells, 0xFF, sizeof(int32_t) * (size_t)nc, s);  // -1 = empty
     if (n > 0)
         hipLaunchKernelGGL(k_vox_mark, dim3(agb_cdiv(n, 256)), dim3(256), 0, s, pos, perm, ptr, elem, n, size, cap, lo,
-                           span, cells, cell_of);
+                           span, cells, cell_of, seed);
     hipLaunchKernelGGL(k_vox_flag, dim3(agb_cdiv(nc, 256)), dim3(256), 0, s, cells, nc, flag);
     agb_launch_exclusive_scan(flag, nc, slot, scan_scratch, n_out_dev, s);
     hipLaunchKernelGGL(k_vox_emit, dim3(agb_cdiv(nc - 1, 256)), dim3(256), 0, s, pos, perm, ptr, elem, nc - 1, size,
-                       cells, slot, coords, keep);
+                       cells, slot, coords, keep, seed);
     hipLaunchKernelGGL(k_vox_out_ptr, dim3(agb_cdiv(B + 1, 64)), dim3(64), 0, s, slot, n_out_dev, cap, B, out_ptr, bbox_ord,
                        bounds);
     AGB_CHECK_LAUNCH("agb_voxelize_last");

@@ -265,13 +265,17 @@ class SparsePlotPipeline:
             batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(lens)).to(dev)
             out = PlotBatch(batch, None, x, pos, None, None, B, None)
         else:
+            perm = seed = None
             if perms is not None:
                 perm = perms
             elif getattr(self, "device_shuffle", False):
-                perm = device_permutations(lens, dev)
+                # the voxel shuffle drawn INSIDE the voxeliser from one seed of torch's host generator (a keyed bijection per
+                # cloud: csrc/voxelize.hip vox_perm) — no permutation tensor, no sort (round 5: voxelize.device_permutations,
+                # 2 ms of host time per batch of 32 plots in torch.argsort / randint / cumsum launches)
+                seed = int(torch.randint(0, 1 << 62, (1,)).item())
             else:
                 perm = draw_permutations(lens)
-            state, to_read = voxelize_last_begin(pos, lens, self.grid.size, perm=perm, extent_hint=extent_hint)
+            state, to_read = voxelize_last_begin(pos, lens, self.grid.size, perm=perm, extent_hint=extent_hint, seed=seed)
             if to_read is None:
                 host = None
             elif reader is not None:       # a pipelined caller: the read-back is started here and finished a step later

@@ -8,6 +8,8 @@ coordinate manager wants.  ``perm`` is the within-cloud shuffle the reference dr
 (grid_transform.py:24); pass it to be comparable, omit it to draw one per cloud the same way.
 Only mode="last" is implemented (the NFI sparse pipelines use it: sparse-xy.yaml:95-99).
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -18,6 +20,7 @@ _P = _lib.ptr
 _V, _I, _F = _lib.c_void_p, _lib.c_int, _lib.c_float
 _lib.declare("agb_voxelize_last_workspace_bytes", [_I, _I, _I])
 _lib.declare("agb_voxelize_last_ws", [_V, _V, _V, _V, _I, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V, _V])
+_lib.declare("agb_voxelize_last_seeded_ws", [_V, ctypes.c_ulonglong, _V, _V, _I, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V, _V])
 
 
 def draw_permutations(lengths):
@@ -68,7 +71,7 @@ class AsyncRead:
         return out
 
 
-def voxelize_last_begin(pos, lengths, size, perm=None, extent_hint=None):
+def voxelize_last_begin(pos, lengths, size, perm=None, extent_hint=None, seed=None):
     """First half of voxelize_last: everything up to (not including) the host read of the new lengths / bounds.  Returns
     (state, to_read): `to_read` is the device tensor whose values ``voxelize_last_end`` needs (None: nothing to voxelize)."""
     lens = _lengths(lengths)
@@ -81,9 +84,10 @@ def voxelize_last_begin(pos, lengths, size, perm=None, extent_hint=None):
     if n == 0:      # nothing to voxelize: every cloud keeps zero voxels
         return (B, dev, None, None), None
     p = pos.to(device=dev, dtype=torch.float32).contiguous()
-    if perm is None:
-        perm = draw_permutations(lens)
-    perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+    if seed is None:
+        if perm is None:
+            perm = draw_permutations(lens)
+        perm = perm.to(device=dev, dtype=torch.int64).contiguous()
     ptr = _ptr_tensor(lens, dev)
     elem = _elem_of_row(ptr, B, n, dev)
     size32 = float(np.float32(size))
@@ -103,8 +107,12 @@ def voxelize_last_begin(pos, lengths, size, perm=None, extent_hint=None):
     coords = torch.empty(max(n, 1), 3, dtype=torch.int32, device=dev)
     keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     out_ptr, n_out, bounds, status = i32(B + 1), i32(1), i32(6), i32(4)
-    _lib.call("agb_voxelize_last_ws", _P(p), _P(perm), _P(ptr), _P(elem), B, n, size32, cap, _P(ws), _P(coords), _P(keep),
-              _P(out_ptr), _P(n_out), _P(bounds), _P(status), _lib.stream())
+    if seed is not None:      # the shuffle drawn on the device from one 64-bit seed: no permutation tensor, no sort
+        _lib.call("agb_voxelize_last_seeded_ws", _P(p), ctypes.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), _P(ptr), _P(elem), B,
+                  n, size32, cap, _P(ws), _P(coords), _P(keep), _P(out_ptr), _P(n_out), _P(bounds), _P(status), _lib.stream())
+    else:
+        _lib.call("agb_voxelize_last_ws", _P(p), _P(perm), _P(ptr), _P(elem), B, n, size32, cap, _P(ws), _P(coords), _P(keep),
+                  _P(out_ptr), _P(n_out), _P(bounds), _P(status), _lib.stream())
     return (B, dev, coords, keep), torch.cat([out_ptr, bounds, status[:1]])   # new lengths + coordinate bounds + status
 
 
@@ -121,10 +129,11 @@ def voxelize_last_end(state, host):
     return coords[:m], keep[:m], np.diff(optr).astype(np.int64), tuple(int(v) for v in host[B + 1:B + 7])
 
 
-def voxelize_last(pos, lengths, size, perm=None, extent_hint=None):
+def voxelize_last(pos, lengths, size, perm=None, extent_hint=None, seed=None):
     """pos: float [N,3] stacked clouds (tensor, any device); lengths: int [B].
-    extent_hint: optional upper bound of (max - min) of pos/size per axis (saves the sizing read-back)."""
-    state, to_read = voxelize_last_begin(pos, lengths, size, perm=perm, extent_hint=extent_hint)
+    extent_hint: optional upper bound of (max - min) of pos/size per axis (saves the sizing read-back).
+    seed (int): draw the shuffle on the device from it (agb_voxelize_last_seeded_ws) instead of taking / drawing `perm`."""
+    state, to_read = voxelize_last_begin(pos, lengths, size, perm=perm, extent_hint=extent_hint, seed=seed)
     return voxelize_last_end(state, None if to_read is None else to_read.tolist())   # one host read
 
 

@@ -496,6 +496,13 @@ size_t agb_voxelize_last_workspace_bytes(int n, int B, int cap);
 int agb_voxelize_last_ws(const float* pos, const long long* perm, const int32_t* ptr, const int32_t* elem, int B, int n,
                          float size, int cap, void* workspace, int32_t* coords, long long* keep, int32_t* out_ptr,
                          int32_t* n_out_dev, int32_t* bounds, int32_t* status, void* stream);
+/* the same with the shuffle drawn ON THE DEVICE from `seed` (no permutation tensor): per cloud a keyed pseudo-random
+ * bijection of its rows (four Feistel rounds, cycle-walked; dpcr-agb_amd/csrc/voxelize.hip vox_perm) — a voxel's
+ * representative is uniformly random over its points, which is all GridSampling3D(mode="last") asks of the shuffle
+ * (grid_transform.py:118-121); reproducible for a seed */
+int agb_voxelize_last_seeded_ws(const float* pos, unsigned long long seed, const int32_t* ptr, const int32_t* elem, int B, int n,
+                                float size, int cap, void* workspace, int32_t* coords, long long* keep, int32_t* out_ptr,
+                                int32_t* n_out_dev, int32_t* bounds, int32_t* status, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Fused multi-tensor AdaBelief step with clip_grad_value_ (replaces core/optimizer/adabelief.py:89-201 +

@@ -77,3 +77,41 @@ def test_gridsampling_transform_feeds_the_sparse_model(device):
         model.forward()
         outs.append(model.output.detach().clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_seeded_device_shuffle_picks_uniform_representatives(device):
+    """agb_voxelize_last_seeded_ws: the shuffle drawn inside the voxeliser from a seed (a keyed pseudo-random bijection per
+    cloud).  (i) it IS a bijection: with one point per voxel every point is kept, for many cloud sizes; (ii) same voxels as the
+    permutation-driven form, the representative a point of its voxel; (iii) reproducible per seed, different across seeds;
+    (iv) every point of a voxel is picked about equally often over many seeds (GridSampling3D(mode="last") asks no more of the
+    shuffle: grid_transform.py:118-121)."""
+    from dpcr_agb_amd.voxelize import voxelize_last
+    # (i) one point per voxel: sizes around powers of two and four (the Feistel domain changes there), several clouds
+    for sizes in ([1, 2, 3, 4, 5], [15, 16, 17, 63, 64, 65], [255, 256, 257, 1000, 4096, 4097], [16000, 9999]):
+        pts = np.concatenate([np.stack([np.arange(n) * 1.0, np.full(n, 3.0 * b), np.zeros(n)], 1) for b, n in enumerate(sizes)])
+        c, keep, lens, _ = voxelize_last(torch.from_numpy(pts.astype(np.float32)).to(device), sizes, 1.0, seed=12345)
+        assert lens.tolist() == list(sizes)
+        assert torch.equal(torch.sort(keep.cpu()).values, torch.arange(sum(sizes)))
+    # (ii) + (iii) on a real cloud
+    rng = np.random.default_rng(0)
+    pos = torch.from_numpy(rng.uniform(0, 1, size=(12000, 3)).astype(np.float32)).to(device)
+    lens = [7000, 5000]
+    c0, k0, l0, b0 = voxelize_last(pos, lens, 0.05, seed=7)
+    c1, k1, l1, _ = voxelize_last(pos, lens, 0.05, seed=7)
+    c2, k2, l2, _ = voxelize_last(pos, lens, 0.05, seed=8)
+    cp, kp, lp, bp = voxelize_last(pos, lens, 0.05)                      # host permutation
+    assert torch.equal(c0, c1) and torch.equal(k0, k1) and torch.equal(c0, cp) and l0.tolist() == lp.tolist() and b0 == bp
+    assert torch.equal(c0, c2) and not torch.equal(k0, k2)
+    cell_of = torch.round(pos[k0] / np.float32(0.05)).to(torch.int32)      # the kept point lies in the voxel it stands for
+    assert torch.equal(cell_of, c0)
+    # (iv) one voxel of 8 points, 4000 seeds: every point wins ~1/8 of the time (binomial sd 0.005)
+    pts = torch.tensor([[0.1 + 0.01 * i, 0.2, 0.3] for i in range(8)] + [[5.0 + i, 0.0, 0.0] for i in range(50)],
+                       dtype=torch.float32, device=device)
+    wins = np.zeros(8)
+    for s in range(4000):
+        _, keep, _, _ = voxelize_last(pts, [58], 1.0, seed=1000 + s)
+        w = [int(k) for k in keep.tolist() if k < 8]
+        assert len(w) == 1
+        wins[w[0]] += 1
+    assert np.abs(wins / 4000 - 0.125).max() < 0.03, wins
