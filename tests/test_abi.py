@@ -92,3 +92,42 @@ def test_split_hints_take_zero_rows():
     assert L.agb_spconv_split_hint(0, 27, 512, 512) == 1
     assert L.agb_dense_split_hint(0, 3840, 256) == 1
     assert L.agb_dense_bn_chunks(0, 64, 64) == 0
+
+
+def test_round6_entry_points_validate_before_any_launch():
+    """The block-level, head and alias entry points: field table from the library itself, arena sizing on the host, argument
+    errors before any launch (safe without a GPU)."""
+    import ctypes
+    from dpcr_agb_amd import _lib
+    import dpcr_agb_amd.fused_blocks as FB
+    import dpcr_agb_amd.head_ops, dpcr_agb_amd.kpconv_ops, dpcr_agb_amd.sparse_ops  # noqa: F401,E401
+    L = _lib.load()
+    idx = FB._fields()
+    assert len(idx) == L.agb_net_field_count() >= 100
+    for name in ("x", "n_out", "c1_w", "c2_nbr", "cd_tile_cls", "se_w1", "keep", "gzero", "pool_nbrT", "c1_wt"):
+        assert name in idx, name
+    tab = FB._Table()
+    tab.set(n_in=211000, n_out=211000, B=32, has_down=0, cmp_mode=1, cmp_il=-1, se_H=4)
+    tab.setp("c1_", K3=27, cin=64, cout=64)
+    tab.setp("c2_", K3=27, cin=64, cout=64)
+    saved, fwd, bwd = (L.agb_net_block_bytes(tab.buf, w) for w in (0, 1, 2))
+    assert saved >= 3 * 211000 * 64 * 4 and fwd > 0 and bwd >= 4 * 211000 * 64 * 4      # z1, a1, z2 / dz2, dr, da1, dz1
+    tab.set(has_down=1, n_in=211000, n_out=61000)
+    tab.setp("c1_", cout=128)
+    tab.setp("c2_", cin=128, cout=128)
+    tab.setp("cd_", K3=1, cin=64, cout=128)
+    assert L.agb_net_block_bytes(tab.buf, 0) >= 5 * 61000 * 128 * 4                      # + zd, r
+    assert L.agb_net_block_fwd(None, None, 0, None, 0, None) == -1 and b"arenas are required" in L.agb_last_error()
+    assert L.agb_net_stem_bwd(tab.buf, None, 0, None, 0, None) == -1
+    # head + loss: T out of range / null arguments
+    assert L.agb_reg_head_fwd(None, 512, 32, 512, 0, None, None, None, None, None, None, 1, None, None, None, None, None) == -1
+    assert b"T 0" in L.agb_last_error()
+    assert L.agb_reg_head_fwd(None, 512, 32, 512, 2, None, None, None, None, None, None, 9, None, None, None, None, None) == -1
+    assert b"loss mask" in L.agb_last_error()
+    # data gradient with an addend: the small-Cin kernels do not take one
+    rc = L.agb_spconv_bwd_data(None, 4, None, None, 0, 0, None, 64, 10, 27, 64, 4, None, None, None, 0, 1, None,
+                               ctypes.c_void_p(16), 64, None)
+    assert rc == -1 and b"addend" in L.agb_last_error()
+    assert _lib.size_call("agb_kpconv_bwd_workspace_bytes", 1000, 15, 16, 32) >= (1000 * 15 * 16 + 15 * 16 * 32) * 4
+    assert L.agb_spconv_weight_transpose_batched(None, 0, 0, None) == -1
+    assert L.agb_weight_twins_batched(None, 3, 10, None) == -1
