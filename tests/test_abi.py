@@ -125,7 +125,8 @@ def test_round6_entry_points_validate_before_any_launch():
     assert L.agb_reg_head_fwd(None, 512, 32, 512, 2, None, None, None, None, None, None, 9, None, None, None, None, None) == -1
     assert b"loss mask" in L.agb_last_error()
     # data gradient with an addend: the small-Cin kernels do not take one
-    rc = L.agb_spconv_bwd_data(None, 4, None, None, 0, 0, None, 64, 10, 27, 64, 4, None, None, None, 0, 1, None,
+    # (dY rows 4 floats wide = the "Cin" of the forward kernels: the stem-like small-Cin path; a non-NULL map pointer)
+    rc = L.agb_spconv_bwd_data(None, 4, None, ctypes.c_void_p(64), 10, 0, None, 64, 10, 27, 64, 4, None, None, None, 0, 1, None,
                                ctypes.c_void_p(16), 64, None)
     assert rc == -1 and b"addend" in L.agb_last_error()
     assert _lib.size_call("agb_kpconv_bwd_workspace_bytes", 1000, 15, 16, 32) >= (1000 * 15 * 16 + 15 * 16 * 32) * 4
