@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..kp_dispositions import kernel_disposition
-from ..kpconv_ops import KPConvSymmetricFunction, KPGatherFunction, KPMaxPoolFunction, as_index
+from ..kpconv_ops import KPConvFusedFunction, KPConvSymmetricFunction, KPGatherFunction, KPMaxPoolFunction, as_index
 from ..norm_ops import ACT_IDS, AddActFunction, batch_norm_act, batch_norm_add_act
 from ..sparse_ops import DenseConvFunction, current as current_options, dense_linear, model_scope, segment_reduce, \
     take_bn_hint
@@ -52,8 +52,11 @@ class KPConv(nn.Module):
         idx = as_index(neighb_inds)
         # same point set on both sides with a symmetric neighbour relation (marked by the input pyramid on uncropped
         # self-searches): the scatter-free backward
-        if q_pts is s_pts and getattr(neighb_inds, "agb_symmetric", False) and x.is_cuda and \
-                KPConvSymmetricFunction.supported(self.K, self.in_channels, self.out_channels):
+        symmetric = q_pts is s_pts and getattr(neighb_inds, "agb_symmetric", False) and x.is_cuda
+        if symmetric and KPConvFusedFunction.supported(self.K, self.in_channels, self.out_channels, idx, current_options()):
+            # gather + contraction in one kernel per direction (csrc/kpfused.hip)
+            return KPConvFusedFunction.apply(x, q_pts, idx, self.kernel_points, self.KP_extent, self.weights)
+        if symmetric and KPConvSymmetricFunction.supported(self.K, self.in_channels, self.out_channels):
             return take_bn_hint(KPConvSymmetricFunction.apply(x, q_pts, idx, self.kernel_points, self.KP_extent,
                                                               self.weights))
         wf = KPGatherFunction.apply(x, q_pts, s_pts, idx, self.kernel_points, self.KP_extent)

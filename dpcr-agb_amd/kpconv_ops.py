@@ -24,6 +24,14 @@ _lib.declare("agb_kpconv_bwd", [_V, _V, _V, _I, _I, _V, _V, _I, _V, _I, _F, _V, 
                                 __import__("ctypes").c_size_t, _V])
 
 
+# the whole layer as one kernel per direction (csrc/kpfused.hip)
+_S = __import__("ctypes").c_size_t
+_lib.declare("agb_kpconv_fused_supported", [_I, _I, _I])
+_lib.declare("agb_kpconv_fused_bwd_workspace_bytes", [_I, _I, _I, _I])        # (size_t: _lib.size_call)
+_lib.declare("agb_kpconv_fused_fwd", [_V, _V, _V, _I, _I, _V, _I, _V, _I, _F, _V, _V, _I, _I, _I, _V])
+_lib.declare("agb_kpconv_fused_bwd", [_V, _V, _V, _I, _I, _V, _I, _V, _I, _F, _V, _V, _I, _V, _I, _V, _I, _V, _S, _I, _I, _V])
+
+
 def is_ragged(idx):
     return hasattr(idx, "row_ptr")
 
@@ -143,6 +151,56 @@ class KPConvSymmetricFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wfd = _gather(dy, pts, pts, idx, (-kernel_points).contiguous(), ctx.extent).view(-1, K * cout)
             dx = dense_product(wfd, weights.permute(0, 2, 1).reshape(K * cout, cin), "dgrad1x1", opts=ctx.opts)
+        return dx, None, None, None, None, dw
+
+
+class KPConvFusedFunction(torch.autograd.Function):
+    """The same layer as KPConvSymmetricFunction (rigid KPConv on ONE point set with a symmetric, ragged neighbour relation,
+    blocks.py:264-400) as ONE kernel per direction: csrc/kpfused.hip gathers a tile of 16 / 32 query rows' weighted
+    neighbourhood features into LDS and contracts them with the kernel weights held in registers — wf[N, 15, Cin] is never
+    written.  Backward: one launch gathers dy with mirrored kernel points and feeds both dx = wfd . W^T and
+    dW[k, c, o] = sum_j x[j, c] wfd[j, k, o] (the symmetry again: the layer keeps x, not the 15x larger wf).  Fixed summation
+    order in both directions (no atomics)."""
+
+    @staticmethod
+    def supported(K, cin, cout, idx, opts):
+        return (opts.fused_kpconv and not opts.low_precision and is_ragged(idx)
+                and bool(_lib.load().agb_kpconv_fused_supported(int(K), int(cin), int(cout))))
+
+    @staticmethod
+    def forward(ctx, x, pts, idx, kernel_points, extent, weights):
+        x, pts, kernel_points, weights = x.contiguous(), pts.contiguous(), kernel_points.contiguous(), weights.contiguous()
+        K, cin, cout = weights.shape
+        N = x.shape[0]
+        out = torch.empty(N, cout, dtype=torch.float32, device=x.device)
+        _lib.CALL_NOTE = {"valid": int(idx.indices.shape[0]), "cin": cin, "cout": cout}
+        _lib.call("agb_kpconv_fused_fwd", _P(pts), _P(idx.row_ptr), _P(idx.indices), idx.limit, N, _P(x), x.stride(0),
+                  _P(kernel_points), K, float(extent), _P(weights), _P(out), out.stride(0), cin, cout, _lib.stream())
+        ctx.ragged = idx
+        ctx.save_for_backward(x, pts, kernel_points, weights)
+        ctx.extent = float(extent)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .sparse_ops import zeros_f32
+        x, pts, kernel_points, weights = ctx.saved_tensors
+        idx = ctx.ragged
+        K, cin, cout = weights.shape
+        N = x.shape[0]
+        dy = dy.contiguous()
+        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[5]
+        dx = torch.empty(N, cin, dtype=torch.float32, device=dy.device) if want_dx else None
+        dw = ws = None
+        nbytes = 0
+        if want_dw:
+            dw = torch.empty(K, cin, cout, dtype=torch.float32, device=dy.device)
+            nbytes = _lib.size_call("agb_kpconv_fused_bwd_workspace_bytes", N, K, cin, cout)
+            ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dy.device)
+        _lib.CALL_NOTE = {"valid": int(idx.indices.shape[0]), "cin": cin, "cout": cout, "dx": bool(want_dx), "dw": bool(want_dw)}
+        _lib.call("agb_kpconv_fused_bwd", _P(pts), _P(idx.row_ptr), _P(idx.indices), idx.limit, N, _P(dy), dy.stride(0),
+                  _P(kernel_points), K, ctx.extent, _P(weights), _P(x), x.stride(0), _P(dx), cin, _P(dw), 0, _P(ws), nbytes,
+                  cin, cout, _lib.stream())
         return dx, None, None, None, None, dw
 
 

@@ -60,18 +60,22 @@ class KernelOptions:
       fused_head           the regression head + loss of MinkowskiBaselineModel as one launch per direction (head_ops.py,
                            csrc/head.hip) instead of ~27 small library kernels; same arithmetic, its own summation order
                            (1e-6 of the library's).  Default on.
+      fused_kpconv         rigid KPConv layers on one point set (16 / 32 channels, ragged symmetric neighbour rows) as ONE
+                           kernel per direction (kpconv_ops.KPConvFusedFunction, csrc/kpfused.hip): the weighted neighbourhood
+                           features never go through HBM; fixed summation order.  Default on (fp32 operands only).
 
     Use: ``model.kernel_options = KernelOptions(precision="bf16")`` (the backbones run their forward pass inside it), or
     ``with KernelOptions(cmp_mode=128): ...`` around direct calls.  Autograd nodes keep the options they were created
     under for their backward pass.  ``DEFAULTS`` (environment-initialised) applies where nothing else is set."""
     __slots__ = ("precision", "cmp_mode", "cmp_interleave", "balanced_tiles", "bn_stats_in_epilogue", "fused_tail",
                  "deterministic_wgrad", "dw_variant", "bf16_storage", "bf16_activations", "closed_form_bias_grad",
-                 "fused_blocks", "fused_head")
+                 "fused_blocks", "fused_head", "fused_kpconv")
     PRECISIONS = ("fp32", "bf16", "bf16x3")
 
     def __init__(self, precision=None, cmp_mode=None, cmp_interleave=None, balanced_tiles=None,
                  bn_stats_in_epilogue=None, fused_tail=None, deterministic_wgrad=None, dw_variant=None,
-                 bf16_storage=None, bf16_activations=None, closed_form_bias_grad=None, fused_blocks=None, fused_head=None, base=None):
+                 bf16_storage=None, bf16_activations=None, closed_form_bias_grad=None, fused_blocks=None, fused_head=None,
+                 fused_kpconv=None, base=None):
         base = base if base is not None else (current() if "DEFAULTS" in globals() else None)
         pick = lambda v, name, dflt: v if v is not None else (getattr(base, name) if base is not None else dflt)  # noqa: E731
         self.precision = pick(precision, "precision", "fp32")
@@ -89,6 +93,7 @@ class KernelOptions:
         self.closed_form_bias_grad = bool(pick(closed_form_bias_grad, "closed_form_bias_grad", True))
         self.fused_blocks = bool(pick(fused_blocks, "fused_blocks", True))
         self.fused_head = bool(pick(fused_head, "fused_head", True))
+        self.fused_kpconv = bool(pick(fused_kpconv, "fused_kpconv", True))
 
     def replace(self, **kw):
         return KernelOptions(base=self, **kw)
@@ -142,7 +147,8 @@ DEFAULTS = KernelOptions(precision=os.environ.get("AGB_CONV_PRECISION", "fp32"),
                          dw_variant=int(os.environ.get("AGB_DW_VARIANT", "0")),
                          bf16_storage=os.environ.get("AGB_BF16_STORAGE", "1") != "0",
                          fused_blocks=os.environ.get("AGB_FUSED_BLOCKS", "1") != "0",
-                         fused_head=os.environ.get("AGB_FUSED_HEAD", "1") != "0")
+                         fused_head=os.environ.get("AGB_FUSED_HEAD", "1") != "0",
+                         fused_kpconv=os.environ.get("AGB_FUSED_KPCONV", "1") != "0")
 
 
 def set_conv_precision(name):

@@ -485,6 +485,26 @@ int agb_kpconv_gather_bwd_csr(const float* q, const float* s, const int32_t* row
 int agb_kp_maxpool_fwd_csr(const float* x, int ldx, const int32_t* row_ptr, const int32_t* indices, int limit,
                            const int32_t* max_count_dev, int Ns, float* y, int32_t* argmax, int N, int C, void* stream);
 
+/* The whole rigid KPConv layer as ONE kernel per direction (csrc/kpfused.hip; replaces the expression
+ * modules/KPConv/blocks.py:304-400: neighbours gathered, influences, matmul to [N, K, Cin], matmul with the kernel weights, sum
+ * over K): a layer whose query and support sets are the SAME points `pts` [N][3] with ragged neighbour rows (row_ptr / indices of
+ * agb_ball_query_fill_csr, rows cut at `limit` entries).  The weighted neighbourhood features wf[N, K, Cin] exist only as tiles
+ * in LDS; fixed summation order in both directions (no atomics, nothing to zero-fill).
+ *   agb_kpconv_fused_supported: 1 where the kernels cover the layer (K <= 16 kernel points, Cin == Cout in {16, 32}); N < 2^24.
+ *   fwd: out [N][ldo] from x [N][ldx], kp [K][3], W [K][Cin][Cout].
+ *   bwd: needs a SYMMETRIC neighbour relation (j in row n <=> n in row j: an uncropped radius search of a point set against
+ *        itself).  dx [N][lddx] (NULL: not wanted) and dW [K][Cin][Cout] (NULL: not wanted; accumulate != 0: added to dW) from dy
+ *        [N][lddy] and the layer input x [N][ldx]; workspace of agb_kpconv_fused_bwd_workspace_bytes bytes (used for dW only). */
+int agb_kpconv_fused_supported(int K, int Cin, int Cout);
+size_t agb_kpconv_fused_bwd_workspace_bytes(int N, int K, int Cin, int Cout);
+int agb_kpconv_fused_fwd(const float* pts, const int32_t* row_ptr, const int32_t* indices, int limit, int N, const float* x,
+                         int ldx, const float* kp, int K, float extent, const float* W, float* out, int ldo, int Cin, int Cout,
+                         void* stream);
+int agb_kpconv_fused_bwd(const float* pts, const int32_t* row_ptr, const int32_t* indices, int limit, int N, const float* dy,
+                         int lddy, const float* kp, int K, float extent, const float* W, const float* x, int ldx, float* dx,
+                         int lddx, float* dW, int accumulate, void* workspace, size_t workspace_bytes, int Cin, int Cout,
+                         void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * GridSampling3D(size, quantize_coords=True, mode="last") for a batch of clouds
  * (replaces core/data_transform/grid_transform.py:112-128).  perm int64[n]: within-cloud shuffle.

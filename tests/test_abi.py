@@ -132,3 +132,21 @@ def test_round6_entry_points_validate_before_any_launch():
     assert _lib.size_call("agb_kpconv_bwd_workspace_bytes", 1000, 15, 16, 32) >= (1000 * 15 * 16 + 15 * 16 * 32) * 4
     assert L.agb_spconv_weight_transpose_batched(None, 0, 0, None) == -1
     assert L.agb_weight_twins_batched(None, 3, 10, None) == -1
+    # the fused KPConv layer: coverage, workspace sizing, argument errors
+    assert L.agb_kpconv_fused_supported(15, 16, 16) == 1 and L.agb_kpconv_fused_supported(15, 32, 32) == 1
+    assert L.agb_kpconv_fused_supported(15, 64, 64) == 0 and L.agb_kpconv_fused_supported(15, 16, 32) == 0
+    assert L.agb_kpconv_fused_supported(17, 16, 16) == 0
+    ws = _lib.size_call("agb_kpconv_fused_bwd_workspace_bytes", 100000, 15, 32, 32)
+    assert ws >= 15 * 32 * 32 * 4 and ws % (15 * 32 * 32 * 4) == 0          # one partial weight gradient per workgroup
+    assert _lib.size_call("agb_kpconv_fused_bwd_workspace_bytes", 100000, 15, 64, 64) == 0
+    f = ctypes.c_float
+    assert L.agb_kpconv_fused_fwd(None, None, None, 40, 100, None, 64, None, 15, f(0.1), None, None, 64, 64, 64, None) == -1
+    assert b"not covered" in L.agb_last_error()
+    assert L.agb_kpconv_fused_fwd(None, None, None, 40, 100, None, 16, None, 15, f(0.1), None, None, 16, 16, 16, None) == -1
+    assert b"null pointer" in L.agb_last_error()
+    assert L.agb_kpconv_fused_fwd(None, None, None, 40, 1 << 24, None, 16, None, 15, f(0.1), None, None, 16, 16, 16, None) == -1
+    assert L.agb_kpconv_fused_fwd(None, None, None, 40, 0, None, 16, None, 15, f(0.1), None, None, 16, 16, 16, None) == 0
+    p1 = ctypes.c_void_p(256)
+    assert L.agb_kpconv_fused_bwd(p1, p1, p1, 40, 100, p1, 16, p1, 15, f(0.1), p1, None, 16, None, 16, p1, 0, None, 0, 16, 16,
+                                  None) == -1
+    assert b"workspace" in L.agb_last_error()

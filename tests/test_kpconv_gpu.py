@@ -101,6 +101,103 @@ def test_kpconv_symmetric_backward(device, g, cin, cout):
         assert rel(dw, wr.grad) < RTOL, form
 
 
+
+def _ragged(nb, ns, device):
+    """kp_index.Neighbors (ragged rows) of a padded neighbour matrix (entries >= ns are padding)."""
+    from dpcr_agb_amd import kp_index
+    nb = np.asarray(nb)
+    counts = (nb < ns).sum(1).astype(np.int32)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    indices = np.concatenate([row[:c] for row, c in zip(nb, counts)]).astype(np.int32)
+    mc = int(counts.max())
+    out = kp_index.Neighbors(D(row_ptr, device), D(indices, device), len(nb), ns, mc,
+                             torch.tensor([mc], dtype=torch.int32, device=device))
+    out.agb_symmetric = True
+    return out
+
+
+@pytest.mark.parametrize("cin", [16, 32])
+def test_kpconv_fused_layer_matches_reference(device, g, cin):
+    """csrc/kpfused.hip (gather + influence + kernel-weight contraction in ONE kernel per direction, wf never in HBM) on the
+    reference's own uncropped radius search: output, dx and dW against an fp64 evaluation of the reference formula
+    (blocks.py:304-400) at 1e-4 and against the two-kernel form of this library at 1e-5; bitwise repeatable."""
+    import dpcr_agb_amd.backbones.kpconv as KB
+    from dpcr_agb_amd import _lib
+    from dpcr_agb_amd.sparse_ops import KernelOptions
+    ns = len(g["points0"])
+    assert _is_symmetric(g["neighbors0"], ns)
+    rng = np.random.default_rng(7)
+    conv = KB.KPConv(15, 3, cin, cin, float(g["L_ext"]), 0.08).to(device)
+    with torch.no_grad():
+        conv.kernel_points.copy_(D(g["L_kp"], device))
+    pts = D(g["points0"], device)
+    xs = rng.standard_normal((ns, cin)).astype(np.float32)
+    gy = rng.standard_normal((ns, cin)).astype(np.float32)
+    res = {}
+    for form in ("two-kernel", "fused", "fused again"):
+        idx = _ragged(g["neighbors0"], ns, device)
+        calls = []
+        orig = _lib.call
+        _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            with KernelOptions(fused_kpconv=form != "two-kernel"):
+                conv.zero_grad()
+                x = D(xs, device, True)
+                y = conv(pts, pts, idx, x)
+                y.backward(D(gy, device))
+        finally:
+            _lib.call = orig
+        fused = [c for c in calls if c.startswith("agb_kpconv_fused")]
+        assert fused == (["agb_kpconv_fused_fwd", "agb_kpconv_fused_bwd"] if form != "two-kernel" else []), calls
+        assert ("agb_kpconv_gather_fwd_csr" in calls) == (form == "two-kernel"), calls
+        res[form] = (y.detach().clone(), x.grad.clone(), conv.weights.grad.clone())
+    xr = torch.from_numpy(xs).double().requires_grad_(True)
+    wr = conv.weights.detach().cpu().double().requires_grad_(True)
+    p64 = torch.from_numpy(g["points0"]).double()
+    yr = R.kpconv(p64, p64, torch.from_numpy(g["neighbors0"]).long(), xr, torch.from_numpy(g["L_kp"]).double(), wr, float(g["L_ext"]))
+    yr.backward(torch.from_numpy(gy).double())
+    for form, (y, dx, dw) in res.items():
+        assert rel(y, yr) < RTOL and rel(dx, xr.grad) < RTOL and rel(dw, wr.grad) < RTOL, form
+    for a, b in zip(res["fused"], res["two-kernel"]):
+        assert rel(a, b) < 1e-5
+    assert all(torch.equal(a, b) for a, b in zip(res["fused"], res["fused again"]))
+
+
+@pytest.mark.parametrize("n,radius", [(1, 0.3), (37, 0.5), (700, 0.45)])
+def test_kpconv_fused_edge_shapes(device, n, radius):
+    """Rows with more than 64 neighbours (a second pass over the row), tiles with fewer than 16 rows, a single point; only the
+    input gradient / only the weight gradient wanted."""
+    from dpcr_agb_amd import kp_index
+    from dpcr_agb_amd.kpconv_ops import KPConvFusedFunction, KPConvSymmetricFunction
+    from dpcr_agb_amd.sparse_ops import current
+    torch.manual_seed(n)
+    pts = torch.rand(n, 3, device=device)
+    lens = np.array([n], dtype=np.int64)
+    nb = kp_index.batch_neighbors_ragged(pts, pts, lens, lens, radius)
+    nb.agb_symmetric = True
+    if n == 700:
+        assert nb.max_count > 64
+    kp = (torch.rand(15, 3, device=device) - 0.5) * radius
+    for C in (16, 32):
+        w = torch.randn(15, C, C, device=device) * 0.1
+        x0, gy = torch.randn(n, C, device=device), torch.randn(n, C, device=device)
+        assert KPConvFusedFunction.supported(15, C, C, nb, current())
+        out = {}
+        for name, fn in (("ref", KPConvSymmetricFunction), ("fused", KPConvFusedFunction)):
+            x, wt = x0.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = fn.apply(x, pts, nb, kp, 0.6 * radius, wt)
+            y.backward(gy)
+            out[name] = (y.detach(), x.grad, wt.grad)
+        for a, b in zip(out["fused"], out["ref"]):
+            assert rel(a, b) < 1e-5, (n, C)
+        # one gradient only
+        x, wt = x0.clone().requires_grad_(True), w.clone()
+        KPConvFusedFunction.apply(x, pts, nb, kp, 0.6 * radius, wt).backward(gy)
+        assert torch.equal(x.grad, out["fused"][1])
+        x, wt = x0.clone(), w.clone().requires_grad_(True)
+        KPConvFusedFunction.apply(x, pts, nb, kp, 0.6 * radius, wt).backward(gy)
+        assert torch.equal(wt.grad, out["fused"][2])
+
 def test_pool_helpers_match_reference(device, g):
     from dpcr_agb_amd.backbones.kpconv import GlobalSumBlock
     from dpcr_agb_amd.kpconv_ops import KPMaxPoolFunction
@@ -206,22 +303,43 @@ def test_input_pyramid_and_network_vs_oracle(device):
         assert nb.agb_symmetric
         if lvl >= 3:
             assert _is_symmetric(nb.cpu().numpy(), len(inp["points"][lvl]))
+    from dpcr_agb_amd.sparse_ops import KernelOptions
     grads = {}
     gy = torch.randn_like(out)
-    for form in ("scatter", "symmetric"):
+    for form in ("scatter", "symmetric", "fused"):
         for nb in inp["neighbors"]:
             nb.agb_symmetric = form != "scatter"
         model.model.zero_grad()
-        o = model.model(O(inp))
-        assert rel(o, ref) < RTOL, form
-        o.backward(gy)
+        with KernelOptions(fused_kpconv=form == "fused"):
+            o = model.model(O(inp))
+            assert rel(o, ref) < RTOL, form
+            o.backward(gy)
         grads[form] = {k: p.grad.clone() for k, p in model.model.named_parameters() if p.grad is not None}
     gmax = max(float(v.abs().max()) for v in grads["scatter"].values())
+
+    def worst(a, b):
+        return max(float((b[k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gmax) for k, v in a.items())
     # same forward kernels, different backward: the two forms agree to rounding
-    bad = {k: float((grads["symmetric"][k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gmax)
-           for k, v in grads["scatter"].items()}
-    bad = {k: e for k, e in bad.items() if e >= RTOL}
-    assert not bad, bad
+    assert worst(grads["scatter"], grads["symmetric"]) < RTOL
+    # The one-kernel layers (csrc/kpfused.hip) sum the forward in another order.  Through 15 blocks of batch-normalised fp32
+    # layers (a handful of rows on the last level) the parameter gradients of EVERY form sit 2e-2 .. 6e-2 from the fp64
+    # gradients of the oracle in the max-norm above (and move by that much between two runs of the atomics of the strided
+    # layers); the fused form must be on that same floor — measured as the mean relative L2 error over the parameter tensors.
+    # (The layer itself is held to 1e-4 / 1e-5 in test_kpconv_fused_layer_matches_reference.)
+    sd64 = {k: v.detach().cpu().double() for k, v in model.model.state_dict().items()}
+    names = dict(model.model.named_parameters())
+    for k in sd64:
+        if k in names:
+            sd64[k].requires_grad_(True)
+    ref64 = R.kpcnn_forward(sd64, ocfg, ob, training=True)
+    ref64.backward(gy.detach().cpu().double())
+    og = {k: v.grad.float().to(device) for k, v in sd64.items() if v.grad is not None and k in grads["scatter"]}
+    assert len(og) > 100
+
+    def mean_l2(a, b):
+        return float(np.mean([float((b[k] - v).norm() / (v.norm() + 1e-3 * gmax)) for k, v in a.items()]))
+    floor = mean_l2(og, grads["scatter"])
+    assert mean_l2(og, grads["fused"]) < 3.0 * floor + 1e-3, (mean_l2(og, grads["fused"]), floor)
 
 
 def test_kpconv_training_step(device):

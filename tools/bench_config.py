@@ -125,6 +125,26 @@ def kp_gather_bwd_cost(args, note=None):
     return valid * K * (10.0 + 2.0 * cin), valid * (12.0 + cin * 4.0) + N * K * cin * 4.0 + N * 16.0
 
 
+def kp_fused_fwd_cost(args, note=None):
+    """agb_kpconv_fused_fwd(pts, row_ptr, indices, limit, N, x, ldx, kp, K, extent, W, out, ldo, Cin, Cout, stream): SURVEY.md
+    8(d) fused KPConv: sum(valid) * (12 + Cin * 4) + N * Cout * 4 + K * Cin * Cout * 4 bytes (+ the index rows: 4 per entry, 4
+    per row); FLOPs = gather sum(valid) * K * (10 + 2 Cin) + contraction 2 N K Cin Cout."""
+    N, K, cin, cout = args[4], args[8], args[13], args[14]
+    valid = (note or {}).get("valid", 0)
+    return (valid * K * (10.0 + 2.0 * cin) + 2.0 * N * K * cin * cout,
+            valid * (12.0 + cin * 4.0 + 4.0) + N * (cout * 4.0 + 16.0) + K * cin * cout * 4.0)
+
+
+def kp_fused_bwd_cost(args, note=None):
+    """agb_kpconv_fused_bwd(pts, row_ptr, indices, limit, N, dy, lddy, kp, K, extent, W, x, ldx, dx, lddx, dW, accumulate,
+    workspace, workspace_bytes, Cin, Cout, stream): the gather on dy, then dx = wfd W^T and dW = x^T wfd from the same tile."""
+    N, K, cin, cout = args[4], args[8], args[19], args[20]
+    note = note or {}
+    valid, both = note.get("valid", 0), int(bool(note.get("dx", True))) + int(bool(note.get("dw", True)))
+    return (valid * K * (10.0 + 2.0 * cout) + both * 2.0 * N * K * cin * cout,
+            valid * (12.0 + cout * 4.0 + 4.0) + N * (both * cin * 4.0 + 16.0) + 2.0 * K * cin * cout * 4.0)
+
+
 def pn_pool_fwd_cost(args):
     """agb_pointnet_pool_fwd_aux(Z, ldz, n, C, ...): the [n, C] pre-activation read once (SURVEY 8(d) PointNet)"""
     return 0.0, args[2] * args[3] * 4.0
@@ -145,11 +165,16 @@ ALL_COSTS = {
     "agb_spconv_bwd_weight_lp": wgrad_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost,
     "agb_dense_fwd_bn": dense_bn_call_cost,
     "agb_kpconv_gather_fwd_csr": kp_gather_fwd_cost, "agb_kpconv_gather_bwd_csr": kp_gather_bwd_cost,
+    "agb_kpconv_fused_fwd": kp_fused_fwd_cost, "agb_kpconv_fused_bwd": kp_fused_bwd_cost,
     "agb_pointnet_pool_fwd_aux": pn_pool_fwd_cost, "agb_pointnet_pool_bwd_aux": pn_pool_bwd_cost,
     "agb_bn_stats_tracked": rows_cost(2, 3, 1), "agb_bn_act_fwd": rows_cost(2, 3, 2), "agb_bn_act_bwd_colsum": rows_cost(4, 5, 3),
 }
 KERNEL_OF_ENTRY.update({"agb_kpconv_gather_fwd_csr": "k_kpconv_gather_mm_fwd", "agb_kpconv_gather_bwd_csr": "k_kpconv_gather_mm_bwd",
+                        "agb_kpconv_fused_fwd": "k_kpconv_fused", "agb_kpconv_fused_bwd": "k_kpconv_fused",
                         "agb_pointnet_pool_fwd_aux": "k_pn_pool_fwd", "agb_pointnet_pool_bwd_aux": "k_pn_bwd"})
+
+
+NOTE_COSTS = (kp_gather_fwd_cost, kp_gather_bwd_cost, kp_fused_fwd_cost, kp_fused_bwd_cost)    # priced with the wrapper's note
 
 
 def kernel_rooflines(groups, config=None, costs=None):
@@ -167,7 +192,7 @@ def kernel_rooflines(groups, config=None, costs=None):
             e["n"] += 1
             if cost is not None:
                 try:
-                    fl, by = cost(args, note) if cost in (kp_gather_fwd_cost, kp_gather_bwd_cost) else cost(args)
+                    fl, by = cost(args, note) if cost in NOTE_COSTS else cost(args)
                 except Exception:
                     fl, by = 0.0, 0.0
                 e["flops"] += fl
