@@ -104,13 +104,15 @@ class PlotBatch:
         out = PlotBatch(mv(self.batch), mv(self.coords), mv(self.x), mv(self.pos), None, None, self._n,
                         self.coord_bounds)
         out.y_reg, out.y_reg_mask, out.y_reg_mask_all = mv(self.y_reg), mv(self.y_reg_mask), self.y_reg_mask_all
-        for extra in ("pos_bounds", "area_name"):
+        for extra in ("pos_bounds", "area_name", "host_ptr"):
             if hasattr(self, extra):
                 setattr(out, extra, getattr(self, extra))
         return out
 
     @property
     def ptr(self):
+        if getattr(self, "host_ptr", None) is not None:     # (the device pipelines know the row counts on the host)
+            return self.host_ptr
         counts = torch.bincount(self.batch.cpu(), minlength=self._n)
         return torch.cat([counts.new_zeros(1), counts.cumsum(0)])
 

@@ -61,7 +61,9 @@ class NFITrainConfig:
     polygons: list = field(default_factory=lambda: [HEXAGON])
     polygon_rotate: float = 180.0
     polygon_size: tuple = (1.0, 1.0)
-    voxel: float = 0.0125
+    voxel: Optional[float] = 0.0125       # None: the point chain (xy.yaml: no GridSampling3D / flip / shift tail)
+    max_points: int = 16000               # sparse-xy.yaml:70 (xy.yaml:70: 6144)
+    min_points: int = 500
 
 
 def rotation_matrix(thetas: torch.Tensor) -> torch.Tensor:
@@ -209,7 +211,8 @@ class SparseTrainPipeline:
         self.cfg = cfg or NFITrainConfig()
         c = self.cfg
         # the deterministic tail (counts, features, voxelisation, coordinate augmentation) is the test pipeline's
-        self.tail = SparsePlotPipeline(nfi_test_transform(c.scale, c.center[:2], c.voxel) + nfi_coord_augmentation())
+        self.tail = SparsePlotPipeline(nfi_test_transform(c.scale, c.center[:2], c.voxel, c.max_points, c.min_points) +
+                                       (nfi_coord_augmentation() if c.voxel is not None else []))
         self.tail.device_shuffle = bool(device_shuffle)
 
     def augment(self, plots: List, draws, device):
@@ -283,6 +286,17 @@ class SparseTrainPipeline:
         pos, x, src, lens = self.tail.fix_counts_end(pos, x, src, host, B)
         return (yield from self.tail.finish_staged(pos, x, src, lens, B, y_reg=y_reg, perms=perms,
                                                    extent_hint=self.tail.grid_extent, reader=AsyncRead))
+
+
+class PointTrainPipeline(SparseTrainPipeline):
+    """xy.yaml train_transform (conf/data/instance/NFI/transforms/xy.yaml:4-75: the chain of the KPConv and PointNet models)
+    for a batch of raw plots -> a point batch on the device (pos, x = [ones, pos_z, xy_distance], batch; ``ptr`` on the host).
+    The same draws and device kernels as the sparse chain up to the features; MaxPoints 6144, no voxel tail."""
+
+    def __init__(self, cfg: Optional[NFITrainConfig] = None):
+        import dataclasses
+        cfg = dataclasses.replace(cfg or NFITrainConfig(), voxel=None) if cfg is not None else NFITrainConfig(voxel=None, max_points=6144)
+        super().__init__(cfg, device_shuffle=False)
 
 
 class StagedBatches:

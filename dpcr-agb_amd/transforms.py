@@ -105,12 +105,15 @@ class ShiftVoxels:
         self.apply_shift, self.p = apply_shift, p
 
 
-def nfi_test_transform(scale=(30.0, 30.0, 40.0), center=(0.5, 0.5), size=0.0125):
-    """sparse-xy.yaml test_transform with the values of conf/data/instance/NFI/default.yaml:18-23."""
-    return [ScalePos(*scale, op="div"), MoveCenterPosPerSample(*center), StartZFromZero(), Polygon2dExtend(HEXAGON),
-            MaxPoints(16000), MinPoints(500), XYZFeature(False, False, True), AddOnes(),
-            AddXYDistanceToCenter(*center), AddFeatsByKeys([True] * 3, ["ones", "pos_z", "xy_distance"]),
-            GridSampling3D(size, quantize_coords=True, mode="last")]
+def nfi_test_transform(scale=(30.0, 30.0, 40.0), center=(0.5, 0.5), size=0.0125, max_points=16000, min_points=500):
+    """sparse-xy.yaml test_transform with the values of conf/data/instance/NFI/default.yaml:18-23.  size = None: the point
+    chain of the KPConv / PointNet models (xy.yaml:76-113: the same list without GridSampling3D, MaxPoints 6144)."""
+    out = [ScalePos(*scale, op="div"), MoveCenterPosPerSample(*center), StartZFromZero(), Polygon2dExtend(HEXAGON),
+           MaxPoints(max_points), MinPoints(min_points), XYZFeature(False, False, True), AddOnes(),
+           AddXYDistanceToCenter(*center), AddFeatsByKeys([True] * 3, ["ones", "pos_z", "xy_distance"])]
+    if size is not None:
+        out.append(GridSampling3D(size, quantize_coords=True, mode="last"))
+    return out
 
 
 def nfi_coord_augmentation():
@@ -262,8 +265,14 @@ class SparsePlotPipeline:
         from .synthetic import PlotBatch
         dev = pos.device
         if self.grid is None:
-            batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(lens)).to(dev)
+            # a point batch (xy.yaml: KPConv / PointNet models): rows, features, plot of every row — built on the device
+            lens_np = np.asarray(lens, dtype=np.int64)
+            ptr = _ptr_tensor(lens_np, dev)
+            m = int(lens_np.sum())
+            batch = _elem_of_row(ptr, B, m, dev)[:m].to(torch.int64)
             out = PlotBatch(batch, None, x, pos, None, None, B, None)
+            out.src = src
+            out.host_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(lens_np)]))   # (data.ptr without a read-back)
         else:
             perm = seed = None
             if perms is not None:

@@ -334,3 +334,58 @@ def test_staged_train_chain_equals_the_waiting_one(device):
         ref = want[j]
         assert torch.equal(out.coords, ref.coords) and torch.equal(out.x, ref.x) and torch.equal(out.batch, ref.batch), j
         assert torch.equal(out.y_reg, ref.y_reg) and out.coord_bounds == ref.coord_bounds, j
+
+
+@pytest.mark.gpu
+def test_point_train_chain_of_the_kpconv_models(device):
+    """PointTrainPipeline = xy.yaml:4-75 (the sparse chain without the voxel tail, MaxPoints 6144): the rows it keeps are rows
+    of the augmented cloud (same draws as the sparse chain, checked against the oracle in
+    test_device_train_chain_matches_oracle), counts obey MaxPoints / MinPoints, features are [1, z, xy distance to the centre],
+    the row offsets are known on the host, the staged form gives the same batch, and the KPConv model trains on it."""
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
+    from dpcr_agb_amd.instance import KPConvModel
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, PointTrainPipeline, StagedBatches, draw_sample
+    cfg = NFITrainConfig(voxel=None, max_points=6144)
+    raws = [raw_plot(700 + i, n)[0] for i, n in enumerate([9000, 16000, 700, 12000, 300])]
+    _seed_all(5)
+    draws = [draw_sample(torch.from_numpy(r), cfg) for r in raws]
+    pipe = PointTrainPipeline(cfg)
+    assert pipe.tail.grid is None and pipe.tail.max_points == 6144 and pipe.tail.flip is None
+    ys = np.arange(10, dtype=np.float32).reshape(5, 2)
+    _seed_all(6)
+    out = pipe(raws, device, y_reg=ys, draws=draws)
+    pos_a, x_a, src_a, optr = pipe.augment(raws, draws, device)
+    optr = optr.cpu().numpy()
+    lens = np.diff(out.ptr.numpy())
+    assert out.coords is None and out.ptr.device.type == "cpu" and int(out.ptr[-1]) == out.pos.shape[0]
+    assert np.array_equal(lens, np.bincount(out.batch.cpu().numpy(), minlength=5))
+    for b in range(5):
+        kept = optr[b + 1] - optr[b]
+        assert lens[b] == (6144 if kept > 6144 else 500 if 0 < kept < 500 else kept), (b, kept, lens[b])
+    assert lens.max() == 6144 and lens.min() == 500            # both branches ran
+    # the rows are rows of the cropped, augmented cloud of their own plot
+    src, rows = out.src.cpu(), src_a.cpu()
+    lookup = {int(s): i for i, s in enumerate(rows[:optr[-1]].tolist())}
+    at = torch.tensor([lookup[int(s)] for s in src.tolist()])
+    assert torch.equal(out.pos.cpu(), pos_a.cpu()[at]) and torch.equal(out.x.cpu(), x_a.cpu()[at])
+    p, x = out.pos.cpu(), out.x.cpu()
+    assert torch.equal(x[:, 0], torch.ones(len(x))) and torch.equal(x[:, 1], p[:, 2])
+    assert torch.allclose(x, T.features(p), rtol=0, atol=1e-6)      # (torch.nn.PairwiseDistance: eps inside the norm)
+    assert torch.equal(out.y_reg.cpu(), torch.from_numpy(ys))
+    # staged: the count read-back picked up a step later — the same batch
+    flight = StagedBatches(PointTrainPipeline(cfg), device, torch.cuda.Stream())
+    flight.submit(raws, y_reg=ys, draws=draws)
+    _seed_all(6)
+    done = flight.advance()
+    torch.cuda.synchronize()
+    assert len(done) == 1 and torch.equal(done[0].pos, out.pos) and torch.equal(done[0].x, out.x)
+    assert torch.equal(done[0].batch, out.batch) and torch.equal(done[0].ptr, out.ptr)
+    # the KPConv model takes the batch as it is
+    torch.manual_seed(0)
+    model = KPConvModel(Opt(MODEL_OPTIONS["KPConv"]), "kpconv", synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_016)))
+    model.to(device).train()
+    model.init_train_objects(TRAINING_NFI)
+    model.set_input(out, device)
+    model.optimize_parameters(epoch=0, batch_size=5, num_batches=10)
+    assert np.isfinite(float(model.loss.detach()))

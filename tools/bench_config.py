@@ -657,9 +657,101 @@ def run_end2end(a):
     print(json.dumps(line), flush=True)
 
 
+def run_kpconv_e2e(a):
+    """The KPConv training step FROM RAW POINTS (SURVEY.md section 8(f)1 for the point models; the reference runs the xy.yaml chain
+    per sample in its DataLoader workers: conf/data/instance/NFI/transforms/xy.yaml:4-75 — the sparse chain without the voxel
+    tail, MaxPoints 6144): raw plots resident on the device -> PointTrainPipeline (draws per sample in DataLoader workers,
+    applied on the device) -> the 5-level input pyramid on the model's side stream -> KPCNN training step."""
+    import random
+    from collections import deque
+    from functools import partial
+    from torch.utils.data import DataLoader
+    from dpcr_agb_amd import synthetic
+    from dpcr_agb_amd.config import MODEL_OPTIONS, TRAINING_NFI, Opt
+    from dpcr_agb_amd.instance import KPConvModel
+    from dpcr_agb_amd.train_transforms import NFITrainConfig, PointTrainPipeline, SampleDraws, StagedBatches, collate_draws
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    B = a.batch or 32
+    cfg = NFITrainConfig(voxel=None, max_points=6144)
+    host_pool = []
+    for i in range(3):
+        raws, ys = [], []
+        for seed in range(i * B, (i + 1) * B):
+            pos, _, y = synthetic.make_plot(seed, a.points)
+            raws.append(np.stack([(pos[:, 0] - 0.5) * 30.0, (pos[:, 1] - 0.5) * 30.0, pos[:, 2] * 40.0 + 3.25], 1).astype(np.float32))
+            ys.append(y)
+        host_pool.append((raws, np.stack(ys)))
+    workers = 0 if a.inline_draws else max(1, min(6, usable_cores() - 2))
+    loader = DataLoader(SampleDraws([r for raws, _ in host_pool for r in raws], cfg, length=1 << 30), batch_size=B, shuffle=False,
+                        num_workers=workers, collate_fn=partial(collate_draws, cfg=cfg), pin_memory=workers > 0,
+                        worker_init_fn=SampleDraws.seed_worker, persistent_workers=workers > 0,
+                        prefetch_factor=4 if workers else None)
+    draws_it = iter(loader)
+    dev = torch.device("cuda:0")
+    ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_032))
+    model = KPConvModel(Opt(MODEL_OPTIONS["KPConv"]), "kpconv", ds)
+    model.to(dev).train()
+    model.init_train_objects(TRAINING_NFI)
+    model.reserve_workspace(dev, main_bytes=8 << 30, side_bytes=4 << 30)
+    pipe = PointTrainPipeline(cfg)
+    pool = [(raws, [torch.from_numpy(r).to(dev) for r in raws], y) for raws, y in host_pool]
+    side = torch.cuda.Stream(device=dev)
+    queue, points = deque(), []
+    flight = StagedBatches(pipe, dev, side)
+
+    def stage(i):
+        _, raws_d, y = pool[i % 3]
+        draws = next(draws_it)
+        done = flight.advance()
+        flight.submit(raws_d, y_reg=y, draws=draws)
+        for batch in done:
+            points.append(int(batch.pos.shape[0]))
+            # the pyramid's side stream continues where the chain's stream left the batch
+            ev = torch.cuda.Event()
+            ev.record(side)
+            batch.ready = ev
+            queue.append(batch)
+
+    n_stage = 0
+    while len(queue) < 2:
+        stage(n_stage)
+        n_stage += 1
+    staged = [n_stage]
+
+    def start_pyramid(batch):
+        if not hasattr(model, "_side_stream"):
+            model._side_stream = torch.cuda.Stream(device=dev)
+        model._side_stream.wait_event(batch.ready)
+        model.prefetch_input(batch, dev)
+
+    start_pyramid(queue[0])
+
+    def step(i):
+        batch = queue.popleft()
+        model.set_input(batch, dev)
+        stage(staged[0])
+        staged[0] += 1
+        start_pyramid(queue[0])           # the next batch's pyramid starts before this step is enqueued
+        model.optimize_parameters(epoch=0, batch_size=B, num_batches=133)
+
+    dt, gaps = timed_loop(step, a.steps, a.warmup)
+    floor_ms = host_floor(step, a.warmup + a.steps)
+    line = dict(metric="training plots/sec KPConv rigid, from raw points", value=round(B * a.steps / dt, 2), unit="plots/s", n_gpus=1,
+                steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+                vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload=f"raw {a.points}-pt synthetic plots resident on the device -> xy.yaml train chain on the device "
+                                     f"(ground removal, dropout, jitter, rotation, added / copied points, polygon crop, MaxPoints 6144, "
+                                     f"features; per-sample draws on the host, in DataLoader workers) -> 5-level input pyramid -> KPCNN "
+                                     f"training step, batch {B}, {np.mean(points[-3:]) / B:.0f} points/plot", global_batch=B,
+                            parallelism="dp1", final_loss=round(float(model.loss.detach()), 5)),
+                step_ms_p10=round(gaps[int(len(gaps) * 0.1)], 3), step_ms_p50=round(gaps[len(gaps) // 2], 3),
+                step_ms_p90=round(gaps[int(len(gaps) * 0.9)], 3), host_enqueue_floor_ms=floor_ms)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", choices=["pointnet", "kpconv", "end2end"])
+    ap.add_argument("which", choices=["pointnet", "kpconv", "end2end", "kpconv_e2e"])
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0)
@@ -680,7 +772,7 @@ def main():
     # hiccups of the KPConv loop: host stalls with zero device allocations and no pageable copy in flight).
     import dpcr_agb_amd
     dpcr_agb_amd.limit_host_threads()
-    {"pointnet": run_pointnet, "kpconv": run_kpconv, "end2end": run_end2end}[a.which](a)
+    {"pointnet": run_pointnet, "kpconv": run_kpconv, "end2end": run_end2end, "kpconv_e2e": run_kpconv_e2e}[a.which](a)
 
 
 if __name__ == "__main__":
