@@ -61,7 +61,9 @@ struct KpfArgs {
 // NW waves per workgroup, RB blocks of 16 rows per tile (the W registers of a wave serve all RB blocks)
 template <int CG, int CO, bool DW, int NW, int RB>
 __global__ __launch_bounds__(64 * NW) void k_kpconv_fused(KpfArgs a) {
-    static_assert(NW % CO == 0 && 16 * RB == 4 * NW, "one column block per wave, four rows per wave");
+    static_assert(NW % CO == 0 && (16 * RB) % NW == 0 && (8 * NW) % (16 * RB) == 0, "one column block per wave, whole rows per wave");
+    constexpr int RPW = 16 * RB / NW;                            // rows of a wave (in lockstep)
+    constexpr int UB = 8 / RPW;                                  // blocks of four neighbours of each row per trip: 32 row fetches in flight
     constexpr int Cg = 16 * CG, Co = 16 * CO, R = 16 * RB;
     constexpr int SPLITK = NW / CO;                              // waves sharing a column block
     constexpr int GW_MAX = (16 * CG + SPLITK - 1) / SPLITK;      // 16-index groups of the reduction per wave (K <= 16)
@@ -123,8 +125,8 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_fused(KpfArgs a) {
             // The four rows of a wave run in lockstep for max(length) trips: the tile's R rows are RANKED by neighbour count
             // (every wave ranks all R: ~3 instructions per row) and wave w takes ranks 4w .. 4w+3 — rows of similar length
             // (at 21 +- 9 neighbours per row, four consecutive rows ran 5.1 trips where 2.7 were needed).
-            int rbeg[4], rlen[4], myrow[4];
-            float qxs[4], qys[4], qzs[4];
+            int rbeg[RPW], rlen[RPW], myrow[RPW];
+            float qxs[RPW], qys[RPW], qzs[RPW];
             int maxlen = 0;
             {
                 const int nl = min(n0 + (lane & (R - 1)), a.N - 1);
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_fused(KpfArgs a) {
                     rank += (lj > len_l || (lj == len_l && j < lane)) ? 1 : 0;          // longest first
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned long long hit = __ballot(lane < R && rank == 4 * wu + r);
+                for (int r = 0; r < RPW; ++r) {
+                    const unsigned long long hit = __ballot(lane < R && rank == RPW * wu + r);
                     const int row = __builtin_ctzll(hit);                                   // (ranks are a permutation of 0 .. R-1)
                     myrow[r] = row;
                     rbeg[r] = __builtin_amdgcn_readlane(lb, row);
@@ -150,40 +152,40 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_fused(KpfArgs a) {
                     qzs[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, plz), row));
                 }
             }
-            kpf_f32x4 acc[4][CG];
+            kpf_f32x4 acc[RPW][CG];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RPW; ++r)
 #pragma unroll
                 for (int t = 0; t < CG; ++t) acc[r][t] = kpf_f32x4{0.f, 0.f, 0.f, 0.f};
             const char* pts_b = reinterpret_cast<const char*>(a.pts);
             const char* feat_b = reinterpret_cast<const char*>(a.feat);
             const unsigned ldfb = 4u * (unsigned)a.ldf, moff = 4u * (unsigned)m;
-            int* ids = reinterpret_cast<int*>(red + SPLITK * R * Co) + 256 * wu;          // [4 rows][64] of this wave
+            int* ids = reinterpret_cast<int*>(red + SPLITK * R * Co) + 64 * RPW * wu;      // [RPW rows][64] of this wave
             for (int h0 = 0; h0 < maxlen; h0 += 64) {
                 // the rows' neighbour indices go through LDS: the trips below then depend on LDS reads only, and the feature
                 // fetches of all four rows stay in flight together (a cross-lane move of a loaded register made every trip
                 // wait for every outstanding fetch)
                 {
-                    int myid[4];
+                    int myid[RPW];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) myid[r] = h0 + lane < rlen[r] ? a.indices[rbeg[r] + h0 + lane] : -1;
+                    for (int r = 0; r < RPW; ++r) myid[r] = h0 + lane < rlen[r] ? a.indices[rbeg[r] + h0 + lane] : -1;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ids[64 * r + lane] = myid[r];
+                    for (int r = 0; r < RPW; ++r) ids[64 * r + lane] = myid[r];
                 }
                 __builtin_amdgcn_wave_barrier();
-                const int ntrip = (min(64, maxlen - h0) + 7) >> 3;
+                const int ntrip = (min(64, maxlen - h0) + 4 * UB - 1) / (4 * UB);
                 const int* idp = ids + g;
-                for (int trip = 0; trip < ntrip; ++trip, idp += 8) {
-                    int id[4][2];
-                    float px[4][2], py[4][2], pz[4][2], fb[4][2][CG];
+                for (int trip = 0; trip < ntrip; ++trip, idp += 4 * UB) {
+                    int id[RPW][UB];
+                    float px[RPW][UB], py[RPW][UB], pz[RPW][UB], fb[RPW][UB][CG];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) id[r][u] = idp[64 * r + 4 * u];
+                        for (int u = 0; u < UB; ++u) id[r][u] = idp[64 * r + 4 * u];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < RPW; ++r) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < UB; ++u) {
                             const unsigned ic = (unsigned)max(id[r][u], 0);
                             const float* pp = reinterpret_cast<const float*>(pts_b + __umul24(ic, 12u));
                             px[r][u] = pp[0], py[r][u] = pp[1], pz[r][u] = pp[2];
@@ -196,9 +198,9 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_fused(KpfArgs a) {
                     //  neighbours in space with similar counts, and a conditional update made the compiler move all
                     //  accumulators between the two register files every trip)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < RPW; ++r) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < UB; ++u) {
                             float av = kpf_influence(px[r][u] - qxs[r], py[r][u] - qys[r], pz[r][u] - qzs[r], kx, ky, kz, a.inv_ext);
                             av = id[r][u] < 0 ? 0.f : av;
 #pragma unroll
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_fused(KpfArgs a) {
                 __builtin_amdgcn_wave_barrier();
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RPW; ++r) {
                 float* trow = tile + myrow[r] * S;
 #pragma unroll
                 for (int t = 0; t < CG; ++t)
@@ -316,12 +318,12 @@ namespace {
 // the shape of a workgroup per channel width: (waves, 16-row blocks per tile)
 template <int CG> struct KpfShape;
 template <> struct KpfShape<1> { static constexpr int NW = 4, RB = 1; };
-template <> struct KpfShape<2> { static constexpr int NW = 8, RB = 2; };
+template <> struct KpfShape<2> { static constexpr int NW = 8, RB = 1; };
 
 template <int CG, int CO>
 constexpr size_t kpf_lds_bytes(int K) {
     return ((size_t)16 * KpfShape<CG>::RB * (K * 16 * CG + 4) +
-            (size_t)(KpfShape<CG>::NW / CO) * 16 * KpfShape<CG>::RB * 16 * CO + (size_t)KpfShape<CG>::NW * 256) * sizeof(float);
+            (size_t)(KpfShape<CG>::NW / CO) * 16 * KpfShape<CG>::RB * 16 * CO + (size_t)16 * KpfShape<CG>::RB * 64) * sizeof(float);
 }
 
 template <int CG, int CO, bool DW>
