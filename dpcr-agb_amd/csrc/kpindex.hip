@@ -15,6 +15,7 @@
 //     and are scaled by (float)(1.0/count); emission order is canonical (cell key ascending per cloud) — the
 //     reference emits in libstdc++ unordered_map iteration order, an artefact no consumer depends on.
 #include "agb_common.h"
+#include <stdlib.h>
 #include "scan.h"
 #include <float.h>
 #include <limits.h>
@@ -109,21 +110,67 @@ __global__ void k_cell_scatter(const float* __restrict__ sup, int ns, const int3
 
 #define BQ_CAP 1024  // hits one query can hold in LDS (the 16k-point plots of BASELINE.json peak at 265)
 
-// one wavefront per query. FILL = false: counts only.
+// The whole wave sorts one query's list of `count` keys (LDS, room for the next power of two >= max(count, 64)) by (d2, index)
+// and writes the row: ragged (row_ptr) or padded with the shadow index ns.
+__device__ __forceinline__ void bq_sort_emit(const int q, const int lane, unsigned long long* __restrict__ skeys, int count,
+                                             int32_t* __restrict__ out, int width, int ns, const int32_t* __restrict__ row_ptr) {
+    if (count <= 64) {
+        // At most one key per lane (the usual case: ~20-40 neighbours): rank = number of smaller keys, counted against
+        // broadcast LDS reads of the list — ~4 instructions per key instead of the 21 compare-exchange passes of a 64-key
+        // bitonic network, which were 70 % of this kernel's instructions.  Keys are distinct (the index is in the low
+        // word): the ranks are a permutation, the order is exactly the sorted one.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long mykey = lane < count ? skeys[lane] : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < count; ++j) rank += skeys[j] < mykey ? 1 : 0;
+        int32_t* row = row_ptr ? out + row_ptr[q] : out + (long long)q * width;
+        if (row_ptr) width = count;
+        if (lane < count && rank < width) row[rank] = (int)(unsigned)(mykey & 0xFFFFFFFFull);
+        if (!row_ptr)
+            for (int j = count + lane; j < width; j += 64) row[j] = ns;
+        return;
+    }
+    // bitonic sort of the hit keys (padded with all-ones) — wave-synchronous on the wave's own LDS slab
+    int n2 = 64;
+    while (n2 < count) n2 <<= 1;
+    for (int i = count + lane; i < n2; i += 64) skeys[i] = ~0ull;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < n2; i += 64) {
+                int l = i ^ j;
+                if (l > i) {
+                    unsigned long long a = skeys[i], c2 = skeys[l];
+                    bool up = (i & k) == 0;
+                    if ((a > c2) == up) {
+                        skeys[i] = c2;
+                        skeys[l] = a;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (row_ptr) {
+        int32_t* row = out + row_ptr[q];
+        for (int j = lane; j < count; j += 64) row[j] = (int)(unsigned)(skeys[j] & 0xFFFFFFFFull);
+        return;
+    }
+    for (int j = lane; j < width; j += 64)
+        out[(long long)q * width + j] = j < count ? (int)(unsigned)(skeys[j] & 0xFFFFFFFFull) : ns;
+}
+
+// one wavefront per query (`skeys`: the wave's slab of BQ_CAP keys). FILL = false: counts only.
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_ball_query(const float* __restrict__ qry, int nq,
-                                                    const int32_t* __restrict__ q_elem,  // batch element of a query
-                                                    CellGrid g, const int32_t* __restrict__ cell_start,
-                                                    const float4* __restrict__ sorted, float r2, int ns,
-                                                    int32_t* __restrict__ counts, int32_t* __restrict__ out,
-                                                    int width, int32_t* status,
-                                                    const int32_t* __restrict__ row_ptr = nullptr) {
+__device__ __forceinline__ void bq_one_query(const int q, const int lane, unsigned long long* __restrict__ skeys,
+                                             const float* __restrict__ qry, const int32_t* __restrict__ q_elem, const CellGrid& g,
+                                             const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted, float r2,
+                                             int ns, int32_t* __restrict__ counts, int32_t* __restrict__ out, int width,
+                                             int32_t* status, const int32_t* __restrict__ row_ptr) {
     // row_ptr != NULL (FILL): ragged output — row q is out[row_ptr[q] .. row_ptr[q + 1]) (the exclusive scan of the count
     // pass), nothing is padded; NULL: the reference's padded matrix out[q * width + j], shadow index ns behind the row
-    __shared__ unsigned long long s_keys[4][FILL ? BQ_CAP : 1];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + w;
-    if (q >= nq) return;
     const float qx = qry[3 * (long long)q], qy = qry[3 * (long long)q + 1], qz = qry[3 * (long long)q + 2];
     const int b = q_elem[q];
     const int cx = cell_coord(qx, g.ox, g.inv_cs, g.X), cy = cell_coord(qy, g.oy, g.inv_cs, g.Y),
@@ -169,7 +216,7 @@ __global__ __launch_bounds__(256) void k_ball_query(const float* __restrict__ qr
         unsigned long long m = __ballot(hit);
         if (FILL && hit) {
             int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < BQ_CAP) s_keys[w][pos] = key;
+            if (pos < BQ_CAP) skeys[pos] = key;
         }
         count += __popcll(m);
     }
@@ -181,52 +228,168 @@ __global__ __launch_bounds__(256) void k_ball_query(const float* __restrict__ qr
         if (lane == 0) atomicAdd(&status[0], 1);
         count = BQ_CAP;
     }
-    if (count <= 64) {
-        // At most one key per lane (the usual case: ~20-40 neighbours): rank = number of smaller keys, counted against
-        // broadcast LDS reads of the list — ~4 instructions per key instead of the 21 compare-exchange passes of a 64-key
-        // bitonic network, which were 70 % of this kernel's instructions.  Keys are distinct (the index is in the low
-        // word): the ranks are a permutation, the order is exactly the sorted one.
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long mykey = lane < count ? s_keys[w][lane] : ~0ull;
-        int rank = 0;
-        for (int j = 0; j < count; ++j) rank += s_keys[w][j] < mykey ? 1 : 0;
-        int32_t* row = row_ptr ? out + row_ptr[q] : out + (long long)q * width;
-        if (row_ptr) width = count;
-        if (lane < count && rank < width) row[rank] = (int)(unsigned)(mykey & 0xFFFFFFFFull);
-        if (!row_ptr)
-            for (int j = count + lane; j < width; j += 64) row[j] = ns;
-        return;
-    }
-    // bitonic sort of the hit keys (padded with all-ones) — wave-synchronous on the wave's own LDS slab
-    int n2 = 64;
-    while (n2 < count) n2 <<= 1;
-    for (int i = count + lane; i < n2; i += 64) s_keys[w][i] = ~0ull;
-    __builtin_amdgcn_wave_barrier();
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < n2; i += 64) {
-                int l = i ^ j;
-                if (l > i) {
-                    unsigned long long a = s_keys[w][i], c2 = s_keys[w][l];
-                    bool up = (i & k) == 0;
-                    if ((a > c2) == up) {
-                        s_keys[w][i] = c2;
-                        s_keys[w][l] = a;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+    bq_sort_emit(q, lane, skeys, count, out, width, ns, row_ptr);
+}
+
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ball_query(const float* __restrict__ qry, int nq,
+                                                    const int32_t* __restrict__ q_elem,  // batch element of a query
+                                                    CellGrid g, const int32_t* __restrict__ cell_start,
+                                                    const float4* __restrict__ sorted, float r2, int ns,
+                                                    int32_t* __restrict__ counts, int32_t* __restrict__ out,
+                                                    int width, int32_t* status,
+                                                    const int32_t* __restrict__ row_ptr = nullptr) {
+    __shared__ unsigned long long s_keys[4][FILL ? BQ_CAP : 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq) return;
+    bq_one_query<FILL>(q, lane, s_keys[w], qry, q_elem, g, cell_start, sorted, r2, ns, counts, out, width, status, row_ptr);
+}
+
+// FOUR queries per wavefront, 16 lanes each (round 6: the one-query-per-wave form spent ~300 wave instructions per query —
+// cell arithmetic, nine run look-ups and a 9-lane prefix for ONE query per wave, a run search per candidate, a rank loop
+// of count iterations for one key per lane).  A quarter walks its nine (dy, dz) runs one after the other, 16 candidates per
+// step (a run of three x-adjacent cells holds ~14 points: no search for "which run holds candidate c"); hits are compacted
+// per quarter with one ballot; every lane ranks its keys (positions sl, sl + 16, ..) against the quarter's list.  Same
+// candidates, same d2 arithmetic, same (d2, index) order as bq_one_query: bit-identical rows.  A query with more than
+// BQ4_CAP hits is redone by the whole wave with bq_one_query on the wave's full slab (4 x BQ4_CAP = BQ_CAP keys) after the
+// other quarters have written their rows.
+#define BQ4_CAP (BQ_CAP / 4)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ball_query4(const float* __restrict__ qry, int nq, const int32_t* __restrict__ q_elem,
+                                                     CellGrid g, const int32_t* __restrict__ cell_start,
+                                                     const float4* __restrict__ sorted, float r2, int ns,
+                                                     int32_t* __restrict__ counts, int32_t* __restrict__ out, int width,
+                                                     int32_t* status, const int32_t* __restrict__ row_ptr = nullptr) {
+    __shared__ unsigned long long s_keys[4][FILL ? BQ_CAP : 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane >> 4, sl = lane & 15;
+    const int q = (blockIdx.x * 4 + w) * 4 + sub;
+    if ((blockIdx.x * 4 + w) * 4 >= nq) return;                  // (whole waves leave: no workgroup barrier in this kernel)
+    const bool live = q < nq;
+    const int qc = live ? q : nq - 1;
+    const float qx = qry[3 * (long long)qc], qy = qry[3 * (long long)qc + 1], qz = qry[3 * (long long)qc + 2];
+    const int b = q_elem[qc];
+    const int cx = cell_coord(qx, g.ox, g.inv_cs, g.X), cy = cell_coord(qy, g.oy, g.inv_cs, g.Y),
+              cz = cell_coord(qz, g.oz, g.inv_cs, g.Z);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.X - 1);
+    // lanes 0..8 of a quarter fetch its 9 (dy, dz) runs; every run covers 3 x-adjacent cells = one contiguous range
+    int beg = 0, len = 0;
+    if (live && sl < 9) {
+        const int yy = cy + (sl % 3) - 1, zz = cz + (sl / 3) - 1;
+        if (yy >= 0 && yy < g.Y && zz >= 0 && zz < g.Z) {
+            const int row = ((b * g.Z + zz) * g.Y + yy) * g.X;
+            beg = cell_start[row + x0];
+            len = cell_start[row + x1 + 1] - beg;
         }
     }
-    if (row_ptr) {
-        int32_t* row = out + row_ptr[q];
-        for (int j = lane; j < count; j += 64) row[j] = (int)(unsigned)(s_keys[w][j] & 0xFFFFFFFFull);
+    unsigned long long* keys = s_keys[w] + (FILL ? BQ4_CAP * sub : 0);
+    int count = 0;
+    auto take = [&](const float4 s, const bool valid) {
+        bool hit = false;
+        unsigned long long key = 0;
+        if (valid) {
+            const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            hit = d2 < r2;
+            key = ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(s.w);
+        }
+        const unsigned m16 = (unsigned)(__ballot(hit) >> (16 * sub)) & 0xFFFFu;
+        if (FILL && hit) {
+            const int pos = count + __popc(m16 & ((1u << sl) - 1u));
+            if (pos < BQ4_CAP) keys[pos] = key;
+        }
+        count += __popc(m16);
+    };
+    // the first 16 candidates of all nine runs are requested before any is looked at (a run holds ~14 points: one memory
+    // round trip per query instead of nine); longer runs continue below
+    int rbs[9], rls[9];
+    float4 sv[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        rbs[r] = __shfl(beg, r, 16);
+        rls[r] = __shfl(len, r, 16);
+        sv[r] = sl < rls[r] ? sorted[rbs[r] + sl] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) take(sv[r], sl < rls[r]);
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+        const int rb = __shfl(beg, r, 16), rl = __shfl(len, r, 16);
+        for (int off = 16; __ballot(off < rl) != 0ull; off += 16) {
+            const int c = off + sl;
+            take(c < rl ? sorted[rb + c] : make_float4(0.f, 0.f, 0.f, 0.f), c < rl);
+        }
+    }
+    if (!FILL) {
+        if (live && sl == 0) counts[q] = count;
         return;
     }
-    for (int j = lane; j < width; j += 64)
-        out[(long long)q * width + j] = j < count ? (int)(unsigned)(s_keys[w][j] & 0xFFFFFFFFull) : ns;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool over = count > BQ4_CAP;                           // (uniform in the quarter)
+    const int cnt = (live && !over) ? count : 0;
+    // rank of every key = number of smaller keys of the quarter's list (keys are distinct: the index is the low word)
+    int32_t* row = nullptr;
+    int wq = width;
+    if (live) {
+        row = row_ptr ? out + row_ptr[q] : out + (long long)q * width;
+        if (row_ptr) wq = count;
+    }
+    // lists of at most 32 keys (the self-searches: ~20-35 neighbours): ranked inside the quarter; longer ones (the pooling
+    // searches: up to ~270 at twice the radius) are sorted by the whole wave below, one query at a time
+    const bool small = cnt <= 32;
+    const int cs = small ? cnt : 0;
+    int csmax = cs;
+    csmax = max(csmax, __shfl_xor(csmax, 16, 64));
+    csmax = max(csmax, __shfl_xor(csmax, 32, 64));
+    if (csmax > 0) {
+        // at most two keys per lane (the usual case: ~20-35 neighbours): every lane meets the keys of the other 15 lanes of its
+        // quarter by rotating them through the 16-lane row (DPP row_ror: no LDS read, no wait)
+        const unsigned long long ka = sl < cs ? keys[sl] : ~0ull, kb = 16 + sl < cs ? keys[16 + sl] : ~0ull;
+        const unsigned kal = (unsigned)ka, kah = (unsigned)(ka >> 32), kbl = (unsigned)kb, kbh = (unsigned)(kb >> 32);
+        int ra = kb < ka ? 1 : 0, rb2 = ka < kb ? 1 : 0;
+        const bool two = csmax > 16;
+#define BQ_ROT(N)                                                                                                          \
+        {                                                                                                                  \
+            const unsigned long long oa = ((unsigned long long)(unsigned)__builtin_amdgcn_mov_dpp((int)kah, 0x120 + N, 0xF, 0xF, false) << 32) | \
+                                          (unsigned)__builtin_amdgcn_mov_dpp((int)kal, 0x120 + N, 0xF, 0xF, false);         \
+            ra += oa < ka ? 1 : 0;                                                                                         \
+            if (two) {                                                                                                     \
+                const unsigned long long ob = ((unsigned long long)(unsigned)__builtin_amdgcn_mov_dpp((int)kbh, 0x120 + N, 0xF, 0xF, false) << 32) | \
+                                              (unsigned)__builtin_amdgcn_mov_dpp((int)kbl, 0x120 + N, 0xF, 0xF, false);     \
+                ra += ob < ka ? 1 : 0;                                                                                     \
+                rb2 += (oa < kb ? 1 : 0) + (ob < kb ? 1 : 0);                                                              \
+            }                                                                                                              \
+        }
+        BQ_ROT(1) BQ_ROT(2) BQ_ROT(3) BQ_ROT(4) BQ_ROT(5) BQ_ROT(6) BQ_ROT(7) BQ_ROT(8) BQ_ROT(9) BQ_ROT(10) BQ_ROT(11)
+        BQ_ROT(12) BQ_ROT(13) BQ_ROT(14) BQ_ROT(15)
+#undef BQ_ROT
+        if (sl < cs && ra < wq) row[ra] = (int)kal;
+        if (16 + sl < cs && rb2 < wq) row[rb2] = (int)kbl;
+    }
+    const unsigned long long big = __ballot(live && !over && !small);
+    if (big != 0ull) {
+        __builtin_amdgcn_wave_barrier();
+        const int qbase = (blockIdx.x * 4 + w) * 4;
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t)
+            if ((big >> (16 * t)) & 1ull)
+                bq_sort_emit(qbase + t, lane, s_keys[w] + BQ4_CAP * t, __shfl(count, 16 * t, 64), out, width, ns, row_ptr);
+    }
+    if (live && small && !over && !row_ptr)
+        for (int j = cnt + sl; j < width; j += 16) row[j] = ns;
+    // queries with more hits than a quarter's list: the whole wave, one query at a time, on the wave's full slab
+    const unsigned long long ov = __ballot(live && over);
+    if (ov != 0ull) {
+        __builtin_amdgcn_wave_barrier();
+        const int qbase = (blockIdx.x * 4 + w) * 4;
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t)
+            if ((ov >> (16 * t)) & 1ull)
+                bq_one_query<true>(qbase + t, lane, s_keys[w], qry, q_elem, g, cell_start, sorted, r2, ns, counts, out, width, status,
+                                   row_ptr);
+    }
 }
 
 // ragged -> the reference's padded matrix (for callers of batch_neighbors; the kernels of this library walk the ragged form)
@@ -441,6 +604,12 @@ int agb_ball_grid_build(const float* supports, int ns, const int32_t* s_ptr, con
     return AGB_OK;
 }
 
+// AGB_BALL_QUERY_V1=1: the one-query-per-wave kernels of rounds 2-5 (A/B: tools/ballquery_ab.py); read once
+static bool bq_use_v1() {
+    static const bool v1 = [] { const char* e = getenv("AGB_BALL_QUERY_V1"); return e && e[0] == '1'; }();
+    return v1;
+}
+
 // counts[nq] and *max_count (device int, zeroed here)
 int agb_ball_query_count(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
                          const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius,
@@ -450,8 +619,12 @@ int agb_ball_query_count(const float* queries, int nq, const int32_t* q_elem, co
     (void)hipMemsetAsync(max_count, 0, sizeof(int32_t), s);
     if (nq > 0) {
         float r2 = radius * radius;
-        hipLaunchKernelGGL(k_ball_query<false>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
-                           cell_start, (const float4*)sorted, r2, 0, counts, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+        if (bq_use_v1())
+            hipLaunchKernelGGL(k_ball_query<false>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
+                               cell_start, (const float4*)sorted, r2, 0, counts, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+        else
+            hipLaunchKernelGGL(k_ball_query4<false>, dim3(agb_cdiv(nq, 16)), dim3(256), 0, s, queries, nq, q_elem, g,
+                               cell_start, (const float4*)sorted, r2, 0, counts, (int32_t*)nullptr, 0, (int32_t*)nullptr);
         int bx = agb_cdiv(nq, 256);
         if (bx > 256) bx = 256;
         hipLaunchKernelGGL(k_max_i32, dim3(bx), dim3(256), 0, s, counts, nq, max_count);
@@ -469,8 +642,12 @@ int agb_ball_query_fill(const float* queries, int nq, const int32_t* q_elem, con
     (void)hipMemsetAsync(status, 0, sizeof(int32_t) * 4, s);
     if (nq > 0 && width > 0) {
         float r2 = radius * radius;
-        hipLaunchKernelGGL(k_ball_query<true>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
-                           cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, out, width, status);
+        if (bq_use_v1())
+            hipLaunchKernelGGL(k_ball_query<true>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
+                               cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, out, width, status);
+        else
+            hipLaunchKernelGGL(k_ball_query4<true>, dim3(agb_cdiv(nq, 16)), dim3(256), 0, s, queries, nq, q_elem, g,
+                               cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, out, width, status);
     }
     AGB_CHECK_LAUNCH("agb_ball_query_fill");
     return AGB_OK;
@@ -502,8 +679,12 @@ int agb_ball_query_fill_csr(const float* queries, int nq, const int32_t* q_elem,
     if (nq > 0) {
         AGB_CHECK_ARG(row_ptr && indices, "agb_ball_query_fill_csr: null pointer");
         float r2 = radius * radius;
-        hipLaunchKernelGGL(k_ball_query<true>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
-                           cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, indices, 0, status, row_ptr);
+        if (bq_use_v1())
+            hipLaunchKernelGGL(k_ball_query<true>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
+                               cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, indices, 0, status, row_ptr);
+        else
+            hipLaunchKernelGGL(k_ball_query4<true>, dim3(agb_cdiv(nq, 16)), dim3(256), 0, s, queries, nq, q_elem, g,
+                               cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, indices, 0, status, row_ptr);
     }
     AGB_CHECK_LAUNCH("agb_ball_query_fill_csr");
     return AGB_OK;

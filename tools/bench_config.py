@@ -44,7 +44,7 @@ def usable_cores():
 # entry points whose launch notes its compute kernel (agb_last_kernel): the roofline entry names that kernel
 KERNEL_NOTED = ("agb_spconv_fwd_opt", "agb_spconv_fwd_lp", "agb_spconv_fwd_tiles", "agb_spconv_fwd_b16", "agb_spconv_fwd_h",
                 "agb_spconv_bwd_weight_lp", "agb_spconv_bwd_weight_ws", "agb_spconv_bwd_weight_b16_ws", "agb_dense_fwd_bn")
-KERNEL_OF_ENTRY = {"agb_ball_query_fill": "k_ball_query<true>", "agb_ball_query_fill_csr": "k_ball_query<true> (ragged rows)"}
+KERNEL_OF_ENTRY = {"agb_ball_query_fill": "k_ball_query4<true>", "agb_ball_query_fill_csr": "k_ball_query4<true> (ragged rows)"}
 
 
 class CallTimer:
