@@ -78,6 +78,19 @@ def test_host_helpers_without_gpu():
         assert torch.get_num_threads() == 3
     finally:
         torch.set_num_threads(old)
+    # NUMA pinning: the GPU's local CPUs from KFD / PCI sysfs without the HIP runtime; harmless where there is no GPU
+    import os
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = dpcr_agb_amd.gpu_local_cpus(0)
+        assert cpus is None or (len(cpus) > 0 and all(isinstance(c, int) for c in cpus))
+        got = dpcr_agb_amd.pin_to_gpu_numa_node()
+        assert got is None or (got <= before and os.sched_getaffinity(0) == got)
+        os.environ["AGB_NUMA_PIN"] = "0"
+        assert dpcr_agb_amd.pin_to_gpu_numa_node() is None
+    finally:
+        os.environ.pop("AGB_NUMA_PIN", None)
+        os.sched_setaffinity(0, before)
     # option validation of the per-call kernel knobs happens before any launch
     rc = _lib.load().agb_spconv_fwd_opt(None, 4, None, None, 0, 0, None, None, 4, 10, 27, 4, 4, None, None, None, 0, 1, None,
                                         7, -1, None)
