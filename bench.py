@@ -354,9 +354,9 @@ OTHER_CONFIGS = (
      ["bench.py", "--model", "SENet50", "--precision", "bf16", "--bf16-rows", "--steps", "30", "--warmup", "8",
       "--no-other-configs"]),
     ("end_to_end", "config 4 from raw points: sparse-xy.yaml train transform chain on the device + MSENet14 step",
-     [os.path.join("tools", "bench_config.py"), "end2end", "--steps", "60", "--warmup", "10"]),
+     [os.path.join("tools", "bench_config.py"), "end2end", "--steps", "150", "--warmup", "15"]),
     ("end_to_end_config3", "config 3 from raw points: xy.yaml train transform chain on the device (MaxPoints 6144) + input pyramid + "
-     "KPCNN step", [os.path.join("tools", "bench_config.py"), "kpconv_e2e", "--steps", "30", "--warmup", "8"]),
+     "KPCNN step", [os.path.join("tools", "bench_config.py"), "kpconv_e2e", "--steps", "40", "--warmup", "8"]),
 )
 # BASELINE.json's metric is "training plots/sec ...; val RMSE": a short fixed-seed training run (reproducible: fixed-order
 # weight-gradient sums, seeded drop-path draws) on synthetic labelled plots, evaluated as eval.py does
