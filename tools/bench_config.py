@@ -280,9 +280,16 @@ def pmc_traffic(kernel, config):
             data = json.load(open(os.path.join(ROOT, rel)))["kernels"]
         except Exception:
             continue
+        want = kernel.split(" (")[0]
         for k, v in data.items():
-            if k.replace("void ", "").strip() == kernel.split(" (")[0]:
+            if k.replace("void ", "").strip() == want:
                 return round(v["hbm_bytes_per_launch"]), rel
+        # a kernel FAMILY (the name an entry point is booked under when it launches one of several instantiations:
+        # k_kpconv_fused<1, 1, false, 4, 1>, <2, 2, true, 8, 1>, ...): the launch-weighted mean of the family
+        fam = [v for k, v in data.items() if k.replace("void ", "").strip().startswith(want + "<")]
+        n = sum(v["launches"] for v in fam)
+        if n > 0:
+            return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / n), rel
     return None, None
 
 
