@@ -624,6 +624,16 @@ def main():
         floor.append((time.perf_counter() - t_f) * 1e3)
     torch.cuda.synchronize()
     floor.sort()
+    # the shader clock while steps execute (six more steps enqueued, sampled before they finish; outside the timed region):
+    # the state a 2-4 % difference between two boxes, or between two runs on one, usually comes from
+    clock_mhz = None
+    try:
+        for i in range(6):
+            _step(args.warmup + args.steps + 8 + i)
+        clock_mhz = int(torch.cuda.clock_rate())
+    except Exception:      # noqa: BLE001 — no SMI library in the image: the line goes out without the clock
+        clock_mhz = None
+    torch.cuda.synchronize()
     # what the exchange looked like, for the driver's scaling run: backend, ranks, buckets and bytes per step; a checksum
     # of every rank's parameters after the timed steps (identical on all ranks when the gradients were averaged) and each
     # rank's host CPU time per step (all threads of the process: what N ranks ask of the node's cores)
@@ -704,6 +714,7 @@ def main():
             "step_ms_p50": round(sorted(gaps)[len(gaps) // 2], 3) if gaps else None,
             "step_ms_p90": round(sorted(gaps)[int(len(gaps) * 0.9)], 3) if gaps else None,
             "step_ms_min": round(min(gaps), 3) if gaps else None,
+            "gpu_clock_mhz_under_load": clock_mhz,
             "device_allocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
             "host_enqueue_ms_p50": round(hm[len(hm) // 2], 3), "host_enqueue_floor_ms": round(floor[len(floor) // 2], 3),
             "host_cpu_ms_per_step_p50": round(hc[len(hc) // 2], 3),
