@@ -284,14 +284,19 @@ class SparsePlotPipeline:
                 seed = int(torch.randint(0, 1 << 62, (1,)).item())
             else:
                 perm = draw_permutations(lens)
-            state, to_read = voxelize_last_begin(pos, lens, self.grid.size, perm=perm, extent_hint=extent_hint, seed=seed)
+            augmented = self.flip is not None or self.shift is not None
+            state, to_read = voxelize_last_begin(pos, lens, self.grid.size, perm=perm, extent_hint=extent_hint, seed=seed,
+                                                 cloud_boxes=augmented)
             if to_read is None:
                 host = None
             elif reader is not None:       # a pipelined caller: the read-back is started here and finished a step later
                 host = yield reader(to_read)
             else:
                 host = to_read.tolist()    # one host read: new lengths + coordinate bounds
-            coords, keep, vlens, bounds = voxelize_last_end(state, host)
+            if augmented:
+                coords, keep, vlens, bounds, boxes = voxelize_last_end(state, host, cloud_boxes=True)
+            else:
+                coords, keep, vlens, bounds = voxelize_last_end(state, host)
             coords = coords.contiguous()
             ptr = _ptr_tensor(vlens, dev)
             m = int(coords.shape[0])
@@ -313,13 +318,16 @@ class SparsePlotPipeline:
                 flips_d, shifts_d = h2d_small(flips, dev), h2d_small(shifts, dev)
                 _lib.call("agb_coords_augment", _P(coords), _P(elem), B, m, _P(flips_d), _P(shifts_d), _P(cmax),
                           _lib.stream())
-                # Box of the augmented coordinates WITHOUT reading them back: a flipped axis of cloud b becomes
-                # max_b - c in [0, max_b - min_b], inside [0, max - min] of the batch; the shift is known here.  An upper
-                # bound of the true box (the coordinate manager sizes its lookup grid from it and checks rows against it).
-                lo, hi = np.asarray(bounds[:3], np.int64), np.asarray(bounds[3:], np.int64)
-                lo_b = np.where(flips != 0, 0, lo[None, :]) + shifts
-                hi_b = np.where(flips != 0, (hi - lo)[None, :], hi[None, :]) + shifts
-                bounds = tuple(int(v) for v in lo_b.min(0)) + tuple(int(v) for v in hi_b.max(0))
+                # The EXACT box of the augmented coordinates without reading them back: every cloud's own box came with the
+                # voxeliser's read; a flipped axis of cloud b becomes max_b - c, i.e. [0, max_b - min_b]; the shift is known
+                # here.  (Round 5 used the batch-wide box for every cloud: up to 1.5x wider per flipped axis, and the
+                # coordinate manager sizes the dense lookup grid of every level from it.)
+                live = np.asarray(vlens) > 0
+                lo_c, hi_c = boxes[:, :3], boxes[:, 3:]
+                lo_b = np.where(flips != 0, 0, lo_c) + shifts
+                hi_b = np.where(flips != 0, hi_c - lo_c, hi_c) + shifts
+                if live.any():
+                    bounds = tuple(int(v) for v in lo_b[live].min(0)) + tuple(int(v) for v in hi_b[live].max(0))
             out = PlotBatch(batch, coords, x[keep], pos[keep], None, None, B, bounds)
             out.src = src[keep]
         if y_reg is not None:

@@ -71,9 +71,11 @@ class AsyncRead:
         return out
 
 
-def voxelize_last_begin(pos, lengths, size, perm=None, extent_hint=None, seed=None):
+def voxelize_last_begin(pos, lengths, size, perm=None, extent_hint=None, seed=None, cloud_boxes=False):
     """First half of voxelize_last: everything up to (not including) the host read of the new lengths / bounds.  Returns
-    (state, to_read): `to_read` is the device tensor whose values ``voxelize_last_end`` needs (None: nothing to voxelize)."""
+    (state, to_read): `to_read` is the device tensor whose values ``voxelize_last_end`` needs (None: nothing to voxelize).
+    cloud_boxes: the box of every cloud's voxel coordinates rides in the same read (``voxelize_last_end(...,
+    cloud_boxes=True)`` returns them): what a per-cloud coordinate augmentation needs to state its exact box."""
     lens = _lengths(lengths)
     B, n = len(lens), int(pos.shape[0])
     if int(lens.sum()) != n:
@@ -113,20 +115,29 @@ def voxelize_last_begin(pos, lengths, size, perm=None, extent_hint=None, seed=No
     else:
         _lib.call("agb_voxelize_last_ws", _P(p), _P(perm), _P(ptr), _P(elem), B, n, size32, cap, _P(ws), _P(coords), _P(keep),
                   _P(out_ptr), _P(n_out), _P(bounds), _P(status), _lib.stream())
-    return (B, dev, coords, keep), torch.cat([out_ptr, bounds, status[:1]])   # new lengths + coordinate bounds + status
+    parts = [out_ptr, bounds, status[:1]]                  # new lengths + coordinate bounds + status
+    if cloud_boxes:
+        from .kp_index import elem_bbox
+        parts.append(elem_bbox(coords.float(), out_ptr, B).reshape(-1).to(torch.int32))     # (|coordinate| < 2^24: exact)
+    return (B, dev, coords, keep), torch.cat(parts)
 
 
-def voxelize_last_end(state, host):
-    """Second half: `host` = the values of ``voxelize_last_begin``'s `to_read` as a list."""
+def voxelize_last_end(state, host, cloud_boxes=False):
+    """Second half: `host` = the values of ``voxelize_last_begin``'s `to_read` as a list.  cloud_boxes: a fifth result, int64
+    [B, 6] = (min xyz, max xyz) of every cloud's voxel coordinates (rows of empty clouds are meaningless)."""
     B, dev, coords, keep = state
     if coords is None:
-        return (torch.empty(0, 3, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
-                np.zeros(B, dtype=np.int64), (0,) * 6)
-    if host[-1]:
+        out = (torch.empty(0, 3, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
+               np.zeros(B, dtype=np.int64), (0,) * 6)
+        return out + (np.zeros((B, 6), np.int64),) if cloud_boxes else out
+    if host[B + 7]:
         raise _lib.AgbError("voxelize_last: a cloud exceeds the reserved cell capacity (extent_hint too small)")
     optr = np.asarray(host[:B + 1], dtype=np.int64)
     m = int(optr[-1])
-    return coords[:m], keep[:m], np.diff(optr).astype(np.int64), tuple(int(v) for v in host[B + 1:B + 7])
+    out = (coords[:m], keep[:m], np.diff(optr).astype(np.int64), tuple(int(v) for v in host[B + 1:B + 7]))
+    if cloud_boxes:
+        out = out + (np.asarray(host[B + 8:B + 8 + 6 * B], dtype=np.int64).reshape(B, 6),)
+    return out
 
 
 def voxelize_last(pos, lengths, size, perm=None, extent_hint=None, seed=None):

@@ -142,6 +142,9 @@ def test_device_chain_with_voxelisation_and_coord_augmentation(device):
     torch.manual_seed(22)
     out = pipe(plots, device, y_reg=np.ones((3, 2), np.float32), perms=torch.from_numpy(np.concatenate(perms)))
     assert torch.equal(out.coords.cpu(), torch.cat(ocs))
+    # the box of the augmented coordinates, stated without reading them back, is the exact one
+    allc = torch.cat(ocs)
+    assert out.coord_bounds == tuple(allc.min(0).values.tolist()) + tuple(allc.max(0).values.tolist())
     assert np.array_equal(np.bincount(out.batch.cpu().numpy(), minlength=3), ol)
     ox = torch.cat([o[1] for o in ops])[torch.from_numpy(ok)]
     assert torch.equal(out.x[:, :2].cpu(), ox[:, :2])
