@@ -117,10 +117,27 @@ def h2d_small(arr, device):
     return _ring().h2d(arr, device) if torch.device(device).type == "cuda" else torch.from_numpy(np.asarray(arr)).to(device)
 
 
+_PTR_CACHE = {}      # (row offsets as bytes, device, stream) -> device tensor: read-only once uploaded
+
+
 def _ptr_tensor(lens, device):
+    """Row offsets int32 [B + 1] of a batch on the device.  One batch's offsets are asked for again and again (the input
+    pyramid of a KPConv batch: 30 times for 5 distinct length vectors — query and support side of every search, the
+    subsampling, the pooling searches; a sparse batch: by the chain, the voxeliser and the model's staging), each an upload of
+    ~35 us of host time: the tensor of the same values requested on the same stream is handed out again (stream order
+    guarantees the upload has happened before any later use on that stream)."""
     p = np.zeros(len(lens) + 1, dtype=np.int32)
     np.cumsum(lens, out=p[1:])
-    return h2d_small(p, device)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return h2d_small(p, device)
+    key = (p.tobytes(), dev.index, _lib.stream())
+    t = _PTR_CACHE.get(key)
+    if t is None:
+        if len(_PTR_CACHE) >= 64:
+            _PTR_CACHE.clear()
+        t = _PTR_CACHE[key] = h2d_small(p, device)
+    return t
 
 
 def elem_bbox(points, ptr, B):

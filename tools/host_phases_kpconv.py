@@ -67,7 +67,8 @@ def main():
             step(i, True)
         pr.disable()
         st = pstats.Stats(pr)
-        st.sort_stats("tottime").print_stats(35)
+        st.sort_stats("tottime").print_stats(30)
+        st.sort_stats("cumulative").print_stats(45)
     else:
         for i in range(4, 4 + args.steps):
             step(i, True)
