@@ -123,13 +123,15 @@ class InstanceBase(torch.nn.Module):
             if not bool(self.reg_y_mask.any()):
                 return
             output, labels = output[self.reg_y_mask], labels[self.reg_y_mask]
-        self.loss_reg = 0
+        loss_reg = 0
         for fn in self.loss_fns["reg"]:
-            self.loss_reg = self.loss_reg + fn(output, labels)
-        self.loss = self.loss + self.reg_weights.mean() * self.loss_reg
+            loss_reg = loss_reg + fn(output, labels)
+        d = self.__dict__      # (plain attributes: nn.Module.__setattr__ costs ~30 us per assignment)
+        d["loss_reg"] = loss_reg
+        d["loss"] = self.loss + self.reg_weights.mean() * loss_reg
 
     def compute_loss(self):
-        self.loss = 0
+        self.__dict__["loss"] = 0
         self.compute_reg_loss()
 
     def get_reg_output(self):

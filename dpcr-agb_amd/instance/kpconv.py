@@ -202,8 +202,10 @@ class KPConvModel(InstanceBase):
             _lib.POLL_HOOK = None
 
     def set_input(self, data, device):
-        self.data_visual = data
-        self.batch_idx = data.batch
+        # (plain attributes through __dict__: nn.Module.__setattr__ costs ~30 us per assignment, twelve of them per step)
+        d = self.__dict__
+        d["data_visual"] = data
+        d["batch_idx"] = data.batch
         pre = getattr(data, "_prefetched", None)
         if pre is not None:
             data._prefetched = None
@@ -226,21 +228,24 @@ class KPConvModel(InstanceBase):
                         if isinstance(u, torch.Tensor) and u.is_cuda:
                             used.append(u)
             self._hold_input(inp, used, cur)
-            self.input = Opt(inp)
+            d["input"] = Opt(inp)
         else:
-            self.input = Opt(self._pyramid(data, device))
+            d["input"] = Opt(self._pyramid(data, device))
         if len(self.loss_fns) > 0:
             bs = len(data)
             if self.has_reg_targets and data.y_reg is not None:
                 mask_all = getattr(data, "y_reg_mask_all", None)
-                self._reg_mask_all = bool(data.y_reg_mask.all()) if mask_all is None else mask_all
-                self.reg_y_mask = data.y_reg_mask.to(device, non_blocking=True).view(bs, -1)
-                self.reg_y = data.y_reg.to(device, non_blocking=True).view(bs, -1)
+                d["_reg_mask_all"] = bool(data.y_reg_mask.all()) if mask_all is None else mask_all
+                d["reg_y_mask"] = data.y_reg_mask.to(device, non_blocking=True).view(bs, -1)
+                d["reg_y"] = data.y_reg.to(device, non_blocking=True).view(bs, -1)
+            else:
+                d["reg_y"] = None      # (a label-less batch: prediction only, base.compute_reg_loss skips the loss)
 
     def forward(self, *args, **kwargs):
         out = self.model(self.input)
-        self.output = self.head(out)
-        self.reg_out = self.convert_outputs(self.output)
+        d = self.__dict__
+        d["output"] = self.head(out)
+        d["reg_out"] = self.convert_outputs(d["output"])
         self.compute_loss()
 
 
