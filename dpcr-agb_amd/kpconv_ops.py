@@ -183,7 +183,6 @@ class KPConvFusedFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .sparse_ops import zeros_f32
         x, pts, kernel_points, weights = ctx.saved_tensors
         idx = ctx.ragged
         K, cin, cout = weights.shape
