@@ -169,18 +169,32 @@ def test_kpconv_bilinear_form_full_size(kp_full, device, lvl, cin, cout):
     g = torch.Generator(device="cpu").manual_seed(lvl)
     x1, x2 = (torch.randn(n, cin, generator=g).to(device) for _ in range(2))
     gy = torch.randn(n, cout, generator=g).to(device)
+    from dpcr_agb_amd import _lib
+    from dpcr_agb_amd.sparse_ops import KernelOptions
     res = {}
-    for form in ("scatter", "symmetric"):
-        nb.agb_symmetric = form == "symmetric"
+    # three forms of the layer: gather + product with the atomic scatter backward; the scatter-free backward on the symmetric
+    # self-search (two kernels per direction); and — 16 / 32 channels — gather + contraction as ONE kernel per direction
+    # (csrc/kpfused.hip), which is what the default options select
+    for form in ("scatter", "symmetric two-kernel", "symmetric"):
+        nb.agb_symmetric = form != "scatter"
         conv.zero_grad()
         x = x1.clone().requires_grad_(True)
-        y = conv(pts, pts, nb, x)
-        y.backward(gy)
+        calls = []
+        orig = _lib.call
+        _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            with KernelOptions(fused_kpconv=form == "symmetric"):
+                y = conv(pts, pts, nb, x)
+                y.backward(gy)
+                # linear in x
+                with torch.no_grad():
+                    y12 = conv(pts, pts, nb, 0.5 * x1 - 2.0 * x2)
+                    y2 = conv(pts, pts, nb, x2)
+        finally:
+            _lib.call = orig
+        assert ("agb_kpconv_fused_bwd" in calls) == (form == "symmetric" and cin <= 32), (form, sorted(set(calls)))
+        assert ("agb_kpconv_gather_bwd_csr" in calls) == (form == "scatter"), (form, sorted(set(calls)))
         res[form] = (y.detach(), x.grad, conv.weights.grad.clone())
-        # linear in x
-        with torch.no_grad():
-            y12 = conv(pts, pts, nb, 0.5 * x1 - 2.0 * x2)
-            y2 = conv(pts, pts, nb, x2)
         assert float((y12 - (0.5 * y.detach() - 2.0 * y2)).abs().max()) < 1e-4 * float(y.detach().abs().max())
         # <y, g> = <x, dx> = <W, dW>   (float64 sums of fp32 products)
         form_y = float((y.detach().double() * gy.double()).sum())
@@ -189,8 +203,9 @@ def test_kpconv_bilinear_form_full_size(kp_full, device, lvl, cin, cout):
         scale = float((y.detach().double().abs() * gy.double().abs()).sum())
         assert abs(form_y - form_x) < 1e-5 * scale and abs(form_y - form_w) < 1e-5 * scale, (form, form_y, form_x, form_w)
     nb.agb_symmetric = True
-    for a, b in zip(res["scatter"], res["symmetric"]):
-        assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
+    for form in ("symmetric two-kernel", "symmetric"):
+        for a, b in zip(res["scatter"], res[form]):
+            assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max()), form
 
 
 # ---------------------------------------------------------------------------------------------------------------------
