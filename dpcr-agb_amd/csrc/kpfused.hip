@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_kpf_reduce_dw(const float* __restrict__
 namespace {
 // the shape of a workgroup per channel width: (waves, 16-row blocks per tile)
 template <int CG> struct KpfShape;
-template <> struct KpfShape<1> { static constexpr int NW = 4, RB = 1; };
+template <> struct KpfShape<1> { static constexpr int NW = 8, RB = 1; };
 template <> struct KpfShape<2> { static constexpr int NW = 8, RB = 1; };
 
 template <int CG, int CO>
