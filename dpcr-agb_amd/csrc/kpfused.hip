@@ -315,27 +315,29 @@ __global__ __launch_bounds__(256) void k_kpf_reduce_dw(const float* __restrict__
 }
 
 namespace {
-// the shape of a workgroup per channel width: (waves, 16-row blocks per tile)
-template <int CG> struct KpfShape;
-template <> struct KpfShape<1> { static constexpr int NW = 8, RB = 1; };
-template <> struct KpfShape<2> { static constexpr int NW = 8, RB = 1; };
+// the shape of a workgroup per channel width and launch kind: (waves, 16-row blocks per tile).  Measured (EXPERIMENTS.md):
+// 16 channels: 8 waves x 2 rows (80 / 108 VGPRs: 6 / 4 waves per SIMD); 32 channels forward: 8 waves (127 VGPRs, two workgroups
+// per CU); 32 channels backward: 16 waves x 1 row — W^T and the weight-gradient accumulators spread over twice the waves
+// (128 instead of 192 VGPRs: one workgroup of 16 waves per CU instead of one of 8)
+template <int CG, bool DW> struct KpfShape { static constexpr int NW = 8, RB = 1; };
+template <> struct KpfShape<2, true> { static constexpr int NW = 16, RB = 1; };
 
-template <int CG, int CO>
+template <int CG, int CO, bool DW>
 constexpr size_t kpf_lds_bytes(int K) {
-    return ((size_t)16 * KpfShape<CG>::RB * (K * 16 * CG + 4) +
-            (size_t)(KpfShape<CG>::NW / CO) * 16 * KpfShape<CG>::RB * 16 * CO + (size_t)16 * KpfShape<CG>::RB * 64) * sizeof(float);
+    return ((size_t)16 * KpfShape<CG, DW>::RB * (K * 16 * CG + 4) +
+            (size_t)(KpfShape<CG, DW>::NW / CO) * 16 * KpfShape<CG, DW>::RB * 16 * CO + (size_t)16 * KpfShape<CG, DW>::RB * 64) * sizeof(float);
 }
 
 template <int CG, int CO, bool DW>
 int kpf_grid(int K, int N) {
     // workgroups resident at once (registers and the K-dependent LDS tile decide): asked once per (instantiation, K)
-    constexpr int NW = KpfShape<CG>::NW, RB = KpfShape<CG>::RB;
+    constexpr int NW = KpfShape<CG, DW>::NW, RB = KpfShape<CG, DW>::RB;
     static int cached[17] = {0};
     if (cached[K] == 0) {
         int dev = 0, cus = 256, per_cu = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const size_t lds = kpf_lds_bytes<CG, CO>(K);
+        const size_t lds = kpf_lds_bytes<CG, CO, DW>(K);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_kpconv_fused<CG, CO, DW, NW, RB>, 64 * NW, lds) != hipSuccess ||
             per_cu < 1)
             per_cu = 2;
@@ -347,8 +349,8 @@ int kpf_grid(int K, int N) {
 
 template <int CG, int CO, bool DW>
 void kpf_launch(const KpfArgs& a, int grid, hipStream_t st) {
-    constexpr int NW = KpfShape<CG>::NW, RB = KpfShape<CG>::RB;
-    const size_t lds = kpf_lds_bytes<CG, CO>(a.K);
+    constexpr int NW = KpfShape<CG, DW>::NW, RB = KpfShape<CG, DW>::RB;
+    const size_t lds = kpf_lds_bytes<CG, CO, DW>(a.K);
     hipLaunchKernelGGL((k_kpconv_fused<CG, CO, DW, NW, RB>), dim3(grid), dim3(64 * NW), lds, st, a);
 }
 }  // namespace

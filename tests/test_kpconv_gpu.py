@@ -193,7 +193,8 @@ def test_kpconv_fused_edge_shapes(device, n, radius):
         # one gradient only
         x, wt = x0.clone().requires_grad_(True), w.clone()
         KPConvFusedFunction.apply(x, pts, nb, kp, 0.6 * radius, wt).backward(gy)
-        assert torch.equal(x.grad, out["fused"][1])
+        # (the launch without a weight gradient may split the reduction over another number of waves: rounding, not bits)
+        assert rel(x.grad, out["fused"][1]) < 2e-6
         x, wt = x0.clone(), w.clone().requires_grad_(True)
         KPConvFusedFunction.apply(x, pts, nb, kp, 0.6 * radius, wt).backward(gy)
         assert torch.equal(wt.grad, out["fused"][2])
