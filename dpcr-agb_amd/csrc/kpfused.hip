@@ -7,11 +7,11 @@
 // gradient) moves 15 * Cin * 4 bytes per row out and back in twice per layer and step: at the 16- and 32-channel levels
 // of the 16 k-point plots that is ~0.4-0.5 GB per launch, 2/3 of those layers' HBM traffic.
 //
-// One workgroup (four waves / 16 rows at 16 channels, eight waves / 32 rows at 32) owns a tile of consecutive query rows at a
+// One workgroup (eight waves; sixteen in the 32-channel backward launch: KpfShape) owns a tile of 16 consecutive query rows at a
 // time (persistent: it walks tiles blockIdx.x, + gridDim.x, ..):
-//   gather       every wave takes FOUR rows of the tile (ranked by neighbour count, so the four have similar lengths) and runs
-//                them in lockstep, 8 neighbours of each per trip: the neighbour indices go through LDS, then the coordinates
-//                and feature rows of all 32 neighbours are requested before any is used.  Per row the product
+//   gather       every wave takes TWO rows of the tile (ONE with sixteen waves; rows ranked by neighbour count, so a wave's rows
+//                have similar lengths) and runs them in lockstep, 32 neighbours in all per trip: the neighbour indices go through LDS, then the coordinates
+//                and feature rows of all 32 neighbours are requested before any is used (template RPW rows x UB blocks of four).  Per row the product
 //                Infl^T (K x H) . X (H x C) on v_mfma_f32_16x16x4_f32 as in kpconv.hip k_kpconv_gather_mm_fwd (lane (k, j)
 //                evaluates ONE influence); the (K x C) results go to the LDS tile  t[row][k * C + c]   (row stride K*C + 4
 //                floats: the 16-byte operand reads of the next phase touch every bank once)
