@@ -10,15 +10,16 @@
 // One workgroup (eight waves; sixteen in the 32-channel backward launch: KpfShape) owns a tile of 16 consecutive query rows at a
 // time (persistent: it walks tiles blockIdx.x, + gridDim.x, ..):
 //   gather       every wave takes TWO rows of the tile (ONE with sixteen waves; rows ranked by neighbour count, so a wave's rows
-//                have similar lengths) and runs them in lockstep, 32 neighbours in all per trip: the neighbour indices go through LDS, then the coordinates
-//                and feature rows of all 32 neighbours are requested before any is used (template RPW rows x UB blocks of four).  Per row the product
+//                have similar lengths) and runs them in lockstep, 32 neighbours in all per trip: the neighbour indices go through
+//                LDS, then the coordinates and feature rows of all 32 neighbours are requested before any is used (template:
+//                RPW rows x UB blocks of four).  Per row the product
 //                Infl^T (K x H) . X (H x C) on v_mfma_f32_16x16x4_f32 as in kpconv.hip k_kpconv_gather_mm_fwd (lane (k, j)
 //                evaluates ONE influence); the (K x C) results go to the LDS tile  t[row][k * C + c]   (row stride K*C + 4
 //                floats: the 16-byte operand reads of the next phase touch every bank once)
 //   contraction  out[16 rows x Cout] = t[16 x K*C] . W[K*C x Cout] on the same instruction: A = 16 rows x 4 reduction indices
 //                read from LDS as one ds_read_b128 per four MFMAs, B = W held in REGISTERS for the lifetime of the workgroup
-//                (16 channels: 16 VGPRs per wave, 32 channels: 60): W is read from L2 once per workgroup, not once per tile.
-//                The four waves split (column block, reduction range) and the partial sums meet in LDS in a fixed order.
+//                (16 channels: 8 VGPRs per wave, 32 channels: 32): W is read from L2 once per workgroup, not once per tile.
+//                The waves split (column block, reduction range) and the partial sums meet in LDS in a fixed order.
 //   weight grad  (backward launch) dWt[K*Cout x Cin] += t^T (K*Cout x 16 rows) . x (16 rows x Cin) with the accumulators in
 //                registers across all tiles of the workgroup; one partial per workgroup, reduced in fixed order afterwards
 //                (deterministic, no atomics).
