@@ -64,7 +64,9 @@ template <int CG, int CO, bool DW, int NW, int RB>
 __global__ __launch_bounds__(64 * NW) void k_kpconv_fused(KpfArgs a) {
     static_assert(NW % CO == 0 && (16 * RB) % NW == 0 && (8 * NW) % (16 * RB) == 0, "one column block per wave, whole rows per wave");
     constexpr int RPW = 16 * RB / NW;                            // rows of a wave (in lockstep)
-    constexpr int UB = 8 / RPW;                                  // blocks of four neighbours of each row per trip: 32 row fetches in flight
+    // blocks of four neighbours of each row per trip: 32 row fetches in flight per wave at 16 channels (the first level: points in
+    // input order, every neighbour row its own HBM sector), 16 at 32 channels (cell-sorted levels: fewer registers, more waves)
+    constexpr int UB = (CG == 1 ? 8 : 4) / RPW;
     constexpr int Cg = 16 * CG, Co = 16 * CO, R = 16 * RB;
     constexpr int SPLITK = NW / CO;                              // waves sharing a column block
     constexpr int GW_MAX = (16 * CG + SPLITK - 1) / SPLITK;      // 16-index groups of the reduction per wave (K <= 16)
