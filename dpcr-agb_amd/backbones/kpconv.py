@@ -280,6 +280,12 @@ class KPCNN(nn.Module):
     def forward(self, batch):
         with model_scope(self):
             x = batch.features.clone().detach()
+            if x.is_cuda and not current_options().low_precision:
+                # W^T of all unary blocks' Linear layers from one launch per optimiser step (fused_blocks.LinearTransposes)
+                from ..fused_blocks import linear_transposes
+                lt = linear_transposes(self, lambda: [m for m in self.modules() if isinstance(m, nn.Linear)])
+                if lt is not None:
+                    lt.ensure()
             for op in self.block_ops:
                 x = op(x, batch)
             return self.head_mlp(x, batch)

@@ -260,6 +260,56 @@ def weight_transposes(model, blocks):
     return wt
 
 
+class _LinearAsConv:
+    """What WeightTransposes asks of a layer, for an nn.Linear: its weight [out, in] as a one-offset kernel [1, out, in] (the
+    transposed form [1, in, out] is the [K, N] operand of the forward product)."""
+    __slots__ = ("lin",)
+
+    def __init__(self, lin):
+        self.lin = lin
+
+    @property
+    def kernel(self):
+        w = self.lin.weight.detach()          # (shares storage and version counter with the parameter)
+        return w.view(1, w.shape[0], w.shape[1])
+
+
+class LinearTransposes(WeightTransposes):
+    """W^T of every nn.Linear a backbone runs through sparse_ops.dense_linear (KPConv's unary blocks: 37 layers), by ONE batched
+    launch per optimiser step instead of one transpose launch per layer and forward pass; every weight carries its view
+    (``weight.agb_wt``: view, weight epoch, version) for DenseLinearFunction to pick up."""
+
+    def __init__(self, linears, device):
+        self.linears = [l for l in linears if l.weight.shape[0] % 4 == 0 and l.weight.shape[1] % 4 == 0
+                        and min(l.weight.shape) >= 12 and l.weight.dtype == torch.float32]
+        super().__init__([_LinearAsConv(l) for l in self.linears], device)
+
+    def _state(self):
+        ws = [l.weight for l in self.linears]
+        return (sparse_ops._WEIGHT_EPOCH[0],) + tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
+
+    def ensure(self):
+        before = self.key
+        super().ensure()
+        if self.key != before or not self.linears or getattr(self.linears[0].weight, "agb_wt", None) is None:
+            epoch = sparse_ops._WEIGHT_EPOCH[0]
+            for lin, conv in zip(self.linears, self.convs):
+                w = lin.weight
+                o = self.offset[id(conv)]
+                w.agb_wt = (self.flat[o:o + w.numel()].view(w.shape[1], w.shape[0]), epoch, w._version)
+
+
+def linear_transposes(model, linears):
+    """The model's LinearTransposes (made on first use; `linears`: callable returning the nn.Linear modules)."""
+    lt = model.__dict__.get("_agb_lt")
+    if lt is None:
+        mods = list(linears())
+        if not mods:
+            return None
+        lt = model.__dict__["_agb_lt"] = LinearTransposes(mods, mods[0].weight.device)
+    return lt
+
+
 # ----------------------------------------------------------------------------------------------------------------- stem
 class _StemCall:
     __slots__ = ("tab", "saved_bytes", "fwd_bytes", "bwd_bytes", "layout", "has", "n", "n_pool", "C", "keepalive")

@@ -957,8 +957,15 @@ class DenseLinearFunction(torch.autograd.Function):
         if opts.low_precision:
             y = spconv_forward_raw(xp, None, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1", None, None, wp, opts=opts)
         else:
-            wt = torch.empty(cin_p, cout_p, dtype=torch.float32, device=x.device)
-            _lib.call("agb_spconv_weight_transpose", _P(wp), _P(wt), 1, cout_p, cin_p, _lib.stream())
+            # W^T [in, out]: from the model's per-step batch of transposes where it keeps one (fused_blocks.LinearTransposes:
+            # one launch per optimiser step for all Linear layers of a backbone), else made here
+            pre = getattr(weight, "agb_wt", None)
+            if (pre is not None and wp is weight and pre[1] == _WEIGHT_EPOCH[0] and pre[2] == weight._version
+                    and pre[0].device == x.device):
+                wt = pre[0]
+            else:
+                wt = torch.empty(cin_p, cout_p, dtype=torch.float32, device=x.device)
+                _lib.call("agb_spconv_weight_transpose", _P(wp), _P(wt), 1, cout_p, cin_p, _lib.stream())
             y = spconv_forward_raw(xp, wt, None, 0, b, n, 1, cin_p, cout_p, "fwd1x1",
                                    bn_stats=any(ctx.needs_input_grad) and cout_p == cout, opts=opts)
         ctx.save_for_backward(xp, wp)
