@@ -252,6 +252,8 @@ _lib.declare("agb_spconv_weight_transpose_batched", [_V, _I, _lib.c_ll, _V])
 def weight_transposes(model, blocks):
     """The model's WeightTransposes over the convolutions of `blocks` (made on first use)."""
     wt = model.__dict__.get("_agb_wt")
+    if wt is not None and wt.convs and wt.convs[0].kernel.device != wt.flat.device:
+        wt = None                                   # (the model moved to another device since)
     if wt is None:
         convs = []
         for blk in blocks:
@@ -302,6 +304,8 @@ class LinearTransposes(WeightTransposes):
 def linear_transposes(model, linears):
     """The model's LinearTransposes (made on first use; `linears`: callable returning the nn.Linear modules)."""
     lt = model.__dict__.get("_agb_lt")
+    if lt is not None and lt.linears and lt.linears[0].weight.device != lt.flat.device:
+        lt = None                                   # (the model moved to another device since)
     if lt is None:
         mods = list(linears())
         if not mods:
