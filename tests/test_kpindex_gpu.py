@@ -150,3 +150,27 @@ def test_ragged_neighbours_equal_the_padded_matrix(device, n_points, radius):
     for a, c in (("padded", "ragged"), ("padded_crop", "ragged_crop")):
         assert torch.equal(res[a][0], res[c][0]) and torch.equal(res[a][1], res[c][1])
         assert float((res[a][2] - res[c][2]).abs().max()) <= 1e-5 * float(res[a][2].abs().max())   # (atomic scatter order)
+
+
+@pytest.mark.parametrize("n,r,path", [(180, 0.9, "quarter lists (<= 32) and whole-wave sorts"), (900, 0.9, "over 256: the wave's full slab"),
+                                      (64, 2.0, "every point a neighbour of every point")])
+def test_ball_query_list_length_paths(device, n, r, path):
+    """k_ball_query4 ranks lists of up to 32 keys inside a 16-lane quarter, sorts longer ones with the whole wave and redoes
+    queries with more than 256 hits on the wave's full slab (csrc/kpindex.hip): dense clusters that reach each of them, padded
+    and ragged form, against the pinned CPU oracle (neighbors.cpp:211-333) — bit-exact."""
+    from dpcr_agb_amd import kp_index
+    rng = np.random.default_rng(n)
+    # two clouds: a dense ball and a sparse shell, so that short and long rows share waves
+    pts = np.concatenate([rng.normal(0, 0.25, (n, 3)), rng.uniform(-3, 3, (n // 2, 3))]).astype(np.float32)
+    lens = np.array([n, n // 2], dtype=np.int32)
+    want = K.batch_neighbors(pts, pts, lens, lens, r)
+    counts = (want < len(pts)).sum(1)
+    if n == 900:
+        assert counts.max() > 256 and counts.min() <= 32
+    if n == 180:
+        assert 32 < counts.max() <= 256
+    got = kp_index.batch_neighbors(pts, pts, lens, lens, r)
+    assert np.array_equal(got, want), path
+    rag = kp_index.batch_neighbors_ragged(pts, pts, lens, lens, r)
+    assert np.array_equal(np.diff(rag.row_ptr.cpu().numpy()), counts)
+    assert np.array_equal(rag.padded().cpu().numpy(), want), path
