@@ -168,7 +168,8 @@ __device__ __forceinline__ void bq_one_query(const int q, const int lane, unsign
                                              const float* __restrict__ qry, const int32_t* __restrict__ q_elem, const CellGrid& g,
                                              const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted, float r2,
                                              int ns, int32_t* __restrict__ counts, int32_t* __restrict__ out, int width,
-                                             int32_t* status, const int32_t* __restrict__ row_ptr) {
+                                             int32_t* status, const int32_t* __restrict__ row_ptr, const int cap = BQ_CAP) {
+    // cap: keys the slab holds (BQ_CAP, or the smaller slab of k_ball_query4 when the caller knows the longest list)
     // row_ptr != NULL (FILL): ragged output — row q is out[row_ptr[q] .. row_ptr[q + 1]) (the exclusive scan of the count
     // pass), nothing is padded; NULL: the reference's padded matrix out[q * width + j], shadow index ns behind the row
     const float qx = qry[3 * (long long)q], qy = qry[3 * (long long)q + 1], qz = qry[3 * (long long)q + 2];
@@ -216,7 +217,7 @@ __device__ __forceinline__ void bq_one_query(const int q, const int lane, unsign
         unsigned long long m = __ballot(hit);
         if (FILL && hit) {
             int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < BQ_CAP) skeys[pos] = key;
+            if (pos < cap) skeys[pos] = key;
         }
         count += __popcll(m);
     }
@@ -224,9 +225,9 @@ __device__ __forceinline__ void bq_one_query(const int q, const int lane, unsign
         if (lane == 0) counts[q] = count;
         return;
     }
-    if (count > BQ_CAP) {
+    if (count > cap) {
         if (lane == 0) atomicAdd(&status[0], 1);
-        count = BQ_CAP;
+        count = cap;
     }
     bq_sort_emit(q, lane, skeys, count, out, width, ns, row_ptr);
 }
@@ -253,16 +254,21 @@ __global__ __launch_bounds__(256) void k_ball_query(const float* __restrict__ qr
 // step (a run of three x-adjacent cells holds ~14 points: no search for "which run holds candidate c"); hits are compacted
 // per quarter with one ballot; every lane ranks its keys (positions sl, sl + 16, ..) against the quarter's list.  Same
 // candidates, same d2 arithmetic, same (d2, index) order as bq_one_query: bit-identical rows.  A query with more than
-// BQ4_CAP hits is redone by the whole wave with bq_one_query on the wave's full slab (4 x BQ4_CAP = BQ_CAP keys) after the
+// cap / 4 hits is redone by the whole wave with bq_one_query on the wave's full slab (cap keys) after the
 // other quarters have written their rows.
-#define BQ4_CAP (BQ_CAP / 4)
+// The slab of a wave holds `cap` keys (dynamic LDS: 4 waves x cap x 8 bytes), a quarter's list cap / 4: with the longest list of
+// the search known (agb_ball_query_fill_csr_m: the count pass's maximum, which the caller has read back anyway) the slab
+// is the next power of two >= max(that, 256) instead of BQ_CAP = 1024 — 8-16 KB of LDS per workgroup instead of 32, twice
+// the waves per CU in a kernel that waits for memory 64 % of its time (level 0 fill pass: 426 -> 286 us).
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_ball_query4(const float* __restrict__ qry, int nq, const int32_t* __restrict__ q_elem,
                                                      CellGrid g, const int32_t* __restrict__ cell_start,
                                                      const float4* __restrict__ sorted, float r2, int ns,
                                                      int32_t* __restrict__ counts, int32_t* __restrict__ out, int width,
-                                                     int32_t* status, const int32_t* __restrict__ row_ptr = nullptr) {
-    __shared__ unsigned long long s_keys[4][FILL ? BQ_CAP : 1];
+                                                     int32_t* status, const int32_t* __restrict__ row_ptr = nullptr,
+                                                     const int cap = BQ_CAP) {
+    extern __shared__ unsigned long long bq_keys_dyn[];              // [4 waves][cap]  (FILL only)
+    const int BQ4_CAP = cap >> 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane >> 4, sl = lane & 15;
     const int q = (blockIdx.x * 4 + w) * 4 + sub;
     if ((blockIdx.x * 4 + w) * 4 >= nq) return;                  // (whole waves leave: no workgroup barrier in this kernel)
@@ -283,7 +289,8 @@ __global__ __launch_bounds__(256) void k_ball_query4(const float* __restrict__ q
             len = cell_start[row + x1 + 1] - beg;
         }
     }
-    unsigned long long* keys = s_keys[w] + (FILL ? BQ4_CAP * sub : 0);
+    unsigned long long* const slab = bq_keys_dyn + (FILL ? (size_t)cap * (threadIdx.x >> 6) : 0);
+    unsigned long long* keys = slab + (FILL ? BQ4_CAP * sub : 0);
     int count = 0;
     auto take = [&](const float4 s, const bool valid) {
         bool hit = false;
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(256) void k_ball_query4(const float* __restrict__ q
 #pragma unroll 1
         for (int t = 0; t < 4; ++t)
             if ((big >> (16 * t)) & 1ull)
-                bq_sort_emit(qbase + t, lane, s_keys[w] + BQ4_CAP * t, __shfl(count, 16 * t, 64), out, width, ns, row_ptr);
+                bq_sort_emit(qbase + t, lane, slab + BQ4_CAP * t, __shfl(count, 16 * t, 64), out, width, ns, row_ptr);
     }
     if (live && small && !over && !row_ptr)
         for (int j = cnt + sl; j < width; j += 16) row[j] = ns;
@@ -387,8 +394,8 @@ __global__ __launch_bounds__(256) void k_ball_query4(const float* __restrict__ q
 #pragma unroll 1
         for (int t = 0; t < 4; ++t)
             if ((ov >> (16 * t)) & 1ull)
-                bq_one_query<true>(qbase + t, lane, s_keys[w], qry, q_elem, g, cell_start, sorted, r2, ns, counts, out, width, status,
-                                   row_ptr);
+                bq_one_query<true>(qbase + t, lane, slab, qry, q_elem, g, cell_start, sorted, r2, ns, counts, out, width, status,
+                                   row_ptr, cap);
     }
 }
 
@@ -624,7 +631,8 @@ int agb_ball_query_count(const float* queries, int nq, const int32_t* q_elem, co
                                cell_start, (const float4*)sorted, r2, 0, counts, (int32_t*)nullptr, 0, (int32_t*)nullptr);
         else
             hipLaunchKernelGGL(k_ball_query4<false>, dim3(agb_cdiv(nq, 16)), dim3(256), 0, s, queries, nq, q_elem, g,
-                               cell_start, (const float4*)sorted, r2, 0, counts, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+                               cell_start, (const float4*)sorted, r2, 0, counts, (int32_t*)nullptr, 0, (int32_t*)nullptr,
+                               (const int32_t*)nullptr, BQ_CAP);
         int bx = agb_cdiv(nq, 256);
         if (bx > 256) bx = 256;
         hipLaunchKernelGGL(k_max_i32, dim3(bx), dim3(256), 0, s, counts, nq, max_count);
@@ -646,8 +654,9 @@ int agb_ball_query_fill(const float* queries, int nq, const int32_t* q_elem, con
             hipLaunchKernelGGL(k_ball_query<true>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
                                cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, out, width, status);
         else
-            hipLaunchKernelGGL(k_ball_query4<true>, dim3(agb_cdiv(nq, 16)), dim3(256), 0, s, queries, nq, q_elem, g,
-                               cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, out, width, status);
+            hipLaunchKernelGGL(k_ball_query4<true>, dim3(agb_cdiv(nq, 16)), dim3(256), 4 * BQ_CAP * sizeof(unsigned long long), s,
+                               queries, nq, q_elem, g, cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, out, width,
+                               status, (const int32_t*)nullptr, BQ_CAP);
     }
     AGB_CHECK_LAUNCH("agb_ball_query_fill");
     return AGB_OK;
@@ -669,24 +678,55 @@ int agb_ball_query_offsets(const int32_t* counts, int nq, int32_t* row_ptr, int3
     return AGB_OK;
 }
 
-int agb_ball_query_fill_csr(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
-                            const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
-                            const int32_t* row_ptr, int32_t* indices, int capacity, int32_t* status, void* stream) {
-    AGB_CHECK_ARG(capacity >= 0, "agb_ball_query_fill_csr: capacity %d", capacity);   // (= row_ptr[nq], read back by the caller)
+// slab of a wave for a search whose longest list is max_count: next power of two >= max(max_count, 256), at most BQ_CAP
+static int bq_slab_keys(int max_count) {
+    int cap = 256;
+    while (cap < max_count && cap < BQ_CAP) cap <<= 1;
+    return cap;
+}
+
+static int bq_fill_csr(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs, const int32_t* dims,
+                       const int32_t* cell_start, const float* sorted, float radius, int ns, const int32_t* row_ptr,
+                       int32_t* indices, int capacity, int cap, int32_t* status, void* stream, const char* who) {
+    AGB_CHECK_ARG(capacity >= 0, "%s: capacity %d", who, capacity);   // (= row_ptr[nq], read back by the caller)
     hipStream_t s = (hipStream_t)stream;
     CellGrid g{origin_cs[0], origin_cs[1], origin_cs[2], 1.0f / origin_cs[3], dims[0], dims[1], dims[2], dims[3]};
     (void)hipMemsetAsync(status, 0, sizeof(int32_t) * 4, s);
     if (nq > 0) {
-        AGB_CHECK_ARG(row_ptr && indices, "agb_ball_query_fill_csr: null pointer");
+        AGB_CHECK_ARG(row_ptr && indices, "%s: null pointer", who);
         float r2 = radius * radius;
         if (bq_use_v1())
             hipLaunchKernelGGL(k_ball_query<true>, dim3(agb_cdiv(nq, 4)), dim3(256), 0, s, queries, nq, q_elem, g,
                                cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, indices, 0, status, row_ptr);
         else
-            hipLaunchKernelGGL(k_ball_query4<true>, dim3(agb_cdiv(nq, 16)), dim3(256), 0, s, queries, nq, q_elem, g,
-                               cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, indices, 0, status, row_ptr);
+            hipLaunchKernelGGL(k_ball_query4<true>, dim3(agb_cdiv(nq, 16)), dim3(256), 4 * (size_t)cap * sizeof(unsigned long long), s,
+                               queries, nq, q_elem, g, cell_start, (const float4*)sorted, r2, ns, (int32_t*)nullptr, indices, 0,
+                               status, row_ptr, cap);
     }
+    return AGB_OK;
+}
+
+int agb_ball_query_fill_csr(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
+                            const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
+                            const int32_t* row_ptr, int32_t* indices, int capacity, int32_t* status, void* stream) {
+    int rc = bq_fill_csr(queries, nq, q_elem, origin_cs, dims, cell_start, sorted, radius, ns, row_ptr, indices, capacity, BQ_CAP,
+                         status, stream, "agb_ball_query_fill_csr");
+    if (rc) return rc;
     AGB_CHECK_LAUNCH("agb_ball_query_fill_csr");
+    return AGB_OK;
+}
+
+// The same with the longest list of the search stated (max_count: *max_count of agb_ball_query_count, which the caller reads back
+// together with row_ptr[nq]): the kernel's LDS slab shrinks to the next power of two >= max(max_count, 256) keys per wave and
+// twice to four times the waves fit a CU.  A list longer than max_count is cut at the slab and counted in status[0].
+int agb_ball_query_fill_csr_m(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs, const int32_t* dims,
+                              const int32_t* cell_start, const float* sorted, float radius, int ns, const int32_t* row_ptr,
+                              int32_t* indices, int capacity, int max_count, int32_t* status, void* stream) {
+    AGB_CHECK_ARG(max_count >= 0, "agb_ball_query_fill_csr_m: max_count %d", max_count);
+    int rc = bq_fill_csr(queries, nq, q_elem, origin_cs, dims, cell_start, sorted, radius, ns, row_ptr, indices, capacity,
+                         bq_slab_keys(max_count), status, stream, "agb_ball_query_fill_csr_m");
+    if (rc) return rc;
+    AGB_CHECK_LAUNCH("agb_ball_query_fill_csr_m");
     return AGB_OK;
 }
 

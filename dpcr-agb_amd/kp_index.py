@@ -31,6 +31,7 @@ _lib.declare("agb_ball_query_count", [_V, _I, _V, _V, _V, _V, _V, _F, _V, _V, _V
 _lib.declare("agb_ball_query_fill", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V])
 _lib.declare("agb_ball_query_offsets", [_V, _I, _V, _V, _V])
 _lib.declare("agb_ball_query_fill_csr", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _V, _V, _I, _V, _V])
+_lib.declare("agb_ball_query_fill_csr_m", [_V, _I, _V, _V, _V, _V, _V, _F, _I, _V, _V, _I, _I, _V, _V])
 _lib.declare("agb_csr_to_padded", [_V, _V, _I, _I, _I, _V, _V])
 _lib.declare("agb_grid_subsample_workspace_bytes", [_I, _I, _I])
 _lib.declare("agb_grid_subsample_ws", [_V, _V, _I, _I, _V, _V, _I, _F, _I, _V, _V, _V, _V, _V, _V, _V])
@@ -330,8 +331,9 @@ def neighbors_finish_csr(job, width, total):
     dev = job.q.device
     indices = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
     status = torch.empty(4, dtype=torch.int32, device=dev)
-    _lib.call("agb_ball_query_fill_csr", _P(job.q), job.nq, _P(job.q_elem), job.origin_cs, job.dims_c, _P(job.cell_start),
-              _P(job.sorted_pts), job.radius, job.ns, _P(job.row_ptr), _P(indices), total, _P(status), _lib.stream())
+    # (the longest list is known here: the kernel sizes its LDS slab from it instead of the 1024-key worst case)
+    _lib.call("agb_ball_query_fill_csr_m", _P(job.q), job.nq, _P(job.q_elem), job.origin_cs, job.dims_c, _P(job.cell_start),
+              _P(job.sorted_pts), job.radius, job.ns, _P(job.row_ptr), _P(indices), total, width, _P(status), _lib.stream())
     return Neighbors(job.row_ptr, indices, job.nq, job.ns, width, job.max_count)
 
 

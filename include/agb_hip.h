@@ -447,6 +447,12 @@ int agb_ball_query_offsets(const int32_t* counts, int nq, int32_t* row_ptr, int3
 int agb_ball_query_fill_csr(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs,
                             const int32_t* dims, const int32_t* cell_start, const float* sorted, float radius, int ns,
                             const int32_t* row_ptr, int32_t* indices, int capacity, int32_t* status, void* stream);
+/* The same with the longest list of the search stated (max_count: the value agb_ball_query_count left in *max_count, which the
+ * caller reads back together with row_ptr[nq]): the kernel sizes its LDS slab from it (next power of two >= max(max_count,
+ * 256) keys per wave instead of 1024) and two to four times the waves fit a CU.  Same rows. */
+int agb_ball_query_fill_csr_m(const float* queries, int nq, const int32_t* q_elem, const float* origin_cs, const int32_t* dims,
+                              const int32_t* cell_start, const float* sorted, float radius, int ns, const int32_t* row_ptr,
+                              int32_t* indices, int capacity, int max_count, int32_t* status, void* stream);
 int agb_csr_to_padded(const int32_t* row_ptr, const int32_t* indices, int nq, int width, int pad, int32_t* out,
                       void* stream);
 /* Grid subsampling (barycentres, optional feature means), canonical order = cell key ascending per cloud.

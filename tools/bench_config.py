@@ -44,7 +44,8 @@ def usable_cores():
 # entry points whose launch notes its compute kernel (agb_last_kernel): the roofline entry names that kernel
 KERNEL_NOTED = ("agb_spconv_fwd_opt", "agb_spconv_fwd_lp", "agb_spconv_fwd_tiles", "agb_spconv_fwd_b16", "agb_spconv_fwd_h",
                 "agb_spconv_bwd_weight_lp", "agb_spconv_bwd_weight_ws", "agb_spconv_bwd_weight_b16_ws", "agb_dense_fwd_bn")
-KERNEL_OF_ENTRY = {"agb_ball_query_fill": "k_ball_query4<true>", "agb_ball_query_fill_csr": "k_ball_query4<true> (ragged rows)"}
+KERNEL_OF_ENTRY = {"agb_ball_query_fill": "k_ball_query4<true>", "agb_ball_query_fill_csr": "k_ball_query4<true> (ragged rows)",
+                   "agb_ball_query_fill_csr_m": "k_ball_query4<true> (ragged rows)"}
 
 
 class CallTimer:
@@ -506,15 +507,18 @@ def run_kpconv(a):
     top_table(groups, 12)
     if a.shapes:
         shape_table(groups)
+    # (agb_ball_query_fill_csr_m: the same argument positions up to `capacity`)
     costs = {"agb_ball_query_fill": ballquery_cost, "agb_ball_query_fill_csr": ballquery_cost_csr,
+             "agb_ball_query_fill_csr_m": ballquery_cost_csr,
              "agb_spconv_fwd_opt": conv_call_cost, "agb_spconv_bwd_weight_ws": wgrad_call_cost,
              "agb_spconv_bwd_weight_lp": wgrad_call_cost}
     roof, per = dominant_roofline(groups, "config3", costs)
     lvl = step_level(per, dt / a.steps * 1e3, "config3")
-    index_names = ("agb_ball_query_fill", "agb_ball_query_fill_csr", "agb_ball_query_offsets", "agb_ball_query_count",
+    index_names = ("agb_ball_query_fill", "agb_ball_query_fill_csr", "agb_ball_query_fill_csr_m", "agb_ball_query_offsets",
+                   "agb_ball_query_count",
                    "agb_ball_grid_build", "agb_grid_subsample_ws", "agb_elem_bbox", "agb_elem_of_row", "agb_rotate_points")
     index_ms = sum(groups[n]["ms"] for n in index_names if n in groups) / 3
-    fill = "agb_ball_query_fill_csr" if "agb_ball_query_fill_csr" in groups else "agb_ball_query_fill"
+    fill = next(n for n in ("agb_ball_query_fill_csr_m", "agb_ball_query_fill_csr", "agb_ball_query_fill") if n in groups)
     bq = roofline_entry(fill, groups[fill], costs[fill], "config3")
     line = dict(metric="training plots/sec KPConv rigid", value=round(B * a.steps / dt, 2), unit="plots/s", n_gpus=1,
                 steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True,
