@@ -92,9 +92,12 @@ def pin_to_gpu_numa_node(index=None):
     import os
     if os.environ.get("AGB_NUMA_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
-    if index is None:
-        index = int(os.environ.get("LOCAL_RANK", "0"))
-    cpus = gpu_local_cpus(index)
+    try:        # (a convenience, never a reason to stop a rank: any surprise in the topology files means "do not pin")
+        if index is None:
+            index = int(os.environ.get("LOCAL_RANK", "0"))
+        cpus = gpu_local_cpus(index)
+    except Exception:
+        return None
     if not cpus:
         return None
     cpus &= os.sched_getaffinity(0)
