@@ -20,8 +20,8 @@ from .. import _lib
 from ..kp_dispositions import kernel_disposition
 from ..kpconv_ops import KPConvFusedFunction, KPConvSymmetricFunction, KPGatherFunction, KPMaxPoolFunction, as_index
 from ..norm_ops import ACT_IDS, AddActFunction, batch_norm_act, batch_norm_add_act
-from ..sparse_ops import DenseConvFunction, current as current_options, dense_linear, model_scope, segment_reduce, \
-    take_bn_hint
+from ..sparse_ops import DenseConvFunction, current as current_options, dense_linear, dense_linear_join, model_scope, \
+    segment_reduce, take_bn_hint
 
 ACTIVATION_NAMES = {"relu": "relu", "gelu": "gelu"}
 # (Linear -> BatchNorm -> + shortcut -> activation of the bottleneck blocks as one node: KernelOptions.fused_tail)
@@ -105,7 +105,14 @@ class UnaryBlock(nn.Module):
         self.act = None if (no_relu or act_name in ACTIVATION_NAMES) else _act_module(act_name)
 
     def forward(self, x, batch=None):
-        x = dense_linear(x, self.mlp.weight, self.mlp.bias)
+        return self._norm_act(dense_linear(x, self.mlp.weight, self.mlp.bias))
+
+    def forward_join(self, x):
+        """(block output, x for the branch that bypasses this block): sparse_ops.dense_linear_join."""
+        z, branch = dense_linear_join(x, self.mlp.weight, self.mlp.bias)
+        return self._norm_act(z), branch
+
+    def _norm_act(self, x):
         if self.no_relu:
             return self.batch_norm(x)
         if self.act is None:
@@ -169,7 +176,11 @@ class ResnetBottleneckBlock(nn.Module):
 
     def forward(self, features, batch):
         q, s, idx = _geometry(self, batch)
-        x = self.unary1(features)
+        if isinstance(self.unary1, UnaryBlock):
+            # the block input feeds unary1 and the shortcut: the shortcut's gradient joins in unary1's data-gradient kernel
+            x, features = self.unary1.forward_join(features)
+        else:
+            x = self.unary1(features)
         x = self.KPConv(q, s, idx, x)
         x = _post(self.batch_norm_conv, self.act_name, None if self._fused_act else self.act, x)
         if "strided" in self.block_name:

@@ -202,7 +202,11 @@ class Bottleneck(nn.Module):
         return self.norm3(self.conv3(out))
 
     def forward(self, x):
-        out = self._main(x)
+        # (x feeds conv1 and the shortcut: the shortcut's gradient joins in conv1's data-gradient kernel)
+        out, x = self.conv1.forward_join(x)
+        out = ME.fused_norm_act(self.norm1, self.relu, out)
+        out = ME.fused_norm_act(self.norm2, self.relu, self.conv2(out))
+        out = self.norm3(self.conv3(out))
         residual = self.downsample(x)
         return _residual_tail(self, out, residual)
 
@@ -281,7 +285,8 @@ class SEBottleneck(Bottleneck):
         return self.se(super()._main(x))
 
     def forward(self, x):
-        out = ME.fused_norm_act(self.norm1, self.relu, self.conv1(x))
+        out, x = self.conv1.forward_join(x)
+        out = ME.fused_norm_act(self.norm1, self.relu, out)
         out = ME.fused_norm_act(self.norm2, self.relu, self.conv2(out))
         return _se_block_forward(self, x, self.conv3(out), self.norm3)
 

@@ -164,6 +164,14 @@ __device__ __forceinline__ unsigned agb_bf16_pair_rows(float v0, float v1, bool 
     const unsigned even_w = agb_pack2_bf16(v0, n0), odd_w = agb_pack2_bf16(n1, v1);
     return odd ? odd_w : even_w;
 }
+// The same with the packed bf16 pair `adw` of another matrix at the lane's STORE position added in fp32 before the one
+// rounding (the addend of a residual join, ConvArgs.addend on bf16 rows).
+__device__ __forceinline__ unsigned agb_bf16_pair_rows_add(float v0, float v1, bool odd, unsigned adw) {
+    const float n0 = agb_lane_xor1(v0), n1 = agb_lane_xor1(v1);
+    const float alo = __uint_as_float(adw << 16), ahi = __uint_as_float(adw & 0xffff0000u);
+    const unsigned even_w = agb_pack2_bf16(v0 + alo, n0 + ahi), odd_w = agb_pack2_bf16(n1 + alo, v1 + ahi);
+    return odd ? odd_w : even_w;
+}
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_t* p, float v) {
     const __bf16 h = (__bf16)v;

@@ -496,17 +496,38 @@ __global__ __launch_bounds__(256) void k_spconv_pipe(ConvArgs a) {
         const int col = n0 + (wn * NT + nt) * 32 + li;
         bvs[nt] = (a.bias && a.ksplit == 1 && col < Cout) ? a.bias[col] : 0.f;
     }
+    if (addp) {
+        // the addend of a residual join: all of this lane's values requested before the first is used (a load, an addition
+        // and a store per element — the addend may alias the output, so every load waited for the store before it —
+        // cost an HBM-bound dense data gradient a third of its time: 61 -> 81 us on KPConv's 128-column layers)
+        float ad[NT][16];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = rows[reg];
-        if (row < 0) continue;
+        for (int reg = 0; reg < 16; ++reg) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = n0 + (wn * NT + nt) * 32 + li;
-            if (col < Cout) {
-                float v = acc[nt][reg] + bvs[nt];
-                if (addp) v += addp[(long long)row * a.ld_add + col];
-                out[(long long)row * ldo + col] = v;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = n0 + (wn * NT + nt) * 32 + li;
+                ad[nt][reg] = (rows[reg] >= 0 && col < Cout) ? addp[(long long)rows[reg] * a.ld_add + col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = rows[reg];
+            if (row < 0) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = n0 + (wn * NT + nt) * 32 + li;
+                if (col < Cout) out[(long long)row * ldo + col] = (acc[nt][reg] + bvs[nt]) + ad[nt][reg];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = rows[reg];
+            if (row < 0) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = n0 + (wn * NT + nt) * 32 + li;
+                if (col < Cout) out[(long long)row * ldo + col] = acc[nt][reg] + bvs[nt];
             }
         }
     }
@@ -900,13 +921,29 @@ __global__ __launch_bounds__(256) void k_spconv_pipe_b16(ConvArgs a) {
             const int rt = row0 + wm * 32 + (reg & 3) + (int)odd + 8 * (reg >> 2) + 4 * lh;
             prow[h2] = PERM ? a.perm[rt] : (rt < a.n_out ? rt : -1);
         }
+        // addend of a residual join (bf16 rows [n_out][ld_add]; data gradients: no bias): the pair at every store position of
+        // this lane, all requested before the first is used, added in fp32 before the one rounding
+        const bf16_t* __restrict__ ad16 = reinterpret_cast<const bf16_t*>(a.addend);
+        unsigned adw[8][NT];
+        if (ad16) {
+#pragma unroll
+            for (int h2 = 0; h2 < 8; ++h2) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + (wn * NT + nt) * 32 + (li & ~1);
+                    adw[h2][nt] = (prow[h2] >= 0 && col < Cout)
+                        ? *reinterpret_cast<const unsigned*>(ad16 + (long long)prow[h2] * a.ld_add + col) : 0u;
+                }
+            }
+        }
 #pragma unroll
         for (int h2 = 0; h2 < 8; ++h2) {
             const int row = prow[h2];
             unsigned w[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                w[nt] = agb_bf16_pair_rows(acc[nt][2 * h2] + bvs[nt], acc[nt][2 * h2 + 1] + bvs[nt], odd);
+                w[nt] = ad16 ? agb_bf16_pair_rows_add(acc[nt][2 * h2] + bvs[nt], acc[nt][2 * h2 + 1] + bvs[nt], odd, adw[h2][nt])
+                             : agb_bf16_pair_rows(acc[nt][2 * h2] + bvs[nt], acc[nt][2 * h2 + 1] + bvs[nt], odd);
             if (row >= 0) {
                 bf16_t* yrow = Y16p + (long long)row * a.ldy + n0 + wn * NT * 32 + (li & ~1);
 #pragma unroll
@@ -3024,7 +3061,9 @@ template <bool Y16>
 static int fwd_b16_impl(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const int32_t* nbr, long long nbr_stride,
                         int kflip, const float* bias, float* Y, int ldy, int n_out, int K3, int Cin, int Cout,
                         const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
-                        float* partial, void* stream) {
+                        float* partial, void* stream, const uint16_t* addend16 = nullptr, int ld_add = 0) {
+    AGB_CHECK_ARG(addend16 == nullptr || (Y16 && ksplit == 1 && ld_add >= Cout && ld_add % 2 == 0),
+                  "agb_spconv_bwd_data_h: an addend needs bf16 output rows, ksplit == 1 and an even ld_add >= Cout (%d)", ld_add);
     AGB_CHECK_ARG(n_out >= 0 && K3 >= 1 && Cin >= 8 && Cout >= 4 && Cin % 8 == 0 && Cout % 4 == 0 && ldx16 % 8 == 0,
                   "agb_spconv_fwd_b16: Cin (%d), ldx16 must be multiples of 8, Cout (%d) of 4", Cin, Cout);
     AGB_CHECK_ARG(!Y16 || ldy % 4 == 0, "agb_spconv_fwd_h: ldy (%d, bf16 elements) must be a multiple of 4", ldy);
@@ -3034,6 +3073,7 @@ static int fwd_b16_impl(const uint16_t* X16, int ldx16, const uint16_t* Wt16, co
     hipStream_t s = (hipStream_t)stream;
     ConvArgs a{reinterpret_cast<const float*>(X16), ldx16, reinterpret_cast<const float*>(Wt16), nbr, nbr_stride, kflip, bias,
                Y, ldy, n_out, K3, Cin, Cout, perm, tile_cls, cls_tab, ksplit, partial, 0, -1};
+    a.addend = reinterpret_cast<const float*>(addend16); a.ld_add = ld_add;
     dim3 block(256);
     if (perm) {
         hipLaunchKernelGGL((k_spconv_pipe_b16<64, true, 64, Y16>), dim3(n_tiles, agb_cdiv(Cout, BN), ksplit), block, 0, s, a);
@@ -3080,6 +3120,20 @@ int agb_spconv_fwd_h(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const
                      float* partial, void* stream) {
     return fwd_b16_impl<true>(X16, ldx16, Wt16, nbr, nbr_stride, kflip, bias, reinterpret_cast<float*>(Y16), ldy16, n_out, K3,
                               Cin, Cout, perm, tile_cls, cls_tab, n_tiles, ksplit, partial, stream);
+}
+
+// The data gradient on bf16 rows under its own name, like agb_spconv_bwd_data:
+//   dX16[q] = bf16( [addend16[q] +] sum_k dY16[map[k][q]] W16[k] )        (fp32 sum, ONE rounding)
+// W16 uint16 [K3][Cin][Cout] (Cin = channels of dX, Cout = channels of dY: for the data gradient the layer's own kernel
+// [K3][Cin][Cout] IS the K-major operand); map / perm / ksplit as agb_spconv_fwd_h.  addend16 (optional, bf16
+// [n_in][ld_add], ksplit == 1): the other gradient of a residual join — a block input that feeds this layer and the
+// shortcut (senet_block.py:99-147, resnet_block.py:93-133).
+int agb_spconv_bwd_data_h(const uint16_t* dY16, int lddy16, const uint16_t* W16, const int32_t* map, long long map_stride,
+                          int kflip, uint16_t* dX16, int lddx16, int n_in, int K3, int Cin, int Cout, const int32_t* perm,
+                          const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit, float* partial,
+                          const uint16_t* addend16, int ld_add, void* stream) {
+    return fwd_b16_impl<true>(dY16, lddy16, W16, map, map_stride, kflip, nullptr, reinterpret_cast<float*>(dX16), lddx16, n_in,
+                              K3, Cout, Cin, perm, tile_cls, cls_tab, n_tiles, ksplit, partial, stream, addend16, ld_add);
 }
 
 int agb_spconv_fwd(const float* X, int ldx, const float* W, const int32_t* nbr, long long nbr_stride, int kflip,

@@ -22,7 +22,7 @@ from . import _lib
 from .coords import CoordinateManager, CoordinateMapKey, _as_int
 from .norm_ops import ACT_IDS, AddActFunction, batch_norm_act
 from .sparse_ops import (BroadcastMulFunction, DenseConvFunction, take_bn_hint, GlobalPoolFunction, MaxPoolFunction,
-                         SparseConvFunction, dense_linear)
+                         SparseConvFunction, dense_conv_join, dense_linear)
 
 
 class SparseTensor:
@@ -163,6 +163,15 @@ class MinkowskiConvolution(nn.Module):
             self.kernel.uniform_(-stdv, stdv)
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
+
+    def forward_join(self, input: SparseTensor):
+        """(self(input), input for the branch that bypasses this layer): for the 1x1 first convolution of a bottleneck block,
+        whose input also feeds the shortcut — the shortcut's gradient then joins in this layer's data-gradient kernel
+        (sparse_ops.dense_conv_join).  Any other layer: (self(input), input)."""
+        if self.use_mm and input.F.is_cuda and DenseConvFunction.supported(self.in_channels, self.out_channels):
+            y, branch = dense_conv_join(input.F, self.kernel, self.bias)
+            return input._like(y), (input if branch is input.F else input._like(branch))
+        return self.forward(input), input
 
     def forward(self, input: SparseTensor, coordinates=None) -> SparseTensor:
         if coordinates is not None:

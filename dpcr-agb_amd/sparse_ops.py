@@ -63,19 +63,22 @@ class KernelOptions:
       fused_kpconv         rigid KPConv layers on one point set (16 / 32 channels, ragged symmetric neighbour rows) as ONE
                            kernel per direction (kpconv_ops.KPConvFusedFunction, csrc/kpfused.hip): the weighted neighbourhood
                            features never go through HBM; fixed summation order.  Default on (fp32 operands only).
+      join_dgrad           a KPConv bottleneck block's input feeds its first Linear AND its shortcut: the shortcut's gradient
+                           rides in the final store of that Linear's data gradient (DenseLinearFunction join form,
+                           agb_spconv_bwd_data's addend) instead of a separate addition pass per block.  Default on (fp32).
 
     Use: ``model.kernel_options = KernelOptions(precision="bf16")`` (the backbones run their forward pass inside it), or
     ``with KernelOptions(cmp_mode=128): ...`` around direct calls.  Autograd nodes keep the options they were created
     under for their backward pass.  ``DEFAULTS`` (environment-initialised) applies where nothing else is set."""
     __slots__ = ("precision", "cmp_mode", "cmp_interleave", "balanced_tiles", "bn_stats_in_epilogue", "fused_tail",
                  "deterministic_wgrad", "dw_variant", "bf16_storage", "bf16_activations", "closed_form_bias_grad",
-                 "fused_blocks", "fused_head", "fused_kpconv")
+                 "fused_blocks", "fused_head", "fused_kpconv", "join_dgrad")
     PRECISIONS = ("fp32", "bf16", "bf16x3")
 
     def __init__(self, precision=None, cmp_mode=None, cmp_interleave=None, balanced_tiles=None,
                  bn_stats_in_epilogue=None, fused_tail=None, deterministic_wgrad=None, dw_variant=None,
                  bf16_storage=None, bf16_activations=None, closed_form_bias_grad=None, fused_blocks=None, fused_head=None,
-                 fused_kpconv=None, base=None):
+                 fused_kpconv=None, join_dgrad=None, base=None):
         base = base if base is not None else (current() if "DEFAULTS" in globals() else None)
         pick = lambda v, name, dflt: v if v is not None else (getattr(base, name) if base is not None else dflt)  # noqa: E731
         self.precision = pick(precision, "precision", "fp32")
@@ -94,6 +97,7 @@ class KernelOptions:
         self.fused_blocks = bool(pick(fused_blocks, "fused_blocks", True))
         self.fused_head = bool(pick(fused_head, "fused_head", True))
         self.fused_kpconv = bool(pick(fused_kpconv, "fused_kpconv", True))
+        self.join_dgrad = bool(pick(join_dgrad, "join_dgrad", True))
 
     def replace(self, **kw):
         return KernelOptions(base=self, **kw)
@@ -148,7 +152,8 @@ DEFAULTS = KernelOptions(precision=os.environ.get("AGB_CONV_PRECISION", "fp32"),
                          bf16_storage=os.environ.get("AGB_BF16_STORAGE", "1") != "0",
                          fused_blocks=os.environ.get("AGB_FUSED_BLOCKS", "1") != "0",
                          fused_head=os.environ.get("AGB_FUSED_HEAD", "1") != "0",
-                         fused_kpconv=os.environ.get("AGB_FUSED_KPCONV", "1") != "0")
+                         fused_kpconv=os.environ.get("AGB_FUSED_KPCONV", "1") != "0",
+                         join_dgrad=os.environ.get("AGB_JOIN_DGRAD", "1") != "0")
 
 
 def set_conv_precision(name):
@@ -174,6 +179,10 @@ _lib.declare("agb_spconv_bwd_data", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _
                                      _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p,
                                      _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
                                      _lib.c_int, _lib.c_void_p])
+_lib.declare("agb_spconv_bwd_data_h", [_lib.c_void_p, _lib.c_int, _lib.c_void_p, _lib.c_void_p, _lib.c_ll, _lib.c_int,
+                                       _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_int, _lib.c_void_p,
+                                       _lib.c_void_p, _lib.c_void_p, _lib.c_int, _lib.c_int, _lib.c_void_p, _lib.c_void_p,
+                                       _lib.c_int, _lib.c_void_p])
 _lib.declare("agb_spconv_split_hint_opt", [_lib.c_int] * 5)
 _lib.declare("agb_spconv_bwd_weight_persistent", [_lib.c_int] * 6)
 _lib.declare("agb_spconv_cmp_geometry", [_lib.c_int] * 8 + [_lib.c_void_p])
@@ -849,8 +858,11 @@ class DenseConvFunction(torch.autograd.Function):
         return cin >= 12 and cout >= 12 and cin % 4 == 0 and cout % 4 == 0
 
     @staticmethod
-    def forward(ctx, feats, kernel, bias):
+    def forward(ctx, feats, kernel, bias, join=False):
+        """join: also return feats itself as a second output (a residual block's shortcut branch); the gradient that
+        comes back for it is the ADDEND of this layer's data gradient (KernelOptions.join_dgrad; dense_conv_join)."""
         cin, cout = kernel.shape
+        ctx.join = bool(join)
         x = feats.contiguous()
         n = x.shape[0]
         w = kernel.contiguous()
@@ -870,10 +882,10 @@ class DenseConvFunction(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bias_shape = None if bias is None else bias.shape
-        return y
+        return (y, feats) if join else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dbranch=None):
         x, w = ctx.saved_tensors
         cin, cout = w.shape
         n = x.shape[0]
@@ -887,9 +899,28 @@ class DenseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if lp:     # the data gradient multiplies by W^T: its K-major form [Cin][Cout] is the kernel itself
                 tw = _twins_for(w, dy, opts, cin, cout, cin, cout)
-                dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None, None if tw else w,
-                                        opts=opts, w16=tw[0] if tw else None,
-                                        out_bf16=(x.dtype == torch.bfloat16) if dy.dtype == torch.bfloat16 else None)
+                if (dbranch is not None and tw and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+                        and dbranch.dtype == torch.bfloat16 and opts.prec_id == 1 and cout % 8 == 0 and dy.stride(0) % 8 == 0
+                        and cin % 4 == 0 and _lib.load().agb_dense_split_hint(n, cout, cin) == 1):
+                    # bf16 rows: the branch gradient joins in fp32 before the data gradient's one rounding
+                    dbranch = dbranch.contiguous()
+                    dx = torch.empty(n, cin, dtype=torch.bfloat16, device=dy.device)
+                    ev = _prof_begin("dgrad1x1", 1, cout, cin, n, False, 1, n)
+                    _lib.call("agb_spconv_bwd_data_h", _P16(dy), dy.stride(0), _P16(tw[0]), None, 0, 0, _P16(dx), dx.stride(0),
+                              n, 1, cin, cout, None, None, None, 0, 1, None, _P16(dbranch), dbranch.stride(0), _lib.stream())
+                    _prof_end(ev, "dgrad1x1", 1, cout, cin, n, int(n), False, 1, n)
+                    dbranch = None
+                else:
+                    dx = spconv_forward_raw(dy, None, None, 0, None, n, 1, cout, cin, "dgrad1x1", None, None,
+                                            None if tw else w, opts=opts, w16=tw[0] if tw else None,
+                                            out_bf16=(x.dtype == torch.bfloat16) if dy.dtype == torch.bfloat16 else None)
+            elif dbranch is not None and dy.dtype == torch.float32 and dbranch.dtype == torch.float32:
+                wt = torch.empty(cout, cin, dtype=torch.float32, device=w.device)
+                if ctx.needs_input_grad[1]:
+                    dk = torch.empty(cin, cout, dtype=torch.float32, device=w.device)
+                _lib.call("agb_spconv_weight_transpose_z", _P(w), _P(wt), _P(dk), 1, cin, cout, _lib.stream())
+                dx = _dense_dgrad_add(dy, wt, dbranch, n, cout, cin)
+                dbranch = None
             else:
                 wt = torch.empty(cout, cin, dtype=torch.float32, device=w.device)
                 if ctx.needs_input_grad[1]:   # the weight-gradient buffer is cleared by the same launch
@@ -907,7 +938,20 @@ class DenseConvFunction(torch.autograd.Function):
                   else dy.sum(0, dtype=torch.float32)).reshape(ctx.bias_shape)
         if dx is not None and dx.dtype != x.dtype:
             dx = dx.to(x.dtype)
-        return dx, dk, db
+        if dbranch is not None:      # (join form where the fused store does not apply: the addition autograd would have made)
+            dx = dbranch if dx is None else dx + dbranch.to(dx.dtype)
+        return dx, dk, db, None
+
+
+def dense_conv_join(feats, kernel, bias):
+    """(y, feats_branch) = (1x1 convolution of feats, feats) for a residual block whose input also feeds the shortcut: the
+    shortcut's gradient is added in this layer's data-gradient kernel (KernelOptions.join_dgrad; fp32 rows: ConvArgs.addend of
+    the register-accumulator kernel, bf16 rows: agb_spconv_bwd_data_h — the sum in fp32 before the one rounding).
+    Bottleneck / SEBottleneck: resnet_block.py:93-133, senet_block.py:99-147."""
+    if (current().join_dgrad and feats.is_cuda and feats.requires_grad and torch.is_grad_enabled()):
+        y, branch = DenseConvFunction.apply(feats, kernel, bias, True)
+        return take_bn_hint(y), branch
+    return take_bn_hint(DenseConvFunction.apply(feats, kernel, bias, False)), feats
 
 
 def dense_product(x, w, kind="fwd1x1", bn_stats=False, opts=None):
@@ -942,9 +986,13 @@ class DenseLinearFunction(torch.autograd.Function):
     feature x kernel-weight contraction (blocks.py:396-400).  Feature widths are zero-padded to a multiple of 4 (>= 12)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, join=False):
+        """join: also return x itself as a second output (the branch of a residual block that bypasses this layer); the
+        gradient that comes back for it is then the ADDEND of this layer's data gradient — dx = dx_branch + dy @ weight leaves
+        in one pass (fp32 operands, unpadded widths: dense_linear_join checks)."""
         n, cin = x.shape
         cout = weight.shape[0]
+        ctx.join = bool(join)
         # both widths are the reduction dimension of one of the three products: at least 12, multiples of 4
         cin_p, cout_p = max(12, (cin + 3) // 4 * 4), max(12, (cout + 3) // 4 * 4)
         xp = (x if cin_p == cin else F.pad(x, (0, cin_p - cin))).contiguous()
@@ -970,10 +1018,12 @@ class DenseLinearFunction(torch.autograd.Function):
                                    bn_stats=any(ctx.needs_input_grad) and cout_p == cout, opts=opts)
         ctx.save_for_backward(xp, wp)
         ctx.dims = (cin, cout, cin_p, cout_p, bias is not None)
+        if join:
+            return y, x
         return y if cout_p == cout else y[:, :cout].contiguous()
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dbranch=None):
         xp, wp = ctx.saved_tensors
         cin, cout, cin_p, cout_p, has_bias = ctx.dims
         n = xp.shape[0]
@@ -985,7 +1035,10 @@ class DenseLinearFunction(torch.autograd.Function):
         lp = opts.low_precision
         if ctx.needs_input_grad[0]:
             # dX = dY @ weight: weight [out, in] is the [K, N] operand as stored; its K-major form is the transpose
-            if lp:
+            if ctx.join and dbranch is not None:
+                dxp = _dense_dgrad_add(dyp, wp, dbranch, n, cout_p, cin_p)
+                dbranch = None
+            elif lp:
                 wkm = wp.t().contiguous()
                 dxp = spconv_forward_raw(dyp, None, None, 0, None, n, 1, cout_p, cin_p, "dgrad1x1", None, None, wkm,
                                          opts=opts)
@@ -1001,13 +1054,44 @@ class DenseLinearFunction(torch.autograd.Function):
             dw = dwp if (cin_p == cin and cout_p == cout) else dwp[:cout, :cin].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum if (colsum is not None and colsum.numel() == cout) else dy.sum(0)
-        return dx, dw, db
+        if dbranch is not None:      # (join form whose own data gradient was not asked for, or is None)
+            dx = dbranch if dx is None else dx + dbranch
+        return dx, dw, db, None
+
+
+def _dense_dgrad_add(dy, w, addend, n, cout, cin):
+    """dx [n, cin] = addend + dy [n, cout] @ w [cout, cin] (agb_spconv_bwd_data on the identity map: the addend joins in the
+    kernel's final store — after its own sum, the value a separate addition gives)."""
+    addend = addend.contiguous()
+    split = _lib.load().agb_dense_split_hint(n, cout, cin)
+    partial = torch.empty(split, n, cin, dtype=torch.float32, device=dy.device) if split > 1 else None
+    dx = torch.empty(n, cin, dtype=torch.float32, device=dy.device)
+    ev = _prof_begin("dgrad1x1", 1, cout, cin, n, False, split, n)
+    _lib.call("agb_spconv_bwd_data", _P(dy), dy.stride(0), _P(w), None, 0, 0, _P(dx), dx.stride(0), n, 1, cin, cout, None,
+              None, None, 0, split, _P(partial), _P(addend), addend.stride(0), _lib.stream())
+    _prof_end(ev, "dgrad1x1", 1, cout, cin, n, int(n), False, split, n)
+    return dx
+
+
+def dense_linear_join(x, weight, bias=None):
+    """(y, x_branch) = (nn.Linear(x), x) for a residual block whose input also feeds a branch that bypasses this layer: the
+    branch's gradient is added in this layer's data-gradient kernel (KernelOptions.join_dgrad; KPConv blocks.py:640-668:
+    unary1 and the shortcut both read the block input).  Falls back to (dense_linear(x), x) where the join form does not
+    apply (bf16 operand modes, padded widths, no gradient wanted)."""
+    cin, cout = x.shape[1], weight.shape[0]
+    opts = current()
+    if (opts.join_dgrad and not opts.low_precision and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
+            and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled()
+            and cin >= 12 and cin % 4 == 0 and cout >= 12 and cout % 4 == 0):
+        y, branch = DenseLinearFunction.apply(x, weight, bias, True)
+        return take_bn_hint(y), branch
+    return dense_linear(x, weight, bias), x
 
 
 def dense_linear(x, weight, bias=None):
     """nn.Linear semantics on the library's own kernels for device tensors with >= 1 row; plain F.linear otherwise."""
     if x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.dtype == torch.float32:
-        return take_bn_hint(DenseLinearFunction.apply(x, weight, bias))
+        return take_bn_hint(DenseLinearFunction.apply(x, weight, bias, False))
     return F.linear(x, weight, bias)
 
 

@@ -245,6 +245,16 @@ int agb_spconv_fwd_h(const uint16_t* X16, int ldx16, const uint16_t* Wt16, const
                      int kflip, const float* bias, uint16_t* Y16, int ldy16, int n_out, int K3, int Cin, int Cout,
                      const int32_t* perm, const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit,
                      float* partial, void* stream);
+/* The data gradient on bf16 rows under its own name (as agb_spconv_bwd_data is for fp32 rows):
+ *   dX16[q] = bf16( [addend16[q] +] sum_k dY16[map[k][q]] W16[k] )     fp32 sum, ONE rounding.
+ * W16 uint16 [K3][Cin][Cout] (Cin = channels of dX, Cout = channels of dY: the layer's kernel itself is the K-major operand
+ * of its data gradient); map / kflip / perm / ksplit as agb_spconv_fwd_h.  addend16 (optional; bf16 [n_in][ld_add], ld_add
+ * even, ksplit == 1): the other gradient of a residual join — a block input that feeds this layer and the shortcut
+ * (resnet_block.py:93-133, senet_block.py:99-147) — added before the rounding instead of by a separate pass. */
+int agb_spconv_bwd_data_h(const uint16_t* dY16, int lddy16, const uint16_t* W16, const int32_t* map, long long map_stride,
+                          int kflip, uint16_t* dX16, int lddx16, int n_in, int K3, int Cin, int Cout, const int32_t* perm,
+                          const int32_t* tile_cls, const int32_t* cls_tab, int n_tiles, int ksplit, float* partial,
+                          const uint16_t* addend16, int ld_add, void* stream);
 /* Both bf16 operand forms of one layer's weights W float[K3][R][C] in one launch: W16 uint16 [K3][R][C] (the data
  * gradient's K-major form) and Wt16 uint16 [K3][C][R] (the forward pass's), round to nearest even. */
 int agb_weight_twins_bf16(const float* W, int K3, int R, int C, uint16_t* W16, uint16_t* Wt16, void* stream);

@@ -199,6 +199,37 @@ def test_kpconv_fused_edge_shapes(device, n, radius):
         KPConvFusedFunction.apply(x, pts, nb, kp, 0.6 * radius, wt).backward(gy)
         assert torch.equal(wt.grad, out["fused"][2])
 
+@pytest.mark.parametrize("n,cin,cout", [(20000, 64, 16), (20000, 128, 32), (5000, 256, 64), (300, 1024, 256), (1, 16, 16)])
+def test_linear_join_adds_the_branch_gradient_in_the_data_gradient_kernel(device, n, cin, cout):
+    """DenseLinearFunction's join form (the input of a bottleneck block feeds unary1 and the shortcut, blocks.py:640-668):
+    dx = d(branch) + dy @ W from one kernel — against the fp64 value, and bit for bit against a separate addition where
+    both forms run the same product kernel (every shape here but the 16 -> 64 data gradient of many rows, which the
+    streaming kernel takes when no addend comes with it)."""
+    from dpcr_agb_amd import sparse_ops as so
+    gen = torch.Generator().manual_seed(n + cin)
+    x0 = torch.randn(n, cin, generator=gen)
+    w = (torch.randn(cout, cin, generator=gen) / cin ** 0.5).to(device).requires_grad_(True)
+    m1, m2 = torch.randn(n, cout, generator=gen).to(device), torch.randn(n, cin, generator=gen).to(device)
+
+    def run(join):
+        x = x0.to(device).requires_grad_(True)
+        w.grad = None
+        with so.KernelOptions(join_dgrad=join):
+            y, branch = so.dense_linear_join(x, w)
+            assert (branch is not x) == join       # (the join form hands out an alias that carries its autograd node)
+            ((y * m1).sum() + (torch.tanh(branch) * m2).sum()).backward()
+        return y.detach(), x.grad, w.grad.clone()
+
+    ya, dxa, dwa = run(True)
+    yb, dxb, dwb = run(False)
+    assert torch.equal(ya, yb) and rel(dwa, dwb) < 1e-5      # (the weight gradient of many rows sums with atomics)
+    xd, wd = x0.double().to(device), w.detach().double()
+    want = (1 - torch.tanh(xd) ** 2) * m2.double() + m1.double() @ wd
+    assert rel(dxa, want) < 2e-6 and rel(dxb, want) < 2e-6
+    if not (n >= 16384 and cout == 16):
+        assert torch.equal(dxa, dxb)
+
+
 def test_pool_helpers_match_reference(device, g):
     from dpcr_agb_amd.backbones.kpconv import GlobalSumBlock
     from dpcr_agb_amd.kpconv_ops import KPMaxPoolFunction

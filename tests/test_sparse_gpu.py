@@ -771,6 +771,49 @@ def test_dense_1x1_conv(device, precision, tol, cin, cout, n):
     assert rel_err(conv.bias.grad, br.grad) < RTOL
 
 
+@pytest.mark.parametrize("rows_bf16", [False, True])
+@pytest.mark.parametrize("cin,cout,n", [(256, 64, 30000), (64, 64, 5000), (512, 128, 3001), (1024, 256, 4000), (64, 16, 333),
+                                        (256, 64, 1)])
+def test_dense_1x1_conv_join_adds_the_branch_gradient(device, rows_bf16, cin, cout, n):
+    """The first 1x1 convolution of a bottleneck block (resnet_block.py:93-133, senet_block.py:99-147) in its join form: the
+    block input also feeds the shortcut, whose gradient is the addend of the convolution's data gradient.  fp32 rows: the
+    value a separate addition gives, bit for bit (same product kernel).  bf16 rows (agb_spconv_bwd_data_h): the sum in
+    fp32, ONE rounding — within half a bf16 ulp of the fp64 value computed from the same bf16 operands, where the separate
+    addition rounds twice."""
+    from dpcr_agb_amd import sparse_ops as so
+    gen = torch.Generator().manual_seed(cin + cout + n)
+    x0 = torch.randn(n, cin, generator=gen)
+    w = (torch.randn(cin, cout, generator=gen) / cin ** 0.5).to(device).requires_grad_(True)
+    g1, g2 = torch.randn(n, cout, generator=gen), torch.randn(n, cin, generator=gen)
+    dt = torch.bfloat16 if rows_bf16 else torch.float32
+    kw = dict(precision="bf16", bf16_activations=True) if rows_bf16 else {}
+
+    def run(join):
+        x = x0.to(device, dt).requires_grad_(True)
+        with so.KernelOptions(join_dgrad=join, **kw):
+            y, branch = so.dense_conv_join(x, w, None)
+            assert (branch is not x) == join and y.dtype == dt
+            torch.autograd.backward([y, branch], [g1.to(device, dt), g2.to(device, dt)])
+        return y.detach(), x.grad
+
+    ya, dxa = run(True)
+    yb, dxb = run(False)
+    assert torch.equal(ya, yb) and dxa.dtype == dt
+    if not rows_bf16:
+        assert torch.equal(dxa, dxb)
+        want = g2.double().to(device) + g1.double().to(device) @ w.detach().double().t()
+        assert rel_err(dxa, want) < 1e-5
+        return
+    # the operands as the kernel sees them: bf16 gradient rows, bf16 twin of the kernel
+    want = g2.to(dt).double().to(device) + g1.to(dt).double().to(device) @ w.detach().to(dt).double().t()
+    ulp = torch.maximum(want.abs(), torch.full_like(want, 1e-30)).log2().floor().exp2() * 2.0 ** -7   # spacing of bf16 at |want|
+    # fp32 accumulation of the kernel: a few 1e-7 of the sum of the terms' magnitudes (matters where the terms cancel)
+    slack = 2e-6 * (g2.to(dt).double().abs().to(device) + g1.to(dt).double().abs().to(device) @ w.detach().double().abs().t())
+    ea, eb = (dxa.double() - want).abs(), (dxb.double() - want).abs()
+    assert float(((ea - slack).clamp(min=0) / ulp).max()) <= 0.5 + 1e-6        # ONE rounding
+    assert rel_err(dxb, want) < 2e-2 and float(ea.mean()) <= float(eb.mean())  # (the separate addition rounds twice)
+
+
 @pytest.mark.parametrize("cin,cout,n", [(240, 16, 40001), (480, 32, 20000), (16, 240, 33333), (32, 480, 17000),
                                         (32, 128, 50000), (128, 32, 16384), (64, 16, 30011), (16, 64, 70000),
                                         (48, 32, 25000), (64, 64, 16400), (16, 12, 20000), (1008, 12, 16385)])
