@@ -1225,15 +1225,23 @@ __global__ __launch_bounds__(64) void k_spconv_cmp(ConvArgs a, int ntiles, int n
             rows[u] = r < rows_per_tile ? s_row[r] : -1;
             ys[u] = *reinterpret_cast<const float4*>(&Ys[min(r, R) * CMP_YS + c4]);
         }
+        // the addend's eight row pieces are requested together, before the first store (the addend may alias the output:
+        // a load placed after a store has to wait for it)
+        float4 ads[8];
+        const bool with_add = a.addend && csplit == 1;
+        if (with_add) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                ads[u] = (rows[u] >= 0 && col_ok)
+                    ? *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (rows[u] >= 0 && col_ok) {
                 float4 y = ys[u];
                 y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
-                if (a.addend && csplit == 1) {
-                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4);
-                    y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
-                }
+                if (with_add) { y.x += ads[u].x; y.y += ads[u].y; y.z += ads[u].z; y.w += ads[u].w; }
                 *reinterpret_cast<float4*>(out + (long long)rows[u] * ldo + n0 + c4) = y;
             }
         }
@@ -1474,15 +1482,23 @@ __global__ __launch_bounds__(64) void k_spconv_cmpt(ConvArgs a, int ntiles, int 
             const float* yr = &Ys[min(r, R) * CMP_YS + pos0];
             ys[u] = make_float4(yr[0], yr[4], yr[8], yr[12]);
         }
+        // the addend's eight row pieces are requested together, before the first store (the addend may alias the output:
+        // a load placed after a store has to wait for it)
+        float4 ads[8];
+        const bool with_add = a.addend && csplit == 1;
+        if (with_add) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                ads[u] = (rows[u] >= 0 && col_ok)
+                    ? *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (rows[u] >= 0 && col_ok) {
                 float4 y = ys[u];
                 y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
-                if (a.addend && csplit == 1) {
-                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4);
-                    y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
-                }
+                if (with_add) { y.x += ads[u].x; y.y += ads[u].y; y.z += ads[u].z; y.w += ads[u].w; }
                 *reinterpret_cast<float4*>(out + (long long)rows[u] * ldo + n0 + c4) = y;
             }
         }
@@ -1597,15 +1613,23 @@ __global__ __launch_bounds__(64) void k_spconv_cma(ConvArgs a, int ntiles, int n
             const float* yr = &Ys[min(r, R) * CMP_YS + pos0];
             ys[u] = make_float4(yr[0], yr[4], yr[8], yr[12]);
         }
+        // the addend's eight row pieces are requested together, before the first store (the addend may alias the output:
+        // a load placed after a store has to wait for it)
+        float4 ads[8];
+        const bool with_add = a.addend && csplit == 1;
+        if (with_add) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                ads[u] = (rows[u] >= 0 && col_ok)
+                    ? *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (rows[u] >= 0 && col_ok) {
                 float4 y = ys[u];
                 y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
-                if (a.addend && csplit == 1) {
-                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long long)rows[u] * a.ld_add + n0 + c4);
-                    y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
-                }
+                if (with_add) { y.x += ads[u].x; y.y += ads[u].y; y.z += ads[u].z; y.w += ads[u].w; }
                 *reinterpret_cast<float4*>(out + (long long)rows[u] * ldo + n0 + c4) = y;
             }
         }

@@ -29,12 +29,21 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     ds = synthetic.SyntheticDataset(stat_seeds=range(10_000, 10_064))
-    model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS[args.model]), "minkowski", ds)
-    model.to(dev).train()
-    model.set_kernel_options(precision=args.precision, bf16_activations=args.bf16_rows)
+    if args.model == "KPConv":
+        from dpcr_agb_amd.instance import KPConvModel
+        model = KPConvModel(Opt(MODEL_OPTIONS["KPConv"]), "kpconv", ds)
+        pool = [synthetic.make_point_batch(list(range(i * args.batch, (i + 1) * args.batch)), n_points=args.points)
+                for i in range(2)]
+        for b in pool:
+            b.pos, b.x = b.pos.to(dev), b.x.to(dev)
+        model.to(dev).train()
+    else:
+        model = MinkowskiBaselineModel(Opt(MODEL_OPTIONS[args.model]), "minkowski", ds)
+        model.to(dev).train()
+        model.set_kernel_options(precision=args.precision, bf16_activations=args.bf16_rows)
+        pool = [synthetic.make_sparse_batch(list(range(i * args.batch, (i + 1) * args.batch)), n_points=args.points).to(dev)
+                for i in range(2)]
     model.init_train_objects(TRAINING_NFI)
-    pool = [synthetic.make_sparse_batch(list(range(i * args.batch, (i + 1) * args.batch)), n_points=args.points).to(dev)
-            for i in range(2)]
 
     def step(i):
         model.set_input(pool[i % 2], dev)
@@ -53,6 +62,10 @@ def main():
         if args.ops == "all":
             if not e.name.startswith("aten::") or (e.cpu_parent is not None and e.cpu_parent.name.startswith("aten::")):
                 continue
+            if e.name in ("aten::empty", "aten::empty_like", "aten::view", "aten::reshape", "aten::slice", "aten::select",
+                          "aten::detach", "aten::empty_strided", "aten::as_strided", "aten::t", "aten::transpose",
+                          "aten::unsqueeze", "aten::squeeze", "aten::view_as", "aten::alias", "aten::contiguous"):
+                continue      # (no kernel behind them, or counted through the copy they make)
         elif e.name not in want:
             continue
         chain, p = [], e.cpu_parent
