@@ -593,6 +593,8 @@ def main():
     threads0 = thread_cpu_times()
     ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
+    ev_start = torch.cuda.Event(enable_timing=True)
+    ev_start.record()
     step_events = []
     for i in range(args.steps):
         if rank == 0 and i % EV_EVERY == 0:   # (no warmup step to pick the kernel from: bracket them all)
@@ -657,6 +659,11 @@ def main():
     if len(step_events) > 1:
         gaps = [step_events[j].elapsed_time(step_events[j + 1]) for j in range(len(step_events) - 1)]
         log("device time between step ends (ms): " + " ".join(f"{g:.2f}" for g in gaps))
+        # the edges of the timed region: it starts on a drained queue (the first step runs at the pace of its enqueue) and
+        # ends when every stream has drained (the input stream's work for the steps after the last one included)
+        log(f"first timed step, from the start of the region to its end event: {ev_start.elapsed_time(step_events[0]):.2f} ms; "
+            f"region {elapsed * 1e3:.2f} ms = {ev_start.elapsed_time(step_events[-1]):.2f} ms to the last step's end event + "
+            f"{elapsed * 1e3 - ev_start.elapsed_time(step_events[-1]):.2f} ms")
         log("host enqueue per step (ms): " + " ".join(f"{h:.2f}" for h in host_ms[-args.steps:]))
     ms1 = torch.cuda.memory_stats()
     log("caching allocator over the timed region: "
