@@ -2079,9 +2079,15 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    int mt, chunk;
+    int mt, chunk, ny0 = blockIdx.y;
     if (chunks >= 16) {  // XCD-aware: the m-tiles of one row chunk run back to back on one XCD
-        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        // ... and, innermost, the OUTPUT column tiles of one m-tile (gridDim.y of them: they share the m-tile's gathered X rows;
+        // in plain order they are gridDim.x workgroups apart).  gridDim.x is a multiple of 8 here: the linear workgroup id
+        // L = x + gridDim.x y has L % 8 = x % 8 = its XCD.
+        const int L = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = L & 7, j = L >> 3, ny = gridDim.y;
+        const int jx = j / ny;
+        ny0 = j - jx * ny;
         mt = jx % m_tiles;
         chunk = (jx / m_tiles) * 8 + xcd;
         if (chunk >= chunks) return;
@@ -2089,7 +2095,7 @@ __global__ __launch_bounds__(256) void k_spconv_dw_cmp(const float* __restrict__
         chunk = blockIdx.x % chunks;
         mt = blockIdx.x / chunks;
     }
-    const int n0 = blockIdx.y * 64;
+    const int n0 = ny0 * 64;
     const int r_begin = chunk * rows_per_wg;
     const int r_end = il_shift ? r_begin + rows_per_wg : min(n_out, r_begin + rows_per_wg);
     const int k = mt / cin_tiles;
