@@ -42,6 +42,8 @@ def main():
         byts = 4.0 * (n * cin + n * cout + cin * cout)
         t_own = timed(lambda: so.spconv_forward_raw(x, w, None, 0, None, n, 1, cin, cout, "fwd1x1"), args.reps)
         kern = _lib.last_kernel()
+        t_bn = timed(lambda: so.spconv_forward_raw(x, w, None, 0, None, n, 1, cin, cout, "fwd1x1", bn_stats=True), args.reps)
+        print(f"    with the BatchNorm-partials epilogue (agb_dense_fwd_bn): {t_bn * 1e3:8.1f} us")
         t_mm = timed(lambda: torch.mm(x, w), args.reps)
         print(f"[{n} x {cin}] @ [{cin} x {cout}]: own {t_own * 1e3:8.1f} us ({flop / t_own / 1e9:6.1f} TF, {byts / t_own / 1e9:5.2f} TB/s; "
               f"{kern})   torch.mm {t_mm * 1e3:8.1f} us ({flop / t_mm / 1e9:6.1f} TF)")
