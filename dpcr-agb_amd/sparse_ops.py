@@ -995,6 +995,9 @@ class DenseLinearFunction(torch.autograd.Function):
         ctx.join = bool(join)
         # both widths are the reduction dimension of one of the three products: at least 12, multiples of 4
         cin_p, cout_p = max(12, (cin + 3) // 4 * 4), max(12, (cout + 3) // 4 * 4)
+        if join and (cin_p != cin or cout_p != cout):
+            raise _lib.AgbError("the join form of the dense layer takes unpadded widths (multiples of 4, >= 12): "
+                                "dense_linear_join falls back to the plain form otherwise")
         xp = (x if cin_p == cin else F.pad(x, (0, cin_p - cin))).contiguous()
         wp = weight if (cin_p == cin and cout_p == cout) else F.pad(weight, (0, cin_p - cin, 0, cout_p - cout))
         wp = wp.contiguous()                                   # [out, in]: K-major for the forward product
