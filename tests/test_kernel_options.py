@@ -51,3 +51,22 @@ def test_bf16_row_storage_is_refused_where_it_does_not_exist(name):
         m.set_kernel_options(precision="bf16", bf16_activations=True)
     m.set_kernel_options(precision="bf16")                           # the operand precision alone is fine
     assert m.model.kernel_options.precision == "bf16"
+
+
+def test_join_forms_fall_back_off_the_device_and_follow_the_option():
+    """KernelOptions.join_dgrad and the join forms of the dense layers (sparse_ops.dense_linear_join / dense_conv_join): on
+    host tensors, without a gradient to carry or with the option off they are the plain layer plus the SAME input tensor —
+    the product path has no CPU kernels, the join form never runs there."""
+    from dpcr_agb_amd import sparse_ops as so
+    assert so.current().join_dgrad and not so.KernelOptions(join_dgrad=False).join_dgrad
+    with so.KernelOptions(join_dgrad=False) as o:
+        assert not so.current().join_dgrad and so.KernelOptions().join_dgrad is False     # inherited by nested scopes
+        assert o.replace(join_dgrad=True).join_dgrad
+    x = torch.randn(5, 16, requires_grad=True)
+    w = torch.randn(12, 16)
+    y, branch = so.dense_linear_join(x, w)
+    assert branch is x and torch.allclose(y, x @ w.t(), atol=1e-6)
+    (y.sum() + (branch * 2).sum()).backward()
+    assert torch.allclose(x.grad, w.sum(0).expand(5, 16) + 2, atol=1e-6)
+    with pytest.raises(Exception):                      # a padded width in the join form itself is refused, host or device
+        so.DenseLinearFunction.apply(torch.randn(4, 10, requires_grad=True), torch.randn(12, 10), None, True)
